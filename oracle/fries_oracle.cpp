@@ -1,0 +1,1222 @@
+// TEST INFRASTRUCTURE ONLY -- see fries_oracle.hpp.  Sequential CPU restatement
+// of the FRIES hot path; every function cites the reference lines it follows.
+// Compile with -ffp-contract=off: the parity contract is plain IEEE-754
+// double arithmetic in the reference's literal operation order (no FMA).
+#include "fries_oracle.hpp"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <stdexcept>
+#include <iostream>
+#include <climits>
+
+namespace fo {
+
+static inline size_t tri_wdiag(size_t i, size_t j) { return j * (j + 1) / 2 + i; }      // math_utils.h I_J_TO_TRI_WDIAG (i <= j)
+static inline size_t tri_nodiag(size_t i, size_t j) { return j * (j - 1) / 2 + i; }     // math_utils.h I_J_TO_TRI_NODIAG (i < j)
+static inline bool bit(det_t d, unsigned i) { return (d >> i) & 1ull; }
+
+// ------------------------------------------------------------------ bit strings
+int occ_list(det_t det, uint8_t *occ) {
+    int n = 0;
+    while (det) {
+        occ[n++] = (uint8_t)__builtin_ctzll(det);
+        det &= det - 1;
+    }
+    return n;
+}
+
+unsigned bits_between(det_t det, unsigned a, unsigned b) {
+    unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    if (hi - lo < 2) return 0;
+    det_t mask = ((hi >= 64 ? 0ull : (1ull << hi)) - 1ull) & ~((1ull << (lo + 1)) - 1ull);
+    return (unsigned)__builtin_popcountll(det & mask);
+}
+
+int excite_sign(unsigned cre, unsigned des, det_t det) {
+    return (bits_between(det, cre, des) % 2 == 0) ? 1 : -1;
+}
+
+int sing_det_parity(det_t *det, const uint8_t *orbs) {
+    *det &= ~(1ull << orbs[0]);
+    int sign = excite_sign(orbs[0], orbs[1], *det);
+    *det |= 1ull << orbs[1];
+    return sign;
+}
+
+int sing_parity(det_t det, const uint8_t *orbs) { return excite_sign(orbs[0], orbs[1], det); }
+
+int doub_det_parity(det_t *det, const uint8_t *orbs) {
+    *det &= ~(1ull << orbs[0]);
+    *det &= ~(1ull << orbs[1]);
+    int sign = excite_sign(orbs[2], orbs[0], *det);
+    sign *= excite_sign(orbs[3], orbs[1], *det);
+    *det |= 1ull << orbs[2];
+    *det |= 1ull << orbs[3];
+    return sign;
+}
+
+int doub_parity(det_t det, const uint8_t *orbs) {
+    det &= ~(1ull << orbs[0]);
+    det &= ~(1ull << orbs[1]);
+    int sign = excite_sign(orbs[2], orbs[0], det);
+    sign *= excite_sign(orbs[3], orbs[1], det);
+    return sign;
+}
+
+det_t sing_det(det_t det, const uint8_t *orbs) { return (det & ~(1ull << orbs[0])) | (1ull << orbs[1]); }
+det_t doub_det(det_t det, const uint8_t *orbs) {
+    det &= ~(1ull << orbs[0]);
+    det &= ~(1ull << orbs[1]);
+    return det | (1ull << orbs[2]) | (1ull << orbs[3]);
+}
+
+det_t gen_hf_det(unsigned n_orb, unsigned n_elec) {
+    det_t half = (1ull << (n_elec / 2)) - 1ull;
+    return half | (half << n_orb);
+}
+
+uint8_t find_nth_virt(const uint8_t *occ, int spin, unsigned n_elec, unsigned n_orb, unsigned n) {
+    unsigned virt = n_orb * spin + n;
+    // the reference reads occ[orb_idx] before testing orb_idx < n_elec; a sentinel
+    // larger than any orbital reproduces what its contiguous rows yield in practice
+    for (size_t k = n_elec / 2 * spin; k < n_elec && occ[k] <= virt; k++) {
+        if (occ[k] <= virt) virt++;
+    }
+    return (uint8_t)virt;
+}
+
+// ------------------------------------------------------------------ integrals
+double Integrals::chem(unsigned i1, unsigned i2, unsigned i3, unsigned i4) const {
+    size_t mn1 = i1 < i2 ? i1 : i2, mx1 = i1 < i2 ? i2 : i1;
+    size_t p1 = tri_wdiag(mn1, mx1);
+    size_t mn2 = i3 < i4 ? i3 : i4, mx2 = i3 < i4 ? i4 : i3;
+    size_t p2 = tri_wdiag(mn2, mx2);
+    size_t mnp = p1 < p2 ? p1 : p2, mxp = p1 < p2 ? p2 : p1;
+    return eri[tri_wdiag(mnp, mxp)];
+}
+
+void Symm::init(const uint8_t *irreps, unsigned n) {
+    n_orb = n;
+    irrep.assign(irreps, irreps + n);
+    lookup.assign((size_t)N_IRREPS * (n + 1), 0);
+    for (unsigned idx = 0; idx < n; idx++) {
+        unsigned s = irreps[idx];
+        unsigned cnt = lookup[s * (n + 1)];
+        lookup[s * (n + 1) + 1 + cnt] = (uint8_t)idx;
+        lookup[s * (n + 1)] = (uint8_t)(cnt + 1);
+    }
+    max_n_symm = 0;
+    for (unsigned s = 0; s < N_IRREPS; s++) if (lk(s, 0) > max_n_symm) max_n_symm = lk(s, 0);
+}
+
+double diag_matrel(const uint8_t *occ, const Integrals &in, unsigned n_elec) {
+    unsigned n_orbs = in.n_orb;
+    double sum = 0;
+    unsigned j, k, e1, e2;
+    for (j = 0; j < n_elec / 2; j++) {
+        e1 = occ[j];
+        sum += in.h[e1 * n_orbs + e1];
+        for (k = j + 1; k < n_elec / 2; k++) {
+            e2 = occ[k];
+            sum += in.phys(e1, e2, e1, e2);
+            sum -= in.phys(e1, e2, e2, e1);
+        }
+        for (k = n_elec / 2; k < n_elec; k++) {
+            e2 = occ[k] - n_orbs;
+            sum += in.phys(e1, e2, e1, e2);
+        }
+    }
+    for (j = n_elec / 2; j < n_elec; j++) {
+        e1 = occ[j] - n_orbs;
+        sum += in.h[e1 * n_orbs + e1];
+        for (k = j + 1; k < n_elec; k++) {
+            e2 = occ[k] - n_orbs;
+            sum += in.phys(e1, e2, e1, e2);
+            sum -= in.phys(e1, e2, e2, e1);
+        }
+    }
+    return sum;
+}
+
+double sing_matrel_nosgn(const uint8_t *ex, const uint8_t *occ, const Integrals &in, unsigned n_elec) {
+    unsigned n = in.n_orb;
+    unsigned o = ex[0] % n, u = ex[1] % n, spin = ex[0] / n;
+    double el = in.h[o * n + u];
+    for (unsigned j = 0; j < n_elec / 2; j++) {
+        el += in.phys(o, occ[j], u, occ[j]);
+        if (spin == 0) el -= in.phys(o, occ[j], occ[j], u);
+    }
+    for (unsigned j = n_elec / 2; j < n_elec; j++) {
+        el += in.phys(o, occ[j] - n, u, occ[j] - n);
+        if (spin == 1) el -= in.phys(o, occ[j] - n, occ[j] - n, u);
+    }
+    return el;
+}
+
+double doub_matrel_nosgn(const uint8_t *ex, const Integrals &in) {
+    unsigned n = in.n_orb;
+    int same = (ex[0] / n) == (ex[1] / n);
+    unsigned s0 = ex[0] % n, s1 = ex[1] % n, s2 = ex[2] % n, s3 = ex[3] % n;
+    double el = in.phys(s0, s1, s2, s3);
+    if (same) el -= in.phys(s0, s1, s3, s2);
+    return el;
+}
+
+size_t sing_ex_symm(det_t det, const uint8_t *occ, unsigned n_elec, unsigned n_orb, std::vector<uint8_t> &out, const uint8_t *irrep) {
+    out.clear();
+    for (unsigned i = 0; i < n_elec / 2; i++) {
+        unsigned io = occ[i];
+        for (unsigned a = 0; a < n_orb; a++)
+            if (!bit(det, a) && irrep[io] == irrep[a]) { out.push_back(io); out.push_back(a); }
+    }
+    for (unsigned i = n_elec / 2; i < n_elec; i++) {
+        unsigned io = occ[i];
+        for (unsigned a = n_orb; a < 2 * n_orb; a++)
+            if (!bit(det, a) && irrep[io - n_orb] == irrep[a - n_orb]) { out.push_back(io); out.push_back(a); }
+    }
+    return out.size() / 2;
+}
+
+size_t doub_ex_symm(det_t det, const uint8_t *occ, unsigned ne, unsigned no, std::vector<uint8_t> &out, const uint8_t *sy) {
+    out.clear();
+    auto push = [&](unsigned a, unsigned b, unsigned c, unsigned d) { out.push_back(a); out.push_back(b); out.push_back(c); out.push_back(d); };
+    unsigned i, j, k, l;
+    for (i = 0; i < ne / 2; i++) {
+        unsigned io = occ[i];
+        for (j = ne / 2; j < ne; j++) {
+            unsigned jo = occ[j];
+            for (k = 0; k < no; k++) if (!bit(det, k))
+                for (l = no; l < 2 * no; l++)
+                    if (!bit(det, l) && (sy[io] ^ sy[jo - no] ^ sy[k] ^ sy[l - no]) == 0) push(io, jo, k, l);
+        }
+    }
+    for (i = 0; i < ne / 2; i++) {
+        unsigned io = occ[i];
+        for (j = i + 1; j < ne / 2; j++) {
+            unsigned jo = occ[j];
+            for (k = 0; k < no; k++) if (!bit(det, k))
+                for (l = k + 1; l < no; l++)
+                    if (!bit(det, l) && (sy[io] ^ sy[jo] ^ sy[k] ^ sy[l]) == 0) push(io, jo, k, l);
+        }
+    }
+    for (i = ne / 2; i < ne; i++) {
+        unsigned io = occ[i];
+        for (j = i + 1; j < ne; j++) {
+            unsigned jo = occ[j];
+            for (k = no; k < 2 * no; k++) if (!bit(det, k))
+                for (l = k + 1; l < 2 * no; l++)
+                    if (!bit(det, l) && (sy[io - no] ^ sy[jo - no] ^ sy[k - no] ^ sy[l - no]) == 0) push(io, jo, k, l);
+        }
+    }
+    return out.size() / 4;
+}
+
+size_t count_singex(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &s) {
+    size_t n = 0;
+    for (unsigned e = 0; e < n_elec; e++) {
+        unsigned orb = occ[e], sy = s.irrep[orb % s.n_orb], spin = orb / s.n_orb;
+        for (unsigned k = 0; k < s.lk(sy, 0); k++)
+            if (!bit(det, s.lk(sy, k + 1) + s.n_orb * spin)) n++;
+    }
+    return n;
+}
+
+void count_symm_virt(unsigned counts[][2], const uint8_t *occ, unsigned n_elec, const Symm &s) {
+    unsigned i;
+    for (i = 0; i < N_IRREPS; i++) { counts[i][0] = s.lk(i, 0); counts[i][1] = s.lk(i, 0); }
+    for (i = 0; i < n_elec / 2; i++) counts[s.irrep[occ[i]]][0] -= 1;
+    for (; i < n_elec; i++) counts[s.irrep[occ[i] - s.n_orb]][1] -= 1;
+}
+
+unsigned count_sing_allowed(const uint8_t *occ, unsigned n_elec, const Symm &s, unsigned counts[][2]) {
+    unsigned n = 0;
+    for (unsigned e = 0; e < n_elec; e++) {
+        unsigned sy = s.irrep[occ[e] % s.n_orb];
+        if (counts[sy][e / (n_elec / 2)] != 0) n++;
+    }
+    return n;
+}
+
+unsigned count_sing_virt(const uint8_t *occ, unsigned n_elec, const Symm &s, unsigned counts[][2], uint8_t *occ_choice) {
+    unsigned n = 0;
+    for (unsigned e = 0; e < n_elec; e++) {
+        unsigned sy = s.irrep[occ[e] % s.n_orb];
+        unsigned va = counts[sy][e / (n_elec / 2)];
+        if (va != 0) {
+            if (n == *occ_choice) { *occ_choice = (uint8_t)e; return va; }
+            n++;
+        }
+    }
+    return 0;
+}
+
+uint8_t virt_from_idx(det_t det, const Symm &s, unsigned irrep, unsigned spin_shift, unsigned index) {
+    for (unsigned k = 0; k < s.lk(irrep, 0); k++) {
+        unsigned orb = spin_shift + s.lk(irrep, 1 + k);
+        if (!bit(det, orb)) {
+            if (index == 0) return (uint8_t)orb;
+            index--;
+        }
+    }
+    return 255;
+}
+
+// ------------------------------------------------------------------ HB-PP tensors
+void HBInfo::set_up(const Integrals &in) {
+    unsigned n = in.n_orb;
+    n_orb = n;
+    size_t i, j, a, b;
+    d_diff.assign((size_t)n * n, 0.0);
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++)
+        for (a = 0; a < n; a++) for (b = 0; b < n; b++)
+            if (i != a && j != b) d_diff[i * n + j] += fabs(in.phys(i, j, a, b));
+    d_same.assign((size_t)n * (n - 1) / 2, 0.0);
+    size_t tri = 0;
+    for (j = 1; j < n; j++) for (i = 0; i < j; i++) {
+        for (a = 0; a < n; a++) for (b = 0; b < a; b++)
+            if (a != j && a != i && b != j && b != i)
+                d_same[tri] += 2 * fabs(in.phys(i, j, a, b) - in.phys(i, j, b, a));
+        tri++;
+    }
+    s_tens.assign(n, 0.0);
+    s_norm = 0;
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < i; j++) s_tens[i] += d_same[tri_nodiag(j, i)];
+        for (j = i + 1; j < n; j++) s_tens[i] += d_same[tri_nodiag(i, j)];
+        for (j = 0; j < n; j++) s_tens[i] += d_diff[i * n + j];
+        s_norm += s_tens[i];
+    }
+    exch_sqrt.assign((size_t)n * (n - 1) / 2, 0.0);
+    tri = 0;
+    for (j = 0; j < n; j++) for (i = 0; i < j; i++) { exch_sqrt[tri] = sqrt(fabs(in.phys(i, j, j, i))); tri++; }
+    diag_sqrt.assign(n, 0.0);
+    for (j = 0; j < n; j++) diag_sqrt[j] = sqrt(fabs(in.phys(j, j, j, j)));
+    exch_norms.assign(n, 0.0);
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < i; j++) exch_norms[i] += exch_sqrt[tri_nodiag(j, i)];
+        exch_norms[i] += diag_sqrt[i];
+        for (j = i + 1; j < n; j++) exch_norms[i] += exch_sqrt[tri_nodiag(i, j)];
+    }
+}
+
+double calc_o1_probs(const HBInfo &t, double *p, unsigned n_elec, const uint8_t *occ, int exclude_first) {
+    double norm = 0;
+    unsigned skip = exclude_first > 0;
+    for (unsigned k = skip; k < n_elec / 2; k++) { p[k - skip] = t.s_tens[occ[k]]; norm += p[k - skip]; }
+    for (unsigned k = n_elec / 2; k < n_elec; k++) { p[k - skip] = t.s_tens[occ[k] - t.n_orb]; norm += p[k - skip]; }
+    double inv = 1. / norm;
+    for (unsigned k = skip; k < n_elec; k++) p[k - skip] *= inv;
+    norm /= t.s_norm;
+    return norm;
+}
+
+double calc_o2_probs(const HBInfo &t, double *p, unsigned n_elec, const uint8_t *occ, unsigned o1_idx) {
+    double norm = 0;
+    unsigned o1 = occ[o1_idx], n = t.n_orb;
+    int sp = o1 / n;
+    unsigned off = (1 - sp) * n_elec / 2;
+    for (unsigned k = off; k < n_elec / 2 + off; k++) { p[k] = t.d_diff[(o1 % n) * n + occ[k] % n]; norm += p[k]; }
+    off = sp * n_elec / 2;
+    for (unsigned k = off; k < o1_idx; k++) { p[k] = t.d_same[tri_nodiag(occ[k] % n, o1 % n)]; norm += p[k]; }
+    for (unsigned k = o1_idx + 1; k < n_elec / 2 + off; k++) { p[k] = t.d_same[tri_nodiag(o1 % n, occ[k] % n)]; norm += p[k]; }
+    p[o1_idx] = 0;
+    double inv = 1. / norm;
+    for (unsigned k = 0; k < n_elec; k++) p[k] *= inv;
+    norm /= t.s_tens[o1 % n];
+    return norm;
+}
+
+double calc_o2_probs_half(const HBInfo &t, double *p, unsigned n_elec, const uint8_t *occ, unsigned o1_idx) {
+    double norm = 0;
+    unsigned o1 = occ[o1_idx], n = t.n_orb;
+    int sp = o1 / n;
+    unsigned upper = n_elec / 2 > o1_idx ? o1_idx : n_elec / 2;
+    for (unsigned k = 0; k < upper; k++) {
+        if (sp == 0) p[k] = t.d_same[tri_nodiag(occ[k], o1)];
+        else p[k] = t.d_diff[(o1 - n) * n + occ[k]];
+        norm += p[k];
+    }
+    for (unsigned k = n_elec / 2; k < o1_idx; k++) {
+        if (sp == 0) p[k] = t.d_diff[o1 * n + occ[k] - n];
+        else p[k] = t.d_same[tri_nodiag(occ[k] - n, o1 - n)];
+        norm += p[k];
+    }
+    double inv = 1. / norm;
+    for (unsigned k = 0; k < o1_idx; k++) p[k] *= inv;
+    norm /= t.s_tens[o1 % n];
+    return norm;
+}
+
+double calc_u1_probs(const HBInfo &t, double *p, unsigned o1_orb, const uint8_t *occ, unsigned n_elec, int exclude_first) {
+    unsigned n = t.n_orb;
+    int sp = o1_orb / n;
+    unsigned o1s = o1_orb % n, off = sp * n;
+    double norm = 0;
+    size_t pi = 0;
+    unsigned oi = n_elec / 2 * sp;
+    auto occ_at = [&](unsigned k) -> unsigned { return k < n_elec ? occ[k] : 255u; };  // see header note on row overrun
+    unsigned cur = occ_at(oi);
+    for (unsigned k = 0; k < o1s; k++) {
+        if (k + off == cur) { oi++; cur = occ_at(oi); }
+        else { p[pi] = t.exch_sqrt[tri_nodiag(k, o1s)]; norm += p[pi]; pi++; }
+    }
+    oi++;
+    cur = occ_at(oi);
+    for (unsigned k = o1s + 1; k < n; k++) {
+        if (k + off == cur) {
+            if (oi < n_elec - 1) { oi++; cur = occ_at(oi); }
+        }
+        else { p[pi] = t.exch_sqrt[tri_nodiag(o1s, k)]; norm += p[pi]; pi++; }
+    }
+    if (exclude_first) { norm -= p[0]; p[0] = 0; }
+    double inv = 1. / norm;
+    for (unsigned k = 0; k < pi; k++) p[k] *= inv;
+    norm /= t.exch_norms[o1s];
+    return norm;
+}
+
+static inline double exch_or_diag(const HBInfo &t, unsigned o, unsigned u) {
+    if (o == u) return t.diag_sqrt[o];
+    unsigned mn = o < u ? o : u, mx = o > u ? o : u;
+    return t.exch_sqrt[tri_nodiag(mn, mx)];
+}
+
+double calc_u2_probs(const HBInfo &t, double *p, unsigned o1, unsigned o2, unsigned u1, const Symm &s, uint16_t *len) {
+    unsigned n = t.n_orb;
+    unsigned o2s = o2 % n, u1s = u1 % n;
+    int same = (o1 / n) == (o2 / n);
+    unsigned ir = s.irrep[o1 % n] ^ s.irrep[o2s] ^ s.irrep[u1s];
+    unsigned num = s.lk(ir, 0);
+    *len = (uint16_t)num;
+    double norm = 0;
+    for (unsigned k = 0; k < num; k++) {
+        unsigned u2 = s.lk(ir, k + 1);
+        if ((same && u2 != u1s) || !same) { p[k] = exch_or_diag(t, o2s, u2); norm += p[k]; }
+        else p[k] = 0;
+    }
+    if (norm != 0) {
+        double inv = 1 / norm;
+        for (unsigned k = 0; k < num; k++) {
+            unsigned u2 = s.lk(ir, k + 1);
+            if ((same && u2 != u1s) || !same) p[k] *= inv;
+        }
+    }
+    norm /= t.exch_norms[o2s];
+    return norm;
+}
+
+double calc_u2_probs_half(const HBInfo &t, double *p, unsigned o1, unsigned o2, unsigned u1, det_t det, const Symm &s, uint16_t *len) {
+    unsigned n = t.n_orb;
+    unsigned o2s = o2 % n, u1s = u1 % n;
+    int u2_spin = o2 / n;
+    int same = (int)(o1 / n) == u2_spin;
+    unsigned ir = s.irrep[o1 % n] ^ s.irrep[o2s] ^ s.irrep[u1s];
+    unsigned num = s.lk(ir, 0);
+    double norm = 0;
+    unsigned k;
+    for (k = 0; k < num; k++) {
+        unsigned u2 = s.lk(ir, k + 1);
+        if (same && u2 >= u1s) break;
+        if (((same && u2 != u1s) || !same) && !bit(det, u2 + n * u2_spin)) { p[k] = exch_or_diag(t, o2s, u2); norm += p[k]; }
+        else p[k] = 0;
+    }
+    *len = (uint16_t)k;
+    if (norm != 0) {
+        double inv = 1 / norm;
+        for (k = 0; k < *len; k++) p[k] *= inv;
+    }
+    norm /= t.exch_norms[o2s];
+    return norm;
+}
+
+double calc_unnorm_wt(const HBInfo &t, const uint8_t *orbs) {
+    unsigned n = t.n_orb;
+    unsigned o1 = orbs[0] % n, o2 = orbs[1] % n, u1 = orbs[2] % n, u2 = orbs[3] % n;
+    unsigned mn11 = o1 < u1 ? o1 : u1, mx11 = o1 > u1 ? o1 : u1;
+    unsigned mn22 = o2 < u2 ? o2 : u2, mx22 = o2 > u2 ? o2 : u2;
+    int same = (orbs[0] / n) == (orbs[1] / n);
+    double w;
+    if (same) {
+        w = t.d_same[tri_nodiag(o1, o2)] * (t.exch_sqrt[tri_nodiag(mn11, mx11)] * t.exch_sqrt[tri_nodiag(mn22, mx22)]) / t.s_norm / t.exch_norms[o1] / t.exch_norms[o2];
+    }
+    else {
+        w = (t.d_diff[o2 * n + o1]) * t.exch_sqrt[tri_nodiag(mn11, mx11)] * t.exch_sqrt[tri_nodiag(mn22, mx22)] / t.s_norm / t.exch_norms[o1] / t.exch_norms[o2];
+    }
+    return w;
+}
+
+double calc_norm_wt(const HBInfo &t, const uint8_t *orbs, const uint8_t *occ, unsigned n_elec, det_t det, const Symm &sy) {
+    unsigned n = t.n_orb;
+    unsigned o1 = orbs[0] % n, o2 = orbs[1] % n, u1 = orbs[2] % n, u2 = orbs[3] % n;
+    int o1_spin = orbs[0] / n, o2_spin = orbs[1] / n;
+    unsigned mn11 = o1 < u1 ? o1 : u1, mx11 = o1 > u1 ? o1 : u1;
+    unsigned mn22 = o2 < u2 ? o2 : u2, mx22 = o2 > u2 ? o2 : u2;
+    int same = o1_spin == o2_spin;
+    size_t k;
+    uint8_t os[64];
+    for (k = 0; k < n_elec; k++) os[k] = occ[k] % n;
+    os[n_elec] = 255;
+    double s_denom = 0;
+    for (k = 0; k < n_elec; k++) s_denom += t.s_tens[os[k]];
+    double d1 = 0;
+    unsigned off = (1 - o1_spin) * n_elec / 2;
+    for (k = off; k < n_elec / 2 + off; k++) d1 += t.d_diff[o1 * n + os[k]];
+    off = o1_spin * n_elec / 2;
+    for (k = off; os[k] < o1; k++) d1 += t.d_same[tri_nodiag(os[k], o1)];
+    for (k++; k < n_elec / 2 + off; k++) d1 += t.d_same[tri_nodiag(o1, os[k])];
+    double d2 = 0;
+    off = (1 - o2_spin) * n_elec / 2;
+    for (k = off; k < n_elec / 2 + off; k++) d2 += t.d_diff[o2 * n + os[k]];
+    off = o2_spin * n_elec / 2;
+    for (k = off; os[k] < o2; k++) d2 += t.d_same[tri_nodiag(os[k], o2)];
+    for (k++; k < n_elec / 2 + off; k++) d2 += t.d_same[tri_nodiag(o2, os[k])];
+
+    double e1v = 0;
+    off = o1_spin * n;
+    for (k = 0; k < o1; k++) if (!bit(det, k + off)) e1v += t.exch_sqrt[tri_nodiag(k, o1)];
+    for (k = o1 + 1; k < n; k++) if (!bit(det, k + off)) e1v += t.exch_sqrt[tri_nodiag(o1, k)];
+    double e2v = 0;
+    off = o2_spin * n;
+    for (k = 0; k < o2; k++) if (!bit(det, k + off)) e2v += t.exch_sqrt[tri_nodiag(k, o2)];
+    for (k = o2 + 1; k < n; k++) if (!bit(det, k + off)) e2v += t.exch_sqrt[tri_nodiag(o2, k)];
+
+    unsigned u1_ir = sy.irrep[u1], u2_ir = sy.irrep[u2];
+    double e2s_no1 = 0, e2s_no2 = 0, e1s_no1 = 0, e1s_no2 = 0;
+    for (k = 0; k < sy.lk(u2_ir, 0); k++) {
+        unsigned so = sy.lk(u2_ir, k + 1);
+        if ((same && so != u1) || !same) e2s_no1 += exch_or_diag(t, o2, so);
+        if ((same && so != u1) || !same) e1s_no1 += exch_or_diag(t, o1, so);
+    }
+    for (k = 0; k < sy.lk(u1_ir, 0); k++) {
+        unsigned so = sy.lk(u1_ir, k + 1);
+        if ((same && so != u2) || !same) e2s_no2 += exch_or_diag(t, o2, so);
+        if ((same && so != u2) || !same) e1s_no2 += exch_or_diag(t, o1, so);
+    }
+    unsigned o1u1 = tri_nodiag(mn11, mx11), o2u2 = tri_nodiag(mn22, mx22);
+    double w;
+    if (same) {
+        unsigned mn12 = o1 < u2 ? o1 : u2, mx12 = o1 > u2 ? o1 : u2;
+        unsigned mn21 = o2 < u1 ? o2 : u1, mx21 = o2 > u1 ? o2 : u1;
+        unsigned o1o2 = tri_nodiag(o1, o2), o1u2 = tri_nodiag(mn12, mx12), o2u1 = tri_nodiag(mn21, mx21);
+        w = t.d_same[o1o2] / s_denom * (
+            t.s_tens[o1] / d1 / e1v * (t.exch_sqrt[o1u1] * t.exch_sqrt[o2u2] / e2s_no1 + t.exch_sqrt[o1u2] * t.exch_sqrt[o2u1] / e2s_no2) +
+            t.s_tens[o2] / d2 / e2v * (t.exch_sqrt[o2u1] * t.exch_sqrt[o1u2] / e1s_no1 + t.exch_sqrt[o2u2] * t.exch_sqrt[o1u1] / e1s_no2));
+    }
+    else {
+        w = (t.s_tens[o1] * t.d_diff[o1 * n + o2] / d1 / e1v / e2s_no1 + t.s_tens[o2] * t.d_diff[o2 * n + o1] / d2 / e2v / e1s_no2) * t.exch_sqrt[o1u1] * t.exch_sqrt[o2u2] / s_denom;
+    }
+    return w;
+}
+
+// ------------------------------------------------------------------ compression
+double find_preserve(const double *values, std::vector<size_t> &srt, std::vector<uint8_t> &keep,
+                     size_t count, unsigned *n_samp, double *global_norm) {
+    double loc = 0, glob = 0;
+    size_t heap_count = count;
+    for (size_t i = 0; i < count; i++) { loc += fabs(values[i]); srt[i] = i; }
+    auto cmp = [values](size_t i, size_t j) { return fabs(values[i]) < fabs(values[j]); };
+    std::make_heap(srt.begin(), srt.begin() + heap_count, cmp);
+    int loc_sampled, glob_sampled = 1, keep_going = 1;
+    double el = 0;
+    size_t mx;
+    *global_norm = loc;
+    bool recalc = false;
+    while (glob_sampled > 0) {
+        glob = loc;
+        loc_sampled = 0;
+        while (keep_going && heap_count > 0 && glob >= 0) {
+            mx = srt[0];
+            el = fabs(values[mx]);
+            if (el >= glob / (*n_samp - loc_sampled)) {
+                keep[mx] = 1;
+                loc_sampled++;
+                loc -= el;
+                glob -= el;
+                heap_count--;
+                if (heap_count) std::pop_heap(srt.begin(), srt.begin() + heap_count + 1, cmp);
+                else keep_going = 0;
+            }
+            else keep_going = 0;
+        }
+        glob_sampled = loc_sampled;
+        (*n_samp) -= glob_sampled;
+        if (glob_sampled == 0 && !recalc) {
+            loc = 0;
+            for (size_t i = 0; i < count; i++) if (!keep[i]) loc += fabs(values[i]);
+            glob_sampled = 1;
+            recalc = true;
+        }
+        else recalc = false;
+        keep_going = 1;
+    }
+    loc = 0;
+    if (glob < 1e-9) *n_samp = 0;
+    else for (size_t i = 0; i < count; i++) if (!keep[i]) loc += fabs(values[i]);
+    return loc;
+}
+
+double seed_sys(double norm, double *rn, unsigned n_samp) {
+    double lbound = 0;
+    double global_norm = lbound;
+    global_norm += norm;
+    *rn *= global_norm / n_samp;
+    *rn += global_norm / n_samp * (int)(lbound * n_samp / global_norm);
+    if (*rn < lbound) *rn += global_norm / n_samp;
+    return lbound;
+}
+
+double sys_comp(double *vals, size_t len, double loc_norm, unsigned n_samp, std::vector<uint8_t> &keep, double rn) {
+    double rn_sys = rn;
+    double tmp_glob = 0;
+    tmp_glob += loc_norm;
+    double lbound;
+    if (n_samp > 0) lbound = seed_sys(loc_norm, &rn_sys, n_samp);
+    else { lbound = 0; rn_sys = INFINITY; }
+    double out_norm = 0;
+    for (size_t i = 0; i < len; i++) {
+        double v = vals[i];
+        if (keep[i]) { out_norm += fabs(v); keep[i] = 0; }
+        else if (v != 0) {
+            lbound += fabs(v);
+            if (rn_sys < lbound) {
+                vals[i] = tmp_glob / n_samp * ((v > 0) - (v < 0));
+                out_norm += tmp_glob / n_samp;
+                rn_sys += tmp_glob / n_samp;
+            }
+            else { vals[i] = 0; keep[i] = 1; }
+        }
+    }
+    return out_norm;
+}
+
+double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
+                     size_t count, unsigned *n_samp, double *wt_remain) {
+    double loc = 0, glob = 0;
+    for (size_t i = 0; i < count; i++) { loc += values[i]; wt_remain[i] = values[i]; }
+    int loc_sampled, glob_sampled = 1;
+    double sub_magn, sub_remain;
+    int last_pass = 0;
+    size_t n_sub = sw.cols;
+    const size_t coarse = 8;
+    size_t n_coarse = count / coarse;
+    double cw[8];
+    while (glob_sampled > 0) {
+        glob = loc;
+        if (glob < 0) break;
+        loc_sampled = 0;
+        for (size_t c = 0; c <= n_coarse; c++) {
+            unsigned flags = 0;
+            size_t lim = (c == n_coarse) ? count % coarse : coarse;
+            double wf = *n_samp - loc_sampled;
+            for (size_t f = 0; f < lim; f++) {
+                size_t i = c * coarse + f;
+                if (wt_remain[i] > 0) {
+                    cw[f] = values[i] * wf;
+                    if (n_div[i] > 0) cw[f] /= n_div[i];
+                    flags += (unsigned)(cw[f] >= glob) << f;
+                }
+            }
+            for (size_t f = 0; f < lim; f++) {
+                if (!((flags >> f) & 1)) continue;
+                size_t i = c * coarse + f;
+                double el = values[i];
+                if (n_div[i] > 0) {
+                    sw.keep[i] |= 1u;
+                    wt_remain[i] = 0;
+                    loc_sampled += n_div[i];
+                    loc -= el;
+                    glob -= el;
+                    if (glob < 0) break;
+                }
+                else {
+                    sub_remain = 0;
+                    const double *row = sw.row(i);
+                    if (sub_sizes) n_sub = sub_sizes[i];
+                    double cwt = cw[f];
+                    size_t full = (n_sub / 8) * 8;
+                    uint32_t kp = sw.keep[i];
+                    for (size_t s = 0; s < n_sub; s++) {
+                        if ((kp >> s) & 1u) continue;
+                        sub_magn = cwt * row[s];
+                        double thr = s < full ? 1e-12 : 1e-10;   // compress_utils.cpp:213 vs :233
+                        if (sub_magn >= glob && fabs(sub_magn) > thr) { kp |= 1u << s; loc_sampled++; }
+                        else sub_remain += sub_magn;
+                    }
+                    sw.keep[i] = kp;
+                    sub_remain /= wf;
+                    double change = wt_remain[i] - sub_remain;
+                    wt_remain[i] = sub_remain;
+                    loc -= change;
+                    glob -= change;
+                }
+            }
+        }
+        glob_sampled = loc_sampled;
+        (*n_samp) -= glob_sampled;
+        if (last_pass && glob_sampled) last_pass = 0;
+        if (glob_sampled == 0 && !last_pass) {
+            last_pass = 1;
+            glob_sampled = 1;
+            loc = 0;
+            for (size_t i = 0; i < count; i++) loc += wt_remain[i];
+        }
+    }
+    loc = 0;
+    if (glob / *n_samp < 1e-8) *n_samp = 0;
+    else for (size_t i = 0; i < count; i++) loc += wt_remain[i];
+    return loc;
+}
+
+size_t sys_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
+               size_t count, unsigned n_samp, const double *wt_remain, double *loc_norm, double rn,
+               double *new_vals, size_t (*new_idx)[2]) {
+    double rn_sys = rn;
+    double tmp_glob = 0;
+    tmp_glob += *loc_norm;
+    double lbound;
+    if (n_samp > 0) lbound = seed_sys(*loc_norm, &rn_sys, n_samp);
+    else { lbound = 0; rn_sys = INFINITY; }
+    double out_norm = 0;
+    size_t num_new = 0, sub_idx;
+    size_t n_sub = sw.cols;
+    for (size_t i = 0; i < count; i++) {
+        double v = values[i];
+        if (v == 0) continue;
+        lbound += wt_remain[i];
+        if (n_div[i] > 0) {
+            if (sw.keep[i] & 1u) {
+                sw.keep[i] &= ~1u;
+                for (sub_idx = 0; sub_idx < n_div[i]; sub_idx++) {
+                    new_vals[num_new] = v / n_div[i];
+                    new_idx[num_new][0] = i; new_idx[num_new][1] = sub_idx;
+                    num_new++;
+                }
+                out_norm += v;
+            }
+            else if (v != 0) {
+                while (rn_sys < lbound) {
+                    sub_idx = (size_t)((lbound - rn_sys) * n_div[i] / v);
+                    if (sub_idx < n_div[i]) {
+                        new_vals[num_new] = tmp_glob / n_samp;
+                        new_idx[num_new][0] = i; new_idx[num_new][1] = sub_idx;
+                        num_new++;
+                        out_norm += tmp_glob / n_samp;
+                    }
+                    rn_sys += tmp_glob / n_samp;
+                }
+            }
+        }
+        else if (wt_remain[i] < v || rn_sys < lbound) {
+            out_norm += (v - wt_remain[i]);
+            double sub_lbound = lbound - wt_remain[i];
+            if (sub_sizes) n_sub = sub_sizes[i];
+            const double *row = sw.row(i);
+            uint32_t kp = sw.keep[i];
+            for (sub_idx = 0; sub_idx < n_sub; sub_idx++) {
+                if (((kp >> sub_idx) & 1u) && row[sub_idx] != 0) {
+                    new_vals[num_new] = v * row[sub_idx];
+                    new_idx[num_new][0] = i; new_idx[num_new][1] = sub_idx;
+                    num_new++;
+                }
+                else {
+                    sub_lbound += v * row[sub_idx];
+                    if (rn_sys < sub_lbound && row[sub_idx] != 0) {
+                        new_vals[num_new] = tmp_glob / n_samp;
+                        new_idx[num_new][0] = i; new_idx[num_new][1] = sub_idx;
+                        num_new++;
+                        out_norm += tmp_glob / n_samp;
+                        rn_sys += tmp_glob / n_samp;
+                    }
+                }
+            }
+            sw.keep[i] = 0;   // reference clears bits 0..n_sub-1; no others are ever set
+        }
+    }
+    *loc_norm = out_norm;
+    return num_new;
+}
+
+size_t comp_sub(const double *values, size_t count, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
+                unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2]) {
+    unsigned tmp_nsamp = n_samp;
+    double loc_norm = find_keep_sub(values, n_div, sw, sub_sizes, count, &tmp_nsamp, wt_remain);
+    return sys_sub(values, n_div, sw, sub_sizes, count, tmp_nsamp, wt_remain, &loc_norm, rn, new_vals, new_idx);
+}
+
+void adjust_shift(double *shift, double one_norm, double *last_norm, double target_norm, double damp) {
+    if (*last_norm) {
+        *shift -= damp * log(one_norm / *last_norm);
+        *last_norm = one_norm;
+    }
+    if (*last_norm == 0 && one_norm > target_norm) *last_norm = one_norm;
+}
+
+// ------------------------------------------------------------------ sparse vector
+uint64_t hash_fxn(const uint8_t *occ, unsigned n_elec, const uint32_t *scr) {
+    uint64_t hash = 0;
+    for (unsigned i = 0; i < n_elec; i++) {
+        // (i + 1) * scrambler_[...] is unsigned int * uint32_t: 32-bit wraparound
+        uint32_t term = (uint32_t)(i + 1) * scr[occ[i]];
+        hash = 1099511628211ULL * hash + term;
+    }
+    return hash;
+}
+
+void Vec::init(size_t size, size_t add_size, unsigned n_el, unsigned nv) {
+    n_elec = n_el; n_vecs = nv; max_size = size; curr_size = 0; adder_cap = add_size; n_nonz = 0; cur = 0;
+    dets.assign(size, 0);
+    vals.assign(nv, std::vector<double>(size, 0.0));
+    occ.assign(size * n_el, 0);
+    diag.assign(size, NAN);
+    active.assign(size, 0);
+    free_stack.clear(); table.clear();
+    add_det.clear(); add_val.clear(); add_ini.clear();
+}
+
+void Vec::expand() {
+    size_t nm = max_size * 2;
+    dets.resize(nm, 0);
+    for (auto &c : vals) c.resize(nm, 0.0);
+    occ.resize(nm * n_elec, 0);
+    diag.resize(nm, NAN);
+    active.resize(nm, 0);
+    max_size = nm;
+}
+
+bool Vec::add(det_t det, double val, uint8_t ini) {
+    if (val != 0) {
+        if (add_det.size() >= adder_cap) throw std::runtime_error("Too many elements added to Adder - must call perform_add() more frequently.");
+        add_det.push_back(det); add_val.push_back(val); add_ini.push_back(ini);
+        return add_det.size() < adder_cap;
+    }
+    return true;
+}
+
+void Vec::perform_add(size_t origin) {
+    uint8_t tmp_occ[64];
+    for (size_t e = 0; e < add_det.size(); e++) {
+        det_t d = add_det[e];
+        int ini = add_ini[e];
+        if ((unsigned)occ_list(d, tmp_occ) != n_elec) throw std::runtime_error("Determinant created with an incorrect number of electrons");
+        ptrdiff_t *ptr = nullptr;
+        auto it = table.find(d);
+        if (it != table.end()) ptr = &it->second;
+        else if (ini) ptr = &table.emplace(d, (ptrdiff_t)-1).first->second;
+        if (ptr && *ptr == -1) {
+            if (!free_stack.empty()) { *ptr = (ptrdiff_t)free_stack.back(); free_stack.pop_back(); }
+            else {
+                if (curr_size >= max_size) expand();
+                *ptr = (ptrdiff_t)curr_size;
+                curr_size++;
+            }
+            size_t pos = (size_t)*ptr;
+            dets[pos] = d;
+            for (unsigned v = 0; v < n_vecs; v++) vals[v][pos] = 0;
+            diag[pos] = NAN;
+            active[pos] = 1;
+            memcpy(&occ[pos * n_elec], tmp_occ, n_elec);
+            n_nonz++;
+        }
+        if (ptr) {
+            size_t pos = (size_t)*ptr;
+            bool nonz = vals[origin][pos] != 0;
+            bool should = ini || nonz;
+            nonini_occ_add += !ini && nonz;
+            if (should) vals[cur][pos] += add_val[e];
+        }
+    }
+    add_det.clear(); add_val.clear(); add_ini.clear();
+}
+
+void Vec::del_at_pos(size_t pos) {
+    if (!active[pos]) return;
+    bool all_zero = true;
+    for (unsigned v = 0; v < n_vecs; v++) if (vals[v][pos] != 0) all_zero = false;
+    if (all_zero) {
+        free_stack.push_back(pos);
+        table.erase(dets[pos]);
+        n_nonz--;
+        active[pos] = 0;
+    }
+}
+
+double Vec::local_norm() const {
+    double norm = 0;
+    for (size_t i = 0; i < curr_size; i++) norm += fabs(vals[cur][i]);
+    return norm;
+}
+
+double Vec::dot(const std::vector<det_t> &d2, const std::vector<double> &v2) const {
+    double numer = 0;
+    for (size_t k = 0; k < d2.size(); k++) {
+        auto it = table.find(d2[k]);
+        if (it != table.end()) numer += v2[k] * vals[cur][(size_t)it->second];
+    }
+    return numer;
+}
+
+// ------------------------------------------------------------------ apply_HBPP_sys
+void HBScratch::init(size_t length, size_t n_subwt) {
+    len = length; vec_len = 0;
+    vec1.assign(length, 0); vec2.assign(length, 0); wt_remain.assign(length, 0);
+    det_idx1.assign(length, 0); det_idx2.assign(length, 0);
+    orb1.assign(length * 4, 0); orb2.assign(length * 4, 0);
+    nsub.assign(length, 0); ndiv.assign(length, 0);
+    comp_idx.assign(length * 2, 0);
+    sw.cols = n_subwt; sw.w.assign(length * n_subwt, 0); sw.keep.assign(length, 0);
+}
+
+void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
+                    const double rn[5], uint32_t n_samp, bool unit_matrel) {
+    std::vector<double> &vec1 = sc.vec1, &vec2 = sc.vec2;
+    SubWts &sw = sc.sw;
+    std::vector<uint32_t> &ndiv = sc.ndiv;
+    std::vector<uint16_t> &nsub = sc.nsub;
+    size_t comp_len = sc.vec_len;
+    std::vector<size_t> &di1 = sc.det_idx1, &di2 = sc.det_idx2;
+    uint8_t (*oi1)[4] = (uint8_t (*)[4])sc.orb1.data();
+    uint8_t (*oi2)[4] = (uint8_t (*)[4])sc.orb2.data();
+    size_t (*cidx)[2] = (size_t (*)[2])sc.comp_idx.data();
+    double *wtr = sc.wt_remain.data();
+    size_t spawn_length = sc.len;
+    const unsigned n_elec = sys.n_elec, n_orb = sys.n_orb;
+    const HBInfo &hb = sys.hb;
+    const Symm &symm = sys.symm;
+    unsigned cts[N_IRREPS][2];
+
+    // ---- singles vs doubles (heat_bathPP.cpp:713-734)
+    sw.reshape(spawn_length, 2);
+    for (size_t d = 0; d < comp_len; d++) {
+        double w = fabs(vec1[d]);
+        vec1[d] = w;
+        if (w > 0) { sw.row(d)[0] = p_doub; sw.row(d)[1] = 1 - p_doub; ndiv[d] = 0; }
+        else ndiv[d] = 1;
+    }
+    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[0], vec2.data(), cidx);
+    if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
+
+    // ---- first occupied orbital (:736-770)
+    sw.reshape(spawn_length, n_elec - new_hb);
+    for (size_t s = 0; s < comp_len; s++) {
+        size_t d = di1[cidx[s][0]];
+        di2[s] = d;
+        oi1[s][0] = (uint8_t)cidx[s][1];
+        const uint8_t *occ = v.orbs_at(d);
+        if (oi1[s][0] == 0) {
+            ndiv[s] = 0;
+            double tw = calc_o1_probs(hb, sw.row(s), n_elec, occ, new_hb);
+            if (new_hb) vec2[s] *= tw;
+        }
+        else {
+            count_symm_virt(cts, occ, n_elec, symm);
+            uint32_t n_occ = count_sing_allowed(occ, n_elec, symm, cts);
+            if (n_occ == 0) { ndiv[s] = 1; vec2[s] = 0; }
+            else ndiv[s] = n_occ;
+        }
+    }
+    comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[1], vec1.data(), cidx);
+    if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
+
+    // ---- unoccupied (single) / 2nd occupied (double) (:772-816)
+    for (size_t s = 0; s < comp_len; s++) {
+        size_t wi = cidx[s][0];
+        size_t d = di2[wi];
+        di1[s] = d;
+        oi2[s][0] = oi1[wi][0];
+        oi2[s][1] = (uint8_t)cidx[s][1];
+        if (oi2[s][1] >= n_elec) {
+            std::cerr << "Error: chosen occupied orbital (first) is out of bounds\n";
+            vec1[s] = 0; ndiv[s] = 1;
+            continue;
+        }
+        const uint8_t *occ = v.orbs_at(d);
+        if (oi2[s][0] == 0) {
+            ndiv[s] = 0;
+            if (new_hb) {
+                oi2[s][1]++;
+                nsub[s] = oi2[s][1];
+                vec1[s] *= calc_o2_probs_half(hb, sw.row(s), n_elec, occ, oi2[s][1]);
+            }
+            else calc_o2_probs(hb, sw.row(s), n_elec, occ, oi2[s][1]);
+        }
+        else {
+            count_symm_virt(cts, occ, n_elec, symm);
+            uint32_t n_virt = count_sing_virt(occ, n_elec, symm, cts, &oi2[s][1]);
+            if (n_virt == 0) { ndiv[s] = 1; vec1[s] = 0; }
+            else { ndiv[s] = n_virt; oi2[s][3] = (uint8_t)n_virt; }
+        }
+    }
+    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, new_hb ? nsub.data() : nullptr, n_samp, wtr, rn[2], vec2.data(), cidx);
+    if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
+
+    // ---- 1st unoccupied (double) (:818-864)
+    sw.reshape(spawn_length, n_orb - n_elec / 2);
+    for (size_t s = 0; s < comp_len; s++) {
+        size_t wi = cidx[s][0];
+        size_t d = di1[wi];
+        di2[s] = d;
+        oi1[s][0] = oi2[wi][0];
+        uint8_t o1_idx = oi2[wi][1];
+        oi1[s][1] = o1_idx;
+        uint8_t o2u1 = (uint8_t)cidx[s][1];
+        oi1[s][2] = o2u1;
+        if (oi1[s][0] == 0) {
+            if (o2u1 >= n_elec) {
+                std::cerr << "Error: chosen occupied orbital (second) is out of bounds\n";
+                vec2[s] = 0; ndiv[s] = 1;
+                continue;
+            }
+            ndiv[s] = 0;
+            const uint8_t *occ = v.orbs_at(d);
+            int o1_spin = o1_idx / (n_elec / 2);
+            int o2_spin = occ[o2u1] / n_orb;
+            uint8_t o1_orb = occ[o1_idx];
+            double tw = calc_u1_probs(hb, sw.row(s), o1_orb, occ, n_elec, new_hb && (o1_spin == o2_spin));
+            if (new_hb) vec2[s] *= tw;
+        }
+        else {
+            uint8_t n_virt = oi2[wi][3];
+            if (o2u1 >= n_virt) { vec1[s] = 0; std::cerr << "Error: index of chosen virtual orbital exceeds maximum\n"; }
+            oi1[s][3] = n_virt;
+            ndiv[s] = 1;
+        }
+    }
+    comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[3], vec1.data(), cidx);
+    if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
+
+    // ---- 2nd unoccupied (double) (:866-915)
+    sw.reshape(spawn_length, symm.max_n_symm);
+    for (size_t s = 0; s < comp_len; s++) {
+        size_t wi = cidx[s][0];
+        size_t d = di2[wi];
+        di1[s] = d;
+        oi2[s][0] = oi1[wi][0];
+        uint8_t o1_idx = oi1[wi][1];
+        oi2[s][1] = o1_idx;
+        uint8_t o2_idx = oi1[wi][2];
+        oi2[s][2] = o2_idx;
+        if (oi2[s][0] == 0) {
+            const uint8_t *occ = v.orbs_at(d);
+            uint8_t u1 = find_nth_virt(occ, o1_idx / (n_elec / 2), n_elec, n_orb, (unsigned)cidx[s][1]);
+            det_t cd = v.dets[d];
+            if (bit(cd, u1)) {
+                std::cerr << "Error: occupied orbital chosen as 1st virtual\n";
+                vec1[s] = 0; ndiv[s] = 1;
+            }
+            else {
+                ndiv[s] = 0;
+                oi2[s][3] = u1;
+                double tw;
+                uint8_t o1_orb = occ[o1_idx], o2_orb = occ[o2_idx];
+                if (new_hb) tw = calc_u2_probs_half(hb, sw.row(s), o1_orb, o2_orb, u1, cd, symm, &nsub[s]);
+                else tw = calc_u2_probs(hb, sw.row(s), o1_orb, o2_orb, u1, symm, &nsub[s]);
+                if (new_hb || tw == 0) vec1[s] *= tw;
+            }
+        }
+        else { oi2[s][3] = oi1[wi][3]; ndiv[s] = 1; }
+    }
+    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nsub.data(), n_samp, wtr, rn[4], vec2.data(), cidx);
+    if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
+
+    // ---- decode, weight, matrix element, parity (:917-991)
+    size_t ns = 0;
+    for (size_t s = 0; s < comp_len; s++) {
+        size_t wi = cidx[s][0];
+        size_t d = di1[wi];
+        di2[ns] = d;
+        const uint8_t *occ = v.orbs_at(d);
+        det_t cd = v.dets[d];
+        uint8_t o1_idx = oi2[wi][1];
+        if (oi2[wi][0] == 0) {
+            uint8_t o2_idx = oi2[wi][2];
+            uint8_t o1 = occ[o1_idx], o2 = occ[o2_idx], u1 = oi2[wi][3];
+            uint8_t u2_ir = symm.irrep[o1 % n_orb] ^ symm.irrep[o2 % n_orb] ^ symm.irrep[u1 % n_orb];
+            uint8_t u2 = symm.lk(u2_ir, (unsigned)cidx[s][1] + 1) + n_orb * (o2 / n_orb);
+            if (bit(cd, u2)) {
+                if (new_hb) std::cerr << "Error: occupied orbital chosen as second virtual in unnormalized heat-bath\n";
+                continue;
+            }
+            if (u1 == u2) { std::cerr << "Error: repeat virtual orbital chosen\n"; continue; }
+            if (u1 > u2) std::swap(u1, u2);
+            if (o1 > o2) std::swap(o1, o2);
+            oi1[ns][0] = o1; oi1[ns][1] = o2; oi1[ns][2] = u1; oi1[ns][3] = u2;
+            double tw = new_hb ? calc_unnorm_wt(hb, oi1[ns]) : calc_norm_wt(hb, oi1[ns], occ, n_elec, cd, symm);
+            double mel = unit_matrel ? 1.0 : doub_matrel_nosgn(oi1[ns], sys.ints);
+            double el = mel * vec2[s] / tw / p_doub;
+            if (fabs(el) > 1e-9) {
+                el *= doub_parity(cd, oi1[ns]);
+                vec1[ns] = el;
+                ns++;
+            }
+        }
+        else {
+            uint8_t o1 = occ[o1_idx];
+            oi1[ns][0] = o1;
+            uint8_t u1_ir = symm.irrep[o1 % n_orb];
+            uint8_t spin = o1 / n_orb;
+            uint8_t u1 = virt_from_idx(cd, symm, u1_ir, n_orb * spin, oi2[wi][2]);
+            if (u1 == 255) { std::cerr << "Error: virtual orbital not found\n"; continue; }
+            oi1[ns][1] = u1;
+            oi1[ns][2] = oi1[ns][3] = 0;
+            count_symm_virt(cts, occ, n_elec, symm);
+            unsigned n_occ = count_sing_allowed(occ, n_elec, symm, cts);
+            double el = unit_matrel ? 1.0 : sing_matrel_nosgn(oi1[ns], occ, sys.ints, n_elec);
+            el *= vec2[s] / (1 - p_doub) * n_occ * oi2[wi][3];
+            if (fabs(el) > 1e-9) {
+                el *= sing_parity(cd, oi1[ns]);
+                vec1[ns] = el;
+                ns++;
+            }
+        }
+    }
+    sc.vec_len = ns;
+}
+
+// ------------------------------------------------------------------ driver
+static inline double uni(std::mt19937 &mt) { return mt() / (1. + UINT32_MAX); }
+
+void Frisys::setup() {
+    const unsigned n_orb = sys.n_orb, n_elec = sys.n_elec;
+    uint8_t tmp[64];
+    hf_det = gen_hf_det(n_orb, n_elec);
+    occ_list(hf_det, tmp);
+    sys.hf_en = diag_matrel(tmp, sys.ints, n_elec);
+    mt.seed(par.seed);
+    proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
+    for (auto &x : proc_scr) x = mt();     // frisys_mol.cpp:133-135
+    for (auto &x : vec_scr) x = mt();      // :142-144
+    unsigned spawn_length = par.mat_nonz * 4;
+    size_t adder_size = spawn_length > 1000000 ? 1000000 : spawn_length;
+    sol.init(par.max_dets, adder_size, n_elec, 2);
+    size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
+    sc.init(spawn_length, n_states);
+
+    // trial = HF; H*trial by full enumeration (:163-214, molecule.cpp:448-665)
+    trial_det = {hf_det}; trial_val = {1.0};
+    {
+        size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
+        Vec ht; ht.init(2 * n_ex, 2 * n_ex, n_elec, 2);
+        ht.add(hf_det, 1, 1); ht.perform_add(0);
+        std::vector<uint8_t> ex;
+        ht.cur = 1;
+        const uint8_t *occ = ht.orbs_at(0);
+        double cur_el = ht.vals[0][0];
+        size_t n_sing = sing_ex_symm(hf_det, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
+        for (size_t e = 0; e < n_sing; e++) {
+            double m = sing_matrel_nosgn(&ex[2 * e], occ, sys.ints, n_elec);
+            det_t nd = hf_det;
+            m *= sing_det_parity(&nd, &ex[2 * e]);
+            m *= cur_el * 1.0;
+            ht.add(nd, m, 1);
+        }
+        ht.perform_add(0);
+        size_t n_doub = doub_ex_symm(hf_det, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
+        for (size_t e = 0; e < n_doub; e++) {
+            double m = doub_matrel_nosgn(&ex[4 * e], sys.ints);
+            det_t nd = hf_det;
+            m *= doub_det_parity(&nd, &ex[4 * e]);
+            m *= cur_el * 1.0;
+            ht.add(nd, m, 1);
+        }
+        ht.perform_add(0);
+        // h_op_diag(htrial, 0, 0, 1) then add_vecs(0, 1)  (molecule.cpp:205-219)
+        for (size_t i = 0; i < ht.curr_size; i++) {
+            double cv = ht.vals[0][i];
+            if (cv != 0) {
+                double de = diag_matrel(ht.orbs_at(i), sys.ints, n_elec) - sys.hf_en;
+                ht.vals[0][i] = cv * (0 + 1 * de);
+            }
+            else ht.vals[0][i] = 0;
+        }
+        ht.add_vecs(0, 1);
+        htrial_det.assign(ht.dets.begin(), ht.dets.begin() + ht.curr_size);
+        htrial_val.assign(ht.vals[0].begin(), ht.vals[0].begin() + ht.curr_size);
+        p_doub = (double)n_doub / (double)(n_sing + n_doub);
+        // n_hf_sing comes from count_singex (:219), identical to n_sing by construction
+        size_t n_sing2 = count_singex(hf_det, occ, n_elec, sys.symm);
+        p_doub = (double)n_doub / (n_sing2 + n_doub);
+    }
+    sol.add(hf_det, 100, 1);       // :277-279
+    sol.perform_add(0);
+    sys.hb.set_up(sys.ints);
+    srt.assign(sol.max_size, 0); keep.assign(sol.max_size, 0);
+    en_shift = 0; last_one_norm = 0; iterat = 0;
+}
+
+void Frisys::iterate(unsigned n_iter) {
+    const double eps = par.eps;
+    const unsigned shift_interval = 10;
+    const double shift_damping = 0.05;
+    for (unsigned it = 0; it < n_iter; it++, iterat++) {
+        IterLog lg{};
+        // :414-421
+        std::copy(sol.vals[0].begin(), sol.vals[0].begin() + sol.curr_size, sc.vec1.begin());
+        for (size_t i = 0; i < sol.curr_size; i++) sc.det_idx1[i] = i;
+        sc.vec_len = sol.curr_size;
+        double rn[5];
+        for (int k = 0; k < 5; k++) rn[k] = uni(mt);
+        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz, false);
+        size_t comp_len = sc.vec_len;
+        lg.num_success = comp_len;
+
+        std::vector<double> &before = sol.vals[0];
+        sol.cur = 1;
+        sol.zero_cur();
+        size_t vec_size = sol.curr_size;
+        const uint8_t (*orbs)[4] = (const uint8_t (*)[4])sc.orb1.data();
+        for (int add_ini = 0; add_ini < 2; add_ini++) {       // :430-471
+            int num_added = 1;
+            size_t s = 0;
+            while (num_added > 0) {
+                num_added = 0;
+                while (s < comp_len) {
+                    size_t d = sc.det_idx2[s];
+                    double cv = before[d];
+                    uint8_t ini = fabs(cv) >= par.init_thresh;
+                    if (ini != add_ini) { s++; continue; }
+                    double add_el = -eps * sc.vec1[s];
+                    if (cv < 0) add_el *= -1;
+                    det_t nd = sol.dets[d];
+                    if (!(orbs[s][2] == 0 && orbs[s][3] == 0)) nd = doub_det(nd, orbs[s]);
+                    else nd = sing_det(nd, orbs[s]);
+                    num_added++;
+                    s++;
+                    if (!sol.add(nd, add_el, ini)) break;
+                }
+                sol.perform_add(0);
+            }
+        }
+        if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
+        // death / cloning :488-499
+        sol.cur = 0;
+        for (size_t i = 0; i < vec_size; i++) {
+            double &cv = sol.vals[0][i];
+            if (cv != 0) {
+                if (std::isnan(sol.diag[i])) sol.diag[i] = diag_matrel(sol.orbs_at(i), sys.ints, sys.n_elec) - sys.hf_en;
+                cv *= 1 - eps * (sol.diag[i] - en_shift);
+            }
+        }
+        sol.add_vecs(0, 1);
+        sol.cur = 1; sol.zero_cur(); sol.cur = 0;
+        // vector compression :502-539
+        unsigned n_samp = par.vec_nonz;
+        double glob_norm;
+        double loc_norm = find_preserve(sol.vals[0].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm);
+        lg.nkept = par.vec_nonz - n_samp;
+        if ((iterat + 1) % shift_interval == 0)
+            adjust_shift(&en_shift, glob_norm, &last_one_norm, par.target_norm, shift_damping / shift_interval / eps);
+        lg.numer = sol.dot(htrial_det, htrial_val);
+        lg.denom = sol.dot(trial_det, trial_val);
+        lg.shift = en_shift; lg.norm = glob_norm;
+        double rn_sys = uni(mt);
+        sys_comp(sol.vals[0].data(), sol.curr_size, loc_norm, n_samp, keep, rn_sys);
+        for (size_t i = 0; i < sol.curr_size; i++) {
+            if (keep[i]) { sol.del_at_pos(i); keep[i] = 0; }
+        }
+        lg.n_nonz = sol.n_nonz; lg.curr_size = sol.curr_size;
+        log.push_back(lg);
+    }
+}
+
+}  // namespace fo

@@ -1,0 +1,234 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the FRI hot path.
+//
+// This is a sequential CPU restatement of the reference algorithm
+// (sgreene8/FRIES @ 2025-02-15).  It exists so that tests/, bench.py's
+// cpu_baseline leg and __graft_entry__.smoke() can check the HIP path.  Nothing
+// under fries_amd/ (the product) may include, link or call it.
+//
+// Conventions that differ from the reference's *representation* (never from
+// its arithmetic):
+//   * a determinant is one uint64_t; bit i == spin orbital i (alpha = 0..n_orb-1,
+//     beta = n_orb..2n_orb-1).  This equals the reference's little-endian byte
+//     string (FRIES/det_store.h:23-26) for 2*n_orb <= 64.
+//   * n_frz == 0 everywhere (FRIES_bin/frisys_mol.cpp:79 hard-codes it).
+//   * one MPI rank (n_procs == 1) unless a function says otherwise; sum_mpi of
+//     one rank is the identity (FRIES/compress_utils.hpp:179-231).
+//
+// Parity status: PINNED.  oracle/ref_harness.cpp links the real reference
+// (built from /root/reference by oracle/Makefile into oracle/_ref/) and checks
+// these functions bit-for-bit; tests/golden/ holds the vectors it emitted.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+#include <stack>
+#include <unordered_map>
+#include <random>
+#include <string>
+
+namespace fo {
+
+typedef uint64_t det_t;
+
+// ---------------------------------------------------------------- bit strings
+// FRIES/math_utils.c:62-98 (find_bits): ascending list of set bits.
+int occ_list(det_t det, uint8_t *occ);
+// FRIES/math_utils.c:9-58 (bits_between): set bits strictly between a and b.
+unsigned bits_between(det_t det, unsigned a, unsigned b);
+// FRIES/fci_utils.c:130-136
+int excite_sign(unsigned cre, unsigned des, det_t det);
+// FRIES/fci_utils.c:46-58 / 60-64
+int sing_det_parity(det_t *det, const uint8_t *orbs);
+int sing_parity(det_t det, const uint8_t *orbs);
+// FRIES/fci_utils.c:66-96
+int doub_det_parity(det_t *det, const uint8_t *orbs);
+int doub_parity(det_t det, const uint8_t *orbs);
+det_t sing_det(det_t det, const uint8_t *orbs);
+det_t doub_det(det_t det, const uint8_t *orbs);
+// FRIES/fci_utils.c:9-43
+det_t gen_hf_det(unsigned n_orb, unsigned n_elec);
+// FRIES/fci_utils.c:138-148
+uint8_t find_nth_virt(const uint8_t *occ, int spin, unsigned n_elec, unsigned n_orb, unsigned n);
+
+// ---------------------------------------------------------------- integrals
+struct Integrals {
+    unsigned n_orb = 0;
+    std::vector<double> h;    // n_orb x n_orb, row major (FRIES/io_utils.cpp:307)
+    std::vector<double> eri;  // 8-fold packed, FRIES/ndarr.hpp:206-244
+    double chem(unsigned i, unsigned j, unsigned k, unsigned l) const;
+    double phys(unsigned i, unsigned j, unsigned k, unsigned l) const { return chem(i, k, j, l); }
+    static size_t packed_len(unsigned n) { size_t p = (size_t)n * (n + 1) / 2; return p * (p + 1) / 2; }
+};
+
+static const unsigned N_IRREPS = 8;  // FRIES/Hamiltonians/near_uniform.hpp (n_irreps)
+
+// FRIES/Hamiltonians/molecule.hpp:265-280, molecule.cpp:1050-1065
+struct Symm {
+    unsigned n_orb = 0;
+    std::vector<uint8_t> irrep;              // per spatial orbital
+    std::vector<uint8_t> lookup;             // N_IRREPS x (n_orb + 1); col 0 = count
+    unsigned max_n_symm = 0;
+    void init(const uint8_t *irreps, unsigned n);
+    uint8_t lk(unsigned ir, unsigned col) const { return lookup[ir * (n_orb + 1) + col]; }
+};
+
+// FRIES/Hamiltonians/molecule.cpp:983-1029 / 76-105 / 26-42
+double diag_matrel(const uint8_t *occ, const Integrals &in, unsigned n_elec);
+double sing_matrel_nosgn(const uint8_t *ex, const uint8_t *occ, const Integrals &in, unsigned n_elec);
+double doub_matrel_nosgn(const uint8_t *ex, const Integrals &in);
+// FRIES/Hamiltonians/molecule.cpp:178-203 / 108-175 / 914-933
+size_t sing_ex_symm(det_t det, const uint8_t *occ, unsigned n_elec, unsigned n_orb, std::vector<uint8_t> &out, const uint8_t *irrep);
+size_t doub_ex_symm(det_t det, const uint8_t *occ, unsigned n_elec, unsigned n_orb, std::vector<uint8_t> &out, const uint8_t *irrep);
+size_t count_singex(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &s);
+
+// FRIES/Hamiltonians/near_uniform.cpp:14-28 / 316-327 / 330-347 / 419-433
+void count_symm_virt(unsigned counts[][2], const uint8_t *occ, unsigned n_elec, const Symm &s);
+unsigned count_sing_allowed(const uint8_t *occ, unsigned n_elec, const Symm &s, unsigned counts[][2]);
+unsigned count_sing_virt(const uint8_t *occ, unsigned n_elec, const Symm &s, unsigned counts[][2], uint8_t *occ_choice);
+uint8_t virt_from_idx(det_t det, const Symm &s, unsigned irrep, unsigned spin_shift, unsigned index);
+
+// ---------------------------------------------------------------- HB-PP
+// FRIES/Hamiltonians/heat_bathPP.hpp:25-34, heat_bathPP.cpp:99-179
+struct HBInfo {
+    unsigned n_orb = 0;
+    std::vector<double> s_tens, d_same, d_diff, exch_sqrt, diag_sqrt, exch_norms;
+    double s_norm = 0;
+    void set_up(const Integrals &in);
+};
+double calc_o1_probs(const HBInfo &t, double *p, unsigned n_elec, const uint8_t *occ, int exclude_first);
+double calc_o2_probs(const HBInfo &t, double *p, unsigned n_elec, const uint8_t *occ, unsigned o1_idx);
+double calc_o2_probs_half(const HBInfo &t, double *p, unsigned n_elec, const uint8_t *occ, unsigned o1_idx);
+double calc_u1_probs(const HBInfo &t, double *p, unsigned o1_orb, const uint8_t *occ, unsigned n_elec, int exclude_first);
+double calc_u2_probs(const HBInfo &t, double *p, unsigned o1, unsigned o2, unsigned u1, const Symm &s, uint16_t *len);
+double calc_u2_probs_half(const HBInfo &t, double *p, unsigned o1, unsigned o2, unsigned u1, det_t det, const Symm &s, uint16_t *len);
+double calc_unnorm_wt(const HBInfo &t, const uint8_t *orbs);
+double calc_norm_wt(const HBInfo &t, const uint8_t *orbs, const uint8_t *occ, unsigned n_elec, det_t det, const Symm &s);
+
+// ---------------------------------------------------------------- compression
+// FRIES/compress_utils.cpp:29-105
+double find_preserve(const double *values, std::vector<size_t> &srt, std::vector<uint8_t> &keep,
+                     size_t count, unsigned *n_samp, double *global_norm);
+// FRIES/compress_utils.cpp:107-127 (one rank)
+double seed_sys(double norm, double *rn, unsigned n_samp);
+// FRIES/compress_utils.cpp:283-327; returns the new local norm
+double sys_comp(double *vals, size_t len, double loc_norm, unsigned n_samp, std::vector<uint8_t> &keep, double rn);
+
+// Sub-weight matrix + keep bits for comp_sub.  keep bit (row, col) lives in a
+// uint32 mask per row; the reference's byte-granular thresholds
+// (compress_utils.cpp:213 vs :233) are reproduced from the column index.
+struct SubWts {
+    size_t cols = 0;
+    std::vector<double> w;        // rows x cols
+    std::vector<uint32_t> keep;   // rows
+    void reshape(size_t rows, size_t c) { cols = c; if (w.size() < rows * c) w.resize(rows * c); if (keep.size() < rows) keep.resize(rows, 0); }
+    double *row(size_t r) { return &w[r * cols]; }
+    const double *row(size_t r) const { return &w[r * cols]; }
+};
+// FRIES/compress_utils.cpp:130-276
+double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
+                     size_t count, unsigned *n_samp, double *wt_remain);
+// FRIES/compress_utils.cpp:702-794
+size_t sys_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
+               size_t count, unsigned n_samp, const double *wt_remain, double *loc_norm, double rn,
+               double *new_vals, size_t (*new_idx)[2]);
+// FRIES/compress_utils.cpp:797-820
+size_t comp_sub(const double *values, size_t count, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
+                unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2]);
+// FRIES/compress_utils.cpp:684-693
+void adjust_shift(double *shift, double one_norm, double *last_norm, double target_norm, double damp);
+
+// ---------------------------------------------------------------- sparse vector
+// FRIES/det_hash.hpp:160-170 (hash_fxn, no phonons)
+uint64_t hash_fxn(const uint8_t *occ, unsigned n_elec, const uint32_t *scrambler);
+
+// Restatement of DistVec<double> + Adder<double> for one rank
+// (FRIES/vec_utils.hpp:121-953, 957-1019).
+struct Vec {
+    unsigned n_elec = 0, n_vecs = 0;
+    size_t max_size = 0, curr_size = 0, adder_cap = 0;
+    int n_nonz = 0;
+    unsigned cur = 0;
+    uint64_t nonini_occ_add = 0;
+    std::vector<det_t> dets;
+    std::vector<std::vector<double>> vals;   // n_vecs columns
+    std::vector<uint8_t> occ;                // max_size x n_elec
+    std::vector<double> diag;                // NaN = not cached
+    std::vector<uint8_t> active;
+    std::vector<size_t> free_stack;          // back() == top
+    std::unordered_map<det_t, ptrdiff_t> table;
+    // pending adds
+    std::vector<det_t> add_det; std::vector<double> add_val; std::vector<uint8_t> add_ini;
+
+    void init(size_t size, size_t add_size, unsigned n_el, unsigned nv);
+    void expand();
+    bool add(det_t det, double val, uint8_t ini);     // vec_utils.hpp:418-423, 957-971
+    void perform_add(size_t origin);                   // vec_utils.hpp:991-1019 -> add_elements :606-641
+    void del_at_pos(size_t pos);                       // vec_utils.hpp:458-476
+    double local_norm() const;                         // vec_utils.hpp:683-689
+    const uint8_t *orbs_at(size_t pos) const { return &occ[pos * n_elec]; }
+    double dot(const std::vector<det_t> &d2, const std::vector<double> &v2) const;  // vec_utils.hpp:228-238
+    void zero_cur() { std::fill(vals[cur].begin(), vals[cur].end(), 0.0); }
+    void add_vecs(unsigned i1, unsigned i2) { for (size_t i = 0; i < curr_size; i++) vals[i1][i] += vals[i2][i] * 1.0; }
+};
+
+// ---------------------------------------------------------------- HB-PP compress-multiply
+// FRIES/Hamiltonians/heat_bathPP.hpp:250-297
+struct HBScratch {
+    size_t len = 0, vec_len = 0;
+    std::vector<double> vec1, vec2, wt_remain;
+    std::vector<size_t> det_idx1, det_idx2;
+    std::vector<uint8_t> orb1, orb2;         // len x 4
+    std::vector<uint16_t> nsub;
+    std::vector<uint32_t> ndiv;
+    std::vector<size_t> comp_idx;            // len x 2
+    SubWts sw;
+    void init(size_t length, size_t n_subwt);
+};
+struct MolSys {
+    unsigned n_orb = 0, n_elec = 0;
+    Integrals ints;
+    Symm symm;
+    HBInfo hb;
+    double hf_en = 0;
+};
+// FRIES/Hamiltonians/heat_bathPP.cpp:686-992.  rn[5] are the five uniforms the
+// reference draws at :729,:765,:811,:859,:910.  unit_matrel selects the
+// |value| == 1 lambdas of tests/test_hamiltonian.cpp:493-500.
+void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
+                    const double rn[5], uint32_t n_samp, bool unit_matrel);
+
+// ---------------------------------------------------------------- driver loop
+struct FrisysParams {
+    double eps = 0.01, target_norm = 0, init_thresh = 0;
+    uint32_t vec_nonz = 0, mat_nonz = 0;
+    size_t max_dets = 0;
+    bool new_hb = true;
+    uint32_t seed = 0;
+};
+struct IterLog {
+    double numer, denom, shift, norm;
+    uint32_t nkept;
+    int n_nonz;
+    size_t curr_size, num_success, comp_len[5];
+};
+// FRIES_bin/frisys_mol.cpp:35-566 with n_procs == 1, HF trial vector, HF start,
+// no dense space, seed injected instead of the wall clock (:104-106).
+struct Frisys {
+    MolSys sys;
+    FrisysParams par;
+    std::mt19937 mt;
+    std::vector<uint32_t> proc_scr, vec_scr;
+    Vec sol;
+    HBScratch sc;
+    std::vector<det_t> trial_det, htrial_det;
+    std::vector<double> trial_val, htrial_val;
+    double p_doub = 0, en_shift = 0, last_one_norm = 0;
+    det_t hf_det = 0;
+    unsigned iterat = 0;
+    std::vector<size_t> srt; std::vector<uint8_t> keep;
+    std::vector<IterLog> log;
+    void setup();
+    void iterate(unsigned n);
+};
+
+}  // namespace fo

@@ -1,0 +1,529 @@
+// TEST INFRASTRUCTURE ONLY.  Pins oracle/fries_oracle.cpp against the REAL
+// reference: this file is our code, but it #includes the reference's headers
+// from /root/reference and links oracle/_ref/libfries_ref.so (the reference's own
+// sources compiled in place by oracle/Makefile).  It only builds where
+// /root/reference exists; its outputs (tests/golden/*) are what travels.
+//
+//   ref_harness unit                       function-by-function bit comparison on random inputs
+//   ref_harness hbpp_all <out>             tests/test_hamiltonian.cpp:454-520 ([new_hb_all]) through both
+//   ref_harness frisys <fcidump> <pg> <n_iter> <seed> <eps> <vec_nonz> <mat_nonz> <max_dets> <init> <target> <HB|HB_unnorm> <out> [snap_every]
+//                                          FRIES_bin/frisys_mol.cpp loop (1 rank, HF start, HF trial) vs fo::Frisys, lockstep
+//   ref_harness dump_ints <fcidump> <pg> <out>   what the reference's parse_fcidump read (binary)
+//   ref_harness time <fcidump> <pg> <n_iter> ...same as frisys...   reference loop only, prints seconds
+#include <FRIES/Hamiltonians/near_uniform.hpp>
+#include <FRIES/io_utils.hpp>
+#include <FRIES/compress_utils.hpp>
+#include <FRIES/Hamiltonians/heat_bathPP.hpp>
+#include <FRIES/Hamiltonians/molecule.hpp>
+#include <FRIES/vec_utils.hpp>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <cinttypes>
+#include "fries_oracle.hpp"
+
+static int n_fail = 0, n_chk = 0;
+#define CHECK(cond, ...) do { n_chk++; if (!(cond)) { n_fail++; if (n_fail < 30) { printf("MISMATCH %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+static inline bool same_bits(double a, double b) { return memcmp(&a, &b, 8) == 0; }
+static fo::det_t to_u64(const uint8_t *bytes, size_t n) { fo::det_t d = 0; memcpy(&d, bytes, n); return d; }
+static void from_u64(fo::det_t d, uint8_t *bytes, size_t n) { memcpy(bytes, &d, n); }
+
+static void fill_oracle_ints(fo::Integrals &oi, const SymmERIs &eris, const Matrix<double> &h, unsigned n) {
+    oi.n_orb = n;
+    oi.h.resize((size_t)n * n);
+    for (unsigned i = 0; i < n; i++) for (unsigned j = 0; j < n; j++) oi.h[i * n + j] = h(i, j);
+    oi.eri.assign(fo::Integrals::packed_len(n), 0.0);
+    for (unsigned j = 0; j < n; j++) for (unsigned i = 0; i <= j; i++)
+        for (unsigned l = 0; l < n; l++) for (unsigned k = 0; k <= l; k++) {
+            size_t p1 = (size_t)j * (j + 1) / 2 + i, p2 = (size_t)l * (l + 1) / 2 + k;
+            if (p1 <= p2) oi.eri[p2 * (p2 + 1) / 2 + p1] = eris.chemist(i, j, k, l);
+        }
+}
+
+static fo::det_t rand_det(std::mt19937 &mt, unsigned n_orb, unsigned n_elec) {
+    fo::det_t d = 0;
+    for (int sp = 0; sp < 2; sp++) {
+        unsigned placed = 0;
+        while (placed < n_elec / 2) {
+            unsigned o = mt() % n_orb + sp * n_orb;
+            if (!((d >> o) & 1)) { d |= 1ull << o; placed++; }
+        }
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------ unit
+static int run_unit() {
+    std::mt19937 mt(1234);
+    const unsigned n_orb = 26, n_elec = 10, nb = CEILING(2 * n_orb, 8);
+    // random symmetric integrals through the reference's own container
+    SymmERIs eris(n_orb);
+    Matrix<double> h(n_orb, n_orb);
+    uint8_t symm[26];
+    for (unsigned i = 0; i < n_orb; i++) symm[i] = mt() % 8;
+    for (unsigned j = 0; j < n_orb; j++) for (unsigned i = 0; i <= j; i++) h(i, j) = h(j, i) = mt() / (1. + UINT32_MAX) - 0.5;
+    for (unsigned j = 0; j < n_orb; j++) for (unsigned i = 0; i <= j; i++)
+        for (unsigned l = 0; l < n_orb; l++) for (unsigned k = 0; k <= l; k++) {
+            size_t p1 = (size_t)j * (j + 1) / 2 + i, p2 = (size_t)l * (l + 1) / 2 + k;
+            if (p1 <= p2) eris.chemist_ordered(i, j, k, l) = mt() / (1. + UINT32_MAX) - 0.5;
+        }
+    fo::MolSys sys; sys.n_orb = n_orb; sys.n_elec = n_elec;
+    fill_oracle_ints(sys.ints, eris, h, n_orb);
+    sys.symm.init(symm, n_orb);
+    SymmInfo rsymm(symm, n_orb);
+    CHECK(rsymm.max_n_symm == sys.symm.max_n_symm, "max_n_symm");
+    for (unsigned s = 0; s < 8; s++) for (unsigned c = 0; c <= n_orb; c++) if (c <= rsymm.symm_lookup(s, 0)) CHECK(rsymm.symm_lookup(s, c) == sys.symm.lk(s, c), "lookup");
+
+    // HF string
+    for (unsigned no = 4; no <= 32; no++) for (unsigned ne = 2; ne <= 2 * no && ne <= 24; ne += 2) {
+        uint8_t b[8] = {0};
+        gen_hf_bitstring(no, ne, b);
+        CHECK(to_u64(b, CEILING(2 * no, 8)) == fo::gen_hf_det(no, ne), "hf det no=%u ne=%u", no, ne);
+    }
+    std::vector<uint32_t> scr(2 * n_orb);
+    for (auto &x : scr) x = mt();
+    HashTable<ssize_t> rht(16, scr);
+
+    hb_info *rhb = set_up(n_orb, n_orb, eris);
+    sys.hb.set_up(sys.ints);
+    CHECK(same_bits(rhb->s_norm, sys.hb.s_norm), "s_norm");
+    for (unsigned i = 0; i < n_orb; i++) {
+        CHECK(same_bits(rhb->s_tens[i], sys.hb.s_tens[i]), "s_tens");
+        CHECK(same_bits(rhb->diag_sqrt[i], sys.hb.diag_sqrt[i]), "diag_sqrt");
+        CHECK(same_bits(rhb->exch_norms[i], sys.hb.exch_norms[i]), "exch_norms");
+    }
+    for (unsigned i = 0; i < n_orb * n_orb; i++) CHECK(same_bits(rhb->d_diff[i], sys.hb.d_diff[i]), "d_diff");
+    for (unsigned i = 0; i < n_orb * (n_orb - 1) / 2; i++) { CHECK(same_bits(rhb->d_same[i], sys.hb.d_same[i]), "d_same"); CHECK(same_bits(rhb->exch_sqrt[i], sys.hb.exch_sqrt[i]), "exch_sqrt"); }
+
+    for (int trial = 0; trial < 400; trial++) {
+        fo::det_t d = rand_det(mt, n_orb, n_elec);
+        uint8_t b[8] = {0}, occ_r[32], occ_o[32];
+        from_u64(d, b, 8);
+        CHECK(find_bits(b, occ_r, nb) == n_elec, "find_bits count");
+        fo::occ_list(d, occ_o);
+        CHECK(memcmp(occ_r, occ_o, n_elec) == 0, "occ list");
+        CHECK(rht.hash_fxn(occ_r, n_elec, NULL, 0) == fo::hash_fxn(occ_o, n_elec, scr.data()), "hash_fxn");
+        for (int k = 0; k < 20; k++) {
+            unsigned a = mt() % (2 * n_orb), c = mt() % (2 * n_orb);
+            if (a != c) CHECK(bits_between(b, a, c) == fo::bits_between(d, a, c), "bits_between %u %u", a, c);
+        }
+        CHECK(same_bits(diag_matrel(occ_r, n_orb, eris, h, 0, n_elec), fo::diag_matrel(occ_o, sys.ints, n_elec)), "diag_matrel");
+        // excitation lists
+        std::vector<uint8_t> so, dbo;
+        static uint8_t sr[4096][2]; static uint8_t dr[200000][4];
+        size_t ns_r = sing_ex_symm(b, occ_r, n_elec, n_orb, sr, symm);
+        size_t ns_o = fo::sing_ex_symm(d, occ_o, n_elec, n_orb, so, symm);
+        CHECK(ns_r == ns_o && memcmp(sr, so.data(), 2 * ns_r) == 0, "sing_ex_symm");
+        CHECK(count_singex(b, occ_r, n_elec, &rsymm) == fo::count_singex(d, occ_o, n_elec, sys.symm), "count_singex");
+        size_t nd_r = doub_ex_symm(b, occ_r, n_elec, n_orb, dr, symm);
+        size_t nd_o = fo::doub_ex_symm(d, occ_o, n_elec, n_orb, dbo, symm);
+        CHECK(nd_r == nd_o && memcmp(dr, dbo.data(), 4 * nd_r) == 0, "doub_ex_symm");
+        for (size_t e = 0; e < ns_r; e++) {
+            CHECK(same_bits(sing_matr_el_nosgn(sr[e], occ_r, n_orb, eris, h, 0, n_elec), fo::sing_matrel_nosgn(sr[e], occ_o, sys.ints, n_elec)), "sing matrel");
+            uint8_t b2[8]; memcpy(b2, b, 8); fo::det_t d2 = d;
+            CHECK(sing_det_parity(b2, sr[e]) == fo::sing_det_parity(&d2, sr[e]) && to_u64(b2, 8) == d2, "sing_det_parity");
+            CHECK(sing_parity(b, sr[e]) == fo::sing_parity(d, sr[e]), "sing_parity");
+        }
+        for (size_t e = 0; e < nd_r; e += 7) {
+            CHECK(same_bits(doub_matr_el_nosgn(dr[e], n_orb, eris, 0), fo::doub_matrel_nosgn(dr[e], sys.ints)), "doub matrel");
+            uint8_t b2[8]; memcpy(b2, b, 8); fo::det_t d2 = d;
+            CHECK(doub_det_parity(b2, dr[e]) == fo::doub_det_parity(&d2, dr[e]) && to_u64(b2, 8) == d2, "doub_det_parity");
+            memcpy(b2, b, 8);
+            CHECK(doub_parity(b2, dr[e]) == fo::doub_parity(d, dr[e]), "doub_parity");
+            CHECK(same_bits(calc_unnorm_wt(rhb, dr[e]), fo::calc_unnorm_wt(sys.hb, dr[e])), "unnorm_wt");
+            CHECK(same_bits(calc_norm_wt(rhb, dr[e], occ_r, n_elec, b, &rsymm), fo::calc_norm_wt(sys.hb, dr[e], occ_o, n_elec, d, sys.symm)), "norm_wt");
+        }
+        // symmetry counters
+        unsigned cr[8][2], co[8][2];
+        count_symm_virt(cr, occ_r, n_elec, &rsymm); fo::count_symm_virt(co, occ_o, n_elec, sys.symm);
+        CHECK(memcmp(cr, co, sizeof(cr)) == 0, "count_symm_virt");
+        CHECK(count_sing_allowed(occ_r, n_elec, symm, n_orb, cr) == fo::count_sing_allowed(occ_o, n_elec, sys.symm, co), "count_sing_allowed");
+        for (uint8_t c = 0; c < n_elec; c++) {
+            uint8_t c1 = c, c2 = c;
+            CHECK(count_sing_virt(occ_r, n_elec, symm, n_orb, cr, &c1) == fo::count_sing_virt(occ_o, n_elec, sys.symm, co, &c2) && c1 == c2, "count_sing_virt");
+        }
+        for (unsigned ir = 0; ir < 8; ir++) for (unsigned ix = 0; ix < 4; ix++) for (unsigned sp = 0; sp < 2; sp++)
+            CHECK(virt_from_idx(b, rsymm.symm_lookup[ir], n_orb * sp, ix) == fo::virt_from_idx(d, sys.symm, ir, n_orb * sp, ix), "virt_from_idx");
+        for (unsigned sp = 0; sp < 2; sp++) for (unsigned k = 0; k < n_orb - n_elec / 2; k++)
+            CHECK(find_nth_virt(occ_r, sp, n_elec, n_orb, k) == fo::find_nth_virt(occ_o, sp, n_elec, n_orb, k), "find_nth_virt");
+        // probability rows
+        double pr[64], po[64];
+        for (int ex = 0; ex < 2; ex++) {
+            memset(pr, 0, sizeof pr); memset(po, 0, sizeof po);
+            double a = calc_o1_probs(rhb, pr, n_elec, occ_r, ex), c = fo::calc_o1_probs(sys.hb, po, n_elec, occ_o, ex);
+            CHECK(same_bits(a, c) && memcmp(pr, po, sizeof pr) == 0, "o1_probs");
+        }
+        for (unsigned o1 = 0; o1 < n_elec; o1++) {
+            memset(pr, 0, sizeof pr); memset(po, 0, sizeof po);
+            double a = calc_o2_probs(rhb, pr, n_elec, occ_r, o1), c = fo::calc_o2_probs(sys.hb, po, n_elec, occ_o, o1);
+            CHECK(same_bits(a, c) && memcmp(pr, po, sizeof pr) == 0, "o2_probs");
+            if (o1 > 0) {
+                memset(pr, 0, sizeof pr); memset(po, 0, sizeof po);
+                a = calc_o2_probs_half(rhb, pr, n_elec, occ_r, o1); c = fo::calc_o2_probs_half(sys.hb, po, n_elec, occ_o, o1);
+                CHECK(same_bits(a, c) && memcmp(pr, po, sizeof pr) == 0, "o2_probs_half");
+            }
+            for (int ex = 0; ex < 2; ex++) {
+                memset(pr, 0, sizeof pr); memset(po, 0, sizeof po);
+                a = calc_u1_probs(rhb, pr, occ_r[o1], occ_r, n_elec, ex); c = fo::calc_u1_probs(sys.hb, po, occ_o[o1], occ_o, n_elec, ex);
+                CHECK(same_bits(a, c) && memcmp(pr, po, sizeof pr) == 0, "u1_probs o1=%u ex=%d", o1, ex);
+            }
+            for (unsigned o2 = 0; o2 < n_elec; o2++) if (o2 != o1) {
+                unsigned u1 = find_nth_virt(occ_r, occ_r[o1] / n_orb, n_elec, n_orb, mt() % (n_orb - n_elec / 2));
+                uint16_t lr = 0, lo = 0;
+                memset(pr, 0, sizeof pr); memset(po, 0, sizeof po);
+                a = calc_u2_probs(rhb, pr, occ_r[o1], occ_r[o2], u1, &rsymm, &lr); c = fo::calc_u2_probs(sys.hb, po, occ_o[o1], occ_o[o2], u1, sys.symm, &lo);
+                CHECK(same_bits(a, c) && lr == lo && memcmp(pr, po, sizeof pr) == 0, "u2_probs");
+                memset(pr, 0, sizeof pr); memset(po, 0, sizeof po);
+                a = calc_u2_probs_half(rhb, pr, occ_r[o1], occ_r[o2], u1, b, &rsymm, &lr); c = fo::calc_u2_probs_half(sys.hb, po, occ_o[o1], occ_o[o2], u1, d, sys.symm, &lo);
+                CHECK((same_bits(a, c) || (a != a && c != c)) && lr == lo && memcmp(pr, po, sizeof pr) == 0, "u2_probs_half");
+            }
+        }
+    }
+    // compression kernels on random vectors
+    for (int trial = 0; trial < 60; trial++) {
+        size_t n = 50 + mt() % 3000;
+        std::vector<double> v(n), v2;
+        for (auto &x : v) { double u = mt() / (1. + UINT32_MAX); x = (mt() & 1 ? 1 : -1) * exp(6 * u) * ((mt() % 7) ? 1 : 0); }
+        v2 = v;
+        unsigned ns_r = 1 + mt() % n, ns_o = ns_r;
+        std::vector<size_t> srt_r(n), srt_o(n);
+        std::vector<bool> keep_r(n, false); std::vector<uint8_t> keep_o(n, 0);
+        double gn_r, gn_o;
+        double ln_r = find_preserve(v.data(), srt_r, keep_r, n, &ns_r, &gn_r);
+        double ln_o = fo::find_preserve(v2.data(), srt_o, keep_o, n, &ns_o, &gn_o);
+        CHECK(same_bits(ln_r, ln_o) && same_bits(gn_r, gn_o) && ns_r == ns_o, "find_preserve scalars");
+        for (size_t i = 0; i < n; i++) CHECK((bool)keep_r[i] == (bool)keep_o[i], "find_preserve keep");
+        double rn = mt() / (1. + UINT32_MAX);
+        double norms[1] = {ln_r};
+        sys_comp(v.data(), n, norms, ns_r, keep_r, rn);
+        double on = fo::sys_comp(v2.data(), n, ln_o, ns_o, keep_o, rn);
+        CHECK(same_bits(norms[0], on), "sys_comp norm");
+        for (size_t i = 0; i < n; i++) CHECK(same_bits(v[i], v2[i]) && (bool)keep_r[i] == (bool)keep_o[i], "sys_comp out");
+    }
+    for (int trial = 0; trial < 60; trial++) {
+        size_t n = 20 + mt() % 2000, ncol = 2 + mt() % 25;
+        bool jag = mt() & 1;
+        std::vector<double> v(n), wr_r(n), wr_o(n);
+        std::vector<uint32_t> nd(n);
+        std::vector<uint16_t> ss(n);
+        Matrix<double> rsw(n, ncol); Matrix<bool> rk(n, ncol);
+        fo::SubWts osw; osw.reshape(n, ncol);
+        for (size_t i = 0; i < n; i++) {
+            double u = mt() / (1. + UINT32_MAX);
+            v[i] = (mt() % 9) ? exp(5 * u) : 0;
+            nd[i] = (mt() % 3 == 0) ? 1 + mt() % 12 : 0;
+            ss[i] = 1 + mt() % ncol;
+            size_t lim = jag ? ss[i] : ncol;
+            double tot = 0;
+            for (size_t c = 0; c < ncol; c++) { double w = (c < lim && (mt() % 5)) ? mt() / (1. + UINT32_MAX) : 0; rsw(i, c) = w; tot += w; }
+            if (tot == 0) { rsw(i, 0) = 1; tot = 1; }
+            for (size_t c = 0; c < ncol; c++) { rsw(i, c) /= tot; osw.row(i)[c] = rsw(i, c); }
+        }
+        unsigned n_samp = 1 + mt() % (2 * n);
+        double rn = mt() / (1. + UINT32_MAX);
+        std::vector<double> nv_r(n * ncol + n * 12 + n_samp), nv_o(nv_r.size());
+        std::vector<size_t> ni_r(2 * nv_r.size()), ni_o(2 * nv_r.size());
+        size_t c_r = comp_sub(v.data(), n, nd.data(), rsw, rk, jag ? ss.data() : NULL, n_samp, wr_r.data(), rn, nv_r.data(), (size_t (*)[2])ni_r.data());
+        size_t c_o = fo::comp_sub(v.data(), n, nd.data(), osw, jag ? ss.data() : nullptr, n_samp, wr_o.data(), rn, nv_o.data(), (size_t (*)[2])ni_o.data());
+        CHECK(c_r == c_o, "comp_sub count %zu %zu", c_r, c_o);
+        for (size_t i = 0; i < n; i++) CHECK(same_bits(wr_r[i], wr_o[i]), "wt_remain");
+        for (size_t i = 0; i < std::min(c_r, c_o); i++) CHECK(same_bits(nv_r[i], nv_o[i]) && ni_r[2 * i] == ni_o[2 * i] && ni_r[2 * i + 1] == ni_o[2 * i + 1], "comp_sub out %zu", i);
+    }
+    printf("UNIT checks=%d fails=%d\n", n_chk, n_fail);
+    return n_fail != 0;
+}
+
+// ------------------------------------------------------------------ reference frisys loop (1 rank)
+struct RefRun {
+    fcidump_input *in;
+    unsigned n_orb, n_elec;
+    size_t det_size;
+    SymmInfo *basis_symm;
+    hb_info *hb;
+    std::mt19937 mt;
+    DistVec<double> *sol, *trial, *htrial;
+    HBCompressSys *comp;
+    std::vector<uintmax_t> trial_hashes, htrial_hashes;
+    double p_doub, hf_en, en_shift = 0, last_one_norm = 0, eps, target, init_thresh;
+    uint32_t vec_nonz, mat_nonz;
+    int new_hb;
+    std::vector<size_t> srt; std::vector<bool> keep;
+    unsigned iterat = 0;
+    std::function<double(uint8_t *, uint8_t *)> sing_sc;
+    std::function<double(uint8_t *)> doub_sc;
+    std::vector<uint32_t> proc_scr, vec_scr;
+    // per-iteration record
+    double numer, denom, glob_norm; unsigned nkept; size_t num_success;
+
+    void setup(const char *path, const char *pg, uint32_t seed, double eps_, uint32_t vnz, uint32_t mnz, size_t max_dets, double ini, double tgt, int nhb) {
+        in = parse_fcidump(path, pg);
+        n_orb = in->n_orb_; n_elec = in->n_elec; det_size = CEILING(2 * n_orb, 8);
+        eps = eps_; vec_nonz = vnz; mat_nonz = mnz; init_thresh = ini; target = tgt; new_hb = nhb;
+        Matrix<double> *h_core = in->hcore; SymmERIs *eris = &in->eris;
+        uint8_t tmp_orbs[64], hf_det[8] = {0};
+        gen_hf_bitstring(n_orb, n_elec, hf_det);
+        find_bits(hf_det, tmp_orbs, det_size);
+        hf_en = diag_matrel(tmp_orbs, n_orb, *eris, *h_core, 0, n_elec);
+        mt.seed(seed);
+        unsigned spawn_length = mat_nonz * 4;
+        size_t adder_size = spawn_length > 1000000 ? 1000000 : spawn_length;
+        unsigned no = n_orb, ne = n_elec; double hfe = hf_en;
+        std::function<double(const uint8_t *)> diag_sc = [no, eris, h_core, ne, hfe](const uint8_t *occ) { return diag_matrel(occ, no, *eris, *h_core, 0, ne) - hfe; };
+        sing_sc = [no, eris, h_core, ne](uint8_t *ex, uint8_t *occ) { return sing_matr_el_nosgn(ex, occ, no, *eris, *h_core, 0, ne); };
+        doub_sc = [no, eris](uint8_t *ex) { return doub_matr_el_nosgn(ex, no, *eris, 0); };
+        basis_symm = new SymmInfo(in->symm, n_orb);
+        proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
+        for (auto &x : proc_scr) x = mt();
+        for (auto &x : vec_scr) x = mt();
+        sol = new DistVec<double>(max_dets, adder_size, n_orb * 2, n_elec, 1, diag_sc, 2, proc_scr, vec_scr);
+        size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
+        comp = new HBCompressSys(spawn_length, n_states);
+        size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
+        trial = new DistVec<double>(2, 2, n_orb * 2, n_elec, 1, proc_scr, vec_scr);
+        htrial = new DistVec<double>(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec, 1, diag_sc, 2, proc_scr, vec_scr);
+        trial->add(hf_det, 1, 1); htrial->add(hf_det, 1, 1);
+        trial->perform_add(0); htrial->perform_add(0);
+        trial_hashes.resize(trial->curr_size());
+        for (size_t i = 0; i < trial->curr_size(); i++) trial_hashes[i] = sol->idx_to_hash(trial->indices()[i], tmp_orbs);
+        std::vector<uint8_t> scratch(4 * n_ex);
+        h_op_offdiag(*htrial, in->symm, n_orb, *eris, *h_core, scratch.data(), scratch.size(), 0, n_elec, 1, 1, 0);
+        htrial->set_curr_vec_idx(0);
+        h_op_diag(*htrial, 0, 0, 1);
+        htrial->add_vecs(0, 1);
+        htrial_hashes.resize(htrial->curr_size());
+        for (size_t i = 0; i < htrial->curr_size(); i++) htrial_hashes[i] = sol->idx_to_hash(htrial->indices()[i], tmp_orbs);
+        sol->gen_orb_list(hf_det, tmp_orbs);
+        size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec, n_orb, (uint8_t (*)[4])scratch.data(), in->symm);
+        size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec, basis_symm);
+        p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
+        sol->add(hf_det, 100, 1);
+        sol->perform_add(0);
+        hb = set_up(n_orb, n_orb, *eris);
+        srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
+    }
+
+    void iterate() {
+        DistVec<double> &sol_vec = *sol;
+        HBCompressSys &cv = *comp;
+        std::copy(sol_vec.values(), sol_vec.values() + sol_vec.curr_size(), cv.vec1.begin());
+        for (size_t i = 0; i < sol_vec.curr_size(); i++) cv.det_indices1[i] = i;
+        cv.vec_len = sol_vec.curr_size();
+        apply_HBPP_sys(sol_vec.occ_orbs(), sol_vec.indices(), &cv, hb, basis_symm, p_doub, new_hb, mt, mat_nonz, sing_sc, doub_sc);
+        size_t comp_len = cv.vec_len;
+        num_success = comp_len;
+        double *before = sol_vec.values();
+        sol_vec.set_curr_vec_idx(1);
+        sol_vec.zero_vec();
+        size_t vec_size = sol_vec.curr_size();
+        for (int add_ini = 0; add_ini < 2; add_ini++) {
+            int num_added = 1;
+            size_t s = 0;
+            while (num_added > 0) {
+                num_added = 0;
+                while (s < comp_len) {
+                    size_t d = cv.det_indices2[s];
+                    double c = before[d];
+                    uint8_t ini = fabs(c) >= init_thresh;
+                    if (ini != add_ini) { s++; continue; }
+                    uint8_t nd[8];
+                    double add_el = -eps * cv.vec1[s];
+                    if (c < 0) add_el *= -1;
+                    memcpy(nd, sol_vec.indices()[d], det_size);
+                    if (!(cv.orb_indices1[s][2] == 0 && cv.orb_indices1[s][3] == 0)) doub_det(nd, cv.orb_indices1[s]);
+                    else sing_det(nd, cv.orb_indices1[s]);
+                    num_added++; s++;
+                    if (!sol_vec.add(nd, add_el, ini)) break;
+                }
+                sol_vec.perform_add(0);
+                sol_vec.set_curr_vec_idx(0);
+                before = sol_vec.values();
+                sol_vec.set_curr_vec_idx(1);
+            }
+        }
+        if (sol_vec.max_size() > srt.size()) { srt.resize(sol_vec.max_size()); keep.resize(sol_vec.max_size(), false); }
+        sol_vec.set_curr_vec_idx(0);
+        for (size_t i = 0; i < vec_size; i++) {
+            double *c = sol_vec[i];
+            if (*c != 0) { double de = sol_vec.matr_el_at_pos(i); *c *= 1 - eps * (de - en_shift); }
+        }
+        sol_vec.add_vecs(0, 1);
+        sol_vec.set_curr_vec_idx(1); sol_vec.zero_vec(); sol_vec.set_curr_vec_idx(0);
+        unsigned n_samp = vec_nonz;
+        double loc_norms[1];
+        loc_norms[0] = find_preserve(sol_vec.values(), srt, keep, sol_vec.curr_size(), &n_samp, &glob_norm);
+        glob_norm += sol_vec.dense_norm();
+        nkept = vec_nonz - n_samp;
+        if ((iterat + 1) % 10 == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, target, 0.05 / 10 / eps);
+        numer = sol_vec.dot(htrial->indices(), htrial->values(), htrial->curr_size(), htrial_hashes);
+        denom = sol_vec.dot(trial->indices(), trial->values(), trial->curr_size(), trial_hashes);
+        double rn_sys = mt() / (1. + UINT32_MAX);
+        sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, keep, rn_sys);
+        for (size_t i = 0; i < sol_vec.curr_size(); i++) if (keep[i]) { sol_vec.del_at_pos(i); keep[i] = 0; }
+        iterat++;
+    }
+};
+
+static void setup_oracle_from_ref(fo::Frisys &fr, RefRun &rr, uint32_t seed, size_t max_dets) {
+    fr.sys.n_orb = rr.n_orb; fr.sys.n_elec = rr.n_elec;
+    fill_oracle_ints(fr.sys.ints, rr.in->eris, *rr.in->hcore, rr.n_orb);
+    fr.sys.symm.init(rr.in->symm, rr.n_orb);
+    fr.par.eps = rr.eps; fr.par.target_norm = rr.target; fr.par.init_thresh = rr.init_thresh;
+    fr.par.vec_nonz = rr.vec_nonz; fr.par.mat_nonz = rr.mat_nonz; fr.par.max_dets = max_dets;
+    fr.par.new_hb = rr.new_hb; fr.par.seed = seed;
+    fr.setup();
+}
+
+static int run_frisys(int argc, char **argv, bool time_only) {
+    if (argc < 14) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10), mnz = strtoul(argv[8], 0, 10);
+    size_t max_dets = strtoull(argv[9], 0, 10); double ini = atof(argv[10]), tgt = atof(argv[11]);
+    int nhb = !strcmp(argv[12], "HB_unnorm");
+    const char *out = argv[13];
+    unsigned snap_every = argc > 14 ? atoi(argv[14]) : 0;
+    RefRun rr;
+    rr.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
+    if (time_only) {
+        unsigned warm = argc > 14 ? atoi(argv[14]) : 0;
+        for (unsigned i = 0; i < warm; i++) rr.iterate();
+        auto t0 = std::chrono::steady_clock::now();
+        size_t spawns = 0;
+        for (unsigned i = 0; i < n_iter; i++) { rr.iterate(); spawns += rr.num_success; }
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("{\"kind\": \"reference\", \"iters\": %u, \"seconds\": %.6f, \"iters_per_s\": %.6f, \"spawns_per_s\": %.3f, \"n_nonz\": %d}\n", n_iter, s, n_iter / s, spawns / s, rr.sol->n_nonz());
+        return 0;
+    }
+    fo::Frisys fr;
+    setup_oracle_from_ref(fr, rr, seed, max_dets);
+    CHECK(same_bits(fr.p_doub, rr.p_doub), "p_doub");
+    CHECK(same_bits(fr.sys.hf_en, rr.hf_en), "hf_en");
+    CHECK(fr.htrial_det.size() == rr.htrial->curr_size(), "htrial size");
+    for (size_t i = 0; i < fr.htrial_det.size() && i < rr.htrial->curr_size(); i++)
+        CHECK(fr.htrial_det[i] == to_u64(rr.htrial->indices()[i], rr.det_size) && same_bits(fr.htrial_val[i], rr.htrial->values()[i]), "htrial el %zu", i);
+    FILE *f = fopen(out, "w");
+    fprintf(f, "# golden trajectory from the reference (frisys_mol.cpp loop, 1 rank); cols: it numer denom norm shift nkept n_nonz curr_size num_success (doubles as C99 hex floats)\n");
+    fprintf(f, "# args:");
+    for (int i = 2; i < 13; i++) fprintf(f, " %s", i == 2 ? "<fcidump>" : argv[i]);
+    fprintf(f, "\n# p_doub %a hf_en %a n_htrial %zu\n", rr.p_doub, rr.hf_en, (size_t)rr.htrial->curr_size());
+    for (unsigned it = 0; it < n_iter; it++) {
+        rr.iterate();
+        fr.iterate(1);
+        const fo::IterLog &lg = fr.log.back();
+        CHECK(same_bits(lg.numer, rr.numer) && same_bits(lg.denom, rr.denom), "it %u numer/denom %a %a | %a %a", it, lg.numer, rr.numer, lg.denom, rr.denom);
+        CHECK(same_bits(lg.norm, rr.glob_norm) && same_bits(lg.shift, rr.en_shift), "it %u norm/shift", it);
+        CHECK(lg.nkept == rr.nkept && lg.n_nonz == rr.sol->n_nonz() && lg.curr_size == rr.sol->curr_size() && lg.num_success == rr.num_success, "it %u counts nkept %u/%u nnz %d/%d size %zu/%zu succ %zu/%zu", it, lg.nkept, rr.nkept, lg.n_nonz, rr.sol->n_nonz(), lg.curr_size, (size_t)rr.sol->curr_size(), lg.num_success, rr.num_success);
+        size_t n = std::min(lg.curr_size, (size_t)rr.sol->curr_size());
+        size_t bad = 0;
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < n; i++) {
+            double rv = rr.sol->values()[i];
+            fo::det_t rd = to_u64(rr.sol->indices()[i], rr.det_size);
+            if (!same_bits(rv, fr.sol.vals[0][i])) bad++;
+            if (rv != 0 && rd != fr.sol.dets[i]) bad++;
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        CHECK(bad == 0, "it %u vector mismatch in %zu slots", it, bad);
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success, hsh);
+        if (snap_every && ((it + 1) % snap_every == 0 || it + 1 == n_iter)) {
+            fprintf(f, "SNAP %u %zu\n", it, (size_t)rr.sol->curr_size());
+            for (size_t i = 0; i < rr.sol->curr_size(); i++) {
+                double rv = rr.sol->values()[i];
+                if (rv != 0) fprintf(f, "%zu %016" PRIx64 " %a\n", i, (uint64_t)to_u64(rr.sol->indices()[i], rr.det_size), rv);
+            }
+            fprintf(f, "ENDSNAP\n");
+        }
+    }
+    fclose(f);
+    printf("FRISYS iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, rr.sol->n_nonz());
+    return n_fail != 0;
+}
+
+// ------------------------------------------------------------------ [new_hb_all]
+static int run_hbpp_all(const char *out) {
+    std::mt19937 mt_obj(0);
+    uint32_t n_orb = 22, n_frz = 2, n_elec = 10, n_elec_unf = n_elec - n_frz, tot_orb = n_orb + n_frz / 2;
+    size_t det_size = CEILING(2 * n_orb, 8);
+    FourDArr eris(tot_orb, tot_orb, tot_orb, tot_orb);
+    for (size_t i = 0; i < tot_orb; i++) for (size_t j = 0; j < tot_orb; j++) for (size_t a = 0; a < tot_orb; a++) for (size_t b = 0; b < tot_orb; b++)
+        eris(i, j, a, b) = mt_obj() / (1. + UINT32_MAX) - 0.5;
+    hb_info *hbtens = set_up(tot_orb, n_orb, eris);
+    Matrix<uint8_t> dets(1, det_size), occ_orbs(1, n_elec_unf);
+    gen_hf_bitstring(n_orb, n_elec_unf, dets[0]);
+    find_bits(dets[0], occ_orbs[0], det_size);
+    uint8_t symm[] = {0, 5, 6, 7, 0, 5, 6, 7, 0, 0, 1, 2, 3, 5, 6, 7, 0, 0, 0, 1, 2, 3};
+    SymmInfo basis_symm(symm, n_orb);
+    uint32_t n_ex = n_orb * n_orb * n_elec_unf * n_elec_unf;
+    size_t n_states = n_elec_unf > (n_orb - n_elec_unf / 2) ? n_elec_unf : n_orb - n_elec_unf / 2;
+    HBCompressSys sv(n_ex, n_states);
+    sv.vec_len = 1; sv.det_indices1[0] = 0; sv.vec1[0] = 1;
+    std::function<double(uint8_t *, uint8_t *)> s1 = [](uint8_t *, uint8_t *) { return 1; };
+    std::function<double(uint8_t *)> d1 = [](uint8_t *) { return 1; };
+    std::mt19937 mt_copy = mt_obj;
+    apply_HBPP_sys(occ_orbs, dets, &sv, hbtens, &basis_symm, 0.95, true, mt_obj, n_ex, s1, d1);
+
+    // oracle side: copy the tensors the reference built from the non-symmetric FourDArr
+    fo::MolSys sys; sys.n_orb = n_orb; sys.n_elec = n_elec_unf;
+    sys.symm.init(symm, n_orb);
+    fo::HBInfo &hb = sys.hb; hb.n_orb = n_orb; hb.s_norm = hbtens->s_norm;
+    hb.s_tens.assign(hbtens->s_tens, hbtens->s_tens + n_orb);
+    hb.d_diff.assign(hbtens->d_diff, hbtens->d_diff + n_orb * n_orb);
+    hb.d_same.assign(hbtens->d_same, hbtens->d_same + n_orb * (n_orb - 1) / 2);
+    hb.exch_sqrt.assign(hbtens->exch_sqrt, hbtens->exch_sqrt + n_orb * (n_orb - 1) / 2);
+    hb.diag_sqrt.assign(hbtens->diag_sqrt, hbtens->diag_sqrt + n_orb);
+    hb.exch_norms.assign(hbtens->exch_norms, hbtens->exch_norms + n_orb);
+    fo::Vec v; v.init(4, 4, n_elec_unf, 1);
+    v.add(fo::gen_hf_det(n_orb, n_elec_unf), 1, 1); v.perform_add(0);
+    fo::HBScratch sc; sc.init(n_ex, n_states);
+    sc.vec_len = 1; sc.det_idx1[0] = 0; sc.vec1[0] = 1;
+    double rn[5];
+    for (int k = 0; k < 5; k++) rn[k] = mt_copy() / (1. + UINT32_MAX);
+    fo::apply_HBPP_sys(v, sc, sys, 0.95, true, rn, n_ex, true);
+    CHECK(sc.vec_len == sv.vec_len, "hbpp_all len %zu %zu", sc.vec_len, (size_t)sv.vec_len);
+    FILE *f = fopen(out, "w");
+    fprintf(f, "# [new_hb_all] tests/test_hamiltonian.cpp:454-520 through the reference: rn[5], then o1 o2 u1 u2 value per sample\n");
+    fprintf(f, "RN %a %a %a %a %a\nN %zu\n", rn[0], rn[1], rn[2], rn[3], rn[4], (size_t)sv.vec_len);
+    size_t bad1 = 0;
+    for (size_t s = 0; s < sv.vec_len; s++) {
+        if (fabs(fabs(sv.vec1[s]) - 1) > 1e-7) bad1++;
+        CHECK(memcmp(sv.orb_indices1[s], &sc.orb1[4 * s], 4) == 0 && same_bits(sv.vec1[s], sc.vec1[s]) && sv.det_indices2[s] == sc.det_idx2[s], "hbpp_all sample %zu", s);
+        fprintf(f, "%u %u %u %u %a\n", sv.orb_indices1[s][0], sv.orb_indices1[s][1], sv.orb_indices1[s][2], sv.orb_indices1[s][3], sv.vec1[s]);
+    }
+    CHECK(bad1 == 0, "|value| != 1 in %zu samples", bad1);
+    // tensors, so the GPU test can run the same case without the FourDArr
+    fprintf(f, "HB %a\n", hb.s_norm);
+    auto dump = [&](const char *nm, const std::vector<double> &x) { fprintf(f, "%s %zu", nm, x.size()); for (double y : x) fprintf(f, " %a", y); fprintf(f, "\n"); };
+    dump("s_tens", hb.s_tens); dump("d_diff", hb.d_diff); dump("d_same", hb.d_same); dump("exch_sqrt", hb.exch_sqrt); dump("diag_sqrt", hb.diag_sqrt); dump("exch_norms", hb.exch_norms);
+    fclose(f);
+    printf("HBPP_ALL n=%zu checks=%d fails=%d\n", (size_t)sv.vec_len, n_chk, n_fail);
+    return n_fail != 0;
+}
+
+static int run_dump_ints(const char *path, const char *pg, const char *out) {
+    fcidump_input *in = parse_fcidump(path, pg);
+    fo::Integrals oi;
+    fill_oracle_ints(oi, in->eris, *in->hcore, in->n_orb_);
+    FILE *f = fopen(out, "wb");
+    uint32_t hdr[2] = {in->n_orb_, in->n_elec};
+    fwrite(hdr, 4, 2, f);
+    fwrite(in->symm, 1, in->n_orb_, f);
+    fwrite(&in->core_en, 8, 1, f);
+    fwrite(oi.h.data(), 8, oi.h.size(), f);
+    fwrite(oi.eri.data(), 8, oi.eri.size(), f);
+    fclose(f);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    MPI_Init(NULL, NULL);
+    int rc = 2;
+    if (argc >= 2 && !strcmp(argv[1], "unit")) rc = run_unit();
+    else if (argc >= 3 && !strcmp(argv[1], "hbpp_all")) rc = run_hbpp_all(argv[2]);
+    else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
+    else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
+    else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
+    else fprintf(stderr, "unknown command\n");
+    MPI_Finalize();
+    return rc;
+}
