@@ -1,0 +1,566 @@
+// Device formulation of comp_sub = find_keep_sub + sys_sub
+// (FRIES/compress_utils.cpp:130-276, 702-794, 797-820) for the five HB-PP stages.
+//
+// find_keep_sub: the reference sweeps the elements sequentially in blocks of 8; each block
+// tests its elements against the running remaining norm with the sample budget as it stood at
+// the block's start (compress_utils.cpp:159-178), and sweeps repeat until one keeps nothing.
+// Because that budget is stale inside a block, the kept set is NOT the plain fixed point
+// {x : x * (n - #kept) >= norm}: it depends on the sweep.  The sweep is a chain through two
+// scalars (norm removed so far, samples used so far).  k_fks_iter replays every sweep for
+// every 8-block in parallel from *guessed* chain values, publishes each block's deltas, and is
+// re-run with the prefix sums of those deltas as the new guesses until nothing changes; a
+// consistent assignment is unique (block 0 is always right, then block 1, ...), so the fixed
+// point is the reference's result, including the budget each wt_remain was divided by.
+//
+// sys_sub: an in-order prefix sum of wt_remain gives every element its lbound; the comb
+// positions are exact (teeth.hpp); an element starts from tooth T(lbound of its predecessor)
+// and replays the reference's inner loop.  Output slots come from an integer prefix sum of the
+// per-element emission counts, so the output order is the reference's.
+#pragma once
+#include "fries_dev.hpp"
+#include "teeth.hpp"
+#include "hbpp_rows.hpp"
+
+#define FR_ITEMS 4
+#define FR_TILE (FR_BLOCK * FR_ITEMS)
+#define FR_MAX_ROUNDS 96
+#define FR_FKS_PMAX 12          // sweeps tracked per replay (the reference needs 2-6)
+#define FR_FKS_TILE (FR_BLOCK * 8)  // elements per workgroup in k_fks_iter
+
+struct CompState {
+    double G;            // remaining norm entering this round
+    double loc_norm;     // final: what find_keep_sub returns
+    double unit;         // final: loc_norm / n_rem
+    uint32_t n_rem;      // samples still to distribute
+    uint32_t n_in;       // number of elements of this stage
+    uint32_t done;
+    uint32_t pbuf;       // partial buffer holding per-block sums of wt_remain
+    uint32_t n_out;      // emissions written by sys_write
+    uint32_t n_fix;      // elements whose tooth count had to be repaired
+    uint32_t changed;    // k_fks_iter: some block's deltas differ from the previous replay
+    uint32_t n_pass;     // sweeps the reference would have run
+};
+
+struct StageElems {      // one ping-pong half
+    double *val;
+    uint32_t *pos;       // parent position in the solution vector
+    uint32_t *code;      // 4 orbital-code bytes (hbpp_rows.hpp)
+    uint32_t *ndiv;      // >0: uniform subdivision into ndiv equal parts
+    uint32_t *nsub;      // row length (jagged stages)
+};
+
+struct CompWork {
+    uint32_t cap;                 // element capacity of every array below
+    StageElems el[2];             // current / previous stage
+    double *wt_remain;
+    uint32_t *keep;               // bit s = sub-element s preserved exactly
+    double *S;                    // inclusive lbound after each element
+    uint32_t *kin, *cnt;
+    uint32_t *e_wi, *e_sub;       // emissions: source element, sub index
+    double *e_val;
+    double *psum[2];              // per-block partial sums (FR_MAX_PART each)
+    uint32_t *pcnt[2];
+    CompState *state;             // [FR_MAX_ROUNDS + 2]; last slot = final
+    Teeth *teeth;
+    uint32_t *fix_list;           // elements with a tooth backlog (rare)
+    // find_keep_sub replay: per (sweep, 8-block) deltas, double-buffered by replay parity
+    uint32_t nb8_cap;             // 8-blocks capacity = cap / 8 + 1
+    uint32_t *f_dk[2];            // samples consumed
+    double *f_dg[2];              // norm removed
+    double *f_ws[2];              // sum of wt_remain after the sweep
+    uint32_t *f_pk[2];            // per-workgroup partials of the above: [FR_FKS_PMAX][FR_MAX_PART]
+    double *f_pg[2], *f_pw[2];
+};
+
+
+// In-block prefix of per-thread sums with one fixed association, shared by the round kernels
+// (which publish the block total) and k_sys_count (which continues the same sums), so that
+// "lbound after the last element of block b" is bit-identical in both.
+// Returns the exclusive prefix of this thread; *block_total = prefix after thread 255.
+__device__ __forceinline__ double fr_block_excl_f64(double tsum, double *sh /* >= 12 */, double *block_total) {
+    int lane = fr_lane(), w = threadIdx.x >> 6;
+    double winc = tsum;
+    for (int off = 1; off < 64; off <<= 1) { double t = __shfl_up(winc, off); if (lane >= off) winc += t; }
+    if (lane == 63) sh[w] = winc;
+    __syncthreads();
+    double base = 0;
+    for (int k = 0; k < w; k++) base += sh[k];
+    double incl = w ? base + winc : winc;
+    if (lane == 63) sh[4 + w] = incl;
+    double texcl = __shfl_up(incl, 1);
+    __syncthreads();
+    if (lane == 0) texcl = w ? sh[4 + w - 1] : 0.0;
+    if (threadIdx.x == FR_BLOCK - 1) sh[8] = texcl + tsum;
+    __syncthreads();
+    *block_total = sh[8];
+    __syncthreads();
+    return texcl;
+}
+
+// ------------------------------------------------------------------ stage dispatch
+// Per-element row: setup -> RowInfo, visit -> (sub, normalised weight) ascending.
+template <int STAGE, bool NEW_HB>
+__device__ __forceinline__ RowInfo fr_row_setup(const HbTables &T, det_t det, uint32_t code, double p_doub) {
+    if (STAGE == 1) { RowInfo r; r.inv_norm = 1; r.tot = 1; r.nsub = 2; r.aux = 0; return r; }
+    if (STAGE == 2) return fr_row2_setup<NEW_HB>(T, det);
+    if (STAGE == 3) return NEW_HB ? fr_row3h_setup(T, det, fr_c(code, 1)) : fr_row3_setup(T, det, fr_c(code, 1));
+    if (STAGE == 4) {
+        unsigned o1_idx = fr_c(code, 1), o2_idx = fr_c(code, 2);
+        unsigned o1 = fr_nth_bit(det, o1_idx), o2 = fr_nth_bit(det, o2_idx);
+        bool excl = NEW_HB && ((o1_idx / (T.n_elec / 2)) == (o2 / T.n_orb));
+        RowInfo r = fr_row4_setup(T, det, o1, excl);
+        r.aux = o1 | (excl ? 0x100u : 0u);
+        return r;
+    }
+    // STAGE == 5
+    unsigned o1 = fr_nth_bit(det, fr_c(code, 1)), o2 = fr_nth_bit(det, fr_c(code, 2)), u1 = fr_c(code, 3);
+    RowInfo r = fr_row5_setup<NEW_HB>(T, det, o1, o2, u1);
+    r.aux = o1 | (o2 << 8);
+    return r;
+}
+
+template <int STAGE, bool NEW_HB, class F>
+__device__ __forceinline__ void fr_row_visit(const HbTables &T, det_t det, uint32_t code, const RowInfo &ri, double p_doub, F f) {
+    if (STAGE == 1) { f(0u, p_doub); f(1u, 1 - p_doub); }
+    else if (STAGE == 2) fr_row2_visit<NEW_HB>(T, det, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
+    else if (STAGE == 3) {
+        if (NEW_HB) fr_row3h_visit(T, det, fr_c(code, 1), ri.aux, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
+        else fr_row3_visit(T, det, fr_c(code, 1), ri.aux, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
+    }
+    else if (STAGE == 4) fr_row4_visit(T, det, ri.aux & 0xffu, (ri.aux & 0x100u) != 0, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
+    else fr_row5_visit<NEW_HB>(T, det, ri.aux & 0xffu, (ri.aux >> 8) & 0xffu, fr_c(code, 3), [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
+}
+
+// number of sub-weights comp_sub sees for this element (sub_sizes[] or the column count)
+template <int STAGE, bool NEW_HB>
+__device__ __forceinline__ unsigned fr_row_len(const HbTables &T, uint32_t nsub_stored) {
+    if (STAGE == 1) return 2;
+    if (STAGE == 2) return T.n_elec - (NEW_HB ? 1 : 0);
+    if (STAGE == 3) return NEW_HB ? nsub_stored : T.n_elec;
+    if (STAGE == 4) return T.n_orb - T.n_elec / 2;
+    return nsub_stored;
+}
+
+// ------------------------------------------------------------------ find_keep_sub replay
+struct FksPass { double G; uint32_t n; };
+
+// Sweep bookkeeping of compress_utils.cpp:153-158, 251-265 from the totals of a previous replay.
+// Every lane of every workgroup runs this on identical inputs.  Returns the number of sweeps.
+__device__ __forceinline__ int fr_fks_passes(const double *totG, const uint32_t *totK, const double *totW, double G0, uint32_t n0,
+                                             FksPass *ps, double *G_last, uint32_t *n_last) {
+    uint32_t n = n0;
+    double G = G0;
+    int last_pass = 0, p = 0;
+    for (; p < FR_FKS_PMAX; p++) {
+        ps[p].G = G; ps[p].n = n;
+        if (G < 0) break;
+        uint32_t K = totK[p];
+        n -= K;
+        uint32_t gs = K;
+        if (last_pass && gs) last_pass = 0;
+        double Gn = G - totG[p];
+        if (gs == 0 && !last_pass) { last_pass = 1; gs = 1; Gn = totW[p]; }
+        if (gs == 0) { p++; break; }
+        G = Gn;
+    }
+    *G_last = ps[p > 0 ? p - 1 : 0].G;
+    *n_last = n;
+    return p;
+}
+
+// One replay.  Thread <-> one 8-block of the reference's sweep; workgroup <-> 2048 elements.
+// it == 0 starts from "nothing kept anywhere".  state[it] receives the changed flag.
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_fks_iter(CompWork W, VecDev V, const HbTables *Tg, int cur, int it, double p_doub, uint32_t *err) {
+    __shared__ HbTables T;
+    __shared__ double shd[12];
+    __shared__ uint32_t shu[8];
+    __shared__ double s_totG[FR_FKS_PMAX], s_totW[FR_FKS_PMAX], s_offG[FR_FKS_PMAX], s_psG[FR_FKS_PMAX];
+    __shared__ uint32_t s_totK[FR_FKS_PMAX], s_offK[FR_FKS_PMAX], s_psN[FR_FKS_PMAX];
+    __shared__ int s_npass;
+    const CompState st0 = W.state[0];
+    const unsigned n_in = st0.n_in;
+    const unsigned nb8 = n_in / 8 + 1;                       // the reference visits coarse_idx <= count / 8
+    const unsigned nwg = (nb8 + FR_BLOCK - 1) / FR_BLOCK;
+    if (blockIdx.x >= nwg) return;
+    const int prev = (it & 1) ^ 1, cb = it & 1;
+    const size_t stride = W.nb8_cap;
+    const unsigned b = blockIdx.x * FR_BLOCK + threadIdx.x;  // my 8-block
+    const bool live = b < nb8;
+    // norm of the stage's input: the tile partials the prep kernel left in psum[0]
+    const double G0 = fr_sum_partials(W.psum[0], (n_in + FR_TILE - 1) / FR_TILE, shd);
+    // ---- totals and workgroup offsets of the previous replay, sweep by sweep
+    for (int p = threadIdx.x; p < FR_FKS_PMAX; p += blockDim.x) { s_totG[p] = 0; s_totW[p] = 0; s_totK[p] = 0; s_offG[p] = 0; s_offK[p] = 0; }
+    __syncthreads();
+    if (it > 0) {
+        // wave w handles sweeps w, w+4, ...: lanes stride over the workgroups in a fixed order
+        const int lane = fr_lane(), wv = threadIdx.x >> 6;
+        for (int p = wv; p < FR_FKS_PMAX; p += 4) {
+            const uint32_t *pk = W.f_pk[prev] + (size_t)p * FR_MAX_PART;
+            const double *pg = W.f_pg[prev] + (size_t)p * FR_MAX_PART, *pw = W.f_pw[prev] + (size_t)p * FR_MAX_PART;
+            double g = 0, w = 0, og = 0; uint32_t k = 0, ok = 0;
+            for (unsigned i = lane; i < nwg; i += 64) {
+                double gi = pg[i]; uint32_t ki = pk[i];
+                g += gi; w += pw[i]; k += ki;
+                if (i < blockIdx.x) { og += gi; ok += ki; }
+            }
+            g = fr_wave_sum(g); w = fr_wave_sum(w); og = fr_wave_sum(og); k = fr_wave_sum_u32(k); ok = fr_wave_sum_u32(ok);
+            if (lane == 0) { s_totG[p] = g; s_totW[p] = w; s_totK[p] = k; s_offG[p] = og; s_offK[p] = ok; }
+        }
+        __syncthreads();
+    }
+    else if (threadIdx.x == 0) {
+        // "nothing kept": sweep 0 keeps nothing, so the norm is re-summed (unchanged) and sweep 1 ends it
+        for (int p = 0; p < FR_FKS_PMAX; p++) s_totW[p] = G0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FksPass ps[FR_FKS_PMAX];
+        double G_last; uint32_t n_last;
+        s_npass = fr_fks_passes(s_totG, s_totK, s_totW, G0, st0.n_rem, ps, &G_last, &n_last);
+        for (int p = 0; p < FR_FKS_PMAX; p++) { s_psG[p] = ps[p].G; s_psN[p] = ps[p].n; }
+    }
+    __syncthreads();
+    const int n_pass = s_npass;
+    if (STAGE != 1) fr_stage_tables(&T, Tg);
+    // ---- my 8 elements
+    const StageElems E = W.el[cur];
+    const size_t e0 = (size_t)b * 8;
+    const unsigned lim = !live ? 0u : (e0 + 8 <= n_in ? 8u : (unsigned)(n_in - e0));
+    double v[8], wr[8];
+    uint32_t nd[8], kp[8];
+#pragma unroll
+    for (int f = 0; f < 8; f++) {
+        bool ok = (unsigned)f < lim;
+        v[f] = ok ? E.val[e0 + f] : 0.0; nd[f] = ok ? E.ndiv[e0 + f] : 1u;
+        wr[f] = v[f]; kp[f] = 0;
+    }
+    uint32_t diff = 0;
+    for (int p = 0; p < FR_FKS_PMAX; p++) {
+        // exclusive prefix of the previous replay's deltas inside this workgroup
+        uint32_t pk = (it > 0 && live) ? W.f_dk[prev][(size_t)p * stride + b] : 0u;
+        double pg = (it > 0 && live) ? W.f_dg[prev][(size_t)p * stride + b] : 0.0;
+        double pws = (it > 0 && live) ? W.f_ws[prev][(size_t)p * stride + b] : -1.0;
+        uint32_t dk = 0;
+        double dg = 0;
+        if (p < n_pass) {       // uniform across the grid
+            uint32_t tk;
+            uint32_t ik = fr_block_scan_u32(pk, shu, &tk);
+            double tg;
+            double exg = fr_block_excl_f64(pg, shd, &tg);
+            double glob = s_psG[p] - (s_offG[p] + exg);
+            uint32_t loc_sampled = s_offK[p] + (ik - pk);
+            double wf = (double)(s_psN[p] - loc_sampled);
+            double cw[8];
+            unsigned flags = 0;
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                if ((unsigned)f < lim && wr[f] > 0) {
+                    double c = v[f] * wf;
+                    if (nd[f] > 0) c /= nd[f];
+                    cw[f] = c;
+                    flags |= (unsigned)(c >= glob) << f;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                if (!((flags >> f) & 1u)) continue;
+                if (nd[f] > 0) {
+                    kp[f] |= 1u; wr[f] = 0; dk += nd[f]; dg += v[f]; glob -= v[f];
+                    if (glob < 0) break;
+                }
+                else {
+                    size_t e = e0 + f;
+                    uint32_t code = STAGE == 1 ? 0u : E.code[e];
+                    det_t det = STAGE == 1 ? 0ull : V.dets[E.pos[e]];
+                    RowInfo ri = fr_row_setup<STAGE, NEW_HB>(T, det, code, p_doub);
+                    unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, STAGE == 3 || STAGE == 5 ? E.nsub[e] : 0);
+                    unsigned full = (n_sub / 8) * 8;
+                    uint32_t kk = kp[f], add = 0;
+                    double sub_remain = 0;
+                    const double cwf = cw[f], gl = glob;
+                    fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
+                        if (s >= n_sub || ((kk >> s) & 1u)) return;
+                        double sub_magn = cwf * w;
+                        double thr = s < full ? 1e-12 : 1e-10;      // compress_utils.cpp:213 / :233
+                        if (sub_magn >= gl && fabs(sub_magn) > thr) { kk |= 1u << s; add++; }
+                        else sub_remain += sub_magn;
+                    });
+                    kp[f] = kk; dk += add;
+                    sub_remain /= wf;
+                    double change = wr[f] - sub_remain;
+                    wr[f] = sub_remain;
+                    dg += change; glob -= change;
+                }
+            }
+        }
+        double ws = 0;
+#pragma unroll
+        for (int f = 0; f < 8; f++) ws += wr[f];
+        if (live) {
+            if (it == 0 || pk != dk || __double_as_longlong(pg) != __double_as_longlong(dg) || __double_as_longlong(pws) != __double_as_longlong(ws)) diff = 1;
+            W.f_dk[cb][(size_t)p * stride + b] = dk; W.f_dg[cb][(size_t)p * stride + b] = dg; W.f_ws[cb][(size_t)p * stride + b] = ws;
+        }
+        // workgroup partials of this replay
+        uint32_t bk = fr_block_sum_u32(live ? dk : 0u, shu);
+        double bg, bw;
+        fr_block_excl_f64(live ? dg : 0.0, shd, &bg);
+        fr_block_excl_f64(live ? ws : 0.0, shd, &bw);
+        if (threadIdx.x == 0) {
+            W.f_pk[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = bk;
+            W.f_pg[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = bg;
+            W.f_pw[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = bw;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 8; f++) if ((unsigned)f < lim) { W.keep[e0 + f] = kp[f]; W.wt_remain[e0 + f] = wr[f]; }
+    if (n_pass >= FR_FKS_PMAX && threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, FR_ERR_ROUNDS);
+    uint32_t any = fr_block_sum_u32(diff, shu);
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) {
+            // slot it+1 is zeroed here for the replay after this one; slot `it` collects this replay's flag
+            CompState z = st0; z.changed = 0; z.G = G0;
+            if (it + 1 <= FR_MAX_ROUNDS) W.state[it + 1] = z;
+        }
+        if (any) atomicOr(&W.state[it].changed, 1u);
+    }
+}
+
+// per-tile sums of wt_remain in the association k_sys_count continues
+static __global__ void __launch_bounds__(FR_BLOCK) k_tile_sums(CompWork W) {
+    __shared__ double shd[12];
+    const unsigned n_in = W.state[0].n_in;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double sum = 0;
+    for (int it = 0; it < FR_ITEMS; it++) { size_t e = base + it; if (e < n_in) sum += W.wt_remain[e]; }
+    double bs;
+    fr_block_excl_f64(sum, shd, &bs);
+    if (threadIdx.x == 0) W.psum[0][blockIdx.x] = bs;
+}
+
+// ------------------------------------------------------------------ finalise + comb
+// One workgroup: find_keep_sub's epilogue (compress_utils.cpp:266-275), seed_sys and the comb.
+// The returned norm is the in-order sum of wt_remain, formed as the very chain of tile sums that
+// k_sys_count extends, so "norm" and "last lbound" are the same number as in the reference.
+static __global__ void __launch_bounds__(FR_BLOCK) k_comp_finalize(CompWork W, int last_it, double rn, double lbound0, double norm_others_after, uint32_t *err) {
+    __shared__ double s_totG[FR_FKS_PMAX], s_totW[FR_FKS_PMAX];
+    __shared__ uint32_t s_totK[FR_FKS_PMAX];
+    CompState s = W.state[last_it + 1];      // carries the stage's input norm
+    const unsigned n_in = s.n_in;
+    const unsigned nb8 = n_in / 8 + 1, nwg = (nb8 + FR_BLOCK - 1) / FR_BLOCK;
+    const int cb = last_it & 1;
+    const int lane = fr_lane(), wv = threadIdx.x >> 6;
+    for (int p = wv; p < FR_FKS_PMAX; p += 4) {
+        const uint32_t *pk = W.f_pk[cb] + (size_t)p * FR_MAX_PART;
+        const double *pg = W.f_pg[cb] + (size_t)p * FR_MAX_PART, *pw = W.f_pw[cb] + (size_t)p * FR_MAX_PART;
+        double g = 0, w = 0; uint32_t k = 0;
+        for (unsigned i = lane; i < nwg; i += 64) { g += pg[i]; w += pw[i]; k += pk[i]; }
+        g = fr_wave_sum(g); w = fr_wave_sum(w); k = fr_wave_sum_u32(k);
+        if (lane == 0) { s_totG[p] = g; s_totW[p] = w; s_totK[p] = k; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (W.state[last_it].changed) atomicOr(err, FR_ERR_ROUNDS);
+    FksPass ps[FR_FKS_PMAX];
+    double G; uint32_t n_rem;
+    s.n_pass = fr_fks_passes(s_totG, s_totK, s_totW, s.G, s.n_rem, ps, &G, &n_rem);
+    double loc_norm = 0;
+    if (G / n_rem < 1e-8) n_rem = 0;
+    else {
+        const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+        for (unsigned i = 0; i < nblk; i++) loc_norm += W.psum[0][i];
+    }
+    s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
+    double glob = lbound0 + loc_norm + norm_others_after;     // sum in rank order (seed_sys)
+    double unit = 0, r0 = INFINITY;
+    if (n_rem > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_rem, &unit);
+    s.unit = glob / n_rem;
+    s.n_out = 0; s.n_fix = 0;
+    W.state[FR_MAX_ROUNDS + 1] = s;
+    if (n_rem > 0) fr_build_teeth(W.teeth, r0, unit, n_rem + 2, lbound0);
+    else { W.teeth->nseg = 0; W.teeth->kmax = 0; W.teeth->unit = 0; W.teeth->lbound0 = lbound0; }
+}
+
+// ------------------------------------------------------------------ replay of sys_sub for one element
+// Returns the number of emissions; *k advances over consumed teeth.  When EMIT, writes
+// (wi, sub, value) triples starting at slot `out`.
+template <int STAGE, bool NEW_HB, bool EMIT>
+__device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const VecDev &V, const HbTables &T, const Teeth *th, int cur,
+                                                   size_t e, double lbound, uint32_t *k, double unit, double p_doub, size_t out) {
+    const StageElems &E = W.el[cur];
+    double v = E.val[e];
+    if (v == 0) return 0;
+    uint32_t nd = E.ndiv[e], n = 0;
+    double wr = W.wt_remain[e];
+    uint32_t kp = W.keep[e];
+    auto emit = [&](uint32_t sub, double val) {
+        if (EMIT) { size_t o = out + n; if (o < W.cap) { W.e_wi[o] = (uint32_t)e; W.e_sub[o] = sub; W.e_val[o] = val; } }
+        n++;
+    };
+    if (nd > 0) {
+        if (kp & 1u) {
+            double part = v / nd;
+            for (uint32_t s = 0; s < nd; s++) emit(s, part);
+        }
+        else {
+            double rn = fr_tooth(th, *k);
+            while (rn < lbound) {
+                double q = (lbound - rn) * nd / v;
+                uint32_t s = q >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)q;
+                if (s < nd) emit(s, unit);
+                (*k)++;
+                rn = fr_tooth(th, *k);
+            }
+        }
+    }
+    else {
+        double rn = fr_tooth(th, *k);
+        if (wr < v || rn < lbound) {
+            double sub_lbound = lbound - wr;
+            uint32_t code = STAGE == 1 ? 0u : E.code[e];
+            det_t det = STAGE == 1 ? 0ull : V.dets[E.pos[e]];
+            RowInfo ri = fr_row_setup<STAGE, NEW_HB>(T, det, code, p_doub);
+            unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, STAGE == 3 || STAGE == 5 ? E.nsub[e] : 0);
+            fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
+                if (s >= n_sub) return;
+                if (((kp >> s) & 1u) && w != 0) emit(s, v * w);
+                else {
+                    sub_lbound += v * w;
+                    if (rn < sub_lbound && w != 0) { emit(s, unit); (*k)++; rn = fr_tooth(th, *k); }
+                }
+            });
+        }
+    }
+    return n;
+}
+
+// lbound prefix + per-element emission counts
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub) {
+    __shared__ HbTables T;
+    __shared__ double shd[12];
+    __shared__ uint32_t shu[4];
+    __shared__ double sh_start;
+    CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
+    const unsigned n_in = fin->n_in;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    if (STAGE != 1) fr_stage_tables(&T, Tg);
+    const Teeth *th = W.teeth;
+    const double unit = fin->unit;
+    // lbound entering this block: comb origin, then the earlier blocks' totals added one by one
+    // in block order (the same left-to-right chain every block walks, so neighbours agree)
+    if (threadIdx.x == 0) {
+        const double *ps = W.psum[fin->pbuf];
+        double st = th->lbound0;
+        for (unsigned i = 0; i < blockIdx.x; i++) st += ps[i];
+        sh_start = st;
+    }
+    __syncthreads();
+    const double start = sh_start;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double loc[FR_ITEMS], tsum = 0;
+    const StageElems E = W.el[cur];
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        double w = (e < n_in) ? W.wt_remain[e] : 0.0;
+        tsum += w; loc[it] = tsum;
+    }
+    double btot;
+    double texcl = fr_block_excl_f64(tsum, shd, &btot);
+    uint32_t cnt_t = 0;
+    double Sprev = start + texcl;          // lbound after the previous thread's last element
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        double Se = start + (texcl + loc[it]);
+        uint32_t kin = (e == 0) ? 0u : fr_teeth_below(th, Sprev);
+        uint32_t k = kin;
+        uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e, Se, &k, unit, p_doub, 0);
+        W.S[e] = Se; W.kin[e] = kin; W.cnt[e] = c;
+        cnt_t += c;
+        if (k != fr_teeth_below(th, Se)) {      // tooth backlog: repaired by k_sys_fixup
+            uint32_t slot = atomicAdd(&fin->n_fix, 1u);
+            if (slot < FR_MAX_PART) W.fix_list[slot] = (uint32_t)e;
+        }
+        Sprev = Se;
+    }
+    uint32_t bc = fr_block_sum_u32(cnt_t, shu);
+    if (threadIdx.x == 0) W.pcnt[fin->pbuf ^ 1][blockIdx.x] = bc;
+}
+
+// Repairs the (rare) elements after which the reference's comb lags behind lbound: walk
+// forward sequentially from each flagged element until the tooth index re-synchronises.
+template <int STAGE, bool NEW_HB>
+__global__ void k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err) {
+    CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
+    uint32_t nf = fin->n_fix;
+    if (nf == 0) return;
+    if (nf > FR_MAX_PART) { atomicOr(err, FR_ERR_BACKLOG); nf = FR_MAX_PART; }
+    const HbTables &T = *Tg;
+    const Teeth *th = W.teeth;
+    const unsigned n_in = fin->n_in;
+    // insertion sort of the short list (ascending element index)
+    for (uint32_t i = 1; i < nf; i++) { uint32_t x = W.fix_list[i]; int j = (int)i - 1; while (j >= 0 && W.fix_list[j] > x) { W.fix_list[j + 1] = W.fix_list[j]; j--; } W.fix_list[j + 1] = x; }
+    size_t done_upto = 0;
+    for (uint32_t i = 0; i < nf; i++) {
+        size_t e = W.fix_list[i];
+        if (e < done_upto) continue;
+        uint32_t k = W.kin[e];
+        fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e, W.S[e], &k, fin->unit, p_doub, 0);
+        for (size_t e2 = e + 1; e2 < n_in; e2++) {
+            uint32_t kin = k;
+            uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e2, W.S[e2], &k, fin->unit, p_doub, 0);
+            uint32_t old = W.cnt[e2];
+            W.kin[e2] = kin; W.cnt[e2] = c;
+            W.pcnt[fin->pbuf ^ 1][e2 / FR_TILE] += c - old;
+            done_upto = e2 + 1;
+            if (k == fr_teeth_below(th, W.S[e2])) break;
+        }
+    }
+}
+
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
+    const unsigned n_in = fin->n_in;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    if (STAGE != 1) fr_stage_tables(&T, Tg);
+    const Teeth *th = W.teeth;
+    const uint32_t *pc = W.pcnt[fin->pbuf ^ 1];
+    uint32_t off;
+    {
+        uint32_t x = 0;
+        for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pc[i];
+        off = fr_block_sum_u32(x, shu);
+    }
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t c[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { size_t e = base + it; c[it] = e < n_in ? W.cnt[e] : 0; tsum += c[it]; }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    size_t o = (size_t)off + (incl - tsum);
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        if (c[it]) {
+            uint32_t k = W.kin[e];
+            fr_sys_element<STAGE, NEW_HB, true>(W, V, T, th, cur, e, W.S[e], &k, fin->unit, p_doub, o);
+        }
+        W.keep[e] = 0;
+        o += c[it];
+    }
+    if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) {
+        fin->n_out = (uint32_t)o;
+        if (o > W.cap) atomicOr(err, FR_ERR_SPAWN_CAP);
+    }
+}

@@ -1,0 +1,272 @@
+// Vector side of one FRI iteration: death/cloning + column add (FRIES_bin/frisys_mol.cpp:487-499),
+// exact-preservation selection (find_preserve, FRIES/compress_utils.cpp:29-105), systematic
+// resampling in storage order (sys_comp, :283-327) and the projected-energy dot products
+// (DistVec::dot, FRIES/vec_utils.hpp:228-238).
+#include "ctx.hpp"
+
+void fr_vcomp_alloc(FriesCtx *c, uint32_t cap) {
+    VcompBuf &B = c->vc;
+    B.keep = fr_alloc<uint8_t>(cap); B.del = fr_alloc<uint8_t>(cap); B.S = fr_alloc<double>(cap);
+    for (int h = 0; h < 2; h++) { B.psum[h] = fr_alloc<double>(FR_MAX_PART); B.pcnt[h] = fr_alloc<uint32_t>(FR_MAX_PART); }
+    B.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
+    B.teeth = fr_alloc<Teeth>(1);
+    B.dots = fr_alloc<double>(2);
+    B.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
+    FR_HIP(hipMemsetAsync(B.keep, 0, cap, c->stream));
+    FR_HIP(hipMemsetAsync(B.del, 0, cap, c->stream));
+    FR_HIP(hipMemsetAsync(B.state, 0, sizeof(CompState) * (FR_MAX_ROUNDS + 2), c->stream));
+    if (fr_blocks(cap, FR_TILE) > FR_MAX_PART) throw FriesError("vector capacity exceeds FR_MAX_PART tiles");
+}
+
+// v0 <- v0 * (1 - eps (H_ii - S)) for the elements that existed before the spawns were merged,
+// then v0 += v1, v1 <- 0; publishes per-block sums of |v0| (round 0 of find_preserve).
+__global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, SysDev S, uint32_t vec_size_before, double eps, double shift, uint32_t n_samp) {
+    __shared__ double shd[12];
+    const uint32_t n = V.st->curr_size;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CompState s{};
+        s.n_rem = n_samp; s.n_in = n; s.done = 0; s.pbuf = 0;
+        B.state[0] = s;
+    }
+    if (blockIdx.x >= nblk) return;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double sum = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        double v = V.v0[i];
+        if (i < vec_size_before && v != 0) {
+            double d = V.diag[i];
+            if (d != d) { d = fr_diag_matrel(V.dets[i], S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[i] = d; }
+            v *= 1 - eps * (d - shift);
+        }
+        v += V.v1[i] * 1.0;
+        V.v0[i] = v; V.v1[i] = 0;
+        sum += fabs(v);
+    }
+    double bs;
+    fr_block_excl_f64(sum, shd, &bs);
+    if (threadIdx.x == 0) { B.psum[0][blockIdx.x] = bs; B.pcnt[0][blockIdx.x] = 0; }
+}
+
+void fr_death_clone(FriesCtx *c, uint32_t vec_size_before) {
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    uint32_t bound = c->h_vst.curr_size;
+    hipLaunchKernelGGL(k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), 0, c->stream, c->vec, c->vc, S, vec_size_before, c->eps, c->en_shift, c->vec_nonz);
+    c->n_kernel_launch++;
+}
+
+// One round of the exact-preservation fixed point: keep every element with
+// |v| >= remaining_norm / remaining_samples (compress_utils.cpp:58).
+__global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int round) {
+    __shared__ double shd[12];
+    __shared__ uint32_t shu[4];
+    const CompState prev = B.state[round - 1];
+    const unsigned n = prev.n_in;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (prev.done) { if (blockIdx.x == 0 && threadIdx.x == 0) B.state[round] = prev; return; }
+    if (blockIdx.x >= nblk && blockIdx.x != 0) return;
+    const int pin = (round - 1) & 1, pout = round & 1;
+    double G = fr_sum_partials(B.psum[pin], nblk, shd);
+    uint32_t kept_prev = fr_sum_partials_u32(B.pcnt[pin], nblk, shu);
+    uint32_t n_rem = prev.n_rem - kept_prev;
+    bool done = (round > 1 && kept_prev == 0) || nblk == 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CompState s = prev;
+        if (round == 1) s.loc_norm = G;          // *global_norm (compress_utils.cpp:50)
+        s.G = G; s.n_rem = n_rem; s.done = done; s.pbuf = pin;
+        B.state[round] = s;
+    }
+    if (done || blockIdx.x >= nblk) return;
+    const double thr = G / n_rem;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double sum = 0;
+    uint32_t kept = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        double a = fabs(V.v0[i]);
+        if (!B.keep[i] && a != 0) {
+            if (a >= thr) { B.keep[i] = 1; kept++; }
+            else sum += a;
+        }
+    }
+    double bs;
+    fr_block_excl_f64(sum, shd, &bs);
+    uint32_t bk = fr_block_sum_u32(kept, shu);
+    if (threadIdx.x == 0) { B.psum[pout][blockIdx.x] = bs; B.pcnt[pout][blockIdx.x] = bk; }
+}
+
+void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm, double *loc_norm) {
+    VcompBuf &B = c->vc;
+    hipStream_t st = c->stream;
+    unsigned grid = fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_TILE);
+    int r = 0, batch = c->rounds_hint[6] + 1;
+    CompState hs{};
+    hs.done = 0;
+    while (!hs.done) {
+        if (r + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - r;
+        if (batch <= 0) throw FriesError("find_preserve did not converge within FR_MAX_ROUNDS rounds");
+        for (int k = 0; k < batch; k++) {
+            r++;
+            hipLaunchKernelGGL(k_fp_round, dim3(grid), dim3(FR_BLOCK), 0, st, c->vec, B, r);
+            c->n_kernel_launch++;
+        }
+        FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        batch = 2;
+    }
+    c->rounds_hint[6] = r > 2 ? r - 1 : 2;
+    c->rounds_hint[7] = r;      // state slot sys_comp reads
+    *glob_norm = hs.loc_norm;
+    uint32_t n_rem = hs.n_rem;
+    double ln = hs.G;
+    if (hs.G < 1e-9) { n_rem = 0; ln = 0; }    // compress_utils.cpp:94-96
+    *n_samp_io = n_rem;
+    *loc_norm = ln;
+}
+
+__global__ void k_vc_teeth(VcompBuf B, int last_round, uint32_t n_samp, double loc_norm, double rn, double lbound0, double norm_after) {
+    CompState s = B.state[last_round];
+    s.n_rem = n_samp; s.loc_norm = loc_norm; s.n_fix = 0; s.n_out = 0;
+    double glob = lbound0 + loc_norm + norm_after;
+    double unit = 0, r0 = INFINITY;
+    if (n_samp > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_samp, &unit);
+    s.unit = glob / n_samp;
+    B.state[FR_MAX_ROUNDS + 1] = s;
+    if (n_samp > 0) fr_build_teeth(B.teeth, r0, unit, n_samp + 2, lbound0);
+    else { B.teeth->nseg = 0; B.teeth->kmax = 0; B.teeth->unit = 0; B.teeth->lbound0 = lbound0; }
+}
+
+// sys_comp body for one element (compress_utils.cpp:307-325).  Returns the new value.
+__device__ __forceinline__ void fr_sc_element(VecDev &V, VcompBuf &B, const Teeth *th, size_t i, double Se, uint32_t *k, double unit, bool write) {
+    double v = V.v0[i];
+    if (B.keep[i]) { if (write) B.keep[i] = 0; return; }
+    if (v == 0) return;
+    if (fr_tooth(th, *k) < Se) {
+        if (write) V.v0[i] = unit * ((v > 0) - (v < 0));
+        (*k)++;
+    }
+    else if (write) { V.v0[i] = 0; B.del[i] = 1; }
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_sc_apply(VecDev V, VcompBuf B, uint32_t *kin_out) {
+    __shared__ double shd[12];
+    __shared__ double sh_start;
+    CompState *fin = &B.state[FR_MAX_ROUNDS + 1];
+    const unsigned n = fin->n_in;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    const Teeth *th = B.teeth;
+    const double unit = fin->unit;
+    if (threadIdx.x == 0) {
+        const double *ps = B.psum[fin->pbuf];
+        double st = th->lbound0;
+        for (unsigned b = 0; b < blockIdx.x; b++) st += ps[b];
+        sh_start = st;
+    }
+    __syncthreads();
+    const double start = sh_start;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double loc[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        double a = (i < n && !B.keep[i]) ? fabs(V.v0[i]) : 0.0;
+        tsum += a; loc[it] = tsum;
+    }
+    double btot;
+    double texcl = fr_block_excl_f64(tsum, shd, &btot);
+    double Sprev = start + texcl;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        double Se = start + (texcl + loc[it]);
+        uint32_t kin = (i == 0) ? 0u : fr_teeth_below(th, Sprev);
+        uint32_t k = kin;
+        B.S[i] = Se; kin_out[i] = kin;
+        // decide without writing first, so a backlog can be repaired before values change
+        bool kept = B.keep[i];
+        double v = V.v0[i];
+        bool sel = !kept && v != 0 && fr_tooth(th, k) < Se;
+        if (sel) k++;
+        if (k != fr_teeth_below(th, Se)) {
+            uint32_t slot = atomicAdd(&fin->n_fix, 1u);
+            if (slot < FR_MAX_PART) B.fix_list[slot] = (uint32_t)i;
+        }
+        Sprev = Se;
+    }
+}
+
+// walks forward from every flagged element, handing the lagging tooth index to its successors
+__global__ void k_sc_fixup(VecDev V, VcompBuf B, uint32_t *kin, uint32_t *err) {
+    CompState *fin = &B.state[FR_MAX_ROUNDS + 1];
+    uint32_t nf = fin->n_fix;
+    if (nf == 0) return;
+    if (nf > FR_MAX_PART) { atomicOr(err, FR_ERR_BACKLOG); nf = FR_MAX_PART; }
+    const Teeth *th = B.teeth;
+    const unsigned n = fin->n_in;
+    for (uint32_t i = 1; i < nf; i++) { uint32_t x = B.fix_list[i]; int j = (int)i - 1; while (j >= 0 && B.fix_list[j] > x) { B.fix_list[j + 1] = B.fix_list[j]; j--; } B.fix_list[j + 1] = x; }
+    size_t done_upto = 0;
+    for (uint32_t q = 0; q < nf; q++) {
+        size_t e = B.fix_list[q];
+        if (e < done_upto) continue;
+        uint32_t k = kin[e];
+        { bool sel = !B.keep[e] && V.v0[e] != 0 && fr_tooth(th, k) < B.S[e]; if (sel) k++; }
+        for (size_t e2 = e + 1; e2 < n; e2++) {
+            kin[e2] = k;
+            bool sel = !B.keep[e2] && V.v0[e2] != 0 && fr_tooth(th, k) < B.S[e2];
+            if (sel) k++;
+            done_upto = e2 + 1;
+            if (k == fr_teeth_below(th, B.S[e2])) break;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_sc_write(VecDev V, VcompBuf B, const uint32_t *kin) {
+    CompState *fin = &B.state[FR_MAX_ROUNDS + 1];
+    const unsigned n = fin->n_in;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = kin[i];
+    fr_sc_element(V, B, B.teeth, i, B.S[i], &k, fin->unit, true);
+}
+
+void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double loc_norm, double rn) {
+    VcompBuf &B = c->vc;
+    hipStream_t st = c->stream;
+    uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
+    uint32_t *kin = c->W.kin;      // HB-PP scratch is idle here
+    hipLaunchKernelGGL(k_vc_teeth, dim3(1), dim3(1), 0, st, B, c->rounds_hint[7], n_samp, loc_norm, rn, 0.0, 0.0);
+    hipLaunchKernelGGL(k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), 0, st, c->vec, B, kin);
+    hipLaunchKernelGGL(k_sc_fixup, dim3(1), dim3(1), 0, st, c->vec, B, kin, c->d_err);
+    hipLaunchKernelGGL(k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), 0, st, c->vec, B, kin);
+    c->n_kernel_launch += 4;
+    fr_vec_delete_flagged(c, &c->vec, B.del, bound);
+}
+
+// block 0: <H trial | v>, block 1: <trial | v>
+__global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, const double *hv, uint32_t nh, const det_t *td, const double *tv, uint32_t nt, double *out) {
+    __shared__ double shd[4];
+    const det_t *d = blockIdx.x == 0 ? hd : td;
+    const double *w = blockIdx.x == 0 ? hv : tv;
+    uint32_t n = blockIdx.x == 0 ? nh : nt;
+    double acc = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t s = fr_hash_find(V, d[i]);
+        if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) acc += w[i] * V.v0[pos]; }
+    }
+    double r = fr_block_sum(acc, shd);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
+void fr_dots(FriesCtx *c, double *numer, double *denom) {
+    hipLaunchKernelGGL(k_dots, dim3(2), dim3(FR_BLOCK), 0, c->stream, c->vec, c->htr_det, c->htr_val, c->n_htrial, c->tr_det, c->tr_val, c->n_trial, c->vc.dots);
+    c->n_kernel_launch++;
+    double h[2];
+    FR_HIP(hipMemcpyAsync(h, c->vc.dots, 16, hipMemcpyDeviceToHost, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));
+    *numer = h[0]; *denom = h[1];
+}

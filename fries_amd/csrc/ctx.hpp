@@ -1,0 +1,106 @@
+// Host-side context of the MI355X FRI engine.  Everything numeric lives in HBM; the host keeps
+// pointers, launch geometry and the handful of scalars the drivers print.
+#pragma once
+#include "fries_dev.hpp"
+#include "comp_kernels.hpp"
+#include <string>
+#include <vector>
+#include <random>
+#include <stdexcept>
+
+struct FriesError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+void fr_set_error(const std::string &msg);
+
+#define FR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { throw FriesError(std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+
+template <class T> static inline T *fr_alloc(size_t n) {
+    T *p = nullptr;
+    FR_HIP(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
+    return p;
+}
+static inline unsigned fr_blocks(size_t n, size_t per) { return (unsigned)((n + per - 1) / per); }
+
+// merge / spawn scratch (vec.hip)
+struct SpawnBuf {
+    uint32_t cap;
+    det_t *det; double *val; uint8_t *ini;     // spawn list in arrival order
+    uint32_t *slot;                            // hash slot or FR_NOPOS (dropped)
+    uint32_t *flag;                            // first-arrival flags / scan scratch
+    uint32_t *key[2], *pay[2];                 // radix sort ping-pong
+    uint32_t *hist;                            // digit histograms
+    uint32_t *pcnt;                            // block partial counts
+    uint32_t *n_spawn;                         // device scalar: list length
+};
+
+// vector-compression scratch (compress.hip)
+struct VcompBuf {
+    uint8_t *keep;          // preserved exactly
+    uint8_t *del;           // zeroed by sys_comp -> delete
+    double *S;              // lbound prefix
+    double *psum[2]; uint32_t *pcnt[2];
+    CompState *state;       // [FR_MAX_ROUNDS + 2]
+    Teeth *teeth;
+    double *dots;           // [2] numerator, denominator
+    uint32_t *fix_list;
+};
+
+struct FriesCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // system
+    uint32_t n_orb = 0, n_elec = 0;
+    double *d_h = nullptr, *d_eris = nullptr;
+    HbTables *d_hb = nullptr;
+    HbTables h_hb;
+    double hf_en = 0, p_doub = 0;
+    det_t hf_det = 0;
+    // solution vector
+    VecDev vec{};
+    VecState h_vst{};
+    // HB-PP work arrays
+    CompWork W{};
+    uint32_t *c_pos = nullptr, *c_orbs = nullptr; double *c_val = nullptr;   // compacted apply_HBPP_sys output
+    uint32_t *d_nsucc = nullptr;
+    SpawnBuf sp{};
+    VcompBuf vc{};
+    uint32_t *d_err = nullptr;
+    // trial vectors (replicated, small)
+    uint32_t n_trial = 0, n_htrial = 0;
+    det_t *tr_det = nullptr, *htr_det = nullptr;
+    double *tr_val = nullptr, *htr_val = nullptr;
+    // driver state (FRIES_bin/frisys_mol.cpp)
+    std::mt19937 mt;
+    std::vector<uint32_t> proc_scr, vec_scr;
+    double eps = 0, target_norm = 0, init_thresh = 0, en_shift = 0, last_one_norm = 0;
+    uint32_t vec_nonz = 0, mat_nonz = 0;
+    bool new_hb = true;
+    unsigned iterat = 0;
+    int rounds_hint[8] = {3, 3, 3, 3, 3, 3, 3, 3};
+    int fks_iters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // last iteration's observables
+    double numer = 0, denom = 0, glob_norm = 0;
+    uint32_t nkept = 0, num_success = 0, comp_len[5] = {0, 0, 0, 0, 0};
+    uint64_t n_kernel_launch = 0;
+};
+
+// vec.hip
+void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap);
+void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out);
+void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool spawn_count_on_device);
+void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n);
+void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
+void fr_spawn_alloc(FriesCtx *c, uint32_t cap);
+// hbpp.hip
+void fr_hbpp_alloc(FriesCtx *c, uint32_t cap);
+void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]);
+void fr_spawn_from_comp(FriesCtx *c);
+// compress.hip
+void fr_vcomp_alloc(FriesCtx *c, uint32_t cap);
+void fr_death_clone(FriesCtx *c, uint32_t vec_size_before);
+void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm, double *loc_norm);
+void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double loc_norm, double rn);
+void fr_dots(FriesCtx *c, double *numer, double *denom);
+// system.hip
+void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
+void fr_h_trial_setup(FriesCtx *c);

@@ -1,0 +1,414 @@
+// frisys_mol iteration loop (FRIES_bin/frisys_mol.cpp:76-552) on the device-resident engine,
+// and the extern "C" boundary (include/fries_hip.h).
+#include "ctx.hpp"
+#include "../../include/fries_hip.h"
+#include <cstring>
+#include <cmath>
+#include <climits>
+
+static thread_local std::string g_err;
+void fr_set_error(const std::string &m) { g_err = m; }
+extern "C" const char *fries_last_error(void) { return g_err.c_str(); }
+
+struct fries_ctx { FriesCtx c; };
+
+void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vector<double> &val,
+                     std::vector<det_t> &out_det, std::vector<double> &out_val, uint32_t *n_sing0, uint32_t *n_doub0);
+void fr_hbpp_apply_unit(FriesCtx *c, uint32_t n_samp, const double rn[5]);
+
+#define FR_API_BEGIN try {
+#define FR_API_END } catch (const std::exception &e) { fr_set_error(e.what()); return -1; } return 0;
+
+// ------------------------------------------------------------------ spawn assembly (frisys_mol.cpp:435-464)
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_build(VecDev V, SpawnBuf S, const uint32_t *c_pos, const uint32_t *c_orbs, const double *c_val,
+                                                          const uint32_t *n_succ, double eps, double init_thresh) {
+    const uint32_t n = *n_succ;
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *S.n_spawn = n;
+    if (j >= n) return;
+    uint32_t pos = c_pos[j], ob = c_orbs[j];
+    double cur = V.v0[pos];
+    det_t d = V.dets[pos];
+    unsigned a = fr_c(ob, 0), b = fr_c(ob, 1), u = fr_c(ob, 2), w = fr_c(ob, 3);
+    double add_el = -eps * c_val[j];
+    if (cur < 0) add_el *= -1;
+    if (!(u == 0 && w == 0)) d = (d & ~(1ull << a) & ~(1ull << b)) | (1ull << u) | (1ull << w);     // doub_det
+    else d = (d & ~(1ull << a)) | (1ull << b);                                                        // sing_det
+    S.det[j] = d; S.val[j] = add_el; S.ini[j] = fabs(cur) >= init_thresh;
+}
+
+static void check_dev_err(FriesCtx *c) {
+    uint32_t e = 0;
+    FR_HIP(hipMemcpyAsync(&e, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));
+    e |= c->h_vst.err;
+    if (!e) return;
+    std::string m = "device error:";
+    if (e & FR_ERR_CAP) m += " vector capacity (max_dets) exceeded;";
+    if (e & FR_ERR_SPAWN_CAP) m += " insufficient memory allocated for matrix compression;";
+    if (e & FR_ERR_NELEC) m += " determinant created with an incorrect number of electrons;";
+    if (e & FR_ERR_HASH_FULL) m += " determinant hash table full;";
+    if (e & FR_ERR_ROUNDS) m += " exact-preservation rounds did not converge;";
+    if (e & FR_ERR_BACKLOG) m += " too many comb repairs;";
+    throw FriesError(m);
+}
+
+static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
+    if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
+    c->eps = p->epsilon; c->target_norm = p->target_norm; c->init_thresh = p->initiator;
+    c->vec_nonz = p->vec_nonz; c->mat_nonz = p->mat_nonz; c->new_hb = p->hb_unnorm != 0;
+    c->en_shift = 0; c->last_one_norm = 0; c->iterat = 0;
+    if (p->max_dets == 0 || p->mat_nonz == 0 || p->vec_nonz == 0) throw FriesError("max_dets, mat_nonz and vec_nonz must be positive");
+    c->mt.seed(p->seed);
+    c->proc_scr.resize(2 * c->n_orb); c->vec_scr.resize(2 * c->n_orb);
+    for (auto &x : c->proc_scr) x = c->mt();        // frisys_mol.cpp:133-135
+    for (auto &x : c->vec_scr) x = c->mt();         // :142-144
+    uint32_t wcap = p->max_dets > p->mat_nonz + 4096 ? p->max_dets : p->mat_nonz + 4096;
+    fr_vec_alloc(c, &c->vec, p->max_dets);
+    fr_hbpp_alloc(c, wcap);
+    fr_spawn_alloc(c, p->mat_nonz + 4096);
+    fr_vcomp_alloc(c, p->max_dets);
+    fr_h_trial_setup(c);
+    // start from 100 * |HF>  (:277-281)
+    double v = 100; uint8_t one = 1; uint32_t n1 = 1;
+    FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
+    fr_vec_merge(c, &c->vec, 1, false);
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_death_clone(c, 0);                            // v0 += v1; v1 = 0
+    check_dev_err(c);
+}
+
+static inline double uni(std::mt19937 &mt) { return mt() / (1. + UINT32_MAX); }
+
+static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
+    hipStream_t st = c->stream;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_vec_maybe_rebuild(c, &c->vec);
+    // systematic matrix compression (:414-422)
+    double rn[5];
+    for (int k = 0; k < 5; k++) rn[k] = uni(c->mt);
+    fr_hbpp_apply(c, c->mat_nonz, rn);
+    uint32_t vec_size = c->h_vst.curr_size;
+    // spawning + annihilation (:429-471)
+    if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
+    if (c->num_success) {
+        hipLaunchKernelGGL(k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), 0, st, c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
+        c->n_kernel_launch++;
+        fr_vec_merge(c, &c->vec, c->num_success, true);
+    }
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (c->h_vst.err) check_dev_err(c);
+    // death / cloning, column add (:487-499)
+    fr_death_clone(c, vec_size);
+    // vector compression (:501-539)
+    uint32_t n_samp = c->vec_nonz;
+    double glob_norm = 0, loc_norm = 0;
+    fr_find_preserve(c, &n_samp, &glob_norm, &loc_norm);
+    c->glob_norm = glob_norm;
+    c->nkept = c->vec_nonz - n_samp;
+    const unsigned shift_interval = 10;
+    const double shift_damping = 0.05;
+    if ((c->iterat + 1) % shift_interval == 0) {     // adjust_shift, compress_utils.cpp:684-693
+        double damp = shift_damping / shift_interval / c->eps;
+        if (c->last_one_norm) { c->en_shift -= damp * log(glob_norm / c->last_one_norm); c->last_one_norm = glob_norm; }
+        if (c->last_one_norm == 0 && glob_norm > c->target_norm) c->last_one_norm = glob_norm;
+    }
+    fr_dots(c, &c->numer, &c->denom);
+    double rn_sys = uni(c->mt);
+    fr_sys_comp(c, n_samp, loc_norm, rn_sys);
+    c->iterat++;
+    if (lg) {
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+        lg->numer = c->numer; lg->denom = c->denom; lg->shift = c->en_shift; lg->norm = c->glob_norm;
+        lg->nkept = c->nkept; lg->n_nonz = c->h_vst.n_nonz; lg->curr_size = c->h_vst.curr_size;
+        lg->num_success = c->num_success;
+        for (int k = 0; k < 5; k++) lg->comp_len[k] = c->comp_len[k];
+        uint32_t e = 0;
+        FR_HIP(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+        lg->err = e | c->h_vst.err;
+    }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int fries_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int fries_ctx_create(fries_ctx **out, int device) {
+    FR_API_BEGIN
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw FriesError("no HIP device available: the FRI engine has no CPU fallback");
+    if (device < 0 || device >= n) throw FriesError("device index out of range");
+    FR_HIP(hipSetDevice(device));
+    fries_ctx *h = new fries_ctx();
+    h->c.device = device;
+    FR_HIP(hipStreamCreate(&h->c.stream));
+    h->c.d_err = fr_alloc<uint32_t>(1);
+    FR_HIP(hipMemset(h->c.d_err, 0, 4));
+    *out = h;
+    FR_API_END
+}
+
+extern "C" void fries_ctx_destroy(fries_ctx *h) {
+    if (!h) return;
+    hipSetDevice(h->c.device);
+    hipDeviceSynchronize();
+    // device allocations are released with the context's device memory pool at process exit;
+    // explicit frees for the large arrays:
+    VecDev &v = h->c.vec;
+    hipFree(v.dets); hipFree(v.v0); hipFree(v.v1); hipFree(v.diag); hipFree(v.active); hipFree(v.free_stack); hipFree(v.hkeys); hipFree(v.hvals); hipFree(v.st);
+    CompWork &W = h->c.W;
+    for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
+    hipFree(W.wt_remain); hipFree(W.keep); hipFree(W.S); hipFree(W.kin); hipFree(W.cnt); hipFree(W.e_wi); hipFree(W.e_sub); hipFree(W.e_val); hipFree(W.state); hipFree(W.teeth); hipFree(W.fix_list);
+    hipFree(h->c.c_pos); hipFree(h->c.c_orbs); hipFree(h->c.c_val); hipFree(h->c.d_nsucc);
+    SpawnBuf &s = h->c.sp;
+    hipFree(s.det); hipFree(s.val); hipFree(s.ini); hipFree(s.slot); hipFree(s.flag);
+    for (int k = 0; k < 2; k++) { hipFree(s.key[k]); hipFree(s.pay[k]); }
+    hipFree(s.hist); hipFree(s.pcnt); hipFree(s.n_spawn);
+    VcompBuf &b = h->c.vc;
+    hipFree(b.keep); hipFree(b.del); hipFree(b.S);
+    for (int k = 0; k < 2; k++) { hipFree(b.psum[k]); hipFree(b.pcnt[k]); }
+    hipFree(b.state); hipFree(b.teeth); hipFree(b.dots); hipFree(b.fix_list);
+    hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
+    hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
+    if (h->c.stream) hipStreamDestroy(h->c.stream);
+    delete h;
+}
+
+extern "C" int fries_set_molecule(fries_ctx *h, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris) {
+    FR_API_BEGIN
+    FR_HIP(hipSetDevice(h->c.device));
+    fr_system_upload(&h->c, n_orb, n_elec, irreps, h_core, eris);
+    FR_API_END
+}
+
+static double *hb_field(HbTables &T, int which, size_t *len) {
+    size_t n = T.n_orb;
+    switch (which) {
+        case 0: *len = n; return T.s_tens;
+        case 1: *len = n * (n - 1) / 2; return T.d_same;
+        case 2: *len = n * n; return T.d_diff;
+        case 3: *len = n * (n - 1) / 2; return T.exch_sqrt;
+        case 4: *len = n; return T.diag_sqrt;
+        case 5: *len = n; return T.exch_norms;
+        case 6: *len = 1; return &T.s_norm;
+    }
+    throw FriesError("unknown tensor id");
+}
+
+extern "C" int fries_get_hb_tensor(fries_ctx *h, int which, double *out, size_t cap, size_t *len) {
+    FR_API_BEGIN
+    size_t n;
+    double *src = hb_field(h->c.h_hb, which, &n);
+    if (len) *len = n;
+    if (cap < n) throw FriesError("output buffer too small");
+    memcpy(out, src, 8 * n);
+    FR_API_END
+}
+
+extern "C" int fries_set_hb_tensor(fries_ctx *h, int which, const double *in, size_t len) {
+    FR_API_BEGIN
+    size_t n;
+    double *dst = hb_field(h->c.h_hb, which, &n);
+    if (len != n) throw FriesError("tensor length mismatch");
+    memcpy(dst, in, 8 * n);
+    FR_HIP(hipMemcpy(h->c.d_hb, &h->c.h_hb, sizeof(HbTables), hipMemcpyHostToDevice));
+    FR_API_END
+}
+
+extern "C" double fries_hf_energy(fries_ctx *h) { return h->c.hf_en; }
+extern "C" double fries_p_doub(fries_ctx *h) { return h->c.p_doub; }
+extern "C" uint64_t fries_kernel_launches(fries_ctx *h) { return h->c.n_kernel_launch; }
+
+__global__ void k_matrel_batch(int kind, const det_t *dets, const uint8_t *orbs, size_t n, const double *hc, const double *eris, unsigned n_orb, double *out, int32_t *sign) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    det_t d = dets[i];
+    const uint8_t *o = orbs ? orbs + 4 * i : nullptr;
+    if (kind == 0) { out[i] = fr_diag_matrel(d, hc, eris, n_orb); if (sign) sign[i] = 1; }
+    else if (kind == 1) { out[i] = fr_sing_matrel(d, o[0], o[1], hc, eris, n_orb); if (sign) sign[i] = fr_sing_parity(d, o[0], o[1]); }
+    else { out[i] = fr_doub_matrel(o[0], o[1], o[2], o[3], eris, n_orb); if (sign) sign[i] = fr_doub_parity(d, o[0], o[1], o[2], o[3]); }
+}
+
+extern "C" int fries_matrel_batch(fries_ctx *h, int kind, const uint64_t *dets, const uint8_t *orbs, size_t n, double *out, int32_t *sign) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
+    if (n == 0) return 0;
+    det_t *dd = fr_alloc<det_t>(n); uint8_t *dob = fr_alloc<uint8_t>(4 * n); double *dout = fr_alloc<double>(n); int32_t *ds = fr_alloc<int32_t>(n);
+    FR_HIP(hipMemcpy(dd, dets, 8 * n, hipMemcpyHostToDevice));
+    if (orbs) FR_HIP(hipMemcpy(dob, orbs, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_matrel_batch, dim3(fr_blocks(n, FR_BLOCK)), dim3(FR_BLOCK), 0, c->stream, kind, dd, orbs ? dob : nullptr, n, c->d_h, c->d_eris, c->n_orb, dout, ds);
+    FR_HIP(hipStreamSynchronize(c->stream));
+    FR_HIP(hipMemcpy(out, dout, 8 * n, hipMemcpyDeviceToHost));
+    if (sign) FR_HIP(hipMemcpy(sign, ds, 4 * n, hipMemcpyDeviceToHost));
+    hipFree(dd); hipFree(dob); hipFree(dout); hipFree(ds);
+    FR_API_END
+}
+
+extern "C" int fries_frisys_setup(fries_ctx *h, const fries_frisys_params *p) {
+    FR_API_BEGIN
+    FR_HIP(hipSetDevice(h->c.device));
+    frisys_setup(&h->c, p);
+    FR_API_END
+}
+
+extern "C" int fries_frisys_iterate(fries_ctx *h, uint32_t n_iter, fries_iter_log *logs) {
+    FR_API_BEGIN
+    FR_HIP(hipSetDevice(h->c.device));
+    for (uint32_t i = 0; i < n_iter; i++) frisys_iterate(&h->c, logs ? &logs[i] : nullptr);
+    check_dev_err(&h->c);
+    FR_API_END
+}
+
+extern "C" int fries_vec_info(fries_ctx *h, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (curr_size) *curr_size = c->h_vst.curr_size;
+    if (n_nonz) *n_nonz = c->h_vst.n_nonz;
+    if (n_free) *n_free = c->h_vst.n_free;
+    FR_API_END
+}
+
+extern "C" int fries_vec_download(fries_ctx *h, uint64_t *dets, double *vals, size_t cap, size_t *n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    size_t m = c->h_vst.curr_size;
+    if (n) *n = m;
+    if (cap < m) throw FriesError("output buffer too small");
+    if (dets) FR_HIP(hipMemcpy(dets, c->vec.dets, 8 * m, hipMemcpyDeviceToHost));
+    if (vals) FR_HIP(hipMemcpy(vals, c->vec.v0, 8 * m, hipMemcpyDeviceToHost));
+    FR_API_END
+}
+
+extern "C" int fries_htrial_download(fries_ctx *h, uint64_t *dets, double *vals, size_t cap, size_t *n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (n) *n = c->n_htrial;
+    if (cap < c->n_htrial) throw FriesError("output buffer too small");
+    FR_HIP(hipMemcpy(dets, c->htr_det, 8 * (size_t)c->n_htrial, hipMemcpyDeviceToHost));
+    FR_HIP(hipMemcpy(vals, c->htr_val, 8 * (size_t)c->n_htrial, hipMemcpyDeviceToHost));
+    FR_API_END
+}
+
+extern "C" int fries_vec_add(fries_ctx *h, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (n > c->sp.cap) throw FriesError("Too many elements added to Adder - must call perform_add() more frequently.");
+    // DistVec::add drops zero values before they reach the adder (vec_utils.hpp:418-423)
+    std::vector<det_t> d; std::vector<double> v; std::vector<uint8_t> f;
+    for (size_t i = 0; i < n; i++) if (vals[i] != 0) { d.push_back(dets[i]); v.push_back(vals[i]); f.push_back(ini[i]); }
+    uint32_t m = (uint32_t)d.size();
+    if (m) {
+        FR_HIP(hipMemcpyAsync(c->sp.det, d.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
+        fr_vec_merge(c, &c->vec, m, false);
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+        fr_death_clone(c, 0);
+    }
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    check_dev_err(c);
+    FR_API_END
+}
+
+extern "C" int fries_vec_load(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    VecDev &v = c->vec;
+    if (n > v.cap) throw FriesError("vector larger than max_dets");
+    FR_HIP(hipMemsetAsync(v.v0, 0, 8 * (size_t)v.cap, c->stream));
+    FR_HIP(hipMemsetAsync(v.v1, 0, 8 * (size_t)v.cap, c->stream));
+    FR_HIP(hipMemsetAsync(v.diag, 0xff, 8 * (size_t)v.cap, c->stream));
+    FR_HIP(hipMemsetAsync(v.active, 0, v.cap, c->stream));
+    FR_HIP(hipMemsetAsync(v.active, 1, n, c->stream));
+    FR_HIP(hipMemcpyAsync(v.dets, dets, 8 * n, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(v.v0, vals, 8 * n, hipMemcpyHostToDevice, c->stream));
+    VecState s{};
+    s.curr_size = (uint32_t)n; s.n_nonz = (int32_t)n; s.n_used = (uint32_t)(v.hcap);   // forces the rebuild below
+    FR_HIP(hipMemcpyAsync(v.st, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
+    c->h_vst = s;
+    fr_vec_maybe_rebuild(c, &v);
+    fr_vec_sync_state(c, &v, &c->h_vst);
+    check_dev_err(c);
+    FR_API_END
+}
+
+extern "C" int fries_apply_hbpp_sys(fries_ctx *h, uint32_t n_samp, const double rn[5], int unit_matrel,
+                                    uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out, uint32_t comp_len[5]) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (unit_matrel) fr_hbpp_apply_unit(c, n_samp, rn); else fr_hbpp_apply(c, n_samp, rn);
+    size_t m = c->num_success;
+    if (n_out) *n_out = m;
+    if (comp_len) for (int k = 0; k < 5; k++) comp_len[k] = c->comp_len[k];
+    check_dev_err(c);
+    if (cap < m) throw FriesError("output buffer too small");
+    if (det_pos) FR_HIP(hipMemcpy(det_pos, c->c_pos, 4 * m, hipMemcpyDeviceToHost));
+    if (orbs) FR_HIP(hipMemcpy(orbs, c->c_orbs, 4 * m, hipMemcpyDeviceToHost));
+    if (vals) FR_HIP(hipMemcpy(vals, c->c_val, 8 * m, hipMemcpyDeviceToHost));
+    FR_API_END
+}
+
+extern "C" int fries_compress_vec(fries_ctx *h, uint32_t n_samp_in, double rn, uint32_t *n_kept, double *glob_norm) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    uint32_t save = c->vec_nonz;
+    c->vec_nonz = n_samp_in;
+    fr_death_clone(c, 0);                    // publishes the |v| block sums; v1 is zero so values are unchanged
+    uint32_t n_samp = n_samp_in;
+    double gn = 0, ln = 0;
+    fr_find_preserve(c, &n_samp, &gn, &ln);
+    fr_sys_comp(c, n_samp, ln, rn);
+    c->vec_nonz = save;
+    if (n_kept) *n_kept = n_samp_in - n_samp;
+    if (glob_norm) *glob_norm = gn;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    check_dev_err(c);
+    FR_API_END
+}
+
+__global__ void k_test_teeth(Teeth *t, double r0, double unit, uint32_t n, double *pos, const double *q, uint32_t nq, uint32_t *below) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fr_build_teeth(t, r0, unit, n, 0.0);
+}
+__global__ void k_test_teeth_eval(const Teeth *t, uint32_t n, double *pos, const double *q, uint32_t nq, uint32_t *below) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] = fr_tooth(t, i);
+    if (i < nq) below[i] = fr_teeth_below(t, q[i]);
+}
+
+extern "C" int fries_test_teeth(fries_ctx *h, double r0, double unit, uint32_t n, double *out_pos, const double *query, uint32_t nq, uint32_t *out_below) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    Teeth *t = fr_alloc<Teeth>(1);
+    double *dp = fr_alloc<double>(n), *dq = fr_alloc<double>(nq);
+    uint32_t *db = fr_alloc<uint32_t>(nq);
+    if (nq) FR_HIP(hipMemcpy(dq, query, 8 * (size_t)nq, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_teeth, dim3(1), dim3(1), 0, c->stream, t, r0, unit, n, dp, dq, nq, db);
+    uint32_t m = n > nq ? n : nq;
+    hipLaunchKernelGGL(k_test_teeth_eval, dim3(fr_blocks(m ? m : 1, FR_BLOCK)), dim3(FR_BLOCK), 0, c->stream, t, n, dp, dq, nq, db);
+    FR_HIP(hipStreamSynchronize(c->stream));
+    if (n) FR_HIP(hipMemcpy(out_pos, dp, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    if (nq) FR_HIP(hipMemcpy(out_below, db, 4 * (size_t)nq, hipMemcpyDeviceToHost));
+    hipFree(t); hipFree(dp); hipFree(dq); hipFree(db);
+    FR_API_END
+}

@@ -1,0 +1,311 @@
+// apply_HBPP_sys on the device (FRIES/Hamiltonians/heat_bathPP.cpp:686-992): five comp_sub
+// stages with on-the-fly sub-weight rows, then weight / matrix element / parity and an
+// order-preserving compaction of the surviving samples.
+#include "ctx.hpp"
+
+// ------------------------------------------------------------------ stage preparation
+// Stage 1 elements are the stored vector elements (frisys_mol.cpp:414-420, heat_bathPP.cpp:714-727).
+__global__ void __launch_bounds__(FR_BLOCK) k_prep1(CompWork W, VecDev V, int cur, uint32_t n_samp) {
+    __shared__ double shd[12];
+    const unsigned n_in = V.st->curr_size;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CompState s{};
+        s.n_rem = n_samp; s.n_in = n_in; s.done = 0; s.pbuf = 0;
+        W.state[0] = s;
+    }
+    if (blockIdx.x >= nblk) return;
+    const StageElems E = W.el[cur];
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double sum = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        double w = fabs(V.v0[e]);
+        E.val[e] = w; E.pos[e] = (uint32_t)e; E.code[e] = 0; E.ndiv[e] = (w > 0) ? 0u : 1u; E.nsub[e] = 2;
+        W.wt_remain[e] = w; W.keep[e] = 0;
+        sum += w;
+    }
+    double bs;
+    fr_block_excl_f64(sum, shd, &bs);
+    if (threadIdx.x == 0) { W.psum[0][blockIdx.x] = bs; W.pcnt[0][blockIdx.x] = 0; }
+}
+
+// Stages 2..5: element e comes from emission e of the previous stage
+// (heat_bathPP.cpp:739-762, 773-809, 821-857, 869-908).
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const HbTables *Tg, int cur, uint32_t n_samp, double p_doub) {
+    __shared__ HbTables T;
+    __shared__ double shd[12];
+    const unsigned n_in = W.state[FR_MAX_ROUNDS + 1].n_out;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CompState s{};
+        s.n_rem = n_samp; s.n_in = n_in; s.done = 0; s.pbuf = 0;
+        W.state[0] = s;
+    }
+    if (blockIdx.x >= nblk) return;
+    fr_stage_tables(&T, Tg);
+    const StageElems E = W.el[cur], P = W.el[cur ^ 1];
+    const unsigned n_elec = T.n_elec, n_orb = T.n_orb;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    double sum = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
+        double val = W.e_val[e];
+        uint32_t pos = P.pos[wi], pc = P.code[wi];
+        det_t det = V.dets[pos];
+        uint32_t code = 0, ndiv = 0, nsub = 0;
+        if (STAGE == 2) {
+            code = fr_code(sub, 0, 0, 0);
+            if (sub == 0) {
+                RowInfo ri = fr_row2_setup<NEW_HB>(T, det);
+                if (NEW_HB) val *= ri.tot;
+                nsub = ri.nsub;
+            }
+            else {
+                unsigned n_occ = fr_count_sing_allowed(T, det);
+                if (n_occ == 0) { ndiv = 1; val = 0; }
+                else ndiv = n_occ;
+            }
+        }
+        else if (STAGE == 3) {
+            unsigned sd = fr_c(pc, 0), c1 = sub;
+            if (c1 >= n_elec) { val = 0; ndiv = 1; code = fr_code(sd, c1, 0, 0); }
+            else if (sd == 0) {
+                if (NEW_HB) {
+                    c1++;
+                    RowInfo ri = fr_row3h_setup(T, det, c1);
+                    nsub = c1;
+                    val *= ri.tot;
+                }
+                else nsub = n_elec;
+                code = fr_code(0, c1, 0, 0);
+            }
+            else {
+                unsigned choice = c1;
+                unsigned n_virt = fr_count_sing_virt(T, det, &choice);
+                if (n_virt == 0) { ndiv = 1; val = 0; code = fr_code(1, choice, 0, 0); }
+                else { ndiv = n_virt; code = fr_code(1, choice, 0, n_virt); }
+            }
+        }
+        else if (STAGE == 4) {
+            unsigned sd = fr_c(pc, 0), o1_idx = fr_c(pc, 1), o2u1 = sub;
+            if (sd == 0) {
+                if (o2u1 >= n_elec) { val = 0; ndiv = 1; code = fr_code(0, o1_idx, o2u1, 0); }
+                else {
+                    code = fr_code(0, o1_idx, o2u1, 0);
+                    RowInfo ri = fr_row_setup<4, NEW_HB>(T, det, code, p_doub);
+                    if (NEW_HB) val *= ri.tot;
+                    nsub = ri.nsub;
+                }
+            }
+            else { code = fr_code(1, o1_idx, o2u1, fr_c(pc, 3)); ndiv = 1; }
+        }
+        else {  // STAGE == 5
+            unsigned sd = fr_c(pc, 0), o1_idx = fr_c(pc, 1), o2_idx = fr_c(pc, 2);
+            if (sd == 0) {
+                unsigned u1 = fr_find_nth_virt(det, o1_idx / (n_elec / 2), n_orb, sub);
+                if (fr_bit(det, u1)) { val = 0; ndiv = 1; code = fr_code(0, o1_idx, o2_idx, u1); }
+                else {
+                    code = fr_code(0, o1_idx, o2_idx, u1);
+                    RowInfo ri = fr_row_setup<5, NEW_HB>(T, det, code, p_doub);
+                    nsub = ri.nsub;
+                    if (NEW_HB || ri.tot == 0) val *= ri.tot;
+                }
+            }
+            else { code = fr_code(1, o1_idx, o2_idx, fr_c(pc, 3)); ndiv = 1; }
+        }
+        E.val[e] = val; E.pos[e] = pos; E.code[e] = code; E.ndiv[e] = ndiv; E.nsub[e] = nsub;
+        W.wt_remain[e] = val; W.keep[e] = 0;
+        sum += val;
+    }
+    double bs;
+    fr_block_excl_f64(sum, shd, &bs);
+    if (threadIdx.x == 0) { W.psum[0][blockIdx.x] = bs; W.pcnt[0][blockIdx.x] = 0; }
+}
+
+// ------------------------------------------------------------------ final evaluation (heat_bathPP.cpp:917-991)
+// f_val[e] == 0 marks an unsuccessful sample.
+template <bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_final_eval(CompWork W, VecDev V, SysDev S, int prev, double p_doub, int unit_matrel,
+                                                         double *f_val, uint32_t *f_orbs, uint32_t *pcnt) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    const unsigned n_in = W.state[FR_MAX_ROUNDS + 1].n_out;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    fr_stage_tables(&T, S.hb);
+    const StageElems P = W.el[prev];
+    const unsigned n_orb = T.n_orb;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
+        double val = W.e_val[e];
+        uint32_t pos = P.pos[wi], pc = P.code[wi];
+        det_t det = V.dets[pos];
+        unsigned o1_idx = fr_c(pc, 1);
+        double el = 0;
+        uint32_t orbs = 0;
+        if (fr_c(pc, 0) == 0) {
+            unsigned o1 = fr_nth_bit(det, o1_idx), o2 = fr_nth_bit(det, fr_c(pc, 2)), u1 = fr_c(pc, 3);
+            unsigned ir = T.irrep[o1 % n_orb] ^ T.irrep[o2 % n_orb] ^ T.irrep[u1 % n_orb];
+            unsigned u2 = T.lookup[ir][sub + 1] + n_orb * (o2 / n_orb);
+            if (!fr_bit(det, u2) && u1 != u2) {
+                if (u1 > u2) { unsigned t = u1; u1 = u2; u2 = t; }
+                if (o1 > o2) { unsigned t = o1; o1 = o2; o2 = t; }
+                orbs = fr_code(o1, o2, u1, u2);
+                double tw = NEW_HB ? fr_unnorm_wt(T, o1, o2, u1, u2) : fr_norm_wt(T, det, o1, o2, u1, u2);
+                double mel = unit_matrel ? 1.0 : fr_doub_matrel(o1, o2, u1, u2, S.eris, n_orb);
+                el = mel * val / tw / p_doub;
+                if (fabs(el) > 1e-9) el *= fr_doub_parity(det, o1, o2, u1, u2);
+                else el = 0;
+            }
+        }
+        else {
+            unsigned o1 = fr_nth_bit(det, o1_idx);
+            unsigned u1 = fr_virt_from_idx(T, det, T.irrep[o1 % n_orb], n_orb * (o1 / n_orb), fr_c(pc, 2));
+            if (u1 != 255) {
+                orbs = fr_code(o1, u1, 0, 0);
+                unsigned n_occ = fr_count_sing_allowed(T, det);
+                el = unit_matrel ? 1.0 : fr_sing_matrel(det, o1, u1, S.h_core, S.eris, n_orb);
+                el *= val / (1 - p_doub) * n_occ * fr_c(pc, 3);
+                if (fabs(el) > 1e-9) el *= fr_sing_parity(det, o1, u1);
+                else el = 0;
+            }
+        }
+        f_val[e] = el; f_orbs[e] = orbs;
+        cnt += (el != 0);
+    }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) pcnt[blockIdx.x] = bc;
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_final_compact(CompWork W, int prev, const double *f_val, const uint32_t *f_orbs, const uint32_t *pcnt,
+                                                            uint32_t *c_pos, uint32_t *c_orbs, double *c_val, uint32_t *n_succ) {
+    __shared__ uint32_t shu[4];
+    const unsigned n_in = W.state[FR_MAX_ROUNDS + 1].n_out;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) { if (blockIdx.x == 0 && threadIdx.x == 0) *n_succ = 0; return; }
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    const StageElems P = W.el[prev];
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t f[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { size_t e = base + it; f[it] = (e < n_in && f_val[e] != 0) ? 1u : 0u; tsum += f[it]; }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t o = off + incl - tsum;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (f[it]) { c_pos[o] = P.pos[W.e_wi[e]]; c_orbs[o] = f_orbs[e]; c_val[o] = f_val[e]; o++; }
+    }
+    if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) *n_succ = o;
+}
+
+// ------------------------------------------------------------------ host orchestration
+void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
+    CompWork &W = c->W;
+    W.cap = cap;
+    for (int h = 0; h < 2; h++) {
+        W.el[h].val = fr_alloc<double>(cap); W.el[h].pos = fr_alloc<uint32_t>(cap); W.el[h].code = fr_alloc<uint32_t>(cap);
+        W.el[h].ndiv = fr_alloc<uint32_t>(cap); W.el[h].nsub = fr_alloc<uint32_t>(cap);
+        W.psum[h] = fr_alloc<double>(FR_MAX_PART); W.pcnt[h] = fr_alloc<uint32_t>(FR_MAX_PART);
+    }
+    W.wt_remain = fr_alloc<double>(cap); W.keep = fr_alloc<uint32_t>(cap); W.S = fr_alloc<double>(cap);
+    W.kin = fr_alloc<uint32_t>(cap); W.cnt = fr_alloc<uint32_t>(cap);
+    W.e_wi = fr_alloc<uint32_t>(cap); W.e_sub = fr_alloc<uint32_t>(cap); W.e_val = fr_alloc<double>(cap);
+    W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
+    W.teeth = fr_alloc<Teeth>(1);
+    W.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
+    W.nb8_cap = cap / 8 + 2;
+    for (int h = 0; h < 2; h++) {
+        W.f_dk[h] = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * W.nb8_cap);
+        W.f_dg[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * W.nb8_cap);
+        W.f_ws[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * W.nb8_cap);
+        W.f_pk[h] = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_MAX_PART);
+        W.f_pg[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_MAX_PART);
+        W.f_pw[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_MAX_PART);
+    }
+    c->c_pos = fr_alloc<uint32_t>(cap); c->c_orbs = fr_alloc<uint32_t>(cap); c->c_val = fr_alloc<double>(cap);
+    c->d_nsucc = fr_alloc<uint32_t>(1);
+    FR_HIP(hipMemset(W.state, 0, sizeof(CompState) * (FR_MAX_ROUNDS + 2)));
+    if (fr_blocks(cap, FR_TILE) > FR_MAX_PART) throw FriesError("work capacity exceeds FR_MAX_PART tiles");
+}
+
+template <int STAGE, bool NEW_HB>
+static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, double rn, uint32_t *n_out_host) {
+    CompWork &W = c->W;
+    hipStream_t st = c->stream;
+    unsigned grid = fr_blocks(n_bound, FR_TILE);
+    if (grid == 0) grid = 1;
+    if (STAGE == 1) hipLaunchKernelGGL(k_prep1, dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, cur, n_samp);
+    else hipLaunchKernelGGL((k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
+    c->n_kernel_launch++;
+    unsigned grid8 = fr_blocks(n_bound / 8 + 1, FR_BLOCK);
+    int it = 0, batch = c->rounds_hint[STAGE];
+    uint32_t changed = 1;
+    while (changed) {
+        if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
+        if (batch <= 0) throw FriesError("find_keep_sub replay did not settle within FR_MAX_ROUNDS iterations");
+        for (int k = 0; k < batch; k++) {
+            hipLaunchKernelGGL((k_fks_iter<STAGE, NEW_HB>), dim3(grid8), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, it, c->p_doub, c->d_err);
+            c->n_kernel_launch++;
+            it++;
+        }
+        FR_HIP(hipMemcpyAsync(&changed, &W.state[it - 1].changed, 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        batch = 2;
+    }
+    c->rounds_hint[STAGE] = it > 2 ? it : 2;
+    c->fks_iters[STAGE] = it;
+    hipLaunchKernelGGL(k_tile_sums, dim3(grid), dim3(FR_BLOCK), 0, st, W);
+    hipLaunchKernelGGL(k_comp_finalize, dim3(1), dim3(FR_BLOCK), 0, st, W, it - 1, rn, 0.0, 0.0, c->d_err);
+    c->n_kernel_launch++;
+    hipLaunchKernelGGL((k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, c->p_doub);
+    hipLaunchKernelGGL((k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), 0, st, W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
+    hipLaunchKernelGGL((k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
+    c->n_kernel_launch += 4;
+    if (n_out_host) {
+        FR_HIP(hipMemcpyAsync(n_out_host, &W.state[FR_MAX_ROUNDS + 1].n_out, 4, hipMemcpyDeviceToHost, st));
+    }
+}
+
+template <bool NEW_HB>
+static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int unit_matrel) {
+    CompWork &W = c->W;
+    hipStream_t st = c->stream;
+    uint32_t bound1 = c->h_vst.curr_size;
+    uint32_t bound = n_samp + 64 < W.cap ? n_samp + 64 : W.cap;     // a stage never emits more than n_samp entries
+    if (bound1 > W.cap) throw FriesError("vector larger than HB-PP work capacity");
+    run_stage<1, NEW_HB>(c, 0, bound1, n_samp, rn[0], &c->comp_len[0]);
+    run_stage<2, NEW_HB>(c, 1, bound, n_samp, rn[1], &c->comp_len[1]);
+    run_stage<3, NEW_HB>(c, 0, bound, n_samp, rn[2], &c->comp_len[2]);
+    run_stage<4, NEW_HB>(c, 1, bound, n_samp, rn[3], &c->comp_len[3]);
+    run_stage<5, NEW_HB>(c, 0, bound, n_samp, rn[4], &c->comp_len[4]);
+    unsigned grid = fr_blocks(bound, FR_TILE);
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    // f_val / f_orbs reuse the S / kin arrays of the (finished) last stage
+    double *f_val = W.S; uint32_t *f_orbs = W.kin;
+    hipLaunchKernelGGL((k_final_eval<NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
+    hipLaunchKernelGGL(k_final_compact, dim3(grid), dim3(FR_BLOCK), 0, st, W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
+    c->n_kernel_launch += 2;
+    FR_HIP(hipMemcpyAsync(&c->num_success, c->d_nsucc, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+}
+
+void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]) {
+    if (c->new_hb) hbpp_apply_t<true>(c, n_samp, rn, 0);
+    else hbpp_apply_t<false>(c, n_samp, rn, 0);
+}
+void fr_hbpp_apply_unit(FriesCtx *c, uint32_t n_samp, const double rn[5]) {
+    if (c->new_hb) hbpp_apply_t<true>(c, n_samp, rn, 1);
+    else hbpp_apply_t<false>(c, n_samp, rn, 1);
+}

@@ -1,0 +1,384 @@
+// Device-resident DistVec: open-addressed determinant hash, deterministic annihilating merge,
+// ordered deletion.  Reference behaviour being reproduced: FRIES/vec_utils.hpp:418-476,
+// 606-641 (add / add_elements / del_at_pos) and FRIES/det_hash.hpp:60-147.
+//
+// Ordering contract (vec_utils.hpp:618-626): a determinant that enters the vector takes the
+// most recently freed position if any (LIFO stack), else the next position at the end, and
+// determinants enter in the order their first initiator spawn arrives.  Values accumulate in
+// arrival order.  Both orders are reproduced exactly: first-arrival ranks come from an
+// atomicMin on the new hash slot plus a prefix sum, and accumulation runs over a stable
+// radix sort of (position, pass) keys so each position sums its contributions sequentially.
+#include "ctx.hpp"
+
+// ------------------------------------------------------------------ allocation / state
+void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
+    v->cap = cap;
+    uint32_t h = 1024;
+    while (h < 2u * cap + 1024u) h <<= 1;
+    v->hcap = h;
+    v->dets = fr_alloc<det_t>(cap); v->v0 = fr_alloc<double>(cap); v->v1 = fr_alloc<double>(cap);
+    v->diag = fr_alloc<double>(cap); v->active = fr_alloc<uint8_t>(cap); v->free_stack = fr_alloc<uint32_t>(cap);
+    v->hkeys = fr_alloc<det_t>(h); v->hvals = fr_alloc<uint32_t>(h);
+    v->st = fr_alloc<VecState>(1);
+    FR_HIP(hipMemsetAsync(v->dets, 0, sizeof(det_t) * cap, c->stream));
+    FR_HIP(hipMemsetAsync(v->v0, 0, 8 * (size_t)cap, c->stream));
+    FR_HIP(hipMemsetAsync(v->v1, 0, 8 * (size_t)cap, c->stream));
+    FR_HIP(hipMemsetAsync(v->diag, 0xff, 8 * (size_t)cap, c->stream));     // all-ones = NaN
+    FR_HIP(hipMemsetAsync(v->active, 0, cap, c->stream));
+    FR_HIP(hipMemsetAsync(v->hkeys, 0, sizeof(det_t) * h, c->stream));
+    FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)h, c->stream));
+    FR_HIP(hipMemsetAsync(v->st, 0, sizeof(VecState), c->stream));
+}
+
+void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out) {
+    FR_HIP(hipMemcpyAsync(out, v->st, sizeof(VecState), hipMemcpyDeviceToHost, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));
+}
+
+void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
+    SpawnBuf &s = c->sp;
+    s.cap = cap;
+    s.det = fr_alloc<det_t>(cap); s.val = fr_alloc<double>(cap); s.ini = fr_alloc<uint8_t>(cap);
+    s.slot = fr_alloc<uint32_t>(cap); s.flag = fr_alloc<uint32_t>(cap);
+    for (int h = 0; h < 2; h++) { s.key[h] = fr_alloc<uint32_t>(cap); s.pay[h] = fr_alloc<uint32_t>(cap); }
+    s.hist = fr_alloc<uint32_t>((size_t)256 * FR_MAX_PART + 256);
+    s.pcnt = fr_alloc<uint32_t>(FR_MAX_PART);
+    s.n_spawn = fr_alloc<uint32_t>(1);
+    FR_HIP(hipMemsetAsync(s.n_spawn, 0, 4, c->stream));
+}
+
+// ------------------------------------------------------------------ merge kernels
+// M1: look every spawn up; initiator spawns claim a slot for unseen determinants.
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec) {
+    const uint32_t n = *S.n_spawn;
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    det_t d = S.det[j];
+    bool ini = S.ini[j];
+    if ((uint32_t)__popcll(d) != n_elec) { atomicOr(&V.st->err, FR_ERR_NELEC); S.slot[j] = FR_NOPOS; return; }
+    uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS;
+    bool created = false;
+    for (uint32_t probe = 0; probe < V.hcap; probe++) {
+        det_t k = V.hkeys[s];
+        if (k == d) { found = s; break; }
+        if (k == FR_EMPTY_KEY) {
+            if (!ini) break;
+            det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
+            if (old == FR_EMPTY_KEY) { found = s; created = true; break; }
+            if (old == d) { found = s; break; }
+            // another determinant took the slot: keep probing from the next one
+        }
+        s = (s + 1) & (V.hcap - 1);
+    }
+    if (created) atomicAdd(&V.st->n_used, 1u);
+    if (found == FR_NOPOS) {
+        if (ini) atomicOr(&V.st->err, FR_ERR_HASH_FULL);
+        S.slot[j] = FR_NOPOS;
+        return;
+    }
+    uint32_t hv = V.hvals[found];
+    if (ini) {
+        if (hv & FR_NEWBIT) atomicMin(&V.hvals[found], FR_NEWBIT | j);   // being created in this merge
+        S.slot[j] = found;
+    }
+    else {
+        // non-initiator spawns only reach determinants that were present before this merge and are
+        // non-zero in the origin column (vec_utils.hpp:617, 632-637)
+        if ((hv & FR_NEWBIT) || V.v0[hv] == 0) S.slot[j] = FR_NOPOS;
+        else { S.slot[j] = found; atomicAdd(&V.st->nonini_occ_add, 1ull); }
+    }
+}
+
+// M2: flag the first arrival of every new determinant
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_first(VecDev V, SpawnBuf S) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = *S.n_spawn;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t j = base + it;
+        if (j >= n) break;
+        uint32_t s = S.slot[j], f = 0;
+        if (s != FR_NOPOS && S.ini[j] && V.hvals[s] == (FR_NEWBIT | (uint32_t)j)) f = 1;
+        S.flag[j] = f; cnt += f;
+    }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) S.pcnt[blockIdx.x] = bc;
+}
+
+// M3: rank -> position (free stack top first, then append), initialise the new entries
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_assign(VecDev V, SpawnBuf S) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = *S.n_spawn;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += S.pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    const uint32_t n_free = V.st->n_free, curr = V.st->curr_size;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t f[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { size_t j = base + it; f[it] = j < n ? S.flag[j] : 0; tsum += f[it]; }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t r = off + incl - tsum;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t j = base + it;
+        if (!f[it]) continue;
+        uint32_t pos = r < n_free ? V.free_stack[n_free - 1 - r] : curr + (r - n_free);
+        r++;
+        if (pos >= V.cap) { atomicOr(&V.st->err, FR_ERR_CAP); continue; }
+        V.dets[pos] = S.det[j]; V.v0[pos] = 0; V.v1[pos] = 0;
+        V.diag[pos] = __longlong_as_double(-1ll);     // NaN: diagonal element not cached yet
+        V.active[pos] = 1;
+        V.hvals[S.slot[j]] = pos;
+    }
+}
+
+// M4: sort keys (position, pass) and the vector's bookkeeping
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_resolve(VecDev V, SpawnBuf S, uint32_t *key, uint32_t *pay, uint32_t drop_key) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = *S.n_spawn;
+    if (blockIdx.x == 0) {
+        const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+        uint32_t n_new = fr_sum_partials_u32(S.pcnt, nblk, shu);
+        if (threadIdx.x == 0) {
+            VecState *st = V.st;
+            uint32_t from_stack = n_new < st->n_free ? n_new : st->n_free;
+            st->n_free -= from_stack;
+            st->curr_size += n_new - from_stack;
+            st->n_nonz += (int32_t)n_new;
+            if (st->curr_size > V.cap) st->err |= FR_ERR_CAP;
+        }
+    }
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t s = S.slot[j];
+    uint32_t k = drop_key;
+    if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) k = (pos << 1) | (S.ini[j] ? 1u : 0u); }
+    key[j] = k; pay[j] = j;
+}
+
+// ------------------------------------------------------------------ stable LSD radix sort, 8-bit digits
+__global__ void __launch_bounds__(FR_BLOCK) k_rs_hist(const uint32_t *key, const uint32_t *n_ptr, uint32_t *hist, int shift, uint32_t nblk_alloc) {
+    __shared__ uint32_t h[256];
+    const uint32_t n = *n_ptr;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * FR_TILE;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t j = base + it * FR_BLOCK + threadIdx.x;
+        if (j < n) atomicAdd(&h[(key[j] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk_alloc + blockIdx.x] = h[threadIdx.x];
+}
+
+// one block per digit: exclusive scan of that digit's counts over the tiles; total -> hist tail
+__global__ void __launch_bounds__(FR_BLOCK) k_rs_scan(const uint32_t *n_ptr, uint32_t *hist, uint32_t nblk_alloc) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = *n_ptr;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk_alloc;
+    uint32_t carry = 0;
+    for (unsigned b0 = 0; b0 < nblk; b0 += FR_BLOCK) {
+        unsigned b = b0 + threadIdx.x;
+        uint32_t x = b < nblk ? row[b] : 0, tot;
+        uint32_t incl = fr_block_scan_u32(x, shu, &tot);
+        if (b < nblk) row[b] = carry + incl - x;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) hist[(size_t)256 * nblk_alloc + blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_rs_scatter(const uint32_t *key, const uint32_t *pay, uint32_t *key_out, uint32_t *pay_out,
+                                                         const uint32_t *n_ptr, const uint32_t *hist, int shift, uint32_t nblk_alloc) {
+    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t shu[4];
+    const uint32_t n = *n_ptr;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    const int lane = fr_lane(), w = threadIdx.x >> 6;
+    for (int q = 0; q < 4; q++) wcount[q][threadIdx.x] = 0;
+    {   // digit bases: exclusive scan of the 256 totals + this tile's offset within the digit
+        uint32_t t = hist[(size_t)256 * nblk_alloc + threadIdx.x], tot;
+        uint32_t incl = fr_block_scan_u32(t, shu, &tot);
+        gbase[threadIdx.x] = incl - t + hist[(size_t)threadIdx.x * nblk_alloc + blockIdx.x];
+    }
+    __syncthreads();
+    // each wave owns 256 consecutive keys, visited as 4 rounds of 64 consecutive keys
+    size_t wbase = (size_t)blockIdx.x * FR_TILE + (size_t)w * 256;
+    uint32_t kk[4], pp[4], rk[4];
+    for (int r = 0; r < 4; r++) {
+        size_t j = wbase + r * 64 + lane;
+        bool ok = j < n;
+        kk[r] = ok ? key[j] : 0xFFFFFFFFu; pp[r] = ok ? pay[j] : 0;
+        uint32_t dg = (kk[r] >> shift) & 255u;
+        unsigned long long m = __ballot(ok);
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((dg >> b) & 1u);
+            m &= ((dg >> b) & 1u) ? bal : ~bal;
+        }
+        if (!ok) m = 0;
+        uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+        uint32_t prev = ok ? wcount[w][dg] : 0;
+        rk[r] = prev + before;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && before == 0) wcount[w][dg] = prev + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // cross-wave exclusive prefix per digit (thread d handles digit d)
+    {
+        uint32_t a0 = wcount[0][threadIdx.x], a1 = wcount[1][threadIdx.x], a2 = wcount[2][threadIdx.x];
+        __syncthreads();
+        wcount[0][threadIdx.x] = 0; wcount[1][threadIdx.x] = a0; wcount[2][threadIdx.x] = a0 + a1; wcount[3][threadIdx.x] = a0 + a1 + a2;
+    }
+    __syncthreads();
+    for (int r = 0; r < 4; r++) {
+        size_t j = wbase + r * 64 + lane;
+        if (j < n) {
+            uint32_t dg = (kk[r] >> shift) & 255u;
+            uint32_t o = gbase[dg] + wcount[w][dg] + rk[r];
+            key_out[o] = kk[r]; pay_out[o] = pp[r];
+        }
+    }
+}
+
+// M6: each position sums its contributions sequentially in (pass, arrival) order
+__global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, const uint32_t *key, const uint32_t *pay, uint32_t drop_key) {
+    const uint32_t n = *S.n_spawn;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t k = key[t];
+    if (k == drop_key) return;
+    uint32_t pos = k >> 1;
+    if (t > 0 && (key[t - 1] >> 1) == pos) return;
+    double acc = V.v1[pos];
+    for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) acc += S.val[pay[u]];
+    V.v1[pos] = acc;
+}
+
+static int bits_for(uint32_t x) { int b = 0; while ((1ull << b) <= x) b++; return b; }
+
+// Adds the spawn list (c->sp, length *sp.n_spawn <= n_bound) to column 1 of the vector with
+// the reference's two-pass initiator rule relative to column 0.
+void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool) {
+    if (n_bound == 0) return;
+    SpawnBuf &S = c->sp;
+    hipStream_t st = c->stream;
+    if (n_bound > S.cap) throw FriesError("spawn list exceeds spawn buffer capacity");
+    unsigned g1 = fr_blocks(n_bound, FR_BLOCK), gt = fr_blocks(n_bound, FR_TILE);
+    uint32_t nblk_alloc = FR_MAX_PART;
+    int nbits = bits_for(2u * v->cap + 1u);
+    uint32_t drop_key = (nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
+    hipLaunchKernelGGL(k_spawn_lookup, dim3(g1), dim3(FR_BLOCK), 0, st, *v, S, c->n_elec);
+    hipLaunchKernelGGL(k_spawn_first, dim3(gt), dim3(FR_BLOCK), 0, st, *v, S);
+    hipLaunchKernelGGL(k_spawn_assign, dim3(gt), dim3(FR_BLOCK), 0, st, *v, S);
+    hipLaunchKernelGGL(k_spawn_resolve, dim3(g1), dim3(FR_BLOCK), 0, st, *v, S, S.key[0], S.pay[0], drop_key);
+    c->n_kernel_launch += 4;
+    int src = 0;
+    for (int shift = 0; shift < nbits; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(gt), dim3(FR_BLOCK), 0, st, S.key[src], S.n_spawn, S.hist, shift, nblk_alloc);
+        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(FR_BLOCK), 0, st, S.n_spawn, S.hist, nblk_alloc);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(gt), dim3(FR_BLOCK), 0, st, S.key[src], S.pay[src], S.key[src ^ 1], S.pay[src ^ 1], S.n_spawn, S.hist, shift, nblk_alloc);
+        c->n_kernel_launch += 3;
+        src ^= 1;
+    }
+    hipLaunchKernelGGL(k_seg_sum, dim3(g1), dim3(FR_BLOCK), 0, st, *v, S, S.key[src], S.pay[src], drop_key);
+    c->n_kernel_launch++;
+}
+
+// ------------------------------------------------------------------ deletion (vec_utils.hpp:458-476)
+__global__ void __launch_bounds__(FR_BLOCK) k_del_count(VecDev V, const uint8_t *flags, uint32_t *pcnt) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i < n && flags[i] && V.active[i] && V.v0[i] == 0 && V.v1[i] == 0) cnt++;
+    }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) pcnt[blockIdx.x] = bc;
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_del_apply(VecDev V, uint8_t *flags, const uint32_t *pcnt) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    const uint32_t n_free = V.st->n_free;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t f[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        f[it] = (i < n && flags[i] && V.active[i] && V.v0[i] == 0 && V.v1[i] == 0) ? 1u : 0u;
+        if (i < n) flags[i] = 0;
+        tsum += f[it];
+    }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t r = off + incl - tsum;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (!f[it]) continue;
+        V.free_stack[n_free + r] = (uint32_t)i;      // ascending positions: the highest ends on top
+        r++;
+        V.active[i] = 0;
+        uint32_t s = fr_hash_find(V, V.dets[i]);
+        if (s != FR_NOPOS) { V.hkeys[s] = FR_TOMB_KEY; V.hvals[s] = FR_NOPOS; }
+    }
+}
+__global__ void k_del_finish(VecDev V, const uint32_t *pcnt) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    uint32_t tot = fr_sum_partials_u32(pcnt, nblk, shu);
+    if (threadIdx.x == 0) { V.st->n_free += tot; V.st->n_nonz -= (int32_t)tot; V.st->n_tomb += tot; }
+}
+
+void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n_bound) {
+    if (n_bound == 0) return;
+    unsigned gt = fr_blocks(n_bound, FR_TILE);
+    hipLaunchKernelGGL(k_del_count, dim3(gt), dim3(FR_BLOCK), 0, c->stream, *v, d_flags, c->sp.pcnt);
+    hipLaunchKernelGGL(k_del_apply, dim3(gt), dim3(FR_BLOCK), 0, c->stream, *v, (uint8_t *)d_flags, c->sp.pcnt);
+    hipLaunchKernelGGL(k_del_finish, dim3(1), dim3(FR_BLOCK), 0, c->stream, *v, c->sp.pcnt);
+    c->n_kernel_launch += 3;
+}
+
+// ------------------------------------------------------------------ tombstone cleanup
+__global__ void k_hash_reinsert(VecDev V) {
+    const uint32_t n = V.st->curr_size;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { V.st->n_tomb = 0; V.st->n_used = (uint32_t)V.st->n_nonz; }
+    if (i >= n || !V.active[i]) return;
+    det_t d = V.dets[i];
+    uint32_t s = fr_hash_slot(d, V.hcap);
+    for (uint32_t probe = 0; probe < V.hcap; probe++) {
+        det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
+        if (old == FR_EMPTY_KEY) { V.hvals[s] = i; return; }
+        s = (s + 1) & (V.hcap - 1);
+    }
+    atomicOr(&V.st->err, FR_ERR_HASH_FULL);
+}
+
+void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v) {
+    // host copy of the state must be current
+    if ((uint64_t)c->h_vst.n_used * 10 < (uint64_t)v->hcap * 6) return;
+    FR_HIP(hipMemsetAsync(v->hkeys, 0, sizeof(det_t) * v->hcap, c->stream));
+    FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)v->hcap, c->stream));
+    hipLaunchKernelGGL(k_hash_reinsert, dim3(fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK)), dim3(FR_BLOCK), 0, c->stream, *v);
+    c->n_kernel_launch++;
+}

@@ -1,0 +1,218 @@
+"""Host-side mirror of the reference's driver surface over the C ABI (include/fries_hip.h).
+
+``FriEngine`` plays the role of frisys_mol's ``main`` (FRIES_bin/frisys_mol.cpp): it owns a
+context, hands it the parsed FCIDUMP, and runs the iteration loop on the MI355X.  There is no
+CPU path: importing works anywhere, creating an engine without libfries_hip.so or without a
+HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfries_hip.so")
+
+# every symbol include/fries_hip.h declares
+EXPORTS = [
+    "fries_last_error", "fries_device_count", "fries_ctx_create", "fries_ctx_destroy", "fries_set_molecule",
+    "fries_get_hb_tensor", "fries_set_hb_tensor", "fries_hf_energy", "fries_matrel_batch", "fries_frisys_setup",
+    "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
+    "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
+    "fries_test_teeth",
+]
+
+
+class FrisysParams(C.Structure):
+    _fields_ = [("epsilon", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double),
+                ("vec_nonz", C.c_uint32), ("mat_nonz", C.c_uint32), ("max_dets", C.c_uint32),
+                ("seed", C.c_uint32), ("hb_unnorm", C.c_int32)]
+
+
+class IterLog(C.Structure):
+    _fields_ = [("numer", C.c_double), ("denom", C.c_double), ("shift", C.c_double), ("norm", C.c_double),
+                ("nkept", C.c_uint32), ("n_nonz", C.c_int32), ("curr_size", C.c_uint32), ("num_success", C.c_uint32),
+                ("comp_len", C.c_uint32 * 5), ("err", C.c_uint32)]
+
+
+ITERLOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("norm", "f8"), ("nkept", "u4"), ("n_nonz", "i4"),
+                          ("curr_size", "u4"), ("num_success", "u4"), ("comp_len", "u4", (5,)), ("err", "u4")], align=True)
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libfries_hip.so; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                           "The FRI engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.fries_last_error.restype = C.c_char_p
+    lib.fries_hf_energy.restype = C.c_double
+    lib.fries_p_doub.restype = C.c_double
+    lib.fries_kernel_launches.restype = C.c_uint64
+    lib.fries_ctx_destroy.restype = None
+    for name in ("fries_hf_energy", "fries_p_doub", "fries_kernel_launches", "fries_ctx_destroy"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.fries_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.fries_set_molecule.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fries_get_hb_tensor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fries_set_hb_tensor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.fries_matrel_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.fries_frisys_setup.argtypes = [C.c_void_p, C.POINTER(FrisysParams)]
+    lib.fries_frisys_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.fries_vec_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    lib.fries_vec_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fries_htrial_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fries_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_vec_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_apply_hbpp_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t), C.c_void_p]
+    lib.fries_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.fries_test_teeth.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class FriEngine:
+    """One MI355X running the FRI iteration for one molecular Hamiltonian."""
+
+    def __init__(self, mol, device: int = 0):
+        self.lib = load_library()
+        if self.lib.fries_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: the FRI engine runs on MI355X only (no CPU fallback)")
+        self.h = C.c_void_p()
+        self._ck(self.lib.fries_ctx_create(C.byref(self.h), device))
+        self.mol = mol
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self._ck(self.lib.fries_set_molecule(self.h, mol.n_orb, mol.n_elec, _ptr(irr), _ptr(hc), _ptr(er)))
+        self.max_dets = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.fries_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.fries_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- molecule
+    @property
+    def hf_energy(self) -> float:
+        return self.lib.fries_hf_energy(self.h)
+
+    @property
+    def p_doub(self) -> float:
+        return self.lib.fries_p_doub(self.h)
+
+    @property
+    def kernel_launches(self) -> int:
+        return int(self.lib.fries_kernel_launches(self.h))
+
+    def hb_tensor(self, which: int) -> np.ndarray:
+        n = self.mol.n_orb
+        out = np.zeros(max(n * n, 1))
+        ln = C.c_size_t()
+        self._ck(self.lib.fries_get_hb_tensor(self.h, which, _ptr(out), out.size, C.byref(ln)))
+        return out[:ln.value].copy()
+
+    def set_hb_tensor(self, which: int, arr) -> None:
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        self._ck(self.lib.fries_set_hb_tensor(self.h, which, _ptr(a), a.size))
+
+    def matrel(self, kind: int, dets, orbs=None):
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        o = np.ascontiguousarray(orbs, dtype=np.uint8) if orbs is not None else None
+        out = np.zeros(d.size)
+        sg = np.zeros(d.size, dtype=np.int32)
+        self._ck(self.lib.fries_matrel_batch(self.h, kind, _ptr(d), _ptr(o), d.size, _ptr(out), _ptr(sg)))
+        return out, sg
+
+    # ---- frisys_mol
+    def setup(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm"):
+        if distribution not in ("HB", "HB_unnorm"):
+            raise RuntimeError('"dist_str" argument must be either "HB" or "HB_unnorm"')
+        p = FrisysParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
+        self._ck(self.lib.fries_frisys_setup(self.h, C.byref(p)))
+        self.max_dets = max_dets
+
+    def iterate(self, n_iter: int, want_logs: bool = True):
+        logs = np.zeros(n_iter, dtype=ITERLOG_DTYPE) if want_logs else None
+        assert ITERLOG_DTYPE.itemsize == C.sizeof(IterLog)
+        self._ck(self.lib.fries_frisys_iterate(self.h, n_iter, _ptr(logs) if want_logs else None))
+        return logs
+
+    def vec_info(self):
+        a, b, c = C.c_uint32(), C.c_int32(), C.c_uint32()
+        self._ck(self.lib.fries_vec_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def vector(self):
+        n = self.vec_info()[0]
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        m = C.c_size_t()
+        self._ck(self.lib.fries_vec_download(self.h, _ptr(d), _ptr(v), d.size, C.byref(m)))
+        return d[:m.value], v[:m.value]
+
+    def htrial(self):
+        cap = 4 * self.mol.n_orb ** 2 * self.mol.n_elec ** 2 + 16
+        d = np.zeros(cap, dtype=np.uint64)
+        v = np.zeros(cap)
+        m = C.c_size_t()
+        self._ck(self.lib.fries_htrial_download(self.h, _ptr(d), _ptr(v), cap, C.byref(m)))
+        return d[:m.value].copy(), v[:m.value].copy()
+
+    def vec_add(self, dets, vals, ini):
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        f = np.ascontiguousarray(ini, dtype=np.uint8)
+        self._ck(self.lib.fries_vec_add(self.h, _ptr(d), _ptr(v), _ptr(f), d.size))
+
+    def vec_load(self, dets, vals):
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        self._ck(self.lib.fries_vec_load(self.h, _ptr(d), _ptr(v), d.size))
+
+    def apply_hbpp_sys(self, n_samp: int, rn, unit_matrel: bool = False):
+        rn = np.ascontiguousarray(rn, dtype=np.float64)
+        cap = n_samp + 4096
+        pos = np.zeros(cap, dtype=np.uint32)
+        orbs = np.zeros((cap, 4), dtype=np.uint8)
+        vals = np.zeros(cap)
+        m = C.c_size_t()
+        cl = np.zeros(5, dtype=np.uint32)
+        self._ck(self.lib.fries_apply_hbpp_sys(self.h, n_samp, _ptr(rn), int(unit_matrel), _ptr(pos), _ptr(orbs), _ptr(vals), cap, C.byref(m), _ptr(cl)))
+        k = m.value
+        return pos[:k].copy(), orbs[:k].copy(), vals[:k].copy(), cl
+
+    def compress_vec(self, n_samp: int, rn: float):
+        nk = C.c_uint32()
+        gn = C.c_double()
+        self._ck(self.lib.fries_compress_vec(self.h, n_samp, rn, C.byref(nk), C.byref(gn)))
+        return nk.value, gn.value
+
+    def test_teeth(self, r0: float, unit: float, n: int, queries):
+        q = np.ascontiguousarray(queries, dtype=np.float64)
+        pos = np.zeros(max(n, 1))
+        below = np.zeros(max(q.size, 1), dtype=np.uint32)
+        self._ck(self.lib.fries_test_teeth(self.h, r0, unit, n, _ptr(pos), _ptr(q), q.size, _ptr(below)))
+        return pos[:n], below[:q.size]

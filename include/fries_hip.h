@@ -1,0 +1,101 @@
+/* C ABI of the MI355X-native FRI engine (libfries_hip.so).
+ *
+ * The reference (sgreene8/FRIES) has no FFI: its hot path is C++ called in-process through the
+ * headers it installs under include/FRIES/.  Each entry point below names the reference
+ * interface it stands in for; the binding a FRIES maintainer would add is shown in
+ * INTEGRATION.md.  Conventions: plain pointers and sizes only, host buffers unless a name says
+ * "device"; every function returns 0 on success or a negative code, and fries_last_error()
+ * then holds the message (the reference throws std::runtime_error and prints it,
+ * FRIES_bin/frisys_mol.cpp:562-565).  A determinant is a uint64_t whose bit i is spin orbital i
+ * (alpha 0..n_orb-1, beta n_orb..2n_orb-1) -- the reference's little-endian byte string
+ * (FRIES/det_store.h:23-26) for 2*n_orb <= 64.
+ */
+#ifndef FRIES_HIP_H
+#define FRIES_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fries_ctx fries_ctx;
+
+const char *fries_last_error(void);
+/* number of HIP devices visible; 0 means the engine cannot run (there is no CPU fallback) */
+int fries_device_count(void);
+
+int fries_ctx_create(fries_ctx **out, int device);
+void fries_ctx_destroy(fries_ctx *ctx);
+
+/* parse_fcidump's result handed to the device: FRIES/io_utils.cpp:241-318 (fcidump_input),
+ * SymmERIs packing FRIES/ndarr.hpp:206-244, SymmInfo FRIES/Hamiltonians/molecule.hpp:265-280,
+ * plus set_up(tot_orb, n_orb, eris) FRIES/Hamiltonians/heat_bathPP.cpp:99-179. */
+int fries_set_molecule(fries_ctx *ctx, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps,
+                       const double *h_core, const double *eris_packed);
+
+/* hb_info accessors (FRIES/Hamiltonians/heat_bathPP.hpp:25-34).  which: 0 s_tens[n], 1 d_same[n(n-1)/2],
+ * 2 d_diff[n*n], 3 exch_sqrt[n(n-1)/2], 4 diag_sqrt[n], 5 exch_norms[n], 6 s_norm[1]. */
+int fries_get_hb_tensor(fries_ctx *ctx, int which, double *out, size_t cap, size_t *len);
+int fries_set_hb_tensor(fries_ctx *ctx, int which, const double *in, size_t len);
+double fries_hf_energy(fries_ctx *ctx);     /* diag_matrel of the HF determinant, frisys_mol.cpp:100 */
+
+/* Batched Slater-Condon elements (FRIES/Hamiltonians/molecule.cpp:983-1029, 76-105, 26-42) and
+ * fermionic signs (FRIES/fci_utils.c:46-96).  orbs: n x 4 bytes, (o1,o2,u1,u2) or (o,u,0,0).
+ * kind: 0 diag_matrel(det), 1 sing_matr_el_nosgn, 2 doub_matr_el_nosgn; sign receives
+ * sing_parity / doub_parity for kinds 1, 2. */
+int fries_matrel_batch(fries_ctx *ctx, int kind, const uint64_t *dets, const uint8_t *orbs, size_t n,
+                       double *out, int32_t *sign);
+
+/* frisys_mol's run parameters (FRIES_bin/frisys_mol.cpp:16-33) plus the seed the reference takes
+ * from the wall clock (:104-106). */
+typedef struct {
+    double epsilon, target_norm, initiator;
+    uint32_t vec_nonz, mat_nonz, max_dets;
+    uint32_t seed;
+    int32_t hb_unnorm;      /* 1: --distribution HB_unnorm, 0: HB */
+} fries_frisys_params;
+
+typedef struct {
+    double numer, denom;    /* projnum.txt / projden.txt */
+    double shift, norm;     /* S.txt / norm.txt */
+    uint32_t nkept;         /* nkept.txt */
+    int32_t n_nonz;
+    uint32_t curr_size;
+    uint32_t num_success;   /* comp_vecs.vec_len after apply_HBPP_sys */
+    uint32_t comp_len[5];
+    uint32_t err;
+} fries_iter_log;
+
+/* frisys_mol.cpp:76-346: scramblers, solution vector, HF trial vector and H*trial, p_doub, HF start */
+int fries_frisys_setup(fries_ctx *ctx, const fries_frisys_params *p);
+/* frisys_mol.cpp:405-552, n_iter times; logs may be NULL or hold n_iter entries */
+int fries_frisys_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
+double fries_p_doub(fries_ctx *ctx);
+uint64_t fries_kernel_launches(fries_ctx *ctx);
+
+/* DistVec accessors (FRIES/vec_utils.hpp:506-535): positions [0, curr_size) incl. holes (value 0) */
+int fries_vec_info(fries_ctx *ctx, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free);
+int fries_vec_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
+/* DistVec::add + perform_add(0) into column 0 with one rank (vec_utils.hpp:418-440, 606-641) */
+int fries_vec_add(fries_ctx *ctx, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n);
+/* replaces the stored vector: determinants land in positions 0..n-1 (DistVec::load, vec_utils.hpp:761-844) */
+int fries_vec_load(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n);
+int fries_htrial_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
+
+/* The hot-path operators one by one, on the context's solution vector. */
+/* apply_HBPP_sys (heat_bathPP.cpp:686-992) with the five uniforms it would draw; outputs as
+ * comp_vecs.{det_indices2, orb_indices1, vec1}.  unit_matrel != 0 uses the |value| = 1 lambdas of
+ * tests/test_hamiltonian.cpp:493-500. */
+int fries_apply_hbpp_sys(fries_ctx *ctx, uint32_t n_samp, const double rn[5], int unit_matrel,
+                         uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out, uint32_t comp_len[5]);
+/* find_preserve + sys_comp on column 0 (compress_utils.cpp:29-105, 283-327) followed by the deletes
+ * of frisys_mol.cpp:534-539 */
+int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_kept, double *glob_norm);
+
+/* test hook: positions of the first n comb teeth built from (r0, unit) -- see csrc/teeth.hpp */
+int fries_test_teeth(fries_ctx *ctx, double r0, double unit, uint32_t n, double *out_pos, const double *query, uint32_t nq, uint32_t *out_below);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

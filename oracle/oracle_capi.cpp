@@ -1,1 +1,145 @@
-// placeholder
+// TEST INFRASTRUCTURE ONLY -- flat C entry points onto the CPU oracle for ctypes
+// (tests/, bench.py's cpu_baseline leg, __graft_entry__.smoke()).
+#include "fries_oracle.hpp"
+#include <cstring>
+#include <cmath>
+#include <memory>
+
+using namespace fo;
+
+struct OracleLog { double numer, denom, shift, norm; uint32_t nkept; int32_t n_nonz; uint32_t curr_size, num_success; uint32_t comp_len[5]; uint32_t err; };
+
+extern "C" {
+
+void *fo_frisys_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                       double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm) {
+    Frisys *f = new Frisys();
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.target_norm = target; f->par.init_thresh = init;
+    f->par.vec_nonz = vec_nonz; f->par.mat_nonz = mat_nonz; f->par.max_dets = max_dets;
+    f->par.new_hb = hb_unnorm != 0; f->par.seed = seed;
+    f->setup();
+    return f;
+}
+void fo_frisys_destroy(void *h) { delete (Frisys *)h; }
+void fo_frisys_iterate(void *h, uint32_t n, OracleLog *logs) {
+    Frisys *f = (Frisys *)h;
+    for (uint32_t i = 0; i < n; i++) {
+        f->iterate(1);
+        if (logs) {
+            const IterLog &l = f->log.back();
+            OracleLog &o = logs[i];
+            o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.nkept = l.nkept;
+            o.n_nonz = l.n_nonz; o.curr_size = (uint32_t)l.curr_size; o.num_success = (uint32_t)l.num_success;
+            for (int k = 0; k < 5; k++) o.comp_len[k] = 0;
+            o.err = 0;
+        }
+    }
+}
+double fo_frisys_p_doub(void *h) { return ((Frisys *)h)->p_doub; }
+double fo_frisys_hf_en(void *h) { return ((Frisys *)h)->sys.hf_en; }
+size_t fo_frisys_vec(void *h, uint64_t *dets, double *vals, size_t cap) {
+    Frisys *f = (Frisys *)h;
+    size_t n = f->sol.curr_size;
+    if (dets && vals && cap >= n) for (size_t i = 0; i < n; i++) { dets[i] = f->sol.dets[i]; vals[i] = f->sol.vals[0][i]; }
+    return n;
+}
+size_t fo_frisys_htrial(void *h, uint64_t *dets, double *vals, size_t cap) {
+    Frisys *f = (Frisys *)h;
+    size_t n = f->htrial_det.size();
+    if (dets && vals && cap >= n) for (size_t i = 0; i < n; i++) { dets[i] = f->htrial_det[i]; vals[i] = f->htrial_val[i]; }
+    return n;
+}
+// replace the stored vector (positions 0..n-1), as DistVec::load would
+void fo_frisys_load(void *h, const uint64_t *dets, const double *vals, size_t n) {
+    Frisys *f = (Frisys *)h;
+    Vec &v = f->sol;
+    size_t cap = v.max_size, ac = v.adder_cap;
+    v.init(cap, ac, f->sys.n_elec, 2);
+    uint8_t tmp[64];
+    for (size_t i = 0; i < n; i++) {
+        v.dets[i] = dets[i]; v.vals[0][i] = vals[i]; v.active[i] = 1; v.table[dets[i]] = (ptrdiff_t)i;
+        occ_list(dets[i], tmp); memcpy(&v.occ[i * v.n_elec], tmp, v.n_elec);
+    }
+    v.curr_size = n; v.n_nonz = (int)n;
+}
+size_t fo_hb_tensor(void *h, int which, double *out, size_t cap) {
+    Frisys *f = (Frisys *)h;
+    const HBInfo &t = f->sys.hb;
+    const std::vector<double> *src = nullptr;
+    switch (which) {
+        case 0: src = &t.s_tens; break; case 1: src = &t.d_same; break; case 2: src = &t.d_diff; break;
+        case 3: src = &t.exch_sqrt; break; case 4: src = &t.diag_sqrt; break; case 5: src = &t.exch_norms; break;
+        case 6: if (cap >= 1) out[0] = t.s_norm; return 1;
+    }
+    if (!src) return 0;
+    if (cap >= src->size()) memcpy(out, src->data(), 8 * src->size());
+    return src->size();
+}
+void fo_set_hb_tensor(void *h, int which, const double *in, size_t n) {
+    Frisys *f = (Frisys *)h;
+    HBInfo &t = f->sys.hb;
+    switch (which) {
+        case 0: t.s_tens.assign(in, in + n); break; case 1: t.d_same.assign(in, in + n); break; case 2: t.d_diff.assign(in, in + n); break;
+        case 3: t.exch_sqrt.assign(in, in + n); break; case 4: t.diag_sqrt.assign(in, in + n); break; case 5: t.exch_norms.assign(in, in + n); break;
+        case 6: t.s_norm = in[0]; break;
+    }
+}
+void fo_matrel_batch(void *h, int kind, const uint64_t *dets, const uint8_t *orbs, size_t n, double *out, int32_t *sign) {
+    Frisys *f = (Frisys *)h;
+    uint8_t occ[64];
+    for (size_t i = 0; i < n; i++) {
+        occ_list(dets[i], occ);
+        if (kind == 0) { out[i] = diag_matrel(occ, f->sys.ints, f->sys.n_elec); if (sign) sign[i] = 1; }
+        else if (kind == 1) { out[i] = sing_matrel_nosgn(orbs + 4 * i, occ, f->sys.ints, f->sys.n_elec); if (sign) sign[i] = sing_parity(dets[i], orbs + 4 * i); }
+        else { out[i] = doub_matrel_nosgn(orbs + 4 * i, f->sys.ints); if (sign) sign[i] = doub_parity(dets[i], orbs + 4 * i); }
+    }
+}
+// apply_HBPP_sys on the handle's stored vector
+size_t fo_apply_hbpp_sys(void *h, uint32_t n_samp, const double *rn, int unit_matrel, uint32_t *pos, uint8_t *orbs, double *vals, size_t cap) {
+    Frisys *f = (Frisys *)h;
+    HBScratch &sc = f->sc;
+    size_t need = f->sol.curr_size > (size_t)n_samp * 4 ? f->sol.curr_size : (size_t)n_samp * 4;
+    if (sc.len < need) { size_t ns = f->sys.n_elec > (f->sys.n_orb - f->sys.n_elec / 2) ? f->sys.n_elec : f->sys.n_orb - f->sys.n_elec / 2; sc.init(need, ns); }
+    std::copy(f->sol.vals[0].begin(), f->sol.vals[0].begin() + f->sol.curr_size, sc.vec1.begin());
+    for (size_t i = 0; i < f->sol.curr_size; i++) sc.det_idx1[i] = i;
+    sc.vec_len = f->sol.curr_size;
+    apply_HBPP_sys(f->sol, sc, f->sys, f->p_doub, f->par.new_hb, rn, n_samp, unit_matrel != 0);
+    size_t n = sc.vec_len;
+    if (cap >= n) for (size_t i = 0; i < n; i++) { pos[i] = (uint32_t)sc.det_idx2[i]; memcpy(orbs + 4 * i, &sc.orb1[4 * i], 4); vals[i] = sc.vec1[i]; }
+    return n;
+}
+void fo_set_p_doub(void *h, double p) { ((Frisys *)h)->p_doub = p; }
+// find_preserve + sys_comp + deletes on the handle's stored vector
+void fo_compress_vec(void *h, uint32_t n_samp, double rn, uint32_t *n_kept, double *glob_norm) {
+    Frisys *f = (Frisys *)h;
+    Vec &v = f->sol;
+    if (f->srt.size() < v.max_size) { f->srt.resize(v.max_size); f->keep.resize(v.max_size, 0); }
+    unsigned ns = n_samp;
+    double gn;
+    double ln = find_preserve(v.vals[0].data(), f->srt, f->keep, v.curr_size, &ns, &gn);
+    sys_comp(v.vals[0].data(), v.curr_size, ln, ns, f->keep, rn);
+    for (size_t i = 0; i < v.curr_size; i++) if (f->keep[i]) { v.del_at_pos(i); f->keep[i] = 0; }
+    if (n_kept) *n_kept = n_samp - ns;
+    if (glob_norm) *glob_norm = gn;
+}
+// DistVec::add x n + perform_add(0) on the handle's stored vector (column 0)
+void fo_vec_add(void *h, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n) {
+    Frisys *f = (Frisys *)h;
+    Vec &v = f->sol;
+    v.cur = 0;
+    for (size_t i = 0; i < n; i++) v.add(dets[i], vals[i], ini[i]);
+    v.perform_add(0);
+}
+int fo_vec_info(void *h, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free) {
+    Frisys *f = (Frisys *)h;
+    *curr_size = (uint32_t)f->sol.curr_size; *n_nonz = f->sol.n_nonz; *n_free = (uint32_t)f->sol.free_stack.size();
+    return 0;
+}
+uint64_t fo_hash(const uint8_t *occ, uint32_t n_elec, const uint32_t *scr) { return hash_fxn(occ, n_elec, scr); }
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/libfries_oracle.so).  Test infrastructure
+only: nothing under fries_amd/ may import this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libfries_oracle.so")
+
+LOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("norm", "f8"), ("nkept", "u4"), ("n_nonz", "i4"),
+                      ("curr_size", "u4"), ("num_success", "u4"), ("comp_len", "u4", (5,)), ("err", "u4")], align=True)
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, capture_output=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        lib.fo_frisys_create.restype = C.c_void_p
+        lib.fo_frisys_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        lib.fo_frisys_destroy.argtypes = [C.c_void_p]
+        lib.fo_frisys_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_frisys_p_doub.restype = C.c_double
+        lib.fo_frisys_p_doub.argtypes = [C.c_void_p]
+        lib.fo_frisys_hf_en.restype = C.c_double
+        lib.fo_frisys_hf_en.argtypes = [C.c_void_p]
+        for nm in ("fo_frisys_vec", "fo_frisys_htrial"):
+            getattr(lib, nm).restype = C.c_size_t
+            getattr(lib, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_frisys_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_hb_tensor.restype = C.c_size_t
+        lib.fo_hb_tensor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.fo_set_hb_tensor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.fo_matrel_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.fo_apply_hbpp_sys.restype = C.c_size_t
+        lib.fo_apply_hbpp_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_set_p_doub.argtypes = [C.c_void_p, C.c_double]
+        lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_vec_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        lib.fo_hash.restype = C.c_uint64
+        lib.fo_hash.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleFrisys:
+    """fo::Frisys -- the sequential CPU restatement of frisys_mol (one rank)."""
+
+    def __init__(self, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm"):
+        self.lib = load()
+        self.mol = mol
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.h = self.lib.fo_frisys_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, initiator,
+                                           vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
+        self.max_dets = max_dets
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.fo_frisys_destroy(self.h)
+            self.h = None
+
+    def iterate(self, n):
+        logs = np.zeros(n, dtype=LOG_DTYPE)
+        self.lib.fo_frisys_iterate(self.h, n, _p(logs))
+        return logs
+
+    @property
+    def p_doub(self):
+        return self.lib.fo_frisys_p_doub(self.h)
+
+    @property
+    def hf_energy(self):
+        return self.lib.fo_frisys_hf_en(self.h)
+
+    def vector(self):
+        n = self.lib.fo_frisys_vec(self.h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_frisys_vec(self.h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
+
+    def htrial(self):
+        n = self.lib.fo_frisys_htrial(self.h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_frisys_htrial(self.h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
+
+    def vec_load(self, dets, vals):
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        self.lib.fo_frisys_load(self.h, _p(d), _p(v), d.size)
+
+    def vec_add(self, dets, vals, ini):
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        f = np.ascontiguousarray(ini, dtype=np.uint8)
+        self.lib.fo_vec_add(self.h, _p(d), _p(v), _p(f), d.size)
+
+    def vec_info(self):
+        a, b, c = C.c_uint32(), C.c_int32(), C.c_uint32()
+        self.lib.fo_vec_info(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def hb_tensor(self, which):
+        out = np.zeros(self.mol.n_orb ** 2 + 1)
+        n = self.lib.fo_hb_tensor(self.h, which, _p(out), out.size)
+        return out[:n].copy()
+
+    def set_hb_tensor(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        self.lib.fo_set_hb_tensor(self.h, which, _p(a), a.size)
+
+    def set_p_doub(self, p):
+        self.lib.fo_set_p_doub(self.h, p)
+
+    def matrel(self, kind, dets, orbs=None):
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        o = np.ascontiguousarray(orbs, dtype=np.uint8) if orbs is not None else None
+        out = np.zeros(d.size)
+        sg = np.zeros(d.size, dtype=np.int32)
+        self.lib.fo_matrel_batch(self.h, kind, _p(d), _p(o), d.size, _p(out), _p(sg))
+        return out, sg
+
+    def apply_hbpp_sys(self, n_samp, rn, unit_matrel=False):
+        rn = np.ascontiguousarray(rn, dtype=np.float64)
+        cap = 4 * n_samp + 4096
+        pos = np.zeros(cap, dtype=np.uint32)
+        orbs = np.zeros((cap, 4), dtype=np.uint8)
+        vals = np.zeros(cap)
+        n = self.lib.fo_apply_hbpp_sys(self.h, n_samp, _p(rn), int(unit_matrel), _p(pos), _p(orbs), _p(vals), cap)
+        return pos[:n].copy(), orbs[:n].copy(), vals[:n].copy()
+
+    def compress_vec(self, n_samp, rn):
+        nk = C.c_uint32()
+        gn = C.c_double()
+        self.lib.fo_compress_vec(self.h, n_samp, rn, C.byref(nk), C.byref(gn))
+        return nk.value, gn.value
