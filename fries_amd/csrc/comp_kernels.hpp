@@ -20,6 +20,7 @@
 #include "fries_dev.hpp"
 #include "teeth.hpp"
 #include "hbpp_rows.hpp"
+#include "seqsum.hpp"
 
 #define FR_ITEMS 4
 #define FR_TILE (FR_BLOCK * FR_ITEMS)
@@ -70,6 +71,14 @@ struct CompWork {
     double *f_ws[2];              // sum of wt_remain after the sweep
     uint32_t *f_pk[2];            // per-workgroup partials of the above: [FR_FKS_PMAX][FR_MAX_PART]
     double *f_pg[2], *f_pw[2];
+    SeqWork seq;                  // exact in-order sum of wt_remain
+};
+
+// wt_remain of the current stage as the addend sequence of sys_sub's lbound (compress_utils.cpp:739)
+struct AccWt {
+    const double *wt; const CompState *st0;
+    __device__ unsigned count() const { return st0->n_in; }
+    __device__ double get(size_t i) const { return wt[i]; }
 };
 
 
@@ -326,24 +335,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_iter(CompWork W, VecDev V, con
     }
 }
 
-// per-tile sums of wt_remain in the association k_sys_count continues
-static __global__ void __launch_bounds__(FR_BLOCK) k_tile_sums(CompWork W) {
-    __shared__ double shd[12];
-    const unsigned n_in = W.state[0].n_in;
-    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
-    if (blockIdx.x >= nblk) return;
-    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
-    double sum = 0;
-    for (int it = 0; it < FR_ITEMS; it++) { size_t e = base + it; if (e < n_in) sum += W.wt_remain[e]; }
-    double bs;
-    fr_block_excl_f64(sum, shd, &bs);
-    if (threadIdx.x == 0) W.psum[0][blockIdx.x] = bs;
-}
-
-// ------------------------------------------------------------------ finalise + comb
 // One workgroup: find_keep_sub's epilogue (compress_utils.cpp:266-275), seed_sys and the comb.
-// The returned norm is the in-order sum of wt_remain, formed as the very chain of tile sums that
-// k_sys_count extends, so "norm" and "last lbound" are the same number as in the reference.
+// The returned norm is the exact in-order sum of wt_remain (seqsum.hpp), i.e. the last lbound.
 static __global__ void __launch_bounds__(FR_BLOCK) k_comp_finalize(CompWork W, int last_it, double rn, double lbound0, double norm_others_after, uint32_t *err) {
     __shared__ double s_totG[FR_FKS_PMAX], s_totW[FR_FKS_PMAX];
     __shared__ uint32_t s_totK[FR_FKS_PMAX];
@@ -368,10 +361,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_comp_finalize(CompWork W, i
     s.n_pass = fr_fks_passes(s_totG, s_totK, s_totW, s.G, s.n_rem, ps, &G, &n_rem);
     double loc_norm = 0;
     if (G / n_rem < 1e-8) n_rem = 0;
-    else {
-        const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
-        for (unsigned i = 0; i < nblk; i++) loc_norm += W.psum[0][i];
-    }
+    else loc_norm = *W.seq.total;
     s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
     double glob = lbound0 + loc_norm + norm_others_after;     // sum in rank order (seed_sys)
     double unit = 0, r0 = INFINITY;
@@ -436,13 +426,12 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const VecD
     return n;
 }
 
-// lbound prefix + per-element emission counts
+// exact lbound prefix + per-element emission counts
 template <int STAGE, bool NEW_HB>
 __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub) {
     __shared__ HbTables T;
-    __shared__ double shd[12];
+    __shared__ SeqShared seqsh;
     __shared__ uint32_t shu[4];
-    __shared__ double sh_start;
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
     const unsigned n_in = fin->n_in;
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
@@ -450,34 +439,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     if (STAGE != 1) fr_stage_tables(&T, Tg);
     const Teeth *th = W.teeth;
     const double unit = fin->unit;
-    // lbound entering this block: comb origin, then the earlier blocks' totals added one by one
-    // in block order (the same left-to-right chain every block walks, so neighbours agree)
-    if (threadIdx.x == 0) {
-        const double *ps = W.psum[fin->pbuf];
-        double st = th->lbound0;
-        for (unsigned i = 0; i < blockIdx.x; i++) st += ps[i];
-        sh_start = st;
-    }
-    __syncthreads();
-    const double start = sh_start;
+    AccWt acc{W.wt_remain, &W.state[0]};
+    double Sx[4], Sprev;
+    fr_seq_prefix4(W.seq, acc, blockIdx.x, &seqsh, Sx, &Sprev);
     size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
-    double loc[FR_ITEMS], tsum = 0;
-    const StageElems E = W.el[cur];
-#pragma unroll
-    for (int it = 0; it < FR_ITEMS; it++) {
-        size_t e = base + it;
-        double w = (e < n_in) ? W.wt_remain[e] : 0.0;
-        tsum += w; loc[it] = tsum;
-    }
-    double btot;
-    double texcl = fr_block_excl_f64(tsum, shd, &btot);
     uint32_t cnt_t = 0;
-    double Sprev = start + texcl;          // lbound after the previous thread's last element
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + it;
         if (e >= n_in) break;
-        double Se = start + (texcl + loc[it]);
+        double Se = Sx[it];
         uint32_t kin = (e == 0) ? 0u : fr_teeth_below(th, Sprev);
         uint32_t k = kin;
         uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e, Se, &k, unit, p_doub, 0);
@@ -490,7 +461,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
         Sprev = Se;
     }
     uint32_t bc = fr_block_sum_u32(cnt_t, shu);
-    if (threadIdx.x == 0) W.pcnt[fin->pbuf ^ 1][blockIdx.x] = bc;
+    if (threadIdx.x == 0) W.pcnt[1][blockIdx.x] = bc;
 }
 
 // Repairs the (rare) elements after which the reference's comb lags behind lbound: walk
@@ -517,7 +488,7 @@ __global__ void k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, d
             uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e2, W.S[e2], &k, fin->unit, p_doub, 0);
             uint32_t old = W.cnt[e2];
             W.kin[e2] = kin; W.cnt[e2] = c;
-            W.pcnt[fin->pbuf ^ 1][e2 / FR_TILE] += c - old;
+            W.pcnt[1][e2 / FR_TILE] += c - old;
             done_upto = e2 + 1;
             if (k == fr_teeth_below(th, W.S[e2])) break;
         }
@@ -534,7 +505,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     if (blockIdx.x >= nblk) return;
     if (STAGE != 1) fr_stage_tables(&T, Tg);
     const Teeth *th = W.teeth;
-    const uint32_t *pc = W.pcnt[fin->pbuf ^ 1];
+    const uint32_t *pc = W.pcnt[1];
     uint32_t off;
     {
         uint32_t x = 0;

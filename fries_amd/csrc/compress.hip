@@ -12,6 +12,8 @@ void fr_vcomp_alloc(FriesCtx *c, uint32_t cap) {
     B.teeth = fr_alloc<Teeth>(1);
     B.dots = fr_alloc<double>(2);
     B.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
+    B.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); B.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); B.seq.total = fr_alloc<double>(1);
+    B.gnorm = fr_alloc<double>(1);
     FR_HIP(hipMemsetAsync(B.keep, 0, cap, c->stream));
     FR_HIP(hipMemsetAsync(B.del, 0, cap, c->stream));
     FR_HIP(hipMemsetAsync(B.state, 0, sizeof(CompState) * (FR_MAX_ROUNDS + 2), c->stream));
@@ -98,10 +100,25 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
     if (threadIdx.x == 0) { B.psum[pout][blockIdx.x] = bs; B.pcnt[pout][blockIdx.x] = bk; }
 }
 
-void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm, double *loc_norm) {
+template <class Acc>
+static void run_seq(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound) {
+    unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
+    hipLaunchKernelGGL((k_seq_sums<Acc>), dim3(grid), dim3(FR_BLOCK), 0, c->stream, Q, acc);
+    hipLaunchKernelGGL((k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), 0, c->stream, Q, acc, 0.0);
+    hipLaunchKernelGGL((k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), 0, c->stream, Q, acc);
+    hipLaunchKernelGGL((k_seq_chain<Acc>), dim3(1), dim3(64), 0, c->stream, Q, acc, 0.0);
+    c->n_kernel_launch += 4;
+}
+
+void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
     VcompBuf &B = c->vc;
     hipStream_t st = c->stream;
-    unsigned grid = fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_TILE);
+    uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
+    unsigned grid = fr_blocks(bound, FR_TILE);
+    // *global_norm: exact in-order sum of |v| (compress_utils.cpp:34-35, :50)
+    AccAbs aa{c->vec.v0, c->vec.st};
+    SeqWork Qg = B.seq; Qg.total = B.gnorm;
+    run_seq(c, Qg, aa, bound);
     int r = 0, batch = c->rounds_hint[6] + 1;
     CompState hs{};
     hs.done = 0;
@@ -114,21 +131,20 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm, doubl
             c->n_kernel_launch++;
         }
         FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
+        FR_HIP(hipMemcpyAsync(glob_norm, B.gnorm, 8, hipMemcpyDeviceToHost, st));
         FR_HIP(hipStreamSynchronize(st));
         batch = 2;
     }
     c->rounds_hint[6] = r > 2 ? r - 1 : 2;
     c->rounds_hint[7] = r;      // state slot sys_comp reads
-    *glob_norm = hs.loc_norm;
     uint32_t n_rem = hs.n_rem;
-    double ln = hs.G;
-    if (hs.G < 1e-9) { n_rem = 0; ln = 0; }    // compress_utils.cpp:94-96
+    if (hs.G < 1e-9) n_rem = 0;     // compress_utils.cpp:94-96
     *n_samp_io = n_rem;
-    *loc_norm = ln;
 }
 
-__global__ void k_vc_teeth(VcompBuf B, int last_round, uint32_t n_samp, double loc_norm, double rn, double lbound0, double norm_after) {
+__global__ void k_vc_teeth(VcompBuf B, int last_round, uint32_t n_samp, double rn, double lbound0, double norm_after) {
     CompState s = B.state[last_round];
+    const double loc_norm = n_samp ? *B.seq.total : 0.0;      // exact in-order sum of the non-preserved |v|
     s.n_rem = n_samp; s.loc_norm = loc_norm; s.n_fix = 0; s.n_out = 0;
     double glob = lbound0 + loc_norm + norm_after;
     double unit = 0, r0 = INFINITY;
@@ -152,42 +168,24 @@ __device__ __forceinline__ void fr_sc_element(VecDev &V, VcompBuf &B, const Teet
 }
 
 __global__ void __launch_bounds__(FR_BLOCK) k_sc_apply(VecDev V, VcompBuf B, uint32_t *kin_out) {
-    __shared__ double shd[12];
-    __shared__ double sh_start;
+    __shared__ SeqShared seqsh;
     CompState *fin = &B.state[FR_MAX_ROUNDS + 1];
     const unsigned n = fin->n_in;
     const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
     const Teeth *th = B.teeth;
-    const double unit = fin->unit;
-    if (threadIdx.x == 0) {
-        const double *ps = B.psum[fin->pbuf];
-        double st = th->lbound0;
-        for (unsigned b = 0; b < blockIdx.x; b++) st += ps[b];
-        sh_start = st;
-    }
-    __syncthreads();
-    const double start = sh_start;
+    AccUnkept acc{V.v0, B.keep, V.st};
+    double Sx[4], Sprev;
+    fr_seq_prefix4(B.seq, acc, blockIdx.x, &seqsh, Sx, &Sprev);
     size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
-    double loc[FR_ITEMS], tsum = 0;
-#pragma unroll
-    for (int it = 0; it < FR_ITEMS; it++) {
-        size_t i = base + it;
-        double a = (i < n && !B.keep[i]) ? fabs(V.v0[i]) : 0.0;
-        tsum += a; loc[it] = tsum;
-    }
-    double btot;
-    double texcl = fr_block_excl_f64(tsum, shd, &btot);
-    double Sprev = start + texcl;
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t i = base + it;
         if (i >= n) break;
-        double Se = start + (texcl + loc[it]);
+        double Se = Sx[it];
         uint32_t kin = (i == 0) ? 0u : fr_teeth_below(th, Sprev);
         uint32_t k = kin;
         B.S[i] = Se; kin_out[i] = kin;
-        // decide without writing first, so a backlog can be repaired before values change
         bool kept = B.keep[i];
         double v = V.v0[i];
         bool sel = !kept && v != 0 && fr_tooth(th, k) < Se;
@@ -234,12 +232,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sc_write(VecDev V, VcompBuf B, con
     fr_sc_element(V, B, B.teeth, i, B.S[i], &k, fin->unit, true);
 }
 
-void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double loc_norm, double rn) {
+void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     VcompBuf &B = c->vc;
     hipStream_t st = c->stream;
     uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
     uint32_t *kin = c->W.kin;      // HB-PP scratch is idle here
-    hipLaunchKernelGGL(k_vc_teeth, dim3(1), dim3(1), 0, st, B, c->rounds_hint[7], n_samp, loc_norm, rn, 0.0, 0.0);
+    AccUnkept au{c->vec.v0, B.keep, c->vec.st};
+    run_seq(c, B.seq, au, bound);
+    hipLaunchKernelGGL(k_vc_teeth, dim3(1), dim3(1), 0, st, B, c->rounds_hint[7], n_samp, rn, 0.0, 0.0);
     hipLaunchKernelGGL(k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), 0, st, c->vec, B, kin);
     hipLaunchKernelGGL(k_sc_fixup, dim3(1), dim3(1), 0, st, c->vec, B, kin, c->d_err);
     hipLaunchKernelGGL(k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), 0, st, c->vec, B, kin);

@@ -43,6 +43,20 @@ struct VcompBuf {
     Teeth *teeth;
     double *dots;           // [2] numerator, denominator
     uint32_t *fix_list;
+    SeqWork seq;            // exact in-order sums of |v|
+    double *gnorm;          // [1] exact in-order sum of all |v| (find_preserve's *global_norm)
+};
+
+// addend sequences of the vector's in-order sums
+struct AccAbs {             // compress_utils.cpp:34-35
+    const double *v; const VecState *st;
+    __device__ unsigned count() const { return st->curr_size; }
+    __device__ double get(size_t i) const { return fabs(v[i]); }
+};
+struct AccUnkept {          // compress_utils.cpp:98-101 and the lbound of sys_comp (:313-314)
+    const double *v; const uint8_t *keep; const VecState *st;
+    __device__ unsigned count() const { return st->curr_size; }
+    __device__ double get(size_t i) const { return keep[i] ? 0.0 : fabs(v[i]); }
 };
 
 struct FriesCtx {
@@ -98,8 +112,8 @@ void fr_spawn_from_comp(FriesCtx *c);
 // compress.hip
 void fr_vcomp_alloc(FriesCtx *c, uint32_t cap);
 void fr_death_clone(FriesCtx *c, uint32_t vec_size_before);
-void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm, double *loc_norm);
-void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double loc_norm, double rn);
+void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm);
+void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
 // system.hip
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);

@@ -105,8 +105,8 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     fr_death_clone(c, vec_size);
     // vector compression (:501-539)
     uint32_t n_samp = c->vec_nonz;
-    double glob_norm = 0, loc_norm = 0;
-    fr_find_preserve(c, &n_samp, &glob_norm, &loc_norm);
+    double glob_norm = 0;
+    fr_find_preserve(c, &n_samp, &glob_norm);
     c->glob_norm = glob_norm;
     c->nkept = c->vec_nonz - n_samp;
     const unsigned shift_interval = 10;
@@ -118,7 +118,7 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     }
     fr_dots(c, &c->numer, &c->denom);
     double rn_sys = uni(c->mt);
-    fr_sys_comp(c, n_samp, loc_norm, rn_sys);
+    fr_sys_comp(c, n_samp, rn_sys);
     c->iterat++;
     if (lg) {
         fr_vec_sync_state(c, &c->vec, &c->h_vst);
@@ -375,9 +375,9 @@ extern "C" int fries_compress_vec(fries_ctx *h, uint32_t n_samp_in, double rn, u
     c->vec_nonz = n_samp_in;
     fr_death_clone(c, 0);                    // publishes the |v| block sums; v1 is zero so values are unchanged
     uint32_t n_samp = n_samp_in;
-    double gn = 0, ln = 0;
-    fr_find_preserve(c, &n_samp, &gn, &ln);
-    fr_sys_comp(c, n_samp, ln, rn);
+    double gn = 0;
+    fr_find_preserve(c, &n_samp, &gn);
+    fr_sys_comp(c, n_samp, rn);
     c->vec_nonz = save;
     if (n_kept) *n_kept = n_samp_in - n_samp;
     if (glob_norm) *glob_norm = gn;
@@ -410,5 +410,50 @@ extern "C" int fries_test_teeth(fries_ctx *h, double r0, double unit, uint32_t n
     if (n) FR_HIP(hipMemcpy(out_pos, dp, 8 * (size_t)n, hipMemcpyDeviceToHost));
     if (nq) FR_HIP(hipMemcpy(out_below, db, 4 * (size_t)nq, hipMemcpyDeviceToHost));
     hipFree(t); hipFree(dp); hipFree(dq); hipFree(db);
+    FR_API_END
+}
+
+// ------------------------------------------------------------------ test hook: exact in-order prefix sums
+struct AccArr {
+    const double *a; unsigned n;
+    __device__ unsigned count() const { return n; }
+    __device__ double get(size_t i) const { return a[i]; }
+};
+__global__ void __launch_bounds__(FR_BLOCK) k_test_seq_apply(SeqWork Q, AccArr acc, double *out) {
+    __shared__ SeqShared sh;
+    double S[4], Sb;
+    fr_seq_prefix4(Q, acc, blockIdx.x, &sh, S, &Sb);
+    size_t base = (size_t)blockIdx.x * FR_SEQ_TILE + (size_t)threadIdx.x * 4;
+    for (int it = 0; it < 4; it++) if (base + it < acc.n) out[base + it] = S[it];
+}
+
+extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, double start, double *out_prefix, double *out_total, uint32_t *n_dirty_tiles, uint32_t *n_dirty_subs) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    unsigned ntile = fr_blocks(n ? n : 1, FR_SEQ_TILE);
+    if (ntile > FR_MAX_PART) throw FriesError("too many elements");
+    SeqWork Q;
+    Q.tiles = fr_alloc<SeqRec>(ntile); Q.subs = fr_alloc<SeqRec>((size_t)ntile * FR_SUBS_PER_TILE); Q.total = fr_alloc<double>(1);
+    double *da = fr_alloc<double>(n), *dout = fr_alloc<double>(n);
+    FR_HIP(hipMemcpy(da, vals, 8 * (size_t)n, hipMemcpyHostToDevice));
+    FR_HIP(hipMemset(Q.subs, 0, sizeof(SeqRec) * (size_t)ntile * FR_SUBS_PER_TILE));
+    AccArr acc{da, n};
+    hipLaunchKernelGGL((k_seq_sums<AccArr>), dim3(ntile), dim3(FR_BLOCK), 0, c->stream, Q, acc);
+    hipLaunchKernelGGL((k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), 0, c->stream, Q, acc, start);
+    hipLaunchKernelGGL((k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), 0, c->stream, Q, acc);
+    hipLaunchKernelGGL((k_seq_chain<AccArr>), dim3(1), dim3(64), 0, c->stream, Q, acc, start);
+    hipLaunchKernelGGL(k_test_seq_apply, dim3(ntile), dim3(FR_BLOCK), 0, c->stream, Q, acc, dout);
+    FR_HIP(hipStreamSynchronize(c->stream));
+    FR_HIP(hipMemcpy(out_prefix, dout, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    FR_HIP(hipMemcpy(out_total, Q.total, 8, hipMemcpyDeviceToHost));
+    std::vector<SeqRec> tl(ntile), sb((size_t)ntile * FR_SUBS_PER_TILE);
+    FR_HIP(hipMemcpy(tl.data(), Q.tiles, sizeof(SeqRec) * ntile, hipMemcpyDeviceToHost));
+    FR_HIP(hipMemcpy(sb.data(), Q.subs, sizeof(SeqRec) * sb.size(), hipMemcpyDeviceToHost));
+    uint32_t dt = 0, ds = 0;
+    for (unsigned t = 0; t < ntile; t++) if (tl[t].dirty) { dt++; for (int j = 0; j < FR_SUBS_PER_TILE; j++) if (sb[(size_t)t * FR_SUBS_PER_TILE + j].dirty) ds++; }
+    if (n_dirty_tiles) *n_dirty_tiles = dt;
+    if (n_dirty_subs) *n_dirty_subs = ds;
+    hipFree(Q.tiles); hipFree(Q.subs); hipFree(Q.total); hipFree(da); hipFree(dout);
     FR_API_END
 }

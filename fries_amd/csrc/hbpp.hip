@@ -225,6 +225,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
     W.teeth = fr_alloc<Teeth>(1);
     W.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
+    W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
     W.nb8_cap = cap / 8 + 2;
     for (int h = 0; h < 2; h++) {
         W.f_dk[h] = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * W.nb8_cap);
@@ -266,7 +267,12 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     }
     c->rounds_hint[STAGE] = it > 2 ? it : 2;
     c->fks_iters[STAGE] = it;
-    hipLaunchKernelGGL(k_tile_sums, dim3(grid), dim3(FR_BLOCK), 0, st, W);
+    AccWt acc{W.wt_remain, &W.state[0]};
+    hipLaunchKernelGGL((k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), 0, st, W.seq, acc);
+    hipLaunchKernelGGL((k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), 0, st, W.seq, acc, 0.0);
+    hipLaunchKernelGGL((k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), 0, st, W.seq, acc);
+    hipLaunchKernelGGL((k_seq_chain<AccWt>), dim3(1), dim3(64), 0, st, W.seq, acc, 0.0);
+    c->n_kernel_launch += 4;
     hipLaunchKernelGGL(k_comp_finalize, dim3(1), dim3(FR_BLOCK), 0, st, W, it - 1, rn, 0.0, 0.0, c->d_err);
     c->n_kernel_launch++;
     hipLaunchKernelGGL((k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, c->p_doub);

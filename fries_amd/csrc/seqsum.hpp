@@ -1,0 +1,315 @@
+// Bit-exact parallel evaluation of a left-to-right floating-point running sum
+//     S_i = fl(S_{i-1} + a_i),  a_i >= 0,
+// which is what the reference computes in `lbound += ...` (FRIES/compress_utils.cpp:314, :739)
+// and in its in-order norms (:35, :82, :100, :262, :272).  A tree sum differs from it by ~sqrt(N)
+// ulps, enough to move a systematic sample across an element boundary once N ~ 1e5.
+//
+// Why it parallelises: while S stays inside one binade [2^e, 2^(e+1)) it is an integer multiple
+// M of ulp = 2^(e-52), and adding a_i adds the integer RN(a_i / ulp) -- except for exact ties,
+// where round-half-even makes the increment depend on the parity of M.  So inside a binade the
+// running sum is an integer prefix sum of per-element "parity maps" (d0, d1) = increment if M is
+// even / odd, and maps compose associatively:  (g then f)_p = g_p + f_{(p + g_p) & 1}.
+// The binade of every partial sum is known in advance from an ordinary (inexact) prefix sum
+// with a rigorous error margin; only the few stretches that may straddle a power of two
+// ("dirty") are added element by element.
+//
+// Granularity: tile = 1024 elements (one workgroup), sub-tile = 64 elements.  Dirty tiles are
+// resolved at sub-tile level, dirty sub-tiles sequentially.  The positive sequence crosses
+// about log2(total / first term) binades, so only a few dozen sub-tiles are ever sequential.
+#pragma once
+#include "fries_dev.hpp"
+
+#define FR_SUBS_PER_TILE 16
+#define FR_SEQ_TILE 1024
+
+struct SeqRec {
+    double approx;      // tile / sub-tile sum in tree order
+    double carry;       // classify: approximate, chain: exact running sum entering the unit
+    long long d0, d1;   // composed parity map of the unit (valid when clean)
+    int e;              // binade exponent of every partial sum inside the unit (valid when clean)
+    uint32_t dirty;
+};
+struct SeqWork {
+    SeqRec *tiles;      // [FR_MAX_PART]
+    SeqRec *subs;       // [FR_MAX_PART * 16]
+    double *total;      // [1] exact sum of everything (+ start)
+};
+
+struct PMap { long long d0, d1; };
+__device__ __forceinline__ PMap fr_pm_id() { PMap m; m.d0 = 0; m.d1 = 0; return m; }
+// g first, then f
+__device__ __forceinline__ PMap fr_pm_compose(const PMap &g, const PMap &f) {
+    PMap h;
+    h.d0 = g.d0 + ((g.d0 & 1) ? f.d1 : f.d0);
+    h.d1 = g.d1 + (((1 + g.d1) & 1) ? f.d1 : f.d0);
+    return h;
+}
+// increment (in ulps of binade e) that adding `a` causes, as a parity map
+__device__ __forceinline__ PMap fr_pm_elem(double a, double scale /* 2^(52-e) */) {
+    PMap m;
+    double x = a * scale;                // exact power-of-two scaling (or underflow to < 0.5)
+    double q = floor(x), f = x - q;      // exact
+    long long qi = (long long)q;
+    if (f < 0.5) { m.d0 = qi; m.d1 = qi; }
+    else if (f > 0.5) { m.d0 = qi + 1; m.d1 = qi + 1; }
+    else { m.d0 = qi + (qi & 1); m.d1 = qi + ((qi & 1) ^ 1); }     // tie: round half to even
+    return m;
+}
+__device__ __forceinline__ int fr_exp_of(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff) - 1023; }
+
+// rigorous relative error bound for both the sequential and the tree sum of n non-negative terms
+__device__ __forceinline__ double fr_seq_eps(unsigned n) { return 4.0 * ((double)n + 2048.0) * 1.1102230246251565e-16; }
+
+// classify a unit whose exact running sum enters within [lo_c, hi_c] = carry*(1 -+ eps) and
+// leaves within sum*(1 -+ eps): clean iff all of it lies strictly inside one binade
+__device__ __forceinline__ bool fr_seq_clean(double carry_apx, double leave_apx, double eps, int *e) {
+    double lo = carry_apx * (1.0 - eps), hi = leave_apx * (1.0 + eps);
+    if (!(lo > 0) || !(hi < 1.0e300)) return false;
+    if (lo < 2.3e-308) return false;             // keep away from subnormals
+    int el = fr_exp_of(lo), eh = fr_exp_of(hi);
+    *e = el;
+    return el == eh && hi < ldexp(1.0, el + 1);
+}
+
+__device__ __forceinline__ double fr_seq_apply_map(double carry, int e, long long d0, long long d1) {
+    double ulp = ldexp(1.0, e - 52);
+    long long M = (long long)(carry * ldexp(1.0, 52 - e));    // exact integer
+    long long d = (M & 1) ? d1 : d0;
+    return (double)(M + d) * ulp;
+}
+
+// ---- S1: tree sums per tile and per 64-element sub-tile
+template <class Acc>
+__global__ void __launch_bounds__(FR_BLOCK) k_seq_sums(SeqWork Q, Acc acc) {
+    __shared__ double shd[4];
+    const unsigned n = acc.count();
+    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
+    if (blockIdx.x >= ntile) return;
+    size_t base = (size_t)blockIdx.x * FR_SEQ_TILE + (size_t)threadIdx.x * 4;
+    double s = 0;
+    for (int it = 0; it < 4; it++) { size_t i = base + it; if (i < n) s += acc.get(i); }
+    double g = s;                                   // 16-lane groups = sub-tiles
+    for (int off = 8; off > 0; off >>= 1) g += __shfl_xor(g, off);
+    if ((threadIdx.x & 15) == 0) Q.subs[(size_t)blockIdx.x * FR_SUBS_PER_TILE + (threadIdx.x >> 4)].approx = g;
+    double t = fr_block_sum(s, shd);
+    if (threadIdx.x == 0) Q.tiles[blockIdx.x].approx = t;
+}
+
+// ---- S2: approximate carries per tile, clean / dirty classification (one workgroup)
+template <class Acc>
+__global__ void __launch_bounds__(FR_BLOCK) k_seq_classify(SeqWork Q, Acc acc, double start) {
+    __shared__ double shd[12];
+    const unsigned n = acc.count();
+    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
+    const double eps = fr_seq_eps(n);
+    double carry = start;
+    for (unsigned t0 = 0; t0 < ntile; t0 += FR_BLOCK) {
+        unsigned t = t0 + threadIdx.x;
+        double a = t < ntile ? Q.tiles[t].approx : 0.0;
+        // inclusive scan of this chunk
+        int lane = fr_lane(), w = threadIdx.x >> 6;
+        double v = a;
+        for (int off = 1; off < 64; off <<= 1) { double x = __shfl_up(v, off); if (lane >= off) v += x; }
+        if (lane == 63) shd[w] = v;
+        __syncthreads();
+        double basev = 0;
+        for (int k = 0; k < w; k++) basev += shd[k];
+        double chunk_tot = shd[0] + shd[1] + shd[2] + shd[3];
+        double incl = basev + v;
+        if (t < ntile) {
+            double c_in = carry + (incl - a), c_out = carry + incl;
+            int e = 0;
+            bool clean = fr_seq_clean(c_in, c_out, eps, &e);
+            Q.tiles[t].carry = c_in; Q.tiles[t].e = e; Q.tiles[t].dirty = clean ? 0u : 1u;
+        }
+        carry += chunk_tot;
+        __syncthreads();
+    }
+}
+
+// ---- S3: parity maps of clean tiles; sub-tile classification + maps inside dirty tiles
+template <class Acc>
+__global__ void __launch_bounds__(FR_BLOCK) k_seq_maps(SeqWork Q, Acc acc) {
+    __shared__ PMap shm[FR_BLOCK];
+    const unsigned n = acc.count();
+    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
+    if (blockIdx.x >= ntile) return;
+    const SeqRec tr = Q.tiles[blockIdx.x];
+    size_t base = (size_t)blockIdx.x * FR_SEQ_TILE + (size_t)threadIdx.x * 4;
+    double a[4];
+    for (int it = 0; it < 4; it++) { size_t i = base + it; a[it] = i < n ? acc.get(i) : 0.0; }
+    if (!tr.dirty) {
+        double scale = ldexp(1.0, 52 - tr.e);
+        PMap m = fr_pm_elem(a[0], scale);
+        for (int it = 1; it < 4; it++) m = fr_pm_compose(m, fr_pm_elem(a[it], scale));
+        shm[threadIdx.x] = m;
+        __syncthreads();
+        for (int stride = 1; stride < FR_BLOCK; stride <<= 1) {        // ordered tree: left operand first
+            PMap r;
+            bool act = (threadIdx.x % (2 * stride)) == 0 && threadIdx.x + stride < FR_BLOCK;
+            if (act) r = fr_pm_compose(shm[threadIdx.x], shm[threadIdx.x + stride]);
+            __syncthreads();
+            if (act) shm[threadIdx.x] = r;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { Q.tiles[blockIdx.x].d0 = shm[0].d0; Q.tiles[blockIdx.x].d1 = shm[0].d1; }
+        return;
+    }
+    // dirty tile: approximate carry of each sub-tile, classification, maps of the clean ones
+    const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
+    SeqRec *sr = &Q.subs[(size_t)blockIdx.x * FR_SUBS_PER_TILE + sub];
+    double c_in = tr.carry;
+    for (int j = 0; j < sub; j++) c_in += Q.subs[(size_t)blockIdx.x * FR_SUBS_PER_TILE + j].approx;
+    double c_out = c_in + sr->approx;
+    int e = 0;
+    bool clean = fr_seq_clean(c_in, c_out, fr_seq_eps(n), &e);
+    PMap m = fr_pm_id();
+    if (clean) {
+        double scale = ldexp(1.0, 52 - e);
+        m = fr_pm_elem(a[0], scale);
+        for (int it = 1; it < 4; it++) m = fr_pm_compose(m, fr_pm_elem(a[it], scale));
+    }
+    shm[threadIdx.x] = m;
+    __syncthreads();
+    if (sl == 0) {
+        PMap r = shm[threadIdx.x];
+        for (int k = 1; k < 16; k++) r = fr_pm_compose(r, shm[threadIdx.x + k]);
+        sr->carry = c_in; sr->e = e; sr->dirty = clean ? 0u : 1u; sr->d0 = r.d0; sr->d1 = r.d1;
+    }
+}
+
+// ---- S4: the chain.  One wave; lane-parallel over runs of clean same-binade tiles.
+template <class Acc>
+__device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start) {
+    const unsigned n = acc.count();
+    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
+    const int lane = fr_lane();
+    double carry = start;
+    unsigned t = 0;
+    while (t < ntile) {
+        unsigned mine = t + lane;
+        SeqRec r;
+        bool have = mine < ntile;
+        if (have) r = Q.tiles[mine]; else { r.dirty = 1; r.e = 0; r.d0 = r.d1 = 0; }
+        int e0 = __shfl(r.e, 0);
+        unsigned d0flag = __shfl((int)r.dirty, 0);
+        if (d0flag) {
+            // tile t may straddle a power of two: walk its sub-tiles (the whole wave follows lane 0)
+            if (lane == 0) Q.tiles[t].carry = carry;
+            for (unsigned j = 0; j < FR_SUBS_PER_TILE; j++) {
+                size_t sidx = (size_t)t * FR_SUBS_PER_TILE + j;
+                size_t e_lo = (size_t)t * FR_SEQ_TILE + (size_t)j * 64;
+                if (e_lo >= n) { if (lane == 0) Q.subs[sidx].carry = carry; continue; }
+                SeqRec s = Q.subs[sidx];
+                if (lane == 0) Q.subs[sidx].carry = carry;
+                if (!s.dirty) carry = fr_seq_apply_map(carry, s.e, s.d0, s.d1);
+                else {
+                    size_t e_hi = e_lo + 64 < n ? e_lo + 64 : n;
+                    double mine_a = (e_lo + lane < e_hi) ? acc.get(e_lo + lane) : 0.0;
+                    for (int k = 0; k < 64; k++) { double ak = __shfl(mine_a, k); carry = carry + ak; }
+                }
+            }
+            t++;
+            continue;
+        }
+        // run of clean tiles in binade e0 starting at t
+        unsigned long long ok = __ballot(have && !r.dirty && r.e == e0);
+        unsigned run = __ffsll((long long)~ok) - 1;       // lanes 0..run-1 form the run (run >= 1)
+        if (run > 64) run = 64;
+        PMap m; m.d0 = r.d0; m.d1 = r.d1;
+        if ((unsigned)lane >= run) m = fr_pm_id();
+        // inclusive ordered scan of maps over lanes
+        for (int off = 1; off < 64; off <<= 1) {
+            PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
+            if (lane >= off) m = fr_pm_compose(o, m);
+        }
+        // exclusive map for my tile = inclusive of the previous lane
+        PMap ex; ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
+        if (lane == 0) ex = fr_pm_id();
+        if ((unsigned)lane < run) Q.tiles[mine].carry = fr_seq_apply_map(carry, e0, ex.d0, ex.d1);
+        PMap last; last.d0 = __shfl(m.d0, (int)run - 1); last.d1 = __shfl(m.d1, (int)run - 1);
+        carry = fr_seq_apply_map(carry, e0, last.d0, last.d1);
+        t += run;
+    }
+    return carry;
+}
+
+template <class Acc>
+__global__ void __launch_bounds__(64) k_seq_chain(SeqWork Q, Acc acc, double start) {
+    double tot = fr_seq_chain_wave(Q, acc, start);
+    if (threadIdx.x == 0) *Q.total = tot;
+}
+
+// ---- S5: exact running sums for the 4 consecutive elements of this thread.
+// All 256 threads of the workgroup owning tile `tile` must call it.  sh: workgroup scratch.
+struct SeqShared { PMap m[FR_BLOCK]; double a[FR_SEQ_TILE]; };
+
+template <class Acc>
+__device__ __forceinline__ void fr_seq_prefix4(const SeqWork &Q, const Acc &acc, unsigned tile, SeqShared *sh, double S[4], double *S_before) {
+    const unsigned n = acc.count();
+    const SeqRec tr = Q.tiles[tile];
+    size_t base = (size_t)tile * FR_SEQ_TILE + (size_t)threadIdx.x * 4;
+    double a[4];
+    for (int it = 0; it < 4; it++) { size_t i = base + it; a[it] = i < n ? acc.get(i) : 0.0; }
+    if (!tr.dirty) {
+        double scale = ldexp(1.0, 52 - tr.e), ulp = ldexp(1.0, tr.e - 52);
+        PMap loc[4];
+        loc[0] = fr_pm_elem(a[0], scale);
+        for (int it = 1; it < 4; it++) loc[it] = fr_pm_compose(loc[it - 1], fr_pm_elem(a[it], scale));
+        // exclusive scan of the per-thread maps across the workgroup (ordered)
+        const int lane = fr_lane(), w = threadIdx.x >> 6;
+        PMap m = loc[3];
+        for (int off = 1; off < 64; off <<= 1) {
+            PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
+            if (lane >= off) m = fr_pm_compose(o, m);
+        }
+        if (lane == 63) sh->m[w] = m;
+        __syncthreads();
+        PMap wbase = fr_pm_id();
+        for (int k = 0; k < w; k++) wbase = fr_pm_compose(wbase, sh->m[k]);
+        PMap ex; ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
+        if (lane == 0) ex = fr_pm_id();
+        ex = fr_pm_compose(wbase, ex);
+        __syncthreads();
+        long long M = (long long)(tr.carry * scale);
+        int p = (int)(M & 1);
+        long long dex = p ? ex.d1 : ex.d0;
+        *S_before = (double)(M + dex) * ulp;
+        for (int it = 0; it < 4; it++) {
+            PMap c = fr_pm_compose(ex, loc[it]);
+            long long d = p ? c.d1 : c.d0;
+            S[it] = (double)(M + d) * ulp;
+        }
+        return;
+    }
+    // dirty tile: per sub-tile
+    const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
+    const SeqRec sr = Q.subs[(size_t)tile * FR_SUBS_PER_TILE + sub];
+    for (int it = 0; it < 4; it++) sh->a[threadIdx.x * 4 + it] = a[it];
+    __syncthreads();
+    size_t sub_lo = (size_t)tile * FR_SEQ_TILE + (size_t)sub * 64;
+    if (sub_lo >= n) { for (int it = 0; it < 4; it++) S[it] = sr.carry; *S_before = sr.carry; __syncthreads(); return; }
+    if (!sr.dirty) {
+        double scale = ldexp(1.0, 52 - sr.e), ulp = ldexp(1.0, sr.e - 52);
+        // sequential composition over the preceding elements of the sub-tile (<= 60 of them)
+        PMap ex = fr_pm_id();
+        const double *sa = &sh->a[sub * 64];
+        for (int k = 0; k < sl * 4; k++) ex = fr_pm_compose(ex, fr_pm_elem(sa[k], scale));
+        long long M = (long long)(sr.carry * scale);
+        int p = (int)(M & 1);
+        *S_before = (double)(M + (p ? ex.d1 : ex.d0)) * ulp;
+        PMap c = ex;
+        for (int it = 0; it < 4; it++) {
+            c = fr_pm_compose(c, fr_pm_elem(a[it], scale));
+            S[it] = (double)(M + (p ? c.d1 : c.d0)) * ulp;
+        }
+    }
+    else {
+        double s = sr.carry;
+        const double *sa = &sh->a[sub * 64];
+        for (int k = 0; k < sl * 4; k++) s = s + sa[k];
+        *S_before = s;
+        for (int it = 0; it < 4; it++) { s = s + a[it]; S[it] = s; }
+    }
+    __syncthreads();
+}

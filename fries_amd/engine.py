@@ -21,7 +21,7 @@ EXPORTS = [
     "fries_get_hb_tensor", "fries_set_hb_tensor", "fries_hf_energy", "fries_matrel_batch", "fries_frisys_setup",
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
-    "fries_test_teeth",
+    "fries_test_teeth", "fries_test_seqsum",
 ]
 
 
@@ -75,6 +75,8 @@ def load_library() -> C.CDLL:
                                          C.POINTER(C.c_size_t), C.c_void_p]
     lib.fries_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.fries_test_teeth.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.fries_test_seqsum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = lib
     return lib
 
@@ -216,3 +218,11 @@ class FriEngine:
         below = np.zeros(max(q.size, 1), dtype=np.uint32)
         self._ck(self.lib.fries_test_teeth(self.h, r0, unit, n, _ptr(pos), _ptr(q), q.size, _ptr(below)))
         return pos[:n], below[:q.size]
+
+    def test_seqsum(self, vals, start: float = 0.0):
+        a = np.ascontiguousarray(vals, dtype=np.float64)
+        out = np.zeros(max(a.size, 1))
+        tot = C.c_double()
+        dt, ds = C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.fries_test_seqsum(self.h, _ptr(a), a.size, start, _ptr(out), C.byref(tot), C.byref(dt), C.byref(ds)))
+        return out[:a.size], tot.value, dt.value, ds.value

@@ -95,6 +95,11 @@ int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_k
 /* test hook: positions of the first n comb teeth built from (r0, unit) -- see csrc/teeth.hpp */
 int fries_test_teeth(fries_ctx *ctx, double r0, double unit, uint32_t n, double *out_pos, const double *query, uint32_t nq, uint32_t *out_below);
 
+/* test hook: bit-exact left-to-right running sums S_i = fl(S_{i-1} + vals[i]) of non-negative
+ * doubles, evaluated in parallel -- see csrc/seqsum.hpp */
+int fries_test_seqsum(fries_ctx *ctx, const double *vals, uint32_t n, double start, double *out_prefix, double *out_total,
+                      uint32_t *n_dirty_tiles, uint32_t *n_dirty_subs);
+
 #ifdef __cplusplus
 }
 #endif
