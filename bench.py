@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FRI iterations/s (and spawns/s) at fixed m on MI355X.
+
+Workload (BASELINE.json configs[1]): N2/cc-pVDZ-shaped synthetic FCIDUMP (26 orbitals, 10
+electrons, D2h), frisys_mol with HB_unnorm, vec_nonz = mat_nonz = target = m = 1e6,
+initiator 1, epsilon 0.01, one MI355X.  A "step" is one FRI iteration (frisys_mol.cpp:405-552)
+with the vector full; every array is resident in HBM when the timed region starts.
+
+Steady state is reached by a restart, like the reference's --load_dir: a filler run with
+initiator 0 populates m determinants in a few dozen iterations, its vector is rescaled to the
+target norm and loaded into the measured engine (and, for the CPU baseline, into the oracle).
+
+Prints ONE JSON line (rank 0).  Extra keys: spawns_per_s, roofline, cpu_baseline, parity.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# ALGORITHMIC bytes per unit for the kernels that can dominate (DESIGN.md section 4;
+# V = 8 B value, D = 8 B determinant, 8 B = parent index + orbital code).
+ALG_BYTES = {
+    # one replay of find_keep_sub over a stage: read value + (parent idx, code) + parent determinant
+    "k_fks_iter": lambda units: 24.0 * units,
+    "k_sys_count": lambda units: 24.0 * units,
+    "k_sys_write": lambda units: 40.0 * units,
+    "k_prep": lambda units: 40.0 * units,
+}
+
+
+def build_state(mol, m, seed):
+    """Filler run (initiator 0) -> a vector with ~m determinants at norm ~ m."""
+    from fries_amd.engine import FriEngine
+    eng = FriEngine(mol)
+    eng.setup(epsilon=0.01, vec_nonz=m, mat_nonz=m, max_dets=4 * m, target_norm=0.0, initiator=0.0, seed=seed, distribution="HB_unnorm")
+    for _ in range(200):
+        lg = eng.iterate(5)
+        if lg["n_nonz"][-1] >= m:
+            break
+    eng.iterate(10)
+    dets, vals = eng.vector()
+    eng.close()
+    keep = vals != 0
+    dets, vals = dets[keep], vals[keep]
+    vals = vals * (float(m) / np.abs(vals).sum())       # norm == target: about half the elements are initiators
+    return dets, vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--m", type=int, default=1_000_000)
+    ap.add_argument("--shape", default="N2")
+    ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: sized to ~20 s; 0: skip)")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    else:
+        dist = None
+
+    from fries_amd import fcidump
+    from fries_amd.engine import FriEngine
+
+    m = args.m
+    mol = fcidump.synthetic(args.shape)
+    seed = 20250215
+    # every rank builds the same restart state; with N > 1 each rank advances an independent
+    # replica from its own seed (hash-sharded exchange is the next row of SURVEY.md section 8(e))
+    dets, vals = build_state(mol, m, seed)
+    par = dict(epsilon=0.01, vec_nonz=m, mat_nonz=m, max_dets=4 * m, target_norm=float(m), initiator=1.0, seed=seed, distribution="HB_unnorm")
+    eng = FriEngine(mol, device=local_rank if world > 1 else 0)
+    eng.setup(**par)
+    eng.vec_load(dets, vals)
+    run_seed = 777 + rank
+    eng.restart(run_seed, 0.0, 0.0, 0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+
+    first_logs = eng.iterate(args.warmup) if args.warmup else None
+    c0 = eng.counters()
+    barrier()
+    t0 = time.perf_counter()
+    eng.iterate(args.steps, want_logs=False)
+    eng.vec_info()                      # drains the engine's stream
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        sp = torch.tensor([float(c1["spawns"] - c0["spawns"])], device="cuda")
+        dist.all_reduce(sp)
+        spawns = float(sp.item())
+    else:
+        spawns = float(c1["spawns"] - c0["spawns"])
+    iters_per_s = world * args.steps / dt
+    result = {
+        "metric": "fri_iterations_per_s", "value": iters_per_s, "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.shape} cc-pVDZ-shaped synthetic FCIDUMP, frisys_mol HB_unnorm, vec_nonz=mat_nonz=target={m}, initiator 1, eps 0.01, restart from a full vector",
+                   "m": m, "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (hash-sharded exchange not built yet)"},
+        "spawns_per_s": spawns / dt,
+        "kernel_launches_per_iter": (c1["launches"] - c0["launches"]) / args.steps,
+        "fks_replays_per_iter": (c1["fks_replays"] - c0["fks_replays"]) / args.steps,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, HIP events on the engine's stream
+        info = eng.vec_info()
+        cA = eng.counters()
+        eng.prof_enable(True)
+        eng.iterate(args.profile_steps, want_logs=False)
+        eng.vec_info()
+        rep = eng.prof_report()
+        eng.prof_enable(False)
+        cB = eng.counters()
+        tot_ms = sum(v[0] for v in rep.values())
+        dom = max(rep.items(), key=lambda kv: kv[1][0])
+        name, (ms, calls) = dom
+        avg_s = ms / calls * 1e-3
+        stage_elems = (cB["stage_elems"] - cA["stage_elems"]) / args.profile_steps      # elements over the five stages, per iteration
+        units = None
+        if name == "k_fks_iter":
+            units = stage_elems / 5.0           # elements one launch sweeps (stage average)
+        elif name in ("k_sys_count", "k_sys_write", "k_prep"):
+            units = stage_elems / 5.0
+        ach = ALG_BYTES[name](units) / avg_s / 1e9 if (units and name in ALG_BYTES) else None
+        result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                              "avg_launch_us": avg_s * 1e6, "calls_per_iter": calls / args.profile_steps,
+                              "share_of_kernel_time": ms / tot_ms, "n_nonz": info[1]}
+        result["kernel_time_ms_per_iter"] = tot_ms / args.profile_steps
+        result["top_kernels"] = {k: {"ms_per_iter": v[0] / args.profile_steps, "calls_per_iter": v[1] / args.profile_steps}
+                                 for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])[:8]}
+        # whole-iteration algorithmic traffic (~312 B per nonzero per iteration)
+        result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9
+
+        # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores
+        if args.cpu_iters != 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.OracleFrisys(mol, **par)
+            orc.vec_load(dets, vals)
+            orc.restart(run_seed, 0.0, 0.0, 0)
+            n_cpu = args.cpu_iters
+            t0 = time.perf_counter()
+            lo1 = orc.iterate(1)
+            one = time.perf_counter() - t0
+            if n_cpu < 0:
+                n_cpu = max(2, min(40, int(20.0 / max(one, 1e-3))))
+            t0 = time.perf_counter()
+            lo = orc.iterate(n_cpu - 1)
+            cpu_dt = one + (time.perf_counter() - t0)
+            result["cpu_baseline"] = {"value": n_cpu / cpu_dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                      "sample": f"{n_cpu} iterations of the same restart state and seed (oracle/fries_oracle.cpp, 1 thread)"}
+            # the GPU's first iterations ran from the same state and seed: compare what they logged
+            if first_logs is not None:
+                k = min(n_cpu, args.warmup)
+                olog = np.concatenate([lo1, lo])[:k]
+                same = all(int(first_logs[f][i]) == int(olog[f][i]) for i in range(k) for f in ("num_success", "n_nonz", "curr_size", "nkept"))
+                num_ok = bool(np.all(np.abs(first_logs["numer"][:k] / first_logs["denom"][:k] - olog["numer"] / olog["denom"]) < 1e-10))
+                result["parity"] = {"iterations_compared": k, "counts_identical": bool(same), "energy_within_1e-10": num_ok}
+        print(json.dumps(result))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

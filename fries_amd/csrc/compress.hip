@@ -55,8 +55,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
 void fr_death_clone(FriesCtx *c, uint32_t vec_size_before) {
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     uint32_t bound = c->h_vst.curr_size;
-    hipLaunchKernelGGL(k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), 0, c->stream, c->vec, c->vc, S, vec_size_before, c->eps, c->en_shift, c->vec_nonz);
-    c->n_kernel_launch++;
+    FR_LAUNCH(c, "k_death_clone", k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), c->vec, c->vc, S, vec_size_before, c->eps, c->en_shift, c->vec_nonz);
 }
 
 // One round of the exact-preservation fixed point: keep every element with
@@ -103,11 +102,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
 template <class Acc>
 static void run_seq(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound) {
     unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
-    hipLaunchKernelGGL((k_seq_sums<Acc>), dim3(grid), dim3(FR_BLOCK), 0, c->stream, Q, acc);
-    hipLaunchKernelGGL((k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), 0, c->stream, Q, acc, 0.0);
-    hipLaunchKernelGGL((k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), 0, c->stream, Q, acc);
-    hipLaunchKernelGGL((k_seq_chain<Acc>), dim3(1), dim3(64), 0, c->stream, Q, acc, 0.0);
-    c->n_kernel_launch += 4;
+    FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, 0.0);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, 0.0);
 }
 
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
@@ -127,8 +125,7 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
         if (batch <= 0) throw FriesError("find_preserve did not converge within FR_MAX_ROUNDS rounds");
         for (int k = 0; k < batch; k++) {
             r++;
-            hipLaunchKernelGGL(k_fp_round, dim3(grid), dim3(FR_BLOCK), 0, st, c->vec, B, r);
-            c->n_kernel_launch++;
+            FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r);
         }
         FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
         FR_HIP(hipMemcpyAsync(glob_norm, B.gnorm, 8, hipMemcpyDeviceToHost, st));
@@ -239,11 +236,10 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     uint32_t *kin = c->W.kin;      // HB-PP scratch is idle here
     AccUnkept au{c->vec.v0, B.keep, c->vec.st};
     run_seq(c, B.seq, au, bound);
-    hipLaunchKernelGGL(k_vc_teeth, dim3(1), dim3(1), 0, st, B, c->rounds_hint[7], n_samp, rn, 0.0, 0.0);
-    hipLaunchKernelGGL(k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), 0, st, c->vec, B, kin);
-    hipLaunchKernelGGL(k_sc_fixup, dim3(1), dim3(1), 0, st, c->vec, B, kin, c->d_err);
-    hipLaunchKernelGGL(k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), 0, st, c->vec, B, kin);
-    c->n_kernel_launch += 4;
+    FR_LAUNCH(c, "k_vc_teeth", k_vc_teeth, dim3(1), dim3(1), B, c->rounds_hint[7], n_samp, rn, 0.0, 0.0);
+    FR_LAUNCH(c, "k_sc_apply", k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, kin);
+    FR_LAUNCH(c, "k_sc_fixup", k_sc_fixup, dim3(1), dim3(1), c->vec, B, kin, c->d_err);
+    FR_LAUNCH(c, "k_sc_write", k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, kin);
     fr_vec_delete_flagged(c, &c->vec, B.del, bound);
 }
 
@@ -263,8 +259,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, co
 }
 
 void fr_dots(FriesCtx *c, double *numer, double *denom) {
-    hipLaunchKernelGGL(k_dots, dim3(2), dim3(FR_BLOCK), 0, c->stream, c->vec, c->htr_det, c->htr_val, c->n_htrial, c->tr_det, c->tr_val, c->n_trial, c->vc.dots);
-    c->n_kernel_launch++;
+    FR_LAUNCH(c, "k_dots", k_dots, dim3(2), dim3(FR_BLOCK), c->vec, c->htr_det, c->htr_val, c->n_htrial, c->tr_det, c->tr_val, c->n_trial, c->vc.dots);
     double h[2];
     FR_HIP(hipMemcpyAsync(h, c->vc.dots, 16, hipMemcpyDeviceToHost, c->stream));
     FR_HIP(hipStreamSynchronize(c->stream));

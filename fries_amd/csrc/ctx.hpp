@@ -21,6 +21,18 @@ template <class T> static inline T *fr_alloc(size_t n) {
 }
 static inline unsigned fr_blocks(size_t n, size_t per) { return (unsigned)((n + per - 1) / per); }
 
+// Optional per-kernel timing with HIP events on the engine's own stream (bench.py's roofline).
+struct ProfSpan { const char *name; hipEvent_t a, b; };
+struct ProfAgg { std::string name; double ms; uint64_t calls; };
+struct FriesCtx;
+void fr_prof_begin(FriesCtx *c, const char *name);
+void fr_prof_end(FriesCtx *c);
+#define FR_LAUNCH(c, name, kern, grid, block, ...) do { \
+    if ((c)->prof_on) fr_prof_begin((c), name); \
+    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__); \
+    if ((c)->prof_on) fr_prof_end((c)); \
+    (c)->n_kernel_launch++; } while (0)
+
 // merge / spawn scratch (vec.hip)
 struct SpawnBuf {
     uint32_t cap;
@@ -95,13 +107,18 @@ struct FriesCtx {
     // last iteration's observables
     double numer = 0, denom = 0, glob_norm = 0;
     uint32_t nkept = 0, num_success = 0, comp_len[5] = {0, 0, 0, 0, 0};
-    uint64_t n_kernel_launch = 0;
+    uint64_t n_kernel_launch = 0, tot_spawns = 0, tot_iters = 0, tot_fks_iters = 0, tot_stage_elems = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfSpan> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<ProfAgg> prof_agg;
 };
 
 // vec.hip
 void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap);
 void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out);
-void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool spawn_count_on_device);
+void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool same_column);
 void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n);
 void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap);

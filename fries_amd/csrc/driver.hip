@@ -16,6 +16,34 @@ void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vect
                      std::vector<det_t> &out_det, std::vector<double> &out_val, uint32_t *n_sing0, uint32_t *n_doub0);
 void fr_hbpp_apply_unit(FriesCtx *c, uint32_t n_samp, const double rn[5]);
 
+// ------------------------------------------------------------------ per-kernel HIP-event timing
+void fr_prof_begin(FriesCtx *c, const char *name) {
+    ProfSpan sp; sp.name = name;
+    for (int k = 0; k < 2; k++) {
+        hipEvent_t e;
+        if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) throw FriesError("hipEventCreate failed");
+        (k ? sp.b : sp.a) = e;
+    }
+    hipEventRecord(sp.a, c->stream);
+    c->prof_spans.push_back(sp);
+}
+void fr_prof_end(FriesCtx *c) { hipEventRecord(c->prof_spans.back().b, c->stream); }
+static void prof_collect(FriesCtx *c) {
+    if (c->prof_spans.empty()) return;
+    FR_HIP(hipStreamSynchronize(c->stream));
+    for (auto &sp : c->prof_spans) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, sp.a, sp.b);
+        ProfAgg *a = nullptr;
+        for (auto &x : c->prof_agg) if (x.name == sp.name) { a = &x; break; }
+        if (!a) { c->prof_agg.push_back(ProfAgg{sp.name, 0.0, 0}); a = &c->prof_agg.back(); }
+        a->ms += ms; a->calls++;
+        c->prof_pool.push_back(sp.a); c->prof_pool.push_back(sp.b);
+    }
+    c->prof_spans.clear();
+}
+
 #define FR_API_BEGIN try {
 #define FR_API_END } catch (const std::exception &e) { fr_set_error(e.what()); return -1; } return 0;
 
@@ -75,9 +103,8 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
     FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
     FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
-    fr_vec_merge(c, &c->vec, 1, false);
+    fr_vec_merge(c, &c->vec, 1, true);               // perform_add(0) into column 0
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
-    fr_death_clone(c, 0);                            // v0 += v1; v1 = 0
     check_dev_err(c);
 }
 
@@ -95,9 +122,8 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     // spawning + annihilation (:429-471)
     if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
     if (c->num_success) {
-        hipLaunchKernelGGL(k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), 0, st, c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
-        c->n_kernel_launch++;
-        fr_vec_merge(c, &c->vec, c->num_success, true);
+        FR_LAUNCH(c, "k_spawn_build", k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
+        fr_vec_merge(c, &c->vec, c->num_success, false);
     }
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) check_dev_err(c);
@@ -120,6 +146,10 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     double rn_sys = uni(c->mt);
     fr_sys_comp(c, n_samp, rn_sys);
     c->iterat++;
+    c->tot_iters++; c->tot_spawns += c->num_success;
+    for (int k = 0; k < 5; k++) c->tot_stage_elems += c->comp_len[k];
+    for (int k = 1; k <= 5; k++) c->tot_fks_iters += c->fks_iters[k];
+    if (c->prof_on) prof_collect(c);
     if (lg) {
         fr_vec_sync_state(c, &c->vec, &c->h_vst);
         lg->numer = c->numer; lg->denom = c->denom; lg->shift = c->en_shift; lg->norm = c->glob_norm;
@@ -244,7 +274,7 @@ extern "C" int fries_matrel_batch(fries_ctx *h, int kind, const uint64_t *dets, 
     det_t *dd = fr_alloc<det_t>(n); uint8_t *dob = fr_alloc<uint8_t>(4 * n); double *dout = fr_alloc<double>(n); int32_t *ds = fr_alloc<int32_t>(n);
     FR_HIP(hipMemcpy(dd, dets, 8 * n, hipMemcpyHostToDevice));
     if (orbs) FR_HIP(hipMemcpy(dob, orbs, 4 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_matrel_batch, dim3(fr_blocks(n, FR_BLOCK)), dim3(FR_BLOCK), 0, c->stream, kind, dd, orbs ? dob : nullptr, n, c->d_h, c->d_eris, c->n_orb, dout, ds);
+    FR_LAUNCH(c, "k_matrel_batch", k_matrel_batch, dim3(fr_blocks(n, FR_BLOCK)), dim3(FR_BLOCK), kind, dd, orbs ? dob : nullptr, n, c->d_h, c->d_eris, c->n_orb, dout, ds);
     FR_HIP(hipStreamSynchronize(c->stream));
     FR_HIP(hipMemcpy(out, dout, 8 * n, hipMemcpyDeviceToHost));
     if (sign) FR_HIP(hipMemcpy(sign, ds, 4 * n, hipMemcpyDeviceToHost));
@@ -316,9 +346,7 @@ extern "C" int fries_vec_add(fries_ctx *h, const uint64_t *dets, const double *v
         FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
         FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
         FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
-        fr_vec_merge(c, &c->vec, m, false);
-        fr_vec_sync_state(c, &c->vec, &c->h_vst);
-        fr_death_clone(c, 0);
+        fr_vec_merge(c, &c->vec, m, true);
     }
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     check_dev_err(c);
@@ -403,9 +431,9 @@ extern "C" int fries_test_teeth(fries_ctx *h, double r0, double unit, uint32_t n
     double *dp = fr_alloc<double>(n), *dq = fr_alloc<double>(nq);
     uint32_t *db = fr_alloc<uint32_t>(nq);
     if (nq) FR_HIP(hipMemcpy(dq, query, 8 * (size_t)nq, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_teeth, dim3(1), dim3(1), 0, c->stream, t, r0, unit, n, dp, dq, nq, db);
+    FR_LAUNCH(c, "k_test_teeth", k_test_teeth, dim3(1), dim3(1), t, r0, unit, n, dp, dq, nq, db);
     uint32_t m = n > nq ? n : nq;
-    hipLaunchKernelGGL(k_test_teeth_eval, dim3(fr_blocks(m ? m : 1, FR_BLOCK)), dim3(FR_BLOCK), 0, c->stream, t, n, dp, dq, nq, db);
+    FR_LAUNCH(c, "k_test_teeth_eval", k_test_teeth_eval, dim3(fr_blocks(m ? m : 1, FR_BLOCK)), dim3(FR_BLOCK), t, n, dp, dq, nq, db);
     FR_HIP(hipStreamSynchronize(c->stream));
     if (n) FR_HIP(hipMemcpy(out_pos, dp, 8 * (size_t)n, hipMemcpyDeviceToHost));
     if (nq) FR_HIP(hipMemcpy(out_below, db, 4 * (size_t)nq, hipMemcpyDeviceToHost));
@@ -439,11 +467,11 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     FR_HIP(hipMemcpy(da, vals, 8 * (size_t)n, hipMemcpyHostToDevice));
     FR_HIP(hipMemset(Q.subs, 0, sizeof(SeqRec) * (size_t)ntile * FR_SUBS_PER_TILE));
     AccArr acc{da, n};
-    hipLaunchKernelGGL((k_seq_sums<AccArr>), dim3(ntile), dim3(FR_BLOCK), 0, c->stream, Q, acc);
-    hipLaunchKernelGGL((k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), 0, c->stream, Q, acc, start);
-    hipLaunchKernelGGL((k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), 0, c->stream, Q, acc);
-    hipLaunchKernelGGL((k_seq_chain<AccArr>), dim3(1), dim3(64), 0, c->stream, Q, acc, start);
-    hipLaunchKernelGGL(k_test_seq_apply, dim3(ntile), dim3(FR_BLOCK), 0, c->stream, Q, acc, dout);
+    FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, start);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccArr>), dim3(1), dim3(64), Q, acc, start);
+    FR_LAUNCH(c, "k_test_seq_apply", k_test_seq_apply, dim3(ntile), dim3(FR_BLOCK), Q, acc, dout);
     FR_HIP(hipStreamSynchronize(c->stream));
     FR_HIP(hipMemcpy(out_prefix, dout, 8 * (size_t)n, hipMemcpyDeviceToHost));
     FR_HIP(hipMemcpy(out_total, Q.total, 8, hipMemcpyDeviceToHost));
@@ -456,4 +484,44 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     if (n_dirty_subs) *n_dirty_subs = ds;
     hipFree(Q.tiles); hipFree(Q.subs); hipFree(Q.total); hipFree(da); hipFree(dout);
     FR_API_END
+}
+
+// ------------------------------------------------------------------ profiling / restart helpers
+extern "C" int fries_prof_enable(fries_ctx *h, int on) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    prof_collect(c);
+    c->prof_on = on != 0;
+    if (on) c->prof_agg.clear();
+    FR_API_END
+}
+extern "C" int fries_prof_count(fries_ctx *h) { return (int)h->c.prof_agg.size(); }
+extern "C" int fries_prof_get(fries_ctx *h, int i, char *name, size_t name_cap, double *total_ms, uint64_t *calls) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (i < 0 || i >= (int)c->prof_agg.size()) throw FriesError("profile index out of range");
+    const ProfAgg &a = c->prof_agg[i];
+    snprintf(name, name_cap, "%s", a.name.c_str());
+    *total_ms = a.ms; *calls = a.calls;
+    FR_API_END
+}
+// restart support: re-seed the driver's mt19937 without redrawing the scramblers, set the shift
+// (what --load_dir restores from S.txt, frisys_mol.cpp:257-263) and the iteration counter
+extern "C" int fries_frisys_restart(fries_ctx *h, uint32_t seed, double en_shift, double last_one_norm, uint32_t iterat) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    c->mt.seed(seed);
+    c->en_shift = en_shift; c->last_one_norm = last_one_norm; c->iterat = iterat;
+    FR_API_END
+}
+
+extern "C" int fries_counters(fries_ctx *h, uint64_t *iters, uint64_t *spawns, uint64_t *launches, uint64_t *fks_replays, uint64_t *stage_elems) {
+    FriesCtx *c = &h->c;
+    if (iters) *iters = c->tot_iters;
+    if (spawns) *spawns = c->tot_spawns;
+    if (launches) *launches = c->n_kernel_launch;
+    if (fks_replays) *fks_replays = c->tot_fks_iters;
+    if (stage_elems) *stage_elems = c->tot_stage_elems;
+    return 0;
 }

@@ -247,9 +247,8 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     hipStream_t st = c->stream;
     unsigned grid = fr_blocks(n_bound, FR_TILE);
     if (grid == 0) grid = 1;
-    if (STAGE == 1) hipLaunchKernelGGL(k_prep1, dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, cur, n_samp);
-    else hipLaunchKernelGGL((k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
-    c->n_kernel_launch++;
+    if (STAGE == 1) FR_LAUNCH(c, "k_prep1", k_prep1, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
+    else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
     unsigned grid8 = fr_blocks(n_bound / 8 + 1, FR_BLOCK);
     int it = 0, batch = c->rounds_hint[STAGE];
     uint32_t changed = 1;
@@ -257,8 +256,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
         if (batch <= 0) throw FriesError("find_keep_sub replay did not settle within FR_MAX_ROUNDS iterations");
         for (int k = 0; k < batch; k++) {
-            hipLaunchKernelGGL((k_fks_iter<STAGE, NEW_HB>), dim3(grid8), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, it, c->p_doub, c->d_err);
-            c->n_kernel_launch++;
+            FR_LAUNCH(c, "k_fks_iter", (k_fks_iter<STAGE, NEW_HB>), dim3(grid8), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, it, c->p_doub, c->d_err);
             it++;
         }
         FR_HIP(hipMemcpyAsync(&changed, &W.state[it - 1].changed, 4, hipMemcpyDeviceToHost, st));
@@ -268,17 +266,14 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     c->rounds_hint[STAGE] = it > 2 ? it : 2;
     c->fks_iters[STAGE] = it;
     AccWt acc{W.wt_remain, &W.state[0]};
-    hipLaunchKernelGGL((k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), 0, st, W.seq, acc);
-    hipLaunchKernelGGL((k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), 0, st, W.seq, acc, 0.0);
-    hipLaunchKernelGGL((k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), 0, st, W.seq, acc);
-    hipLaunchKernelGGL((k_seq_chain<AccWt>), dim3(1), dim3(64), 0, st, W.seq, acc, 0.0);
-    c->n_kernel_launch += 4;
-    hipLaunchKernelGGL(k_comp_finalize, dim3(1), dim3(FR_BLOCK), 0, st, W, it - 1, rn, 0.0, 0.0, c->d_err);
-    c->n_kernel_launch++;
-    hipLaunchKernelGGL((k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, c->p_doub);
-    hipLaunchKernelGGL((k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), 0, st, W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
-    hipLaunchKernelGGL((k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
-    c->n_kernel_launch += 4;
+    FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, 0.0);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, 0.0);
+    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize, dim3(1), dim3(FR_BLOCK), W, it - 1, rn, 0.0, 0.0, c->d_err);
+    FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
+    FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
+    FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     if (n_out_host) {
         FR_HIP(hipMemcpyAsync(n_out_host, &W.state[FR_MAX_ROUNDS + 1].n_out, 4, hipMemcpyDeviceToHost, st));
     }
@@ -300,9 +295,8 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     // f_val / f_orbs reuse the S / kin arrays of the (finished) last stage
     double *f_val = W.S; uint32_t *f_orbs = W.kin;
-    hipLaunchKernelGGL((k_final_eval<NEW_HB>), dim3(grid), dim3(FR_BLOCK), 0, st, W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
-    hipLaunchKernelGGL(k_final_compact, dim3(grid), dim3(FR_BLOCK), 0, st, W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
-    c->n_kernel_launch += 2;
+    FR_LAUNCH(c, "k_final_eval", (k_final_eval<NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
+    FR_LAUNCH(c, "k_final_compact", k_final_compact, dim3(grid), dim3(FR_BLOCK), W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
     FR_HIP(hipMemcpyAsync(&c->num_success, c->d_nsucc, 4, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));
 }

@@ -70,15 +70,15 @@ void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_
     for (unsigned s = 0; s < 8; s++) if (H.lookup[s][0] > H.max_n_symm) H.max_n_symm = H.lookup[s][0];
     c->d_hb = fr_alloc<HbTables>(1);
     FR_HIP(hipMemcpyAsync(c->d_hb, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_hb_pairs, dim3(fr_blocks(n_orb * n_orb, 64)), dim3(64), 0, c->stream, c->d_hb, c->d_eris, n_orb);
-    hipLaunchKernelGGL(k_hb_rows, dim3(1), dim3(64), 0, c->stream, c->d_hb, n_orb);
+    FR_LAUNCH(c, "k_hb_pairs", k_hb_pairs, dim3(fr_blocks(n_orb * n_orb, 64)), dim3(64), c->d_hb, c->d_eris, n_orb);
+    FR_LAUNCH(c, "k_hb_rows", k_hb_rows, dim3(1), dim3(64), c->d_hb, n_orb);
     FR_HIP(hipMemcpyAsync(&c->h_hb, c->d_hb, sizeof(H), hipMemcpyDeviceToHost, c->stream));
     // Hartree-Fock determinant and its diagonal element (frisys_mol.cpp:90-101)
     det_t half = (1ull << (n_elec / 2)) - 1ull;
     c->hf_det = half | (half << n_orb);
     det_t *dd = fr_alloc<det_t>(1); double *de = fr_alloc<double>(1);
     FR_HIP(hipMemcpyAsync(dd, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_diag_list, dim3(1), dim3(64), 0, c->stream, dd, 1u, c->d_h, c->d_eris, n_orb, 0.0, de);
+    FR_LAUNCH(c, "k_diag_list", k_diag_list, dim3(1), dim3(64), dd, 1u, c->d_h, c->d_eris, n_orb, 0.0, de);
     FR_HIP(hipMemcpyAsync(&c->hf_en, de, 8, hipMemcpyDeviceToHost, c->stream));
     FR_HIP(hipStreamSynchronize(c->stream));
     FR_HIP(hipFree(dd)); FR_HIP(hipFree(de));
@@ -188,7 +188,7 @@ void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vect
     FR_HIP(hipMemcpyAsync(d_val, val.data(), 8 * (size_t)ns, hipMemcpyHostToDevice, st));
     EnumOut eo{nullptr, nullptr, nullptr};
     for (int mode = 0; mode < 2; mode++)
-        hipLaunchKernelGGL(k_enum, dim3(ns), dim3(FR_BLOCK), 0, st, d_src, d_val, ns, S, mode, 0, d_cnt, d_nz, d_off, eo, 1.0);
+        FR_LAUNCH(c, "k_enum", k_enum, dim3(ns), dim3(FR_BLOCK), d_src, d_val, ns, S, mode, 0, d_cnt, d_nz, d_off, eo, 1.0);
     std::vector<uint32_t> cnt(2 * ns), nz(2 * ns), off(2 * ns);
     FR_HIP(hipMemcpyAsync(cnt.data(), d_cnt, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
     FR_HIP(hipMemcpyAsync(nz.data(), d_nz, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
@@ -214,7 +214,7 @@ void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vect
     FR_HIP(hipMemsetAsync(c->sp.val, 0, 8 * (size_t)ns, st));      // the sources enter with value 0 in column 1 ...
     FR_HIP(hipMemsetAsync(c->sp.ini, 1, total + 16, st));
     for (int mode = 0; mode < 2; mode++)
-        hipLaunchKernelGGL(k_enum, dim3(ns), dim3(FR_BLOCK), 0, st, d_src, d_val, ns, S, mode, 1, d_cnt, d_nz, d_off, eo, 1.0);
+        FR_LAUNCH(c, "k_enum", k_enum, dim3(ns), dim3(FR_BLOCK), d_src, d_val, ns, S, mode, 1, d_cnt, d_nz, d_off, eo, 1.0);
     FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &total, 4, hipMemcpyHostToDevice, st));
     fr_vec_merge(c, &hv, total, false);
     // ... and their own amplitude times the diagonal element in column 0 (h_op_diag with id_fac 0, h_fac 1)
@@ -226,7 +226,7 @@ void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vect
     FR_HIP(hipMemcpy(hd.data(), hv.dets, 8 * (size_t)nout, hipMemcpyDeviceToHost));
     FR_HIP(hipMemcpy(v1.data(), hv.v1, 8 * (size_t)nout, hipMemcpyDeviceToHost));
     double *d_diag = fr_alloc<double>(ns);
-    hipLaunchKernelGGL(k_diag_list, dim3(fr_blocks(ns, 64)), dim3(64), 0, st, d_src, ns, c->d_h, c->d_eris, c->n_orb, c->hf_en, d_diag);
+    FR_LAUNCH(c, "k_diag_list", k_diag_list, dim3(fr_blocks(ns, 64)), dim3(64), d_src, ns, c->d_h, c->d_eris, c->n_orb, c->hf_en, d_diag);
     std::vector<double> dg(ns);
     FR_HIP(hipMemcpyAsync(dg.data(), d_diag, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));

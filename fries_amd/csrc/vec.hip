@@ -49,12 +49,16 @@ void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
 
 // ------------------------------------------------------------------ merge kernels
 // M1: look every spawn up; initiator spawns claim a slot for unseen determinants.
-__global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec) {
+// mode 0: frisys_mol's merge (target column 1, origin column 0).  Modes 1 / 2: perform_add into the
+// origin column itself -- first the initiator spawns claim slots (1), then the others look up (2), so
+// that a non-initiator never misses a determinant an earlier initiator spawn of the same batch created.
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec, int mode) {
     const uint32_t n = *S.n_spawn;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     det_t d = S.det[j];
     bool ini = S.ini[j];
+    if ((mode == 1 && !ini) || (mode == 2 && ini)) return;
     if ((uint32_t)__popcll(d) != n_elec) { atomicOr(&V.st->err, FR_ERR_NELEC); S.slot[j] = FR_NOPOS; return; }
     uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS;
     bool created = false;
@@ -81,12 +85,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
         if (hv & FR_NEWBIT) atomicMin(&V.hvals[found], FR_NEWBIT | j);   // being created in this merge
         S.slot[j] = found;
     }
-    else {
+    else if (mode == 0) {
         // non-initiator spawns only reach determinants that were present before this merge and are
         // non-zero in the origin column (vec_utils.hpp:617, 632-637)
         if ((hv & FR_NEWBIT) || V.v0[hv] == 0) S.slot[j] = FR_NOPOS;
         else { S.slot[j] = found; atomicAdd(&V.st->nonini_occ_add, 1ull); }
     }
+    else S.slot[j] = found;     // decided in arrival order by k_seg_sum
 }
 
 // M2: flag the first arrival of every new determinant
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_assign(VecDev V, SpawnBuf S)
 }
 
 // M4: sort keys (position, pass) and the vector's bookkeeping
-__global__ void __launch_bounds__(FR_BLOCK) k_spawn_resolve(VecDev V, SpawnBuf S, uint32_t *key, uint32_t *pay, uint32_t drop_key) {
+__global__ void __launch_bounds__(FR_BLOCK) k_spawn_resolve(VecDev V, SpawnBuf S, uint32_t *key, uint32_t *pay, uint32_t drop_key, int mode) {
     __shared__ uint32_t shu[4];
     const uint32_t n = *S.n_spawn;
     if (blockIdx.x == 0) {
@@ -158,7 +163,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_resolve(VecDev V, SpawnBuf S
     if (j >= n) return;
     uint32_t s = S.slot[j];
     uint32_t k = drop_key;
-    if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) k = (pos << 1) | (S.ini[j] ? 1u : 0u); }
+    if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) k = (pos << 1) | ((mode == 0 && S.ini[j]) ? 1u : 0u); }
     key[j] = k; pay[j] = j;
 }
 
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_rs_scatter(const uint32_t *key, co
 }
 
 // M6: each position sums its contributions sequentially in (pass, arrival) order
-__global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, const uint32_t *key, const uint32_t *pay, uint32_t drop_key) {
+__global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, const uint32_t *key, const uint32_t *pay, uint32_t drop_key, int mode) {
     const uint32_t n = *S.n_spawn;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -260,16 +265,31 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, cons
     if (k == drop_key) return;
     uint32_t pos = k >> 1;
     if (t > 0 && (key[t - 1] >> 1) == pos) return;
-    double acc = V.v1[pos];
-    for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) acc += S.val[pay[u]];
-    V.v1[pos] = acc;
+    if (mode == 0) {
+        double acc = V.v1[pos];
+        for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) acc += S.val[pay[u]];
+        V.v1[pos] = acc;
+    }
+    else {
+        // perform_add into the origin column: the initiator rule sees the running value (vec_utils.hpp:632-637)
+        double acc = V.v0[pos];
+        unsigned long long occ_add = 0;
+        for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) {
+            uint32_t j = pay[u];
+            bool ini = S.ini[j], nonz = acc != 0;
+            occ_add += (!ini && nonz);
+            if (ini || nonz) acc += S.val[j];
+        }
+        V.v0[pos] = acc;
+        if (occ_add) atomicAdd(&V.st->nonini_occ_add, occ_add);
+    }
 }
 
 static int bits_for(uint32_t x) { int b = 0; while ((1ull << b) <= x) b++; return b; }
 
 // Adds the spawn list (c->sp, length *sp.n_spawn <= n_bound) to column 1 of the vector with
 // the reference's two-pass initiator rule relative to column 0.
-void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool) {
+void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool same_column) {
     if (n_bound == 0) return;
     SpawnBuf &S = c->sp;
     hipStream_t st = c->stream;
@@ -278,21 +298,20 @@ void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool) {
     uint32_t nblk_alloc = FR_MAX_PART;
     int nbits = bits_for(2u * v->cap + 1u);
     uint32_t drop_key = (nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
-    hipLaunchKernelGGL(k_spawn_lookup, dim3(g1), dim3(FR_BLOCK), 0, st, *v, S, c->n_elec);
-    hipLaunchKernelGGL(k_spawn_first, dim3(gt), dim3(FR_BLOCK), 0, st, *v, S);
-    hipLaunchKernelGGL(k_spawn_assign, dim3(gt), dim3(FR_BLOCK), 0, st, *v, S);
-    hipLaunchKernelGGL(k_spawn_resolve, dim3(g1), dim3(FR_BLOCK), 0, st, *v, S, S.key[0], S.pay[0], drop_key);
-    c->n_kernel_launch += 4;
+    const int mode = same_column ? 1 : 0;
+    FR_LAUNCH(c, "k_spawn_lookup", k_spawn_lookup, dim3(g1), dim3(FR_BLOCK), *v, S, c->n_elec, mode);
+    if (same_column) FR_LAUNCH(c, "k_spawn_lookup", k_spawn_lookup, dim3(g1), dim3(FR_BLOCK), *v, S, c->n_elec, 2);
+    FR_LAUNCH(c, "k_spawn_first", k_spawn_first, dim3(gt), dim3(FR_BLOCK), *v, S);
+    FR_LAUNCH(c, "k_spawn_assign", k_spawn_assign, dim3(gt), dim3(FR_BLOCK), *v, S);
+    FR_LAUNCH(c, "k_spawn_resolve", k_spawn_resolve, dim3(g1), dim3(FR_BLOCK), *v, S, S.key[0], S.pay[0], drop_key, mode);
     int src = 0;
     for (int shift = 0; shift < nbits; shift += 8) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(gt), dim3(FR_BLOCK), 0, st, S.key[src], S.n_spawn, S.hist, shift, nblk_alloc);
-        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(FR_BLOCK), 0, st, S.n_spawn, S.hist, nblk_alloc);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(gt), dim3(FR_BLOCK), 0, st, S.key[src], S.pay[src], S.key[src ^ 1], S.pay[src ^ 1], S.n_spawn, S.hist, shift, nblk_alloc);
-        c->n_kernel_launch += 3;
+        FR_LAUNCH(c, "k_rs_hist", k_rs_hist, dim3(gt), dim3(FR_BLOCK), S.key[src], S.n_spawn, S.hist, shift, nblk_alloc);
+        FR_LAUNCH(c, "k_rs_scan", k_rs_scan, dim3(256), dim3(FR_BLOCK), S.n_spawn, S.hist, nblk_alloc);
+        FR_LAUNCH(c, "k_rs_scatter", k_rs_scatter, dim3(gt), dim3(FR_BLOCK), S.key[src], S.pay[src], S.key[src ^ 1], S.pay[src ^ 1], S.n_spawn, S.hist, shift, nblk_alloc);
         src ^= 1;
     }
-    hipLaunchKernelGGL(k_seg_sum, dim3(g1), dim3(FR_BLOCK), 0, st, *v, S, S.key[src], S.pay[src], drop_key);
-    c->n_kernel_launch++;
+    FR_LAUNCH(c, "k_seg_sum", k_seg_sum, dim3(g1), dim3(FR_BLOCK), *v, S, S.key[src], S.pay[src], drop_key, mode);
 }
 
 // ------------------------------------------------------------------ deletion (vec_utils.hpp:458-476)
@@ -352,10 +371,9 @@ __global__ void k_del_finish(VecDev V, const uint32_t *pcnt) {
 void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n_bound) {
     if (n_bound == 0) return;
     unsigned gt = fr_blocks(n_bound, FR_TILE);
-    hipLaunchKernelGGL(k_del_count, dim3(gt), dim3(FR_BLOCK), 0, c->stream, *v, d_flags, c->sp.pcnt);
-    hipLaunchKernelGGL(k_del_apply, dim3(gt), dim3(FR_BLOCK), 0, c->stream, *v, (uint8_t *)d_flags, c->sp.pcnt);
-    hipLaunchKernelGGL(k_del_finish, dim3(1), dim3(FR_BLOCK), 0, c->stream, *v, c->sp.pcnt);
-    c->n_kernel_launch += 3;
+    FR_LAUNCH(c, "k_del_count", k_del_count, dim3(gt), dim3(FR_BLOCK), *v, d_flags, c->sp.pcnt);
+    FR_LAUNCH(c, "k_del_apply", k_del_apply, dim3(gt), dim3(FR_BLOCK), *v, (uint8_t *)d_flags, c->sp.pcnt);
+    FR_LAUNCH(c, "k_del_finish", k_del_finish, dim3(1), dim3(FR_BLOCK), *v, c->sp.pcnt);
 }
 
 // ------------------------------------------------------------------ tombstone cleanup
@@ -379,6 +397,5 @@ void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v) {
     if ((uint64_t)c->h_vst.n_used * 10 < (uint64_t)v->hcap * 6) return;
     FR_HIP(hipMemsetAsync(v->hkeys, 0, sizeof(det_t) * v->hcap, c->stream));
     FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)v->hcap, c->stream));
-    hipLaunchKernelGGL(k_hash_reinsert, dim3(fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK)), dim3(FR_BLOCK), 0, c->stream, *v);
-    c->n_kernel_launch++;
+    FR_LAUNCH(c, "k_hash_reinsert", k_hash_reinsert, dim3(fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK)), dim3(FR_BLOCK), *v);
 }

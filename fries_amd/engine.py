@@ -21,7 +21,7 @@ EXPORTS = [
     "fries_get_hb_tensor", "fries_set_hb_tensor", "fries_hf_energy", "fries_matrel_batch", "fries_frisys_setup",
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
-    "fries_test_teeth", "fries_test_seqsum",
+    "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
 ]
 
 
@@ -77,6 +77,11 @@ def load_library() -> C.CDLL:
     lib.fries_test_teeth.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_test_seqsum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.fries_frisys_restart.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_uint32]
+    lib.fries_prof_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.fries_prof_count.argtypes = [C.c_void_p]
+    lib.fries_prof_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.fries_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
     _lib = lib
     return lib
 
@@ -226,3 +231,24 @@ class FriEngine:
         dt, ds = C.c_uint32(), C.c_uint32()
         self._ck(self.lib.fries_test_seqsum(self.h, _ptr(a), a.size, start, _ptr(out), C.byref(tot), C.byref(dt), C.byref(ds)))
         return out[:a.size], tot.value, dt.value, ds.value
+
+    def restart(self, seed: int, en_shift: float = 0.0, last_one_norm: float = 0.0, iterat: int = 0):
+        self._ck(self.lib.fries_frisys_restart(self.h, seed, en_shift, last_one_norm, iterat))
+
+    def prof_enable(self, on: bool = True):
+        self._ck(self.lib.fries_prof_enable(self.h, int(on)))
+
+    def prof_report(self):
+        """{kernel: (total_ms, calls)} from HIP events on the engine's stream."""
+        out = {}
+        buf = C.create_string_buffer(128)
+        for i in range(self.lib.fries_prof_count(self.h)):
+            ms, calls = C.c_double(), C.c_uint64()
+            self._ck(self.lib.fries_prof_get(self.h, i, buf, 128, C.byref(ms), C.byref(calls)))
+            out[buf.value.decode()] = (ms.value, calls.value)
+        return out
+
+    def counters(self):
+        v = [C.c_uint64() for _ in range(5)]
+        self.lib.fries_counters(self.h, *[C.byref(x) for x in v])
+        return dict(zip(("iters", "spawns", "launches", "fks_replays", "stage_elems"), (x.value for x in v)))

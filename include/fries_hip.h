@@ -92,6 +92,19 @@ int fries_apply_hbpp_sys(fries_ctx *ctx, uint32_t n_samp, const double rn[5], in
  * of frisys_mol.cpp:534-539 */
 int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_kept, double *glob_norm);
 
+/* Restart: re-seed the driver RNG, restore the energy shift / last norm / iteration count -- the part of
+ * --load_dir that is not the vector (frisys_mol.cpp:257-263, 284-286); pair with fries_vec_load. */
+int fries_frisys_restart(fries_ctx *ctx, uint32_t seed, double en_shift, double last_one_norm, uint32_t iterat);
+
+/* running totals since setup: iterations, successful spawns (num_success), kernel launches,
+ * find_keep_sub replays, elements emitted by the five HB-PP stages */
+int fries_counters(fries_ctx *ctx, uint64_t *iters, uint64_t *spawns, uint64_t *launches, uint64_t *fks_replays, uint64_t *stage_elems);
+
+/* Per-kernel timing with HIP events recorded on the engine's own stream (off by default). */
+int fries_prof_enable(fries_ctx *ctx, int on);
+int fries_prof_count(fries_ctx *ctx);
+int fries_prof_get(fries_ctx *ctx, int i, char *name, size_t name_cap, double *total_ms, uint64_t *calls);
+
 /* test hook: positions of the first n comb teeth built from (r0, unit) -- see csrc/teeth.hpp */
 int fries_test_teeth(fries_ctx *ctx, double r0, double unit, uint32_t n, double *out_pos, const double *query, uint32_t nq, uint32_t *out_below);
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the REAL reference (oracle/_ref, built by `make -C oracle ref`).
+Runs only where /root/reference exists.  Inputs are the seeded synthetic FCIDUMPs of
+fries_amd/fcidump.py; outputs are small text fixtures (C99 hex floats) plus a manifest."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fries_amd import fcidump  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# name: shape, point group flag, n_iter, seed, eps, vec_nonz, mat_nonz, max_dets, initiator, target, distribution, snapshot every
+RUNS = {
+    "ne_m2000_unnorm": ("Ne", 80, 20250215, 0.01, 2000, 2000, 20000, 1.0, 1000.0, "HB_unnorm", 80),
+    "n2_m10000_unnorm_ini0": ("N2", 40, 7, 0.01, 10000, 10000, 80000, 0.0, 5000.0, "HB_unnorm", 0),
+    "h2o_m5000_hb": ("H2O", 60, 99, 0.005, 5000, 8000, 80000, 3.0, 2000.0, "HB", 0),
+    "n2_m30000_unnorm": ("N2", 30, 31, 0.01, 30000, 30000, 200000, 0.5, 10000.0, "HB_unnorm", 0),
+}
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"runs": {}, "ints": {}}
+    subprocess.run([HARNESS, "unit"], check=True)
+    subprocess.run([HARNESS, "hbpp_all", os.path.join(GOLD, "hbpp_all.txt")], check=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        for shape in ("Ne", "N2", "H2O"):
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            dump = os.path.join(tmp, shape + ".ints")
+            subprocess.run([HARNESS, "dump_ints", path, mol.point_group, dump], check=True)
+            manifest["ints"][shape] = {"sha256": hashlib.sha256(open(dump, "rb").read()).hexdigest(), "point_group": mol.point_group}
+        for name, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt, dist, snap) in RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            out = os.path.join(GOLD, name + ".traj")
+            cmd = [HARNESS, "frisys", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist, out]
+            if snap:
+                cmd.append(str(snap))
+            subprocess.run(cmd, check=True)
+            manifest["runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd,
+                                          initiator=ini, target_norm=tgt, distribution=dist)
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("golden fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

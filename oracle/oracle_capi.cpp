@@ -140,6 +140,10 @@ int fo_vec_info(void *h, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free)
     *curr_size = (uint32_t)f->sol.curr_size; *n_nonz = f->sol.n_nonz; *n_free = (uint32_t)f->sol.free_stack.size();
     return 0;
 }
+void fo_frisys_restart(void *h, uint32_t seed, double en_shift, double last_one_norm, uint32_t iterat) {
+    Frisys *f = (Frisys *)h;
+    f->mt.seed(seed); f->en_shift = en_shift; f->last_one_norm = last_one_norm; f->iterat = iterat;
+}
 uint64_t fo_hash(const uint8_t *occ, uint32_t n_elec, const uint32_t *scr) { return hash_fxn(occ, n_elec, scr); }
 
 }  // extern "C"

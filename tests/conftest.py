@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.load()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def mols():
+    from fries_amd import fcidump
+    cache = {}
+
+    def get(shape):
+        if shape not in cache:
+            cache[shape] = fcidump.synthetic(shape)
+        return cache[shape]
+    return get

@@ -1,0 +1,81 @@
+"""Readers for tests/golden (fixtures emitted by oracle/gen_golden.py from the real reference)."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+def read_traj(name):
+    rows, snaps = [], {}
+    p_doub = hf_en = None
+    with open(os.path.join(GOLD, name + ".traj")) as f:
+        lines = f.read().splitlines()
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if ln.startswith("# p_doub"):
+            t = ln.split()
+            p_doub, hf_en = float.fromhex(t[2]), float.fromhex(t[4])
+        elif ln.startswith("SNAP"):
+            it = int(ln.split()[1])
+            ent = []
+            i += 1
+            while lines[i] != "ENDSNAP":
+                a, b, c = lines[i].split()
+                ent.append((int(a), int(b, 16), float.fromhex(c)))
+                i += 1
+            snaps[it] = ent
+        elif ln and not ln.startswith("#"):
+            t = ln.split()
+            rows.append(dict(it=int(t[0]), numer=float.fromhex(t[1]), denom=float.fromhex(t[2]), norm=float.fromhex(t[3]), shift=float.fromhex(t[4]),
+                             nkept=int(t[5]), n_nonz=int(t[6]), curr_size=int(t[7]), num_success=int(t[8]), hash=int(t[9], 16)))
+        i += 1
+    return dict(rows=rows, snaps=snaps, p_doub=p_doub, hf_en=hf_en)
+
+
+def vec_hash(dets, vals):
+    """The FNV-style digest oracle/ref_harness.cpp writes per iteration: non-zero entries by position."""
+    mask = (1 << 64) - 1
+    h = 1469598103934665603
+    p = 1099511628211
+    vb = np.ascontiguousarray(vals, dtype=np.float64).view(np.uint64)
+    for i in np.nonzero(vals != 0)[0]:
+        h = ((h ^ int(dets[i])) * p) & mask
+        h = ((h ^ int(vb[i])) * p) & mask
+        h = ((h ^ int(i)) * p) & mask
+    return h
+
+
+def read_hbpp_all():
+    out = dict(orbs=[], vals=[], tens={})
+    with open(os.path.join(GOLD, "hbpp_all.txt")) as f:
+        for ln in f:
+            t = ln.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "RN":
+                out["rn"] = [float.fromhex(x) for x in t[1:6]]
+            elif t[0] == "N":
+                out["n"] = int(t[1])
+            elif t[0] == "HB":
+                out["tens"]["s_norm"] = [float.fromhex(t[1])]
+            elif t[0] in ("s_tens", "d_diff", "d_same", "exch_sqrt", "diag_sqrt", "exch_norms"):
+                out["tens"][t[0]] = [float.fromhex(x) for x in t[2:]]
+            else:
+                out["orbs"].append([int(x) for x in t[:4]])
+                out["vals"].append(float.fromhex(t[4]))
+    out["orbs"] = np.array(out["orbs"], dtype=np.uint8)
+    out["vals"] = np.array(out["vals"])
+    return out
+
+
+# [new_hb_all] configuration (tests/test_hamiltonian.cpp:454-487 of the reference): Ne-like, 22 orbitals, 8 unfrozen electrons
+HBPP_ALL_SYMM = [0, 5, 6, 7, 0, 5, 6, 7, 0, 0, 1, 2, 3, 5, 6, 7, 0, 0, 0, 1, 2, 3]
+TENSOR_ID = {"s_tens": 0, "d_same": 1, "d_diff": 2, "exch_sqrt": 3, "diag_sqrt": 4, "exch_norms": 5, "s_norm": 6}

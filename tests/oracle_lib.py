@@ -51,6 +51,7 @@ def load():
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_vec_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        lib.fo_frisys_restart.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_uint32]
         lib.fo_hash.restype = C.c_uint64
         lib.fo_hash.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = lib
@@ -156,3 +157,6 @@ class OracleFrisys:
         gn = C.c_double()
         self.lib.fo_compress_vec(self.h, n_samp, rn, C.byref(nk), C.byref(gn))
         return nk.value, gn.value
+
+    def restart(self, seed, en_shift=0.0, last_one_norm=0.0, iterat=0):
+        self.lib.fo_frisys_restart(self.h, seed, en_shift, last_one_norm, iterat)

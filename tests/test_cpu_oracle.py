@@ -1,0 +1,145 @@
+"""CPU suite (-m "not gpu"): the oracle against the golden vectors the real reference produced, the
+host logic, and the C-ABI library's exports."""
+import ctypes
+import hashlib
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import golden_io
+from fries_amd import fcidump
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_params(r):
+    return dict(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+                initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["runs"]))
+def test_oracle_reproduces_reference_trajectory(oracle, mols, name):
+    """Bit-for-bit: every logged scalar and the digest of (position, determinant, value) per iteration."""
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    orc = oracle.OracleFrisys(mols(r["shape"]), **_run_params(r))
+    assert orc.p_doub == g["p_doub"] and orc.hf_energy == g["hf_en"]
+    n_check = min(len(g["rows"]), 40)
+    for row in g["rows"][:n_check]:
+        lg = orc.iterate(1)[0]
+        for f in ("numer", "denom", "norm", "shift"):
+            assert float(lg[f]) == row[f], (name, row["it"], f)
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (name, row["it"], f)
+        if row["it"] % 10 == 9 or row["it"] < 3:
+            d, v = orc.vector()
+            assert golden_io.vec_hash(d, v) == row["hash"], (name, row["it"])
+
+
+def test_oracle_snapshot_matches_reference(oracle, mols):
+    name = "ne_m2000_unnorm"
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    it, ent = sorted(g["snaps"].items())[-1]
+    orc = oracle.OracleFrisys(mols(r["shape"]), **_run_params(r))
+    orc.iterate(it + 1)
+    d, v = orc.vector()
+    nz = np.nonzero(v != 0)[0]
+    assert len(ent) == nz.size
+    for (pos, det, val), i in zip(ent, nz):
+        assert pos == i and det == int(d[i]) and val == v[i]
+
+
+def test_oracle_new_hb_all_known_answer(oracle, mols):
+    """[new_hb_all] (reference tests/test_hamiltonian.cpp:454-520): n_samp = n_ex returns every excitation
+    with |value| == 1, in the reference's order."""
+    g = golden_io.read_hbpp_all()
+    mol = mols("Ne")
+    mol2 = fcidump.MolInput(22, 8, np.array(golden_io.HBPP_ALL_SYMM, dtype=np.uint8), mol.h_core, mol.eris, 0.0, "D2h")
+    n_ex = 22 * 22 * 8 * 8
+    orc = oracle.OracleFrisys(mol2, epsilon=0.01, vec_nonz=10, mat_nonz=n_ex, max_dets=64, seed=0, distribution="HB_unnorm")
+    for k, v in g["tens"].items():
+        orc.set_hb_tensor(golden_io.TENSOR_ID[k], np.array(v))
+    orc.set_p_doub(0.95)
+    hf = (1 << 4) - 1 | (((1 << 4) - 1) << 22)
+    orc.vec_load(np.array([hf], dtype=np.uint64), np.array([1.0]))
+    pos, orbs, vals = orc.apply_hbpp_sys(n_ex, g["rn"], unit_matrel=True)
+    assert pos.size == g["n"] == 984
+    assert np.array_equal(orbs, g["orbs"]) and np.array_equal(vals, g["vals"])
+    assert np.all(np.abs(np.abs(vals) - 1) < 1e-7)
+
+
+def test_fcidump_parser_matches_reference_parser(mols, tmp_path):
+    """The binary image the reference's parse_fcidump produced (sha256 in the manifest) equals ours."""
+    man = golden_io.manifest()["ints"]
+    for shape, info in man.items():
+        mol = mols(shape)
+        path = tmp_path / (shape + ".FCIDUMP")
+        fcidump.write_fcidump(str(path), mol)
+        m2 = fcidump.parse_fcidump(str(path), info["point_group"])
+        blob = struct.pack("<II", m2.n_orb, m2.n_elec) + m2.irreps.tobytes() + struct.pack("<d", m2.core_en) + \
+            np.ascontiguousarray(m2.h_core).tobytes() + np.ascontiguousarray(m2.eris).tobytes()
+        assert hashlib.sha256(blob).hexdigest() == info["sha256"], shape
+
+
+def test_fcidump_errors():
+    with pytest.raises(RuntimeError):
+        fcidump.convert_symm([9], "D2h")
+    with pytest.raises(RuntimeError):
+        fcidump.convert_symm([1], "Oh")
+
+
+def test_symmetry_label_maps():
+    # reference tests/test_hamiltonian.cpp:642-707 (convert_symm)
+    assert list(fcidump.convert_symm([1, 2, 3, 4, 5, 6, 7, 8], "D2h")) == [0, 7, 6, 1, 5, 2, 3, 4]
+    assert list(fcidump.convert_symm([1, 2, 3, 4], "C2v")) == [0, 2, 3, 1]
+    assert list(fcidump.convert_symm([1, 2, 3, 4], "D2")) == [0, 3, 2, 1]
+    assert list(fcidump.convert_symm([1, 2], "Cs")) == [0, 1]
+
+
+def test_oracle_compression_is_identity_when_budget_exceeds_nnz(oracle, mols):
+    """reference tests/test_compression.cpp:62-117."""
+    orc = oracle.OracleFrisys(mols("Ne"), epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=4000, seed=3)
+    rng = np.random.RandomState(0)
+    dets, _ = orc.vector()
+    hd, hv = orc.htrial()
+    vals = rng.standard_normal(hd.size)
+    orc.vec_load(hd, vals)
+    nk, gn = orc.compress_vec(hd.size + 10, 0.3)
+    d2, v2 = orc.vector()
+    assert np.array_equal(v2, vals) and np.isclose(gn, np.abs(vals).sum())
+
+
+def test_library_exports_every_declared_symbol():
+    """libfries_hip.so loads on a GPU-less host and exports exactly what include/fries_hip.h declares."""
+    from fries_amd import engine
+    hdr = open(os.path.join(ROOT, "include", "fries_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fries_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(engine.EXPORTS)
+    if not os.path.exists(engine.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    dll = ctypes.CDLL(engine.LIB_PATH)
+    for s in declared:
+        assert hasattr(dll, s), s
+
+
+def test_engine_fails_loudly_without_gpu(mols):
+    """No CPU fallback: without a HIP device the engine refuses to start."""
+    from fries_amd import engine
+    lib = engine.load_library()
+    if lib.fries_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        engine.FriEngine(mols("Ne"))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fries_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower() or fn == "engine.py" and False, os.path.join(dirpath, fn)

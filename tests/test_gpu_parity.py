@@ -1,0 +1,270 @@
+"""GPU suite (-m gpu): the hand-written HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs and against the golden vectors the real reference produced.
+Bar: integers (positions, determinants, counts) and stored doubles bit-exact; projected energy
+numer/denom within 1e-10 (their mixed-sign dot products are summed in a tree on the GPU)."""
+import numpy as np
+import pytest
+
+import golden_io
+from fries_amd import fcidump
+
+pytestmark = pytest.mark.gpu
+ENERGY_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from fries_amd.engine import FriEngine
+    return FriEngine
+
+
+def rand_dets(rng, n_orb, n_elec, n):
+    out = np.zeros(n, dtype=np.uint64)
+    for i in range(n):
+        d = 0
+        for sp in range(2):
+            for o in rng.choice(n_orb, n_elec // 2, replace=False):
+                d |= 1 << (int(o) + sp * n_orb)
+        out[i] = d
+    return out
+
+
+def compare_iter(lg, lo, eng, orc, check_values=True):
+    for f in ("num_success", "n_nonz", "curr_size", "nkept"):
+        assert int(lg[f]) == int(lo[f]), f
+    assert float(lg["norm"]) == float(lo["norm"]) and float(lg["shift"]) == float(lo["shift"])
+    assert abs(lg["numer"] / lg["denom"] - lo["numer"] / lo["denom"]) < ENERGY_TOL
+    assert int(lg["err"]) == 0
+    if check_values:
+        gd, gv = eng.vector()
+        cd, cv = orc.vector()
+        nz = cv != 0
+        assert gd.size == cd.size
+        assert np.array_equal(gv, cv)
+        assert np.array_equal(gd[nz], cd[nz])
+
+
+@pytest.mark.parametrize("shape", ["Ne", "N2", "H2O"])
+def test_system_tables_and_matrix_elements(Engine, oracle, mols, shape):
+    mol = mols(shape)
+    eng = Engine(mol)
+    orc = oracle.OracleFrisys(mol, epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=1000, seed=1)
+    assert eng.hf_energy == orc.hf_energy
+    for w in range(7):
+        assert np.array_equal(eng.hb_tensor(w), orc.hb_tensor(w)), w
+    rng = np.random.RandomState(5)
+    dets = rand_dets(rng, mol.n_orb, mol.n_elec, 3000)
+    a, _ = eng.matrel(0, dets)
+    b, _ = orc.matrel(0, dets)
+    assert np.array_equal(a, b)
+    # singles / doubles with random (not nec. symmetry-allowed) orbitals: arithmetic parity only
+    n = mol.n_orb
+    orbs = np.zeros((dets.size, 4), dtype=np.uint8)
+    for i, d in enumerate(dets):
+        occ = [k for k in range(2 * n) if (int(d) >> k) & 1]
+        vir = [k for k in range(2 * n) if not (int(d) >> k) & 1]
+        o = sorted(rng.choice(occ, 2, replace=False))
+        u = sorted(rng.choice([v for v in vir if v // n == o[0] // n] if i % 2 else vir, 2, replace=False))
+        orbs[i] = [o[0], o[1], u[0], u[1]]
+    so = orbs.copy()
+    for i in range(dets.size):                      # single: same spin
+        sp = so[i, 0] // n
+        cand = [k for k in range(sp * n, sp * n + n) if not (int(dets[i]) >> k) & 1]
+        so[i, 1] = cand[rng.randint(len(cand))]
+    for kind, ob in ((1, so), (2, orbs)):
+        a, sa = eng.matrel(kind, dets, ob)
+        b, sb = orc.matrel(kind, dets, ob)
+        assert np.array_equal(a, b) and np.array_equal(sa, sb), kind
+    eng.close()
+
+
+def test_comb_teeth_are_the_reference_sequence(Engine, mols):
+    """Tooth k must equal fl(fl(r0 + u) + u ...) (compress_utils.cpp:318), not r0 + k*u."""
+    eng = Engine(mols("Ne"))
+    rng = np.random.RandomState(2)
+    for r0f, unit, n in [(0.37, 1.234567e-3, 300000), (0.0, 0.1, 5000), (0.999, 7.7e-7, 100000), (0.5, 1.0, 70000), (1e-9, 3.3, 1000)]:
+        r0 = r0f * unit
+        ref = np.empty(n)
+        x = r0
+        for k in range(n):
+            ref[k] = x
+            x = x + unit
+        q = np.sort(np.concatenate([rng.random_sample(3000) * ref[-1] * 1.01, ref[rng.randint(0, n, 200)]]))
+        pos, below = eng.test_teeth(r0, unit, n, q)
+        assert np.array_equal(pos, ref)
+        assert np.array_equal(below, np.searchsorted(ref, q, side="left"))
+    eng.close()
+
+
+def test_exact_sequential_sums(Engine, mols):
+    """seqsum.hpp against numpy's left-to-right cumsum, bit for bit."""
+    eng = Engine(mols("Ne"))
+    rng = np.random.RandomState(3)
+    cases = [rng.random_sample(5), rng.random_sample(1024), np.exp(8 * rng.random_sample(70001)) * (rng.random_sample(70001) > 0.1),
+             rng.random_sample(1000003), np.full(300000, 0.1234567), np.ldexp(rng.randint(1, 8, 200000).astype(float), -3),
+             np.where(rng.random_sample(100000) > 0.9, rng.random_sample(100000), 0.0), np.exp(20 * rng.random_sample(2000000))]
+    for a in cases:
+        out, tot, dirty_tiles, dirty_subs = eng.test_seqsum(a)
+        ref = np.cumsum(a)
+        assert np.array_equal(out, ref) and tot == ref[-1]
+        assert dirty_subs < 200
+    eng.close()
+
+
+def test_new_hb_all_known_answer_on_gpu(Engine, mols):
+    """Reference tests/test_hamiltonian.cpp:454-520 through the HIP path: every excitation once, |value| = 1,
+    orbitals in the reference's order."""
+    g = golden_io.read_hbpp_all()
+    mol = mols("Ne")
+    mol2 = fcidump.MolInput(22, 8, np.array(golden_io.HBPP_ALL_SYMM, dtype=np.uint8), mol.h_core, mol.eris, 0.0, "D2h")
+    n_ex = 22 * 22 * 8 * 8
+    eng = Engine(mol2)
+    eng.setup(epsilon=0.01, vec_nonz=10, mat_nonz=n_ex, max_dets=64, seed=0, distribution="HB_unnorm")
+    for k, v in g["tens"].items():
+        eng.set_hb_tensor(golden_io.TENSOR_ID[k], np.array(v))
+    hf = (1 << 4) - 1 | (((1 << 4) - 1) << 22)
+    eng.vec_load(np.array([hf], dtype=np.uint64), np.array([1.0]))
+    # p_doub of this test is 0.95, not the HF ratio: go through the oracle-free path by scaling afterwards is not
+    # possible, so the engine exposes it via setup only; reproduce it by loading the tensors and comparing orbitals
+    pos, orbs, vals, _ = eng.apply_hbpp_sys(n_ex, g["rn"], unit_matrel=True)
+    assert pos.size == 984 and np.all(pos == 0)
+    assert sorted(map(tuple, orbs.tolist())) == sorted(map(tuple, g["orbs"].tolist()))
+    eng.close()
+
+
+RUNS = [
+    ("Ne", dict(epsilon=0.01, vec_nonz=2000, mat_nonz=2000, max_dets=20000, target_norm=1000.0, initiator=1.0, seed=20250215, distribution="HB_unnorm"), 70),
+    ("N2", dict(epsilon=0.01, vec_nonz=10000, mat_nonz=10000, max_dets=80000, target_norm=5000.0, initiator=0.0, seed=7, distribution="HB_unnorm"), 40),
+    ("H2O", dict(epsilon=0.005, vec_nonz=5000, mat_nonz=8000, max_dets=80000, target_norm=2000.0, initiator=3.0, seed=99, distribution="HB"), 50),
+    ("N2", dict(epsilon=0.01, vec_nonz=100000, mat_nonz=100000, max_dets=600000, target_norm=30000.0, initiator=0.0, seed=5, distribution="HB_unnorm"), 25),
+    ("N2", dict(epsilon=0.01, vec_nonz=50000, mat_nonz=120000, max_dets=600000, target_norm=30000.0, initiator=0.5, seed=6, distribution="HB"), 25),
+]
+
+
+@pytest.mark.parametrize("case", range(len(RUNS)))
+def test_frisys_trajectory_matches_oracle(Engine, oracle, mols, case):
+    shape, par, n_iter = RUNS[case]
+    mol = mols(shape)
+    eng = Engine(mol)
+    eng.setup(**par)
+    orc = oracle.OracleFrisys(mol, **par)
+    assert eng.p_doub == orc.p_doub
+    hd, hv = eng.htrial()
+    od, ov = orc.htrial()
+    assert np.array_equal(hd, od) and np.array_equal(hv, ov)
+    for it in range(n_iter):
+        lg, lo = eng.iterate(1)[0], orc.iterate(1)[0]
+        compare_iter(lg, lo, eng, orc, check_values=(it % 5 == 4 or it < 3 or it == n_iter - 1))
+    eng.close()
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["runs"]))
+def test_frisys_trajectory_matches_reference_golden(Engine, mols, name):
+    """Directly against what the real reference logged (no oracle in between)."""
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    eng = Engine(mols(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    assert eng.p_doub == g["p_doub"] and eng.hf_energy == g["hf_en"]
+    for row in g["rows"]:
+        lg = eng.iterate(1)[0]
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (row["it"], f)
+        assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"]
+        assert abs(lg["numer"] / lg["denom"] - row["numer"] / row["denom"]) < ENERGY_TOL
+        if row["it"] % 10 == 9:
+            d, v = eng.vector()
+            assert golden_io.vec_hash(d, v) == row["hash"], row["it"]
+    eng.close()
+
+
+def test_vector_add_and_annihilation_semantics(Engine, oracle, mols):
+    """DistVec add / perform_add rules (reference tests/test_vector.cpp:192-224, vec_utils.hpp:606-641):
+    initiator spawns create determinants, non-initiator spawns only reach occupied ones, opposite signs cancel,
+    freed positions are reused last-in-first-out."""
+    mol = mols("Ne")
+    par = dict(epsilon=0.01, vec_nonz=500, mat_nonz=500, max_dets=5000, seed=4)
+    eng = Engine(mol)
+    eng.setup(**par)
+    orc = oracle.OracleFrisys(mol, **par)
+    rng = np.random.RandomState(9)
+    pool = rand_dets(rng, mol.n_orb, mol.n_elec, 300)
+    for rnd in range(6):
+        idx = rng.randint(0, pool.size, 400)
+        vals = np.round(rng.standard_normal(400), 1)          # many exact cancellations and zeros
+        ini = (rng.random_sample(400) < 0.5).astype(np.uint8)
+        eng.vec_add(pool[idx], vals, ini)
+        orc.vec_add(pool[idx], vals, ini)
+        gd, gv = eng.vector()
+        cd, cv = orc.vector()
+        assert eng.vec_info() == orc.vec_info()
+        nz = cv != 0
+        assert np.array_equal(gd[nz], cd[nz]) and np.array_equal(gv, cv)
+        # compress so that positions are freed and later reused
+        a = eng.compress_vec(60, 0.25 + 0.1 * rnd)
+        b = orc.compress_vec(60, 0.25 + 0.1 * rnd)
+        assert a[0] == b[0]
+        assert eng.vec_info() == orc.vec_info()
+    eng.close()
+
+
+def test_compression_is_identity_when_budget_exceeds_nnz(Engine, mols):
+    """reference tests/test_compression.cpp:62-117."""
+    mol = mols("Ne")
+    eng = Engine(mol)
+    eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=4000, seed=3)
+    hd, _ = eng.htrial()
+    vals = np.random.RandomState(0).standard_normal(hd.size)
+    eng.vec_load(hd, vals)
+    nk, gn = eng.compress_vec(hd.size + 10, 0.3)
+    d2, v2 = eng.vector()
+    assert np.array_equal(v2, vals) and gn == np.cumsum(np.abs(vals))[-1]
+    eng.close()
+
+
+def test_full_size_invariants_m1e6(Engine, mols):
+    """BASELINE.json's full size (m = 1e6) through size-independent properties: the compression conserves the
+    one-norm, keeps at most vec_nonz elements, every stored determinant has n_elec electrons and is unique, and a
+    second engine fed the same state and seed reproduces the run bit for bit."""
+    mol = mols("N2")
+    m = 1_000_000
+    par = dict(epsilon=0.01, vec_nonz=m, mat_nonz=m, max_dets=3 * m, target_norm=0.0, initiator=0.0, seed=13, distribution="HB_unnorm")
+    eng = Engine(mol)
+    eng.setup(**par)
+    for _ in range(40):
+        lg = eng.iterate(1)[0]
+        if lg["n_nonz"] >= m:
+            break
+    logs = eng.iterate(4)
+    assert int(logs["err"].max()) == 0
+    d, v = eng.vector()
+    nz = v != 0
+    assert nz.sum() <= m + 1 and nz.sum() == logs["n_nonz"][-1]
+    dn = d[nz]
+    assert np.unique(dn).size == dn.size
+    pop = np.zeros(dn.size, dtype=np.int64)
+    x = dn.copy()
+    for _ in range(64):
+        pop += (x & np.uint64(1)).astype(np.int64)
+        x >>= np.uint64(1)
+    assert np.all(pop == mol.n_elec)
+    # one-norm conservation of find_preserve + sys_comp
+    before = np.abs(v).sum()
+    nk, gn = eng.compress_vec(m // 2, 0.4321)
+    d2, v2 = eng.vector()
+    assert abs(np.abs(v2).sum() - before) < 1e-9 * before and abs(gn - before) < 1e-9 * before
+    assert (v2 != 0).sum() <= m // 2 + 1
+    # determinism: replay the same state and seed in a fresh engine
+    eng2 = Engine(mol)
+    eng2.setup(**par)
+    eng2.vec_load(d2, v2)
+    eng.vec_load(d2, v2)
+    eng.restart(99)
+    eng2.restart(99)
+    la, lb = eng.iterate(3), eng2.iterate(3)
+    for f in ("num_success", "n_nonz", "curr_size", "nkept", "norm", "numer", "denom"):
+        assert np.array_equal(la[f], lb[f]), f
+    assert np.array_equal(eng.vector()[1], eng2.vector()[1])
+    eng.close()
+    eng2.close()
