@@ -245,7 +245,18 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_iter(CompWork W, VecDev V, con
         wr[f] = v[f]; kp[f] = 0;
     }
     uint32_t diff = 0;
-    for (int p = 0; p < FR_FKS_PMAX; p++) {
+    const int p_lim = n_pass + 1 < FR_FKS_PMAX ? n_pass + 1 : FR_FKS_PMAX;      // sweeps beyond n_pass keep nothing
+    for (int p = p_lim; p < FR_FKS_PMAX; p++) {
+        if (live) {
+            uint32_t pk = it > 0 ? W.f_dk[prev][(size_t)p * stride + b] : 1u;
+            if (pk != 0) diff = 1;
+            W.f_dk[cb][(size_t)p * stride + b] = 0; W.f_dg[cb][(size_t)p * stride + b] = 0; W.f_ws[cb][(size_t)p * stride + b] = 0;
+        }
+        if (threadIdx.x == 0) {
+            W.f_pk[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = 0; W.f_pg[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = 0; W.f_pw[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = 0;
+        }
+    }
+    for (int p = 0; p < p_lim; p++) {
         // exclusive prefix of the previous replay's deltas inside this workgroup
         uint32_t pk = (it > 0 && live) ? W.f_dk[prev][(size_t)p * stride + b] : 0u;
         double pg = (it > 0 && live) ? W.f_dg[prev][(size_t)p * stride + b] : 0.0;

@@ -64,6 +64,7 @@ __device__ __forceinline__ double fr_seq_eps(unsigned n) { return 4.0 * ((double
 // leaves within sum*(1 -+ eps): clean iff all of it lies strictly inside one binade
 __device__ __forceinline__ bool fr_seq_clean(double carry_apx, double leave_apx, double eps, int *e) {
     double lo = carry_apx * (1.0 - eps), hi = leave_apx * (1.0 + eps);
+    if (hi == 0) { *e = 0; return true; }        // nothing but zeros so far: every map is the identity
     if (!(lo > 0) || !(hi < 1.0e300)) return false;
     if (lo < 2.3e-308) return false;             // keep away from subnormals
     int el = fr_exp_of(lo), eh = fr_exp_of(hi);
