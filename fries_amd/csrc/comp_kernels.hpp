@@ -24,8 +24,8 @@
 
 #define FR_ITEMS 4
 #define FR_TILE (FR_BLOCK * FR_ITEMS)
-#define FR_MAX_ROUNDS 96
-#define FR_FKS_PMAX 12          // sweeps tracked per replay (the reference needs 2-6)
+#define FR_MAX_ROUNDS 600
+#define FR_FKS_PMAX 64          // sweeps tracked per replay (the reference needs 2-6 in steady state, more when the budget exceeds the elements)
 #define FR_FKS_TILE (FR_BLOCK * 8)  // elements per workgroup in k_fks_iter
 
 struct CompState {
@@ -48,6 +48,8 @@ struct StageElems {      // one ping-pong half
     uint32_t *code;      // 4 orbital-code bytes (hbpp_rows.hpp)
     uint32_t *ndiv;      // >0: uniform subdivision into ndiv equal parts
     uint32_t *nsub;      // row length (jagged stages)
+    double *rinv;        // cached 1 / norm of the element's row (non-uniform elements)
+    uint32_t *raux;      // cached RowInfo::aux
 };
 
 struct CompWork {
@@ -64,13 +66,6 @@ struct CompWork {
     CompState *state;             // [FR_MAX_ROUNDS + 2]; last slot = final
     Teeth *teeth;
     uint32_t *fix_list;           // elements with a tooth backlog (rare)
-    // find_keep_sub replay: per (sweep, 8-block) deltas, double-buffered by replay parity
-    uint32_t nb8_cap;             // 8-blocks capacity = cap / 8 + 1
-    uint32_t *f_dk[2];            // samples consumed
-    double *f_dg[2];              // norm removed
-    double *f_ws[2];              // sum of wt_remain after the sweep
-    uint32_t *f_pk[2];            // per-workgroup partials of the above: [FR_FKS_PMAX][FR_MAX_PART]
-    double *f_pg[2], *f_pw[2];
     SeqWork seq;                  // exact in-order sum of wt_remain
 };
 
@@ -106,6 +101,23 @@ __device__ __forceinline__ double fr_block_excl_f64(double tsum, double *sh /* >
     return texcl;
 }
 
+// exclusive scans across the 64 lanes of a wave (storage order), no LDS, no barrier
+__device__ __forceinline__ uint32_t fr_wave_excl_u32(uint32_t x, uint32_t *total) {
+    int lane = fr_lane();
+    uint32_t v = x;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v += t; }
+    *total = __shfl(v, 63);
+    return v - x;
+}
+__device__ __forceinline__ double fr_wave_excl_f64(double x, double *total) {
+    int lane = fr_lane();
+    double v = x;
+    for (int off = 1; off < 64; off <<= 1) { double t = __shfl_up(v, off); if (lane >= off) v += t; }
+    *total = __shfl(v, 63);
+    double e = __shfl_up(v, 1);
+    return lane ? e : 0.0;
+}
+
 // ------------------------------------------------------------------ stage dispatch
 // Per-element row: setup -> RowInfo, visit -> (sub, normalised weight) ascending.
 template <int STAGE, bool NEW_HB>
@@ -138,6 +150,12 @@ __device__ __forceinline__ void fr_row_visit(const HbTables &T, det_t det, uint3
     }
     else if (STAGE == 4) fr_row4_visit(T, det, ri.aux & 0xffu, (ri.aux & 0x100u) != 0, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
     else fr_row5_visit<NEW_HB>(T, det, ri.aux & 0xffu, (ri.aux >> 8) & 0xffu, fr_c(code, 3), [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
+}
+
+// RowInfo of a stored element: the prep kernel cached what the visit needs
+__device__ __forceinline__ RowInfo fr_row_cached(const StageElems &E, size_t e) {
+    RowInfo r; r.inv_norm = E.rinv[e]; r.aux = E.raux[e]; r.nsub = E.nsub[e]; r.tot = 0;
+    return r;
 }
 
 // number of sub-weights comp_sub sees for this element (sub_sizes[] or the column count)
@@ -175,213 +193,6 @@ __device__ __forceinline__ int fr_fks_passes(const double *totG, const uint32_t 
     *G_last = ps[p > 0 ? p - 1 : 0].G;
     *n_last = n;
     return p;
-}
-
-// One replay.  Thread <-> one 8-block of the reference's sweep; workgroup <-> 2048 elements.
-// it == 0 starts from "nothing kept anywhere".  state[it] receives the changed flag.
-template <int STAGE, bool NEW_HB>
-__global__ void __launch_bounds__(FR_BLOCK) k_fks_iter(CompWork W, VecDev V, const HbTables *Tg, int cur, int it, double p_doub, uint32_t *err) {
-    __shared__ HbTables T;
-    __shared__ double shd[12];
-    __shared__ uint32_t shu[8];
-    __shared__ double s_totG[FR_FKS_PMAX], s_totW[FR_FKS_PMAX], s_offG[FR_FKS_PMAX], s_psG[FR_FKS_PMAX];
-    __shared__ uint32_t s_totK[FR_FKS_PMAX], s_offK[FR_FKS_PMAX], s_psN[FR_FKS_PMAX];
-    __shared__ int s_npass;
-    const CompState st0 = W.state[0];
-    const unsigned n_in = st0.n_in;
-    const unsigned nb8 = n_in / 8 + 1;                       // the reference visits coarse_idx <= count / 8
-    const unsigned nwg = (nb8 + FR_BLOCK - 1) / FR_BLOCK;
-    if (blockIdx.x >= nwg) return;
-    const int prev = (it & 1) ^ 1, cb = it & 1;
-    const size_t stride = W.nb8_cap;
-    const unsigned b = blockIdx.x * FR_BLOCK + threadIdx.x;  // my 8-block
-    const bool live = b < nb8;
-    // norm of the stage's input: the tile partials the prep kernel left in psum[0]
-    const double G0 = fr_sum_partials(W.psum[0], (n_in + FR_TILE - 1) / FR_TILE, shd);
-    // ---- totals and workgroup offsets of the previous replay, sweep by sweep
-    for (int p = threadIdx.x; p < FR_FKS_PMAX; p += blockDim.x) { s_totG[p] = 0; s_totW[p] = 0; s_totK[p] = 0; s_offG[p] = 0; s_offK[p] = 0; }
-    __syncthreads();
-    if (it > 0) {
-        // wave w handles sweeps w, w+4, ...: lanes stride over the workgroups in a fixed order
-        const int lane = fr_lane(), wv = threadIdx.x >> 6;
-        for (int p = wv; p < FR_FKS_PMAX; p += 4) {
-            const uint32_t *pk = W.f_pk[prev] + (size_t)p * FR_MAX_PART;
-            const double *pg = W.f_pg[prev] + (size_t)p * FR_MAX_PART, *pw = W.f_pw[prev] + (size_t)p * FR_MAX_PART;
-            double g = 0, w = 0, og = 0; uint32_t k = 0, ok = 0;
-            for (unsigned i = lane; i < nwg; i += 64) {
-                double gi = pg[i]; uint32_t ki = pk[i];
-                g += gi; w += pw[i]; k += ki;
-                if (i < blockIdx.x) { og += gi; ok += ki; }
-            }
-            g = fr_wave_sum(g); w = fr_wave_sum(w); og = fr_wave_sum(og); k = fr_wave_sum_u32(k); ok = fr_wave_sum_u32(ok);
-            if (lane == 0) { s_totG[p] = g; s_totW[p] = w; s_totK[p] = k; s_offG[p] = og; s_offK[p] = ok; }
-        }
-        __syncthreads();
-    }
-    else if (threadIdx.x == 0) {
-        // "nothing kept": sweep 0 keeps nothing, so the norm is re-summed (unchanged) and sweep 1 ends it
-        for (int p = 0; p < FR_FKS_PMAX; p++) s_totW[p] = G0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        FksPass ps[FR_FKS_PMAX];
-        double G_last; uint32_t n_last;
-        s_npass = fr_fks_passes(s_totG, s_totK, s_totW, G0, st0.n_rem, ps, &G_last, &n_last);
-        for (int p = 0; p < FR_FKS_PMAX; p++) { s_psG[p] = ps[p].G; s_psN[p] = ps[p].n; }
-    }
-    __syncthreads();
-    const int n_pass = s_npass;
-    if (STAGE != 1) fr_stage_tables(&T, Tg);
-    // ---- my 8 elements
-    const StageElems E = W.el[cur];
-    const size_t e0 = (size_t)b * 8;
-    const unsigned lim = !live ? 0u : (e0 + 8 <= n_in ? 8u : (unsigned)(n_in - e0));
-    double v[8], wr[8];
-    uint32_t nd[8], kp[8];
-#pragma unroll
-    for (int f = 0; f < 8; f++) {
-        bool ok = (unsigned)f < lim;
-        v[f] = ok ? E.val[e0 + f] : 0.0; nd[f] = ok ? E.ndiv[e0 + f] : 1u;
-        wr[f] = v[f]; kp[f] = 0;
-    }
-    uint32_t diff = 0;
-    const int p_lim = n_pass + 1 < FR_FKS_PMAX ? n_pass + 1 : FR_FKS_PMAX;      // sweeps beyond n_pass keep nothing
-    for (int p = p_lim; p < FR_FKS_PMAX; p++) {
-        if (live) {
-            uint32_t pk = it > 0 ? W.f_dk[prev][(size_t)p * stride + b] : 1u;
-            if (pk != 0) diff = 1;
-            W.f_dk[cb][(size_t)p * stride + b] = 0; W.f_dg[cb][(size_t)p * stride + b] = 0; W.f_ws[cb][(size_t)p * stride + b] = 0;
-        }
-        if (threadIdx.x == 0) {
-            W.f_pk[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = 0; W.f_pg[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = 0; W.f_pw[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = 0;
-        }
-    }
-    for (int p = 0; p < p_lim; p++) {
-        // exclusive prefix of the previous replay's deltas inside this workgroup
-        uint32_t pk = (it > 0 && live) ? W.f_dk[prev][(size_t)p * stride + b] : 0u;
-        double pg = (it > 0 && live) ? W.f_dg[prev][(size_t)p * stride + b] : 0.0;
-        double pws = (it > 0 && live) ? W.f_ws[prev][(size_t)p * stride + b] : -1.0;
-        uint32_t dk = 0;
-        double dg = 0;
-        if (p < n_pass) {       // uniform across the grid
-            uint32_t tk;
-            uint32_t ik = fr_block_scan_u32(pk, shu, &tk);
-            double tg;
-            double exg = fr_block_excl_f64(pg, shd, &tg);
-            double glob = s_psG[p] - (s_offG[p] + exg);
-            uint32_t loc_sampled = s_offK[p] + (ik - pk);
-            double wf = (double)(s_psN[p] - loc_sampled);
-            double cw[8];
-            unsigned flags = 0;
-#pragma unroll
-            for (int f = 0; f < 8; f++) {
-                if ((unsigned)f < lim && wr[f] > 0) {
-                    double c = v[f] * wf;
-                    if (nd[f] > 0) c /= nd[f];
-                    cw[f] = c;
-                    flags |= (unsigned)(c >= glob) << f;
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < 8; f++) {
-                if (!((flags >> f) & 1u)) continue;
-                if (nd[f] > 0) {
-                    kp[f] |= 1u; wr[f] = 0; dk += nd[f]; dg += v[f]; glob -= v[f];
-                    if (glob < 0) break;
-                }
-                else {
-                    size_t e = e0 + f;
-                    uint32_t code = STAGE == 1 ? 0u : E.code[e];
-                    det_t det = STAGE == 1 ? 0ull : V.dets[E.pos[e]];
-                    RowInfo ri = fr_row_setup<STAGE, NEW_HB>(T, det, code, p_doub);
-                    unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, STAGE == 3 || STAGE == 5 ? E.nsub[e] : 0);
-                    unsigned full = (n_sub / 8) * 8;
-                    uint32_t kk = kp[f], add = 0;
-                    double sub_remain = 0;
-                    const double cwf = cw[f], gl = glob;
-                    fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
-                        if (s >= n_sub || ((kk >> s) & 1u)) return;
-                        double sub_magn = cwf * w;
-                        double thr = s < full ? 1e-12 : 1e-10;      // compress_utils.cpp:213 / :233
-                        if (sub_magn >= gl && fabs(sub_magn) > thr) { kk |= 1u << s; add++; }
-                        else sub_remain += sub_magn;
-                    });
-                    kp[f] = kk; dk += add;
-                    sub_remain /= wf;
-                    double change = wr[f] - sub_remain;
-                    wr[f] = sub_remain;
-                    dg += change; glob -= change;
-                }
-            }
-        }
-        double ws = 0;
-#pragma unroll
-        for (int f = 0; f < 8; f++) ws += wr[f];
-        if (live) {
-            if (it == 0 || pk != dk || __double_as_longlong(pg) != __double_as_longlong(dg) || __double_as_longlong(pws) != __double_as_longlong(ws)) diff = 1;
-            W.f_dk[cb][(size_t)p * stride + b] = dk; W.f_dg[cb][(size_t)p * stride + b] = dg; W.f_ws[cb][(size_t)p * stride + b] = ws;
-        }
-        // workgroup partials of this replay
-        uint32_t bk = fr_block_sum_u32(live ? dk : 0u, shu);
-        double bg, bw;
-        fr_block_excl_f64(live ? dg : 0.0, shd, &bg);
-        fr_block_excl_f64(live ? ws : 0.0, shd, &bw);
-        if (threadIdx.x == 0) {
-            W.f_pk[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = bk;
-            W.f_pg[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = bg;
-            W.f_pw[cb][(size_t)p * FR_MAX_PART + blockIdx.x] = bw;
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < 8; f++) if ((unsigned)f < lim) { W.keep[e0 + f] = kp[f]; W.wt_remain[e0 + f] = wr[f]; }
-    if (n_pass >= FR_FKS_PMAX && threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, FR_ERR_ROUNDS);
-    uint32_t any = fr_block_sum_u32(diff, shu);
-    if (threadIdx.x == 0) {
-        if (blockIdx.x == 0) {
-            // slot it+1 is zeroed here for the replay after this one; slot `it` collects this replay's flag
-            CompState z = st0; z.changed = 0; z.G = G0;
-            if (it + 1 <= FR_MAX_ROUNDS) W.state[it + 1] = z;
-        }
-        if (any) atomicOr(&W.state[it].changed, 1u);
-    }
-}
-
-// One workgroup: find_keep_sub's epilogue (compress_utils.cpp:266-275), seed_sys and the comb.
-// The returned norm is the exact in-order sum of wt_remain (seqsum.hpp), i.e. the last lbound.
-static __global__ void __launch_bounds__(FR_BLOCK) k_comp_finalize(CompWork W, int last_it, double rn, double lbound0, double norm_others_after, uint32_t *err) {
-    __shared__ double s_totG[FR_FKS_PMAX], s_totW[FR_FKS_PMAX];
-    __shared__ uint32_t s_totK[FR_FKS_PMAX];
-    CompState s = W.state[last_it + 1];      // carries the stage's input norm
-    const unsigned n_in = s.n_in;
-    const unsigned nb8 = n_in / 8 + 1, nwg = (nb8 + FR_BLOCK - 1) / FR_BLOCK;
-    const int cb = last_it & 1;
-    const int lane = fr_lane(), wv = threadIdx.x >> 6;
-    for (int p = wv; p < FR_FKS_PMAX; p += 4) {
-        const uint32_t *pk = W.f_pk[cb] + (size_t)p * FR_MAX_PART;
-        const double *pg = W.f_pg[cb] + (size_t)p * FR_MAX_PART, *pw = W.f_pw[cb] + (size_t)p * FR_MAX_PART;
-        double g = 0, w = 0; uint32_t k = 0;
-        for (unsigned i = lane; i < nwg; i += 64) { g += pg[i]; w += pw[i]; k += pk[i]; }
-        g = fr_wave_sum(g); w = fr_wave_sum(w); k = fr_wave_sum_u32(k);
-        if (lane == 0) { s_totG[p] = g; s_totW[p] = w; s_totK[p] = k; }
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    if (W.state[last_it].changed) atomicOr(err, FR_ERR_ROUNDS);
-    FksPass ps[FR_FKS_PMAX];
-    double G; uint32_t n_rem;
-    s.n_pass = fr_fks_passes(s_totG, s_totK, s_totW, s.G, s.n_rem, ps, &G, &n_rem);
-    double loc_norm = 0;
-    if (G / n_rem < 1e-8) n_rem = 0;
-    else loc_norm = *W.seq.total;
-    s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
-    double glob = lbound0 + loc_norm + norm_others_after;     // sum in rank order (seed_sys)
-    double unit = 0, r0 = INFINITY;
-    if (n_rem > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_rem, &unit);
-    s.unit = glob / n_rem;
-    s.n_out = 0; s.n_fix = 0;
-    W.state[FR_MAX_ROUNDS + 1] = s;
-    if (n_rem > 0) fr_build_teeth(W.teeth, r0, unit, n_rem + 2, lbound0);
-    else { W.teeth->nseg = 0; W.teeth->kmax = 0; W.teeth->unit = 0; W.teeth->lbound0 = lbound0; }
 }
 
 // ------------------------------------------------------------------ replay of sys_sub for one element
@@ -422,8 +233,8 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const VecD
             double sub_lbound = lbound - wr;
             uint32_t code = STAGE == 1 ? 0u : E.code[e];
             det_t det = STAGE == 1 ? 0ull : V.dets[E.pos[e]];
-            RowInfo ri = fr_row_setup<STAGE, NEW_HB>(T, det, code, p_doub);
-            unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, STAGE == 3 || STAGE == 5 ? E.nsub[e] : 0);
+            RowInfo ri = fr_row_cached(E, e);
+            unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
             fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
                 if (s >= n_sub) return;
                 if (((kp >> s) & 1u) && w != 0) emit(s, v * w);

@@ -3,6 +3,7 @@
 #pragma once
 #include "fries_dev.hpp"
 #include "comp_kernels.hpp"
+#include "fks2.hpp"
 #include <string>
 #include <vector>
 #include <random>
@@ -86,6 +87,7 @@ struct FriesCtx {
     VecState h_vst{};
     // HB-PP work arrays
     CompWork W{};
+    Fks2Work F2{};
     uint32_t *c_pos = nullptr, *c_orbs = nullptr; double *c_val = nullptr;   // compacted apply_HBPP_sys output
     uint32_t *d_nsucc = nullptr;
     SpawnBuf sp{};
@@ -110,6 +112,7 @@ struct FriesCtx {
     uint64_t n_kernel_launch = 0, tot_spawns = 0, tot_iters = 0, tot_fks_iters = 0, tot_stage_elems = 0;
     // profiling
     bool prof_on = false;
+    int dbg = 0;
     std::vector<ProfSpan> prof_spans;
     std::vector<hipEvent_t> prof_pool;
     std::vector<ProfAgg> prof_agg;

@@ -177,6 +177,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     FR_HIP(hipSetDevice(device));
     fries_ctx *h = new fries_ctx();
     h->c.device = device;
+    if (getenv("FRIES_DBG")) h->c.dbg = atoi(getenv("FRIES_DBG"));
     FR_HIP(hipStreamCreate(&h->c.stream));
     h->c.d_err = fr_alloc<uint32_t>(1);
     FR_HIP(hipMemset(h->c.d_err, 0, 4));

@@ -2,6 +2,7 @@
 // stages with on-the-fly sub-weight rows, then weight / matrix element / parity and an
 // order-preserving compaction of the surviving samples.
 #include "ctx.hpp"
+#include "fks2.hpp"
 
 // ------------------------------------------------------------------ stage preparation
 // Stage 1 elements are the stored vector elements (frisys_mol.cpp:414-420, heat_bathPP.cpp:714-727).
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep1(CompWork W, VecDev V, int cu
         size_t e = base + it;
         if (e >= n_in) break;
         double w = fabs(V.v0[e]);
-        E.val[e] = w; E.pos[e] = (uint32_t)e; E.code[e] = 0; E.ndiv[e] = (w > 0) ? 0u : 1u; E.nsub[e] = 2;
+        E.val[e] = w; E.pos[e] = (uint32_t)e; E.code[e] = 0; E.ndiv[e] = (w > 0) ? 0u : 1u; E.nsub[e] = 2; E.rinv[e] = 1.0; E.raux[e] = 0;
         W.wt_remain[e] = w; W.keep[e] = 0;
         sum += w;
     }
@@ -57,13 +58,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const H
         double val = W.e_val[e];
         uint32_t pos = P.pos[wi], pc = P.code[wi];
         det_t det = V.dets[pos];
-        uint32_t code = 0, ndiv = 0, nsub = 0;
+        uint32_t code = 0, ndiv = 0, nsub = 0, raux = 0;
+        double rinv = 1.0;
         if (STAGE == 2) {
             code = fr_code(sub, 0, 0, 0);
             if (sub == 0) {
                 RowInfo ri = fr_row2_setup<NEW_HB>(T, det);
                 if (NEW_HB) val *= ri.tot;
-                nsub = ri.nsub;
+                nsub = ri.nsub; rinv = ri.inv_norm; raux = ri.aux;
             }
             else {
                 unsigned n_occ = fr_count_sing_allowed(T, det);
@@ -78,10 +80,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const H
                 if (NEW_HB) {
                     c1++;
                     RowInfo ri = fr_row3h_setup(T, det, c1);
-                    nsub = c1;
+                    nsub = c1; rinv = ri.inv_norm; raux = ri.aux;
                     val *= ri.tot;
                 }
-                else nsub = n_elec;
+                else { RowInfo ri = fr_row3_setup(T, det, c1); nsub = n_elec; rinv = ri.inv_norm; raux = ri.aux; }
                 code = fr_code(0, c1, 0, 0);
             }
             else {
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const H
                     code = fr_code(0, o1_idx, o2u1, 0);
                     RowInfo ri = fr_row_setup<4, NEW_HB>(T, det, code, p_doub);
                     if (NEW_HB) val *= ri.tot;
-                    nsub = ri.nsub;
+                    nsub = ri.nsub; rinv = ri.inv_norm; raux = ri.aux;
                 }
             }
             else { code = fr_code(1, o1_idx, o2u1, fr_c(pc, 3)); ndiv = 1; }
@@ -112,13 +114,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const H
                 else {
                     code = fr_code(0, o1_idx, o2_idx, u1);
                     RowInfo ri = fr_row_setup<5, NEW_HB>(T, det, code, p_doub);
-                    nsub = ri.nsub;
+                    nsub = ri.nsub; rinv = ri.inv_norm; raux = ri.aux;
                     if (NEW_HB || ri.tot == 0) val *= ri.tot;
                 }
             }
             else { code = fr_code(1, o1_idx, o2_idx, fr_c(pc, 3)); ndiv = 1; }
         }
-        E.val[e] = val; E.pos[e] = pos; E.code[e] = code; E.ndiv[e] = ndiv; E.nsub[e] = nsub;
+        E.val[e] = val; E.pos[e] = pos; E.code[e] = code; E.ndiv[e] = ndiv; E.nsub[e] = nsub; E.rinv[e] = rinv; E.raux[e] = raux;
         W.wt_remain[e] = val; W.keep[e] = 0;
         sum += val;
     }
@@ -210,6 +212,27 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_compact(CompWork W, int prev
     if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) *n_succ = o;
 }
 
+// find_keep_sub's epilogue (compress_utils.cpp:266-275), seed_sys and the comb, from the settled replay
+static __global__ void k_comp_finalize2(CompWork W, Fks2Work F, double rn, double lbound0, double norm_others_after) {
+    const FksScal *S = F.scal;
+    CompState s = W.state[0];
+    double G = S->G_last;
+    uint32_t n_rem = S->n_last;
+    s.n_pass = S->n_pass;
+    double loc_norm = 0;
+    if (G / n_rem < 1e-8) n_rem = 0;
+    else loc_norm = *W.seq.total;
+    s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
+    double glob = lbound0 + loc_norm + norm_others_after;     // sum in rank order (seed_sys)
+    double unit = 0, r0 = INFINITY;
+    if (n_rem > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_rem, &unit);
+    s.unit = glob / n_rem;
+    s.n_out = 0; s.n_fix = 0;
+    W.state[FR_MAX_ROUNDS + 1] = s;
+    if (n_rem > 0) fr_build_teeth(W.teeth, r0, unit, n_rem + 2, lbound0);
+    else { W.teeth->nseg = 0; W.teeth->kmax = 0; W.teeth->unit = 0; W.teeth->lbound0 = lbound0; }
+}
+
 // ------------------------------------------------------------------ host orchestration
 void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     CompWork &W = c->W;
@@ -217,6 +240,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     for (int h = 0; h < 2; h++) {
         W.el[h].val = fr_alloc<double>(cap); W.el[h].pos = fr_alloc<uint32_t>(cap); W.el[h].code = fr_alloc<uint32_t>(cap);
         W.el[h].ndiv = fr_alloc<uint32_t>(cap); W.el[h].nsub = fr_alloc<uint32_t>(cap);
+        W.el[h].rinv = fr_alloc<double>(cap); W.el[h].raux = fr_alloc<uint32_t>(cap);
         W.psum[h] = fr_alloc<double>(FR_MAX_PART); W.pcnt[h] = fr_alloc<uint32_t>(FR_MAX_PART);
     }
     W.wt_remain = fr_alloc<double>(cap); W.keep = fr_alloc<uint32_t>(cap); W.S = fr_alloc<double>(cap);
@@ -226,14 +250,16 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.teeth = fr_alloc<Teeth>(1);
     W.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
-    W.nb8_cap = cap / 8 + 2;
-    for (int h = 0; h < 2; h++) {
-        W.f_dk[h] = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * W.nb8_cap);
-        W.f_dg[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * W.nb8_cap);
-        W.f_ws[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * W.nb8_cap);
-        W.f_pk[h] = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_MAX_PART);
-        W.f_pg[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_MAX_PART);
-        W.f_pw[h] = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_MAX_PART);
+    {
+        Fks2Work &F = c->F2;
+        F.nb8_cap = cap / 8 + 2;
+        size_t n8 = (size_t)FR_FKS_PMAX * F.nb8_cap;
+        F.dk8 = fr_alloc<uint32_t>(n8); F.dg8 = fr_alloc<double>(n8); F.ws8 = fr_alloc<double>(n8);
+        F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
+        F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
+        F.ck = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cg = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cw = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
+        FR_HIP(hipMemset(F.hist, 0, 4 * (FR_MAX_ROUNDS + 2)));
+        FR_HIP(hipMemset(F.scal, 0, sizeof(FksScal)));
     }
     c->c_pos = fr_alloc<uint32_t>(cap); c->c_orbs = fr_alloc<uint32_t>(cap); c->c_val = fr_alloc<double>(cap);
     c->d_nsucc = fr_alloc<uint32_t>(1);
@@ -249,28 +275,36 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (grid == 0) grid = 1;
     if (STAGE == 1) FR_LAUNCH(c, "k_prep1", k_prep1, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
     else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
-    unsigned grid8 = fr_blocks(n_bound / 8 + 1, FR_BLOCK);
+    Fks2Work &F = c->F2;
+    unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
+    unsigned nchunk = fr_blocks((size_t)n_bound / 8 + 1, FR_FKS_CHUNK);
+    if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
+    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F);
     int it = 0, batch = c->rounds_hint[STAGE];
     uint32_t changed = 1;
     while (changed) {
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
         if (batch <= 0) throw FriesError("find_keep_sub replay did not settle within FR_MAX_ROUNDS iterations");
         for (int k = 0; k < batch; k++) {
-            FR_LAUNCH(c, "k_fks_iter", (k_fks_iter<STAGE, NEW_HB>), dim3(grid8), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, it, c->p_doub, c->d_err);
+            FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
+            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it);
+            FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err);
             it++;
         }
-        FR_HIP(hipMemcpyAsync(&changed, &W.state[it - 1].changed, 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipMemcpyAsync(&changed, &F.hist[it - 1], 4, hipMemcpyDeviceToHost, st));
         FR_HIP(hipStreamSynchronize(st));
         batch = 2;
     }
     c->rounds_hint[STAGE] = it > 2 ? it : 2;
     c->fks_iters[STAGE] = it;
+    // settled: recompute every wt_remain with the budget of its last flagged sweep
+    FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
     AccWt acc{W.wt_remain, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, 0.0);
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, 0.0);
-    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize, dim3(1), dim3(FR_BLOCK), W, it - 1, rn, 0.0, 0.0, c->d_err);
+    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(1), W, F, rn, 0.0, 0.0);
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
     FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);

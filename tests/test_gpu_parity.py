@@ -251,10 +251,10 @@ def test_full_size_invariants_m1e6(Engine, mols):
     assert np.all(pop == mol.n_elec)
     # one-norm conservation of find_preserve + sys_comp
     before = np.abs(v).sum()
-    nk, gn = eng.compress_vec(m // 2, 0.4321)
+    nk, gn = eng.compress_vec(7 * m // 10, 0.4321)
     d2, v2 = eng.vector()
     assert abs(np.abs(v2).sum() - before) < 1e-9 * before and abs(gn - before) < 1e-9 * before
-    assert (v2 != 0).sum() <= m // 2 + 1
+    assert (v2 != 0).sum() <= 7 * m // 10 + 1
     # determinism: replay the same state and seed in a fresh engine
     eng2 = Engine(mol)
     eng2.setup(**par)
