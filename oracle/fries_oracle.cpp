@@ -3,6 +3,9 @@
 // Compile with -ffp-contract=off: the parity contract is plain IEEE-754
 // double arithmetic in the reference's literal operation order (no FMA).
 #include "fries_oracle.hpp"
+#include <mutex>
+#include <condition_variable>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <algorithm>
@@ -11,6 +14,76 @@
 #include <climits>
 
 namespace fo {
+
+// ------------------------------------------------------------------ in-process ranks
+struct CommShared {
+    int size;
+    std::mutex mu; std::condition_variable cv;
+    int waiting = 0; uint64_t gen = 0;
+    std::vector<const void *> slot;
+    bool failed = false;
+    explicit CommShared(int n) : size(n), slot(n, nullptr) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) throw std::runtime_error("another rank failed");
+        uint64_t g = gen;
+        if (++waiting == size) { waiting = 0; gen++; cv.notify_all(); }
+        else {
+            cv.wait(lk, [&] { return gen != g || failed; });
+            if (failed && gen == g) throw std::runtime_error("another rank failed");
+        }
+    }
+    void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+};
+CommShared *comm_create(int size) { return new CommShared(size); }
+void comm_destroy(CommShared *s) { delete s; }
+const Comm &Comm::self() { static const Comm c; return c; }
+void Comm::barrier() const { if (size > 1) sh->barrier(); }
+void Comm::allgather(const void *in, void *out, size_t bytes) const {
+    if (size == 1) { memcpy(out, in, bytes); return; }
+    sh->slot[rank] = in;
+    sh->barrier();
+    for (int p = 0; p < size; p++) memcpy((uint8_t *)out + (size_t)p * bytes, sh->slot[p], bytes);
+    sh->barrier();
+}
+void Comm::alltoallv(const std::vector<std::vector<uint8_t>> &send, std::vector<std::vector<uint8_t>> &recv) const {
+    recv.assign(size, {});
+    if (size == 1) { recv[0] = send[0]; return; }
+    sh->slot[rank] = &send;
+    sh->barrier();
+    for (int p = 0; p < size; p++) recv[p] = (*(const std::vector<std::vector<uint8_t>> *)sh->slot[p])[rank];
+    sh->barrier();
+}
+double Comm::sum(double x) const {
+    if (size == 1) { double g = 0; g += x; return g; }
+    double all[256];
+    allgather(&x, all, sizeof(double));
+    double g = 0;
+    for (int p = 0; p < size; p++) g += all[p];
+    return g;
+}
+int Comm::sum(int x) const {
+    if (size == 1) return x;
+    int all[256];
+    allgather(&x, all, sizeof(int));
+    int g = 0;
+    for (int p = 0; p < size; p++) g += all[p];
+    return g;
+}
+void run_ranks(int size, const std::function<void(const Comm &)> &fn) {
+    if (size == 1) { fn(Comm::self()); return; }
+    CommShared *sh = comm_create(size);
+    std::vector<std::thread> th;
+    std::vector<std::string> err(size);
+    for (int r = 0; r < size; r++) th.emplace_back([&, r] {
+        Comm c; c.rank = r; c.size = size; c.sh = sh;
+        try { fn(c); } catch (std::exception &e) { err[r] = e.what(); sh->fail(); }
+    });
+    for (auto &t : th) t.join();
+    comm_destroy(sh);
+    for (int r = 0; r < size; r++) if (!err[r].empty() && err[r] != "another rank failed") throw std::runtime_error("rank " + std::to_string(r) + ": " + err[r]);
+}
+
 
 static inline size_t tri_wdiag(size_t i, size_t j) { return j * (j + 1) / 2 + i; }      // math_utils.h I_J_TO_TRI_WDIAG (i <= j)
 static inline size_t tri_nodiag(size_t i, size_t j) { return j * (j - 1) / 2 + i; }     // math_utils.h I_J_TO_TRI_NODIAG (i < j)
@@ -511,7 +584,7 @@ double calc_norm_wt(const HBInfo &t, const uint8_t *orbs, const uint8_t *occ, un
 
 // ------------------------------------------------------------------ compression
 double find_preserve(const double *values, std::vector<size_t> &srt, std::vector<uint8_t> &keep,
-                     size_t count, unsigned *n_samp, double *global_norm) {
+                     size_t count, unsigned *n_samp, double *global_norm, const Comm &cm) {
     double loc = 0, glob = 0;
     size_t heap_count = count;
     for (size_t i = 0; i < count; i++) { loc += fabs(values[i]); srt[i] = i; }
@@ -520,10 +593,10 @@ double find_preserve(const double *values, std::vector<size_t> &srt, std::vector
     int loc_sampled, glob_sampled = 1, keep_going = 1;
     double el = 0;
     size_t mx;
-    *global_norm = loc;
+    *global_norm = cm.sum(loc);
     bool recalc = false;
     while (glob_sampled > 0) {
-        glob = loc;
+        glob = cm.sum(loc);
         loc_sampled = 0;
         while (keep_going && heap_count > 0 && glob >= 0) {
             mx = srt[0];
@@ -539,7 +612,7 @@ double find_preserve(const double *values, std::vector<size_t> &srt, std::vector
             }
             else keep_going = 0;
         }
-        glob_sampled = loc_sampled;
+        glob_sampled = cm.sum(loc_sampled);
         (*n_samp) -= glob_sampled;
         if (glob_sampled == 0 && !recalc) {
             loc = 0;
@@ -556,22 +629,23 @@ double find_preserve(const double *values, std::vector<size_t> &srt, std::vector
     return loc;
 }
 
-double seed_sys(double norm, double *rn, unsigned n_samp) {
+double seed_sys(const double *norms, double *rn, unsigned n_samp, const Comm &cm) {
     double lbound = 0;
+    for (int p = 0; p < cm.rank; p++) lbound += norms[p];
     double global_norm = lbound;
-    global_norm += norm;
+    for (int p = cm.rank; p < cm.size; p++) global_norm += norms[p];
     *rn *= global_norm / n_samp;
     *rn += global_norm / n_samp * (int)(lbound * n_samp / global_norm);
     if (*rn < lbound) *rn += global_norm / n_samp;
     return lbound;
 }
 
-double sys_comp(double *vals, size_t len, double loc_norm, unsigned n_samp, std::vector<uint8_t> &keep, double rn) {
-    double rn_sys = rn;
+void sys_comp(double *vals, size_t len, double *loc_norms, unsigned n_samp, std::vector<uint8_t> &keep, double rn, const Comm &cm) {
+    double rn_sys = rn;    // every rank is handed rank 0's draw (MPI_Bcast at :291)
     double tmp_glob = 0;
-    tmp_glob += loc_norm;
+    for (int p = 0; p < cm.size; p++) tmp_glob += loc_norms[p];
     double lbound;
-    if (n_samp > 0) lbound = seed_sys(loc_norm, &rn_sys, n_samp);
+    if (n_samp > 0) lbound = seed_sys(loc_norms, &rn_sys, n_samp, cm);
     else { lbound = 0; rn_sys = INFINITY; }
     double out_norm = 0;
     for (size_t i = 0; i < len; i++) {
@@ -587,11 +661,13 @@ double sys_comp(double *vals, size_t len, double loc_norm, unsigned n_samp, std:
             else { vals[i] = 0; keep[i] = 1; }
         }
     }
-    return out_norm;
+    std::vector<double> all(cm.size);
+    cm.allgather(&out_norm, all.data(), sizeof(double));     // :326
+    for (int p = 0; p < cm.size; p++) loc_norms[p] = all[p];
 }
 
 double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
-                     size_t count, unsigned *n_samp, double *wt_remain) {
+                     size_t count, unsigned *n_samp, double *wt_remain, const Comm &cm) {
     double loc = 0, glob = 0;
     for (size_t i = 0; i < count; i++) { loc += values[i]; wt_remain[i] = values[i]; }
     int loc_sampled, glob_sampled = 1;
@@ -602,7 +678,7 @@ double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, co
     size_t n_coarse = count / coarse;
     double cw[8];
     while (glob_sampled > 0) {
-        glob = loc;
+        glob = cm.sum(loc);
         if (glob < 0) break;
         loc_sampled = 0;
         for (size_t c = 0; c <= n_coarse; c++) {
@@ -652,7 +728,7 @@ double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, co
                 }
             }
         }
-        glob_sampled = loc_sampled;
+        glob_sampled = cm.sum(loc_sampled);
         (*n_samp) -= glob_sampled;
         if (last_pass && glob_sampled) last_pass = 0;
         if (glob_sampled == 0 && !last_pass) {
@@ -669,13 +745,13 @@ double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, co
 }
 
 size_t sys_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
-               size_t count, unsigned n_samp, const double *wt_remain, double *loc_norm, double rn,
-               double *new_vals, size_t (*new_idx)[2]) {
+               size_t count, unsigned n_samp, const double *wt_remain, double *loc_norms, double rn,
+               double *new_vals, size_t (*new_idx)[2], const Comm &cm) {
     double rn_sys = rn;
     double tmp_glob = 0;
-    tmp_glob += *loc_norm;
+    for (int p = 0; p < cm.size; p++) tmp_glob += loc_norms[p];
     double lbound;
-    if (n_samp > 0) lbound = seed_sys(*loc_norm, &rn_sys, n_samp);
+    if (n_samp > 0) lbound = seed_sys(loc_norms, &rn_sys, n_samp, cm);
     else { lbound = 0; rn_sys = INFINITY; }
     double out_norm = 0;
     size_t num_new = 0, sub_idx;
@@ -733,15 +809,17 @@ size_t sys_sub(const double *values, const uint32_t *n_div, SubWts &sw, const ui
             sw.keep[i] = 0;   // reference clears bits 0..n_sub-1; no others are ever set
         }
     }
-    *loc_norm = out_norm;
+    loc_norms[cm.rank] = out_norm;
     return num_new;
 }
 
 size_t comp_sub(const double *values, size_t count, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
-                unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2]) {
+                unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2], const Comm &cm) {
     unsigned tmp_nsamp = n_samp;
-    double loc_norm = find_keep_sub(values, n_div, sw, sub_sizes, count, &tmp_nsamp, wt_remain);
-    return sys_sub(values, n_div, sw, sub_sizes, count, tmp_nsamp, wt_remain, &loc_norm, rn, new_vals, new_idx);
+    std::vector<double> loc_norms(cm.size);
+    double mine = find_keep_sub(values, n_div, sw, sub_sizes, count, &tmp_nsamp, wt_remain, cm);
+    cm.allgather(&mine, loc_norms.data(), sizeof(double));   // :818
+    return sys_sub(values, n_div, sw, sub_sizes, count, tmp_nsamp, wt_remain, loc_norms.data(), rn, new_vals, new_idx, cm);
 }
 
 void adjust_shift(double *shift, double one_norm, double *last_norm, double target_norm, double damp) {
@@ -763,7 +841,8 @@ uint64_t hash_fxn(const uint8_t *occ, unsigned n_elec, const uint32_t *scr) {
     return hash;
 }
 
-void Vec::init(size_t size, size_t add_size, unsigned n_el, unsigned nv) {
+void Vec::init(size_t size, size_t add_size, unsigned n_el, unsigned nv, const Comm &c, const uint32_t *pscr) {
+    cm = c; proc_scr = pscr;
     n_elec = n_el; n_vecs = nv; max_size = size; curr_size = 0; adder_cap = add_size; n_nonz = 0; cur = 0;
     dets.assign(size, 0);
     vals.assign(nv, std::vector<double>(size, 0.0));
@@ -771,7 +850,14 @@ void Vec::init(size_t size, size_t add_size, unsigned n_el, unsigned nv) {
     diag.assign(size, NAN);
     active.assign(size, 0);
     free_stack.clear(); table.clear();
-    add_det.clear(); add_val.clear(); add_ini.clear();
+    add_det.assign(cm.size, {}); add_val.assign(cm.size, {}); add_ini.assign(cm.size, {});
+}
+
+int Vec::idx_to_proc(det_t det) const {
+    if (cm.size == 1) return 0;
+    uint8_t o[64];
+    unsigned n = (unsigned)occ_list(det, o);
+    return (int)(hash_fxn(o, n, proc_scr) % (uint64_t)cm.size);
 }
 
 void Vec::expand() {
@@ -786,18 +872,45 @@ void Vec::expand() {
 
 bool Vec::add(det_t det, double val, uint8_t ini) {
     if (val != 0) {
-        if (add_det.size() >= adder_cap) throw std::runtime_error("Too many elements added to Adder - must call perform_add() more frequently.");
-        add_det.push_back(det); add_val.push_back(val); add_ini.push_back(ini);
-        return add_det.size() < adder_cap;
+        int d = idx_to_proc(det);
+        if (add_det[d].size() >= adder_cap) throw std::runtime_error("Too many elements added to Adder - must call perform_add() more frequently.");
+        add_det[d].push_back(det); add_val[d].push_back(val); add_ini[d].push_back(ini);
+        return add_det[d].size() < adder_cap;
     }
     return true;
 }
 
 void Vec::perform_add(size_t origin) {
+    // Alltoallv of (index, value, initiator) triples; the receive buffer is ordered by source rank and,
+    // within one source, by the order of its add() calls (vec_utils.hpp:991-1019).
+    std::vector<det_t> rdet; std::vector<double> rval; std::vector<uint8_t> rini;
+    if (cm.size == 1) { rdet.swap(add_det[0]); rval.swap(add_val[0]); rini.swap(add_ini[0]); }
+    else {
+        std::vector<std::vector<uint8_t>> snd(cm.size), rcv;
+        for (int d = 0; d < cm.size; d++) {
+            size_t n = add_det[d].size();
+            snd[d].resize(n * 17);
+            if (n) {
+                memcpy(snd[d].data(), add_det[d].data(), n * 8);
+                memcpy(snd[d].data() + n * 8, add_val[d].data(), n * 8);
+                memcpy(snd[d].data() + n * 16, add_ini[d].data(), n);
+            }
+        }
+        cm.alltoallv(snd, rcv);
+        for (int sr = 0; sr < cm.size; sr++) {
+            size_t n = rcv[sr].size() / 17, o = rdet.size();
+            rdet.resize(o + n); rval.resize(o + n); rini.resize(o + n);
+            if (n) {
+                memcpy(&rdet[o], rcv[sr].data(), n * 8);
+                memcpy(&rval[o], rcv[sr].data() + n * 8, n * 8);
+                memcpy(&rini[o], rcv[sr].data() + n * 16, n);
+            }
+        }
+    }
     uint8_t tmp_occ[64];
-    for (size_t e = 0; e < add_det.size(); e++) {
-        det_t d = add_det[e];
-        int ini = add_ini[e];
+    for (size_t e = 0; e < rdet.size(); e++) {
+        det_t d = rdet[e];
+        int ini = rini[e];
         if ((unsigned)occ_list(d, tmp_occ) != n_elec) throw std::runtime_error("Determinant created with an incorrect number of electrons");
         ptrdiff_t *ptr = nullptr;
         auto it = table.find(d);
@@ -823,10 +936,10 @@ void Vec::perform_add(size_t origin) {
             bool nonz = vals[origin][pos] != 0;
             bool should = ini || nonz;
             nonini_occ_add += !ini && nonz;
-            if (should) vals[cur][pos] += add_val[e];
+            if (should) vals[cur][pos] += rval[e];
         }
     }
-    add_det.clear(); add_val.clear(); add_ini.clear();
+    for (int d = 0; d < cm.size; d++) { add_det[d].clear(); add_val[d].clear(); add_ini[d].clear(); }
 }
 
 void Vec::del_at_pos(size_t pos) {
@@ -868,7 +981,7 @@ void HBScratch::init(size_t length, size_t n_subwt) {
 }
 
 void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
-                    const double rn[5], uint32_t n_samp, bool unit_matrel) {
+                    const double rn[5], uint32_t n_samp, bool unit_matrel, const Comm &cm) {
     std::vector<double> &vec1 = sc.vec1, &vec2 = sc.vec2;
     SubWts &sw = sc.sw;
     std::vector<uint32_t> &ndiv = sc.ndiv;
@@ -893,7 +1006,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         if (w > 0) { sw.row(d)[0] = p_doub; sw.row(d)[1] = 1 - p_doub; ndiv[d] = 0; }
         else ndiv[d] = 1;
     }
-    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[0], vec2.data(), cidx);
+    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[0], vec2.data(), cidx, cm);
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- first occupied orbital (:736-770)
@@ -915,7 +1028,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
             else ndiv[s] = n_occ;
         }
     }
-    comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[1], vec1.data(), cidx);
+    comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[1], vec1.data(), cidx, cm);
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- unoccupied (single) / 2nd occupied (double) (:772-816)
@@ -947,7 +1060,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
             else { ndiv[s] = n_virt; oi2[s][3] = (uint8_t)n_virt; }
         }
     }
-    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, new_hb ? nsub.data() : nullptr, n_samp, wtr, rn[2], vec2.data(), cidx);
+    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, new_hb ? nsub.data() : nullptr, n_samp, wtr, rn[2], vec2.data(), cidx, cm);
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- 1st unoccupied (double) (:818-864)
@@ -982,7 +1095,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
             ndiv[s] = 1;
         }
     }
-    comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[3], vec1.data(), cidx);
+    comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[3], vec1.data(), cidx, cm);
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- 2nd unoccupied (double) (:866-915)
@@ -1016,7 +1129,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         }
         else { oi2[s][3] = oi1[wi][3]; ndiv[s] = 1; }
     }
-    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nsub.data(), n_samp, wtr, rn[4], vec2.data(), cidx);
+    comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nsub.data(), n_samp, wtr, rn[4], vec2.data(), cidx, cm);
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- decode, weight, matrix element, parity (:917-991)
@@ -1086,9 +1199,10 @@ void Frisys::setup() {
     proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
     for (auto &x : proc_scr) x = mt();     // frisys_mol.cpp:133-135
     for (auto &x : vec_scr) x = mt();      // :142-144
-    unsigned spawn_length = par.mat_nonz * 4;
+    unsigned spawn_length = par.mat_nonz * 4 / cm.size;     // :121
     size_t adder_size = spawn_length > 1000000 ? 1000000 : spawn_length;
-    sol.init(par.max_dets, adder_size, n_elec, 2);
+    sol.init(par.max_dets, adder_size, n_elec, 2, cm, proc_scr.data());
+    hf_proc = sol.idx_to_proc(hf_det);
     size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
     sc.init(spawn_length, n_states);
 
@@ -1096,14 +1210,18 @@ void Frisys::setup() {
     trial_det = {hf_det}; trial_val = {1.0};
     {
         size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
-        Vec ht; ht.init(2 * n_ex, 2 * n_ex, n_elec, 2);
-        ht.add(hf_det, 1, 1); ht.perform_add(0);
+        Vec ht; ht.init(2 * n_ex, 2 * n_ex, n_elec, 2, cm, proc_scr.data());
+        if (cm.rank == hf_proc) ht.add(hf_det, 1, 1);
+        ht.perform_add(0);
         std::vector<uint8_t> ex;
         ht.cur = 1;
-        const uint8_t *occ = ht.orbs_at(0);
-        double cur_el = ht.vals[0][0];
+        // only the rank that owns HF holds a non-zero element; the others join the collectives empty
+        uint8_t hf_occ[64];
+        occ_list(hf_det, hf_occ);
+        const uint8_t *occ = hf_occ;
+        double cur_el = cm.rank == hf_proc ? ht.vals[0][0] : 0;
         size_t n_sing = sing_ex_symm(hf_det, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
-        for (size_t e = 0; e < n_sing; e++) {
+        for (size_t e = 0; e < n_sing && cm.rank == hf_proc; e++) {
             double m = sing_matrel_nosgn(&ex[2 * e], occ, sys.ints, n_elec);
             det_t nd = hf_det;
             m *= sing_det_parity(&nd, &ex[2 * e]);
@@ -1112,7 +1230,7 @@ void Frisys::setup() {
         }
         ht.perform_add(0);
         size_t n_doub = doub_ex_symm(hf_det, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
-        for (size_t e = 0; e < n_doub; e++) {
+        for (size_t e = 0; e < n_doub && cm.rank == hf_proc; e++) {
             double m = doub_matrel_nosgn(&ex[4 * e], sys.ints);
             det_t nd = hf_det;
             m *= doub_det_parity(&nd, &ex[4 * e]);
@@ -1130,14 +1248,27 @@ void Frisys::setup() {
             else ht.vals[0][i] = 0;
         }
         ht.add_vecs(0, 1);
-        htrial_det.assign(ht.dets.begin(), ht.dets.begin() + ht.curr_size);
-        htrial_val.assign(ht.vals[0].begin(), ht.vals[0].begin() + ht.curr_size);
+        // collect_procs (vec_utils.hpp:920-952): every rank ends with all shards, concatenated in rank order
+        {
+            std::vector<std::vector<uint8_t>> snd(cm.size), rcv;
+            size_t n = ht.curr_size;
+            std::vector<uint8_t> mine(n * 16);
+            if (n) { memcpy(mine.data(), ht.dets.data(), n * 8); memcpy(mine.data() + n * 8, ht.vals[0].data(), n * 8); }
+            for (int d = 0; d < cm.size; d++) snd[d] = mine;
+            if (cm.size == 1) rcv = snd; else cm.alltoallv(snd, rcv);
+            htrial_det.clear(); htrial_val.clear();
+            for (int sr = 0; sr < cm.size; sr++) {
+                size_t k = rcv[sr].size() / 16, o = htrial_det.size();
+                htrial_det.resize(o + k); htrial_val.resize(o + k);
+                if (k) { memcpy(&htrial_det[o], rcv[sr].data(), k * 8); memcpy(&htrial_val[o], rcv[sr].data() + k * 8, k * 8); }
+            }
+        }
         p_doub = (double)n_doub / (double)(n_sing + n_doub);
         // n_hf_sing comes from count_singex (:219), identical to n_sing by construction
         size_t n_sing2 = count_singex(hf_det, occ, n_elec, sys.symm);
         p_doub = (double)n_doub / (n_sing2 + n_doub);
     }
-    sol.add(hf_det, 100, 1);       // :277-279
+    if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);       // :277-279
     sol.perform_add(0);
     sys.hb.set_up(sys.ints);
     srt.assign(sol.max_size, 0); keep.assign(sol.max_size, 0);
@@ -1155,8 +1286,9 @@ void Frisys::iterate(unsigned n_iter) {
         for (size_t i = 0; i < sol.curr_size; i++) sc.det_idx1[i] = i;
         sc.vec_len = sol.curr_size;
         double rn[5];
-        for (int k = 0; k < 5; k++) rn[k] = uni(mt);
-        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz, false);
+        for (int k = 0; k < 5; k++) rn[k] = uni(mt);     // comp_sub broadcasts rank 0's draw (compress_utils.cpp:806);
+                                                           // all ranks seed alike here, so the streams agree
+        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz, false, cm);
         size_t comp_len = sc.vec_len;
         lg.num_success = comp_len;
 
@@ -1185,6 +1317,7 @@ void Frisys::iterate(unsigned n_iter) {
                     if (!sol.add(nd, add_el, ini)) break;
                 }
                 sol.perform_add(0);
+                num_added = cm.sum(num_added);      // :469
             }
         }
         if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
@@ -1202,15 +1335,17 @@ void Frisys::iterate(unsigned n_iter) {
         // vector compression :502-539
         unsigned n_samp = par.vec_nonz;
         double glob_norm;
-        double loc_norm = find_preserve(sol.vals[0].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm);
+        std::vector<double> loc_norms(cm.size);
+        double mine = find_preserve(sol.vals[0].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm, cm);
         lg.nkept = par.vec_nonz - n_samp;
         if ((iterat + 1) % shift_interval == 0)
             adjust_shift(&en_shift, glob_norm, &last_one_norm, par.target_norm, shift_damping / shift_interval / eps);
-        lg.numer = sol.dot(htrial_det, htrial_val);
-        lg.denom = sol.dot(trial_det, trial_val);
+        lg.numer = cm.sum(sol.dot(htrial_det, htrial_val));      // :512-517
+        lg.denom = cm.sum(sol.dot(trial_det, trial_val));
         lg.shift = en_shift; lg.norm = glob_norm;
-        double rn_sys = uni(mt);
-        sys_comp(sol.vals[0].data(), sol.curr_size, loc_norm, n_samp, keep, rn_sys);
+        double rn_sys = uni(mt);    // the reference draws on rank 0 only and broadcasts (:528, compress_utils.cpp:291)
+        cm.allgather(&mine, loc_norms.data(), sizeof(double));
+        sys_comp(sol.vals[0].data(), sol.curr_size, loc_norms.data(), n_samp, keep, rn_sys, cm);
         for (size_t i = 0; i < sol.curr_size; i++) {
             if (keep[i]) { sol.del_at_pos(i); keep[i] = 0; }
         }

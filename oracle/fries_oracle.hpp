@@ -25,10 +25,30 @@
 #include <unordered_map>
 #include <random>
 #include <string>
+#include <functional>
 
 namespace fo {
 
 typedef uint64_t det_t;
+
+// ---------------------------------------------------------------- ranks
+// The reference's only parallelism is hash-sharding over MPI ranks with blocking collectives on
+// MPI_COMM_WORLD.  Comm emulates exactly those collectives between in-process ranks
+// (one std::thread per rank, see run_ranks); size == 1 needs no threads.
+struct CommShared;
+struct Comm {
+    int rank = 0, size = 1;
+    CommShared *sh = nullptr;
+    void barrier() const;
+    void allgather(const void *in, void *out, size_t bytes) const;              // MPI_Allgather, rank order
+    // MPI_Alltoallv of byte strings: send[d] goes to rank d; recv[s] is what rank s sent here
+    void alltoallv(const std::vector<std::vector<uint8_t>> &send, std::vector<std::vector<uint8_t>> &recv) const;
+    double sum(double x) const;          // sum_mpi: all-gather, then add in rank order (compress_utils.hpp:177-187)
+    int sum(int x) const;
+    static const Comm &self();
+};
+CommShared *comm_create(int size);
+void comm_destroy(CommShared *);
 
 // ---------------------------------------------------------------- bit strings
 // FRIES/math_utils.c:62-98 (find_bits): ascending list of set bits.
@@ -107,11 +127,11 @@ double calc_norm_wt(const HBInfo &t, const uint8_t *orbs, const uint8_t *occ, un
 // ---------------------------------------------------------------- compression
 // FRIES/compress_utils.cpp:29-105
 double find_preserve(const double *values, std::vector<size_t> &srt, std::vector<uint8_t> &keep,
-                     size_t count, unsigned *n_samp, double *global_norm);
-// FRIES/compress_utils.cpp:107-127 (one rank)
-double seed_sys(double norm, double *rn, unsigned n_samp);
-// FRIES/compress_utils.cpp:283-327; returns the new local norm
-double sys_comp(double *vals, size_t len, double loc_norm, unsigned n_samp, std::vector<uint8_t> &keep, double rn);
+                     size_t count, unsigned *n_samp, double *global_norm, const Comm &cm = Comm::self());
+// FRIES/compress_utils.cpp:107-127
+double seed_sys(const double *norms, double *rn, unsigned n_samp, const Comm &cm = Comm::self());
+// FRIES/compress_utils.cpp:283-327; loc_norms[size]: in = every rank's remaining norm, out = every rank's new norm
+void sys_comp(double *vals, size_t len, double *loc_norms, unsigned n_samp, std::vector<uint8_t> &keep, double rn, const Comm &cm = Comm::self());
 
 // Sub-weight matrix + keep bits for comp_sub.  keep bit (row, col) lives in a
 // uint32 mask per row; the reference's byte-granular thresholds
@@ -126,14 +146,14 @@ struct SubWts {
 };
 // FRIES/compress_utils.cpp:130-276
 double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
-                     size_t count, unsigned *n_samp, double *wt_remain);
+                     size_t count, unsigned *n_samp, double *wt_remain, const Comm &cm = Comm::self());
 // FRIES/compress_utils.cpp:702-794
 size_t sys_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
-               size_t count, unsigned n_samp, const double *wt_remain, double *loc_norm, double rn,
-               double *new_vals, size_t (*new_idx)[2]);
+               size_t count, unsigned n_samp, const double *wt_remain, double *loc_norms, double rn,
+               double *new_vals, size_t (*new_idx)[2], const Comm &cm = Comm::self());
 // FRIES/compress_utils.cpp:797-820
 size_t comp_sub(const double *values, size_t count, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
-                unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2]);
+                unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2], const Comm &cm = Comm::self());
 // FRIES/compress_utils.cpp:684-693
 void adjust_shift(double *shift, double one_norm, double *last_norm, double target_norm, double damp);
 
@@ -156,10 +176,13 @@ struct Vec {
     std::vector<uint8_t> active;
     std::vector<size_t> free_stack;          // back() == top
     std::unordered_map<det_t, ptrdiff_t> table;
-    // pending adds
-    std::vector<det_t> add_det; std::vector<double> add_val; std::vector<uint8_t> add_ini;
+    // pending adds, one buffer per destination rank (Adder, vec_utils.hpp:98-106)
+    std::vector<std::vector<det_t>> add_det; std::vector<std::vector<double>> add_val; std::vector<std::vector<uint8_t>> add_ini;
+    Comm cm;                                 // ranks this vector is sharded over
+    const uint32_t *proc_scr = nullptr;      // proc_hash_ scrambler (vec_utils.hpp:137)
 
-    void init(size_t size, size_t add_size, unsigned n_el, unsigned nv);
+    void init(size_t size, size_t add_size, unsigned n_el, unsigned nv, const Comm &c = Comm::self(), const uint32_t *pscr = nullptr);
+    int idx_to_proc(det_t det) const;         // vec_utils.hpp:360-379
     void expand();
     bool add(det_t det, double val, uint8_t ini);     // vec_utils.hpp:418-423, 957-971
     void perform_add(size_t origin);                   // vec_utils.hpp:991-1019 -> add_elements :606-641
@@ -195,7 +218,7 @@ struct MolSys {
 // reference draws at :729,:765,:811,:859,:910.  unit_matrel selects the
 // |value| == 1 lambdas of tests/test_hamiltonian.cpp:493-500.
 void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
-                    const double rn[5], uint32_t n_samp, bool unit_matrel);
+                    const double rn[5], uint32_t n_samp, bool unit_matrel, const Comm &cm = Comm::self());
 
 // ---------------------------------------------------------------- driver loop
 struct FrisysParams {
@@ -227,8 +250,12 @@ struct Frisys {
     unsigned iterat = 0;
     std::vector<size_t> srt; std::vector<uint8_t> keep;
     std::vector<IterLog> log;
+    Comm cm;
+    int hf_proc = 0;
     void setup();
     void iterate(unsigned n);
 };
+// runs fn(rank) on `size` in-process ranks that share one communicator (fn receives its Comm)
+void run_ranks(int size, const std::function<void(const Comm &)> &fn);
 
 }  // namespace fo

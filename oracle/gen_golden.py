@@ -24,6 +24,14 @@ RUNS = {
     "n2_m30000_unnorm": ("N2", 30, 31, 0.01, 30000, 30000, 200000, 0.5, 10000.0, "HB_unnorm", 0),
 }
 
+# multi-rank runs under mpiexec -n P: name -> (n_ranks, same tuple as RUNS without the snapshot field)
+MPI_RUNS = {
+    "n2_m10000_unnorm_p2": (2, ("N2", 40, 7, 0.01, 10000, 10000, 80000, 0.0, 5000.0, "HB_unnorm")),
+    "n2_m10000_unnorm_p4": (4, ("N2", 40, 7, 0.01, 10000, 10000, 80000, 1.0, 5000.0, "HB_unnorm")),
+    "h2o_m5000_hb_p3": (3, ("H2O", 40, 99, 0.005, 5000, 8000, 80000, 3.0, 2000.0, "HB")),
+}
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
@@ -48,6 +56,16 @@ def main():
             subprocess.run(cmd, check=True)
             manifest["runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd,
                                           initiator=ini, target_norm=tgt, distribution=dist)
+        manifest["mpi_runs"] = {}
+        for name, (n_ranks, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt, dist)) in MPI_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            out = os.path.join(GOLD, name + ".traj")
+            cmd = [MPIEXEC, "-n", str(n_ranks), HARNESS, "frisys_mpi", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz),
+                   str(maxd), repr(ini), repr(tgt), dist, out]
+            subprocess.run(cmd, check=True)
+            manifest["mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz,
+                                              max_dets=maxd, initiator=ini, target_norm=tgt, distribution=dist)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

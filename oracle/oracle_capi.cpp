@@ -2,6 +2,8 @@
 // (tests/, bench.py's cpu_baseline leg, __graft_entry__.smoke()).
 #include "fries_oracle.hpp"
 #include <cstring>
+#include <cstdio>
+#include <stdexcept>
 #include <cmath>
 #include <memory>
 
@@ -122,7 +124,7 @@ void fo_compress_vec(void *h, uint32_t n_samp, double rn, uint32_t *n_kept, doub
     unsigned ns = n_samp;
     double gn;
     double ln = find_preserve(v.vals[0].data(), f->srt, f->keep, v.curr_size, &ns, &gn);
-    sys_comp(v.vals[0].data(), v.curr_size, ln, ns, f->keep, rn);
+    sys_comp(v.vals[0].data(), v.curr_size, &ln, ns, f->keep, rn);
     for (size_t i = 0; i < v.curr_size; i++) if (f->keep[i]) { v.del_at_pos(i); f->keep[i] = 0; }
     if (n_kept) *n_kept = n_samp - ns;
     if (glob_norm) *glob_norm = gn;
@@ -145,5 +147,54 @@ void fo_frisys_restart(void *h, uint32_t seed, double en_shift, double last_one_
     f->mt.seed(seed); f->en_shift = en_shift; f->last_one_norm = last_one_norm; f->iterat = iterat;
 }
 uint64_t fo_hash(const uint8_t *occ, uint32_t n_elec, const uint32_t *scr) { return hash_fxn(occ, n_elec, scr); }
+
+
+// ---- P in-process ranks (std::thread per rank) sharing one communicator: the reference under mpiexec -n P
+struct OracleRanks { std::vector<std::unique_ptr<Frisys>> fr; };
+
+static void fill_log(const IterLog &l, OracleLog &o) {
+    o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.nkept = l.nkept;
+    o.n_nonz = l.n_nonz; o.curr_size = (uint32_t)l.curr_size; o.num_success = (uint32_t)l.num_success;
+    for (int k = 0; k < 5; k++) o.comp_len[k] = 0;
+    o.err = 0;
+}
+
+void *fo_ranks_create(uint32_t n_ranks, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                      double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm) {
+    OracleRanks *R = new OracleRanks();
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        Frisys *f = new Frisys();
+        f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+        f->sys.ints.n_orb = n_orb;
+        f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+        f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+        f->sys.symm.init(irreps, n_orb);
+        f->par.eps = eps; f->par.target_norm = target; f->par.init_thresh = init;
+        f->par.vec_nonz = vec_nonz; f->par.mat_nonz = mat_nonz; f->par.max_dets = max_dets;
+        f->par.new_hb = hb_unnorm != 0; f->par.seed = seed;
+        R->fr.emplace_back(f);
+    }
+    try {
+        run_ranks((int)n_ranks, [&](const Comm &c) { Frisys &f = *R->fr[c.rank]; f.cm = c; f.setup(); });
+    } catch (std::exception &e) { fprintf(stderr, "fo_ranks_create: %s\n", e.what()); delete R; return nullptr; }
+    return R;
+}
+void fo_ranks_destroy(void *h) { delete (OracleRanks *)h; }
+// logs: [n_ranks][n] row-major
+int fo_ranks_iterate(void *h, uint32_t n, OracleLog *logs) {
+    OracleRanks *R = (OracleRanks *)h;
+    int P = (int)R->fr.size();
+    try {
+        run_ranks(P, [&](const Comm &c) {
+            Frisys &f = *R->fr[c.rank];
+            f.cm = c; f.sol.cm = c;
+            for (uint32_t i = 0; i < n; i++) { f.iterate(1); if (logs) fill_log(f.log.back(), logs[(size_t)c.rank * n + i]); }
+        });
+    } catch (std::exception &e) { fprintf(stderr, "fo_ranks_iterate: %s\n", e.what()); return 1; }
+    return 0;
+}
+void *fo_ranks_get(void *h, uint32_t rank) { return ((OracleRanks *)h)->fr[rank].get(); }   // a Frisys* for fo_frisys_vec etc.
+int fo_ranks_hf_proc(void *h) { return ((OracleRanks *)h)->fr[0]->hf_proc; }
+int fo_idx_to_proc(void *h, uint64_t det) { return ((Frisys *)h)->sol.idx_to_proc(det); }
 
 }  // extern "C"

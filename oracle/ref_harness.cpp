@@ -197,7 +197,7 @@ static int run_unit() {
         double rn = mt() / (1. + UINT32_MAX);
         double norms[1] = {ln_r};
         sys_comp(v.data(), n, norms, ns_r, keep_r, rn);
-        double on = fo::sys_comp(v2.data(), n, ln_o, ns_o, keep_o, rn);
+        double on = ln_o; fo::sys_comp(v2.data(), n, &on, ns_o, keep_o, rn);
         CHECK(same_bits(norms[0], on), "sys_comp norm");
         for (size_t i = 0; i < n; i++) CHECK(same_bits(v[i], v2[i]) && (bool)keep_r[i] == (bool)keep_o[i], "sys_comp out");
     }
@@ -250,6 +250,8 @@ struct RefRun {
     int new_hb;
     std::vector<size_t> srt; std::vector<bool> keep;
     unsigned iterat = 0;
+    int n_procs = 1, proc_rank = 0;
+    unsigned hf_proc = 0;
     std::function<double(uint8_t *, uint8_t *)> sing_sc;
     std::function<double(uint8_t *)> doub_sc;
     std::vector<uint32_t> proc_scr, vec_scr;
@@ -266,7 +268,9 @@ struct RefRun {
         find_bits(hf_det, tmp_orbs, det_size);
         hf_en = diag_matrel(tmp_orbs, n_orb, *eris, *h_core, 0, n_elec);
         mt.seed(seed);
-        unsigned spawn_length = mat_nonz * 4;
+        MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
+        MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
+        unsigned spawn_length = mat_nonz * 4 / n_procs;
         size_t adder_size = spawn_length > 1000000 ? 1000000 : spawn_length;
         unsigned no = n_orb, ne = n_elec; double hfe = hf_en;
         std::function<double(const uint8_t *)> diag_sc = [no, eris, h_core, ne, hfe](const uint8_t *occ) { return diag_matrel(occ, no, *eris, *h_core, 0, ne) - hfe; };
@@ -276,14 +280,17 @@ struct RefRun {
         proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
         for (auto &x : proc_scr) x = mt();
         for (auto &x : vec_scr) x = mt();
-        sol = new DistVec<double>(max_dets, adder_size, n_orb * 2, n_elec, 1, diag_sc, 2, proc_scr, vec_scr);
+        sol = new DistVec<double>(max_dets, adder_size, n_orb * 2, n_elec, n_procs, diag_sc, 2, proc_scr, vec_scr);
+        hf_proc = sol->idx_to_proc(hf_det);
         size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
         comp = new HBCompressSys(spawn_length, n_states);
         size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
-        trial = new DistVec<double>(2, 2, n_orb * 2, n_elec, 1, proc_scr, vec_scr);
-        htrial = new DistVec<double>(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec, 1, diag_sc, 2, proc_scr, vec_scr);
-        trial->add(hf_det, 1, 1); htrial->add(hf_det, 1, 1);
+        unsigned tot_trial = CEILING(1 * 2, n_procs);
+        trial = new DistVec<double>(tot_trial + 2, tot_trial + 2, n_orb * 2, n_elec, n_procs, proc_scr, vec_scr);
+        htrial = new DistVec<double>(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec, n_procs, diag_sc, 2, proc_scr, vec_scr);
+        if ((int)hf_proc == proc_rank) { trial->add(hf_det, 1, 1); htrial->add(hf_det, 1, 1); }
         trial->perform_add(0); htrial->perform_add(0);
+        trial->collect_procs();
         trial_hashes.resize(trial->curr_size());
         for (size_t i = 0; i < trial->curr_size(); i++) trial_hashes[i] = sol->idx_to_hash(trial->indices()[i], tmp_orbs);
         std::vector<uint8_t> scratch(4 * n_ex);
@@ -291,13 +298,14 @@ struct RefRun {
         htrial->set_curr_vec_idx(0);
         h_op_diag(*htrial, 0, 0, 1);
         htrial->add_vecs(0, 1);
+        htrial->collect_procs();
         htrial_hashes.resize(htrial->curr_size());
         for (size_t i = 0; i < htrial->curr_size(); i++) htrial_hashes[i] = sol->idx_to_hash(htrial->indices()[i], tmp_orbs);
         sol->gen_orb_list(hf_det, tmp_orbs);
         size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec, n_orb, (uint8_t (*)[4])scratch.data(), in->symm);
         size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec, basis_symm);
         p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-        sol->add(hf_det, 100, 1);
+        if ((int)hf_proc == proc_rank) sol->add(hf_det, 100, 1);
         sol->perform_add(0);
         hb = set_up(n_orb, n_orb, *eris);
         srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
@@ -339,6 +347,7 @@ struct RefRun {
                 sol_vec.set_curr_vec_idx(0);
                 before = sol_vec.values();
                 sol_vec.set_curr_vec_idx(1);
+                num_added = sum_mpi(num_added, proc_rank, n_procs);
             }
         }
         if (sol_vec.max_size() > srt.size()) { srt.resize(sol_vec.max_size()); keep.resize(sol_vec.max_size(), false); }
@@ -350,14 +359,18 @@ struct RefRun {
         sol_vec.add_vecs(0, 1);
         sol_vec.set_curr_vec_idx(1); sol_vec.zero_vec(); sol_vec.set_curr_vec_idx(0);
         unsigned n_samp = vec_nonz;
-        double loc_norms[1];
-        loc_norms[0] = find_preserve(sol_vec.values(), srt, keep, sol_vec.curr_size(), &n_samp, &glob_norm);
+        double loc_norms[64];
+        loc_norms[proc_rank] = find_preserve(sol_vec.values(), srt, keep, sol_vec.curr_size(), &n_samp, &glob_norm);
         glob_norm += sol_vec.dense_norm();
         nkept = vec_nonz - n_samp;
         if ((iterat + 1) % 10 == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, target, 0.05 / 10 / eps);
         numer = sol_vec.dot(htrial->indices(), htrial->values(), htrial->curr_size(), htrial_hashes);
         denom = sol_vec.dot(trial->indices(), trial->values(), trial->curr_size(), trial_hashes);
-        double rn_sys = mt() / (1. + UINT32_MAX);
+        numer = sum_mpi(numer, proc_rank, n_procs);
+        denom = sum_mpi(denom, proc_rank, n_procs);
+        double rn_sys = 0;
+        if (proc_rank == 0) rn_sys = mt() / (1. + UINT32_MAX);
+        MPI_Allgather(MPI_IN_PLACE, 0, MPI_DOUBLE, loc_norms, 1, MPI_DOUBLE, MPI_COMM_WORLD);
         sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, keep, rn_sys);
         for (size_t i = 0; i < sol_vec.curr_size(); i++) if (keep[i]) { sol_vec.del_at_pos(i); keep[i] = 0; }
         iterat++;
@@ -515,6 +528,35 @@ static int run_dump_ints(const char *path, const char *pg, const char *out) {
     return 0;
 }
 
+// mpiexec -n P ref_harness frisys_mpi <same args as frisys> : every rank writes <out>.r<rank>
+static int run_frisys_mpi(int argc, char **argv) {
+    if (argc < 14) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10), mnz = strtoul(argv[8], 0, 10);
+    size_t max_dets = strtoull(argv[9], 0, 10); double ini = atof(argv[10]), tgt = atof(argv[11]);
+    int nhb = !strcmp(argv[12], "HB_unnorm");
+    RefRun rr;
+    rr.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
+    char fn[1024];
+    snprintf(fn, sizeof fn, "%s.r%d", argv[13], rr.proc_rank);
+    FILE *f = fopen(fn, "w");
+    fprintf(f, "# golden trajectory from the reference under mpiexec -n %d, rank %d; cols: it numer denom norm shift nkept n_nonz curr_size num_success digest\n", rr.n_procs, rr.proc_rank);
+    fprintf(f, "# p_doub %a hf_en %a n_htrial %zu hf_proc %u\n", rr.p_doub, rr.hf_en, (size_t)rr.htrial->curr_size(), rr.hf_proc);
+    for (unsigned it = 0; it < n_iter; it++) {
+        rr.iterate();
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < rr.sol->curr_size(); i++) {
+            double rv = rr.sol->values()[i];
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(rr.sol->indices()[i], rr.det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success, hsh);
+    }
+    fclose(f);
+    if (rr.proc_rank == 0) printf("FRISYS_MPI ranks=%d iters=%u\n", rr.n_procs, n_iter);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     MPI_Init(NULL, NULL);
     int rc = 2;
@@ -522,6 +564,7 @@ int main(int argc, char **argv) {
     else if (argc >= 3 && !strcmp(argv[1], "hbpp_all")) rc = run_hbpp_all(argv[2]);
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
+    else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
     else fprintf(stderr, "unknown command\n");
     MPI_Finalize();

@@ -12,10 +12,12 @@ def manifest():
         return json.load(f)
 
 
-def read_traj(name):
+def read_traj(name, rank=None):
+    """rank=None: a single-rank .traj; rank=r: the .traj.r<r> file rank r wrote under mpiexec."""
     rows, snaps = [], {}
     p_doub = hf_en = None
-    with open(os.path.join(GOLD, name + ".traj")) as f:
+    n_htrial = hf_proc = None
+    with open(os.path.join(GOLD, name + ".traj" + ("" if rank is None else f".r{rank}"))) as f:
         lines = f.read().splitlines()
     i = 0
     while i < len(lines):
@@ -23,6 +25,8 @@ def read_traj(name):
         if ln.startswith("# p_doub"):
             t = ln.split()
             p_doub, hf_en = float.fromhex(t[2]), float.fromhex(t[4])
+            if len(t) > 8:
+                n_htrial, hf_proc = int(t[6]), int(t[8])
         elif ln.startswith("SNAP"):
             it = int(ln.split()[1])
             ent = []
@@ -37,7 +41,7 @@ def read_traj(name):
             rows.append(dict(it=int(t[0]), numer=float.fromhex(t[1]), denom=float.fromhex(t[2]), norm=float.fromhex(t[3]), shift=float.fromhex(t[4]),
                              nkept=int(t[5]), n_nonz=int(t[6]), curr_size=int(t[7]), num_success=int(t[8]), hash=int(t[9], 16)))
         i += 1
-    return dict(rows=rows, snaps=snaps, p_doub=p_doub, hf_en=hf_en)
+    return dict(rows=rows, snaps=snaps, p_doub=p_doub, hf_en=hf_en, n_htrial=n_htrial, hf_proc=hf_proc)
 
 
 def vec_hash(dets, vals):

@@ -54,6 +54,14 @@ def load():
         lib.fo_frisys_restart.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_uint32]
         lib.fo_hash.restype = C.c_uint64
         lib.fo_hash.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_ranks_create.restype = C.c_void_p
+        lib.fo_ranks_create.argtypes = [C.c_uint32] + lib.fo_frisys_create.argtypes
+        lib.fo_ranks_destroy.argtypes = [C.c_void_p]
+        lib.fo_ranks_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_ranks_get.restype = C.c_void_p
+        lib.fo_ranks_get.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_ranks_hf_proc.argtypes = [C.c_void_p]
+        lib.fo_idx_to_proc.argtypes = [C.c_void_p, C.c_uint64]
         _lib = lib
     return _lib
 
@@ -160,3 +168,60 @@ class OracleFrisys:
 
     def restart(self, seed, en_shift=0.0, last_one_norm=0.0, iterat=0):
         self.lib.fo_frisys_restart(self.h, seed, en_shift, last_one_norm, iterat)
+
+
+class OracleRanks:
+    """P in-process ranks of fo::Frisys sharing one communicator -- the reference under `mpiexec -n P`
+    (hash-sharded determinants, all-to-all spawns, rank-ordered sum_mpi)."""
+
+    def __init__(self, n_ranks, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm"):
+        self.lib = load()
+        self.n_ranks = n_ranks
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.h = self.lib.fo_ranks_create(n_ranks, mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, initiator,
+                                          vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
+        if not self.h:
+            raise RuntimeError("oracle ranks failed to set up")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.fo_ranks_destroy(self.h)
+            self.h = None
+
+    def iterate(self, n):
+        """-> logs[n_ranks, n]"""
+        logs = np.zeros((self.n_ranks, n), dtype=LOG_DTYPE)
+        if self.lib.fo_ranks_iterate(self.h, n, _p(logs)):
+            raise RuntimeError("oracle ranks failed")
+        return logs
+
+    @property
+    def hf_proc(self):
+        return self.lib.fo_ranks_hf_proc(self.h)
+
+    def _rank(self, r):
+        return self.lib.fo_ranks_get(self.h, r)
+
+    def vector(self, r):
+        h = self._rank(r)
+        n = self.lib.fo_frisys_vec(h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_frisys_vec(h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
+
+    def htrial(self, r=0):
+        h = self._rank(r)
+        n = self.lib.fo_frisys_htrial(h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_frisys_htrial(h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
+
+    def p_doub(self, r=0):
+        return self.lib.fo_frisys_p_doub(self._rank(r))
+
+    def idx_to_proc(self, det):
+        return self.lib.fo_idx_to_proc(self._rank(0), int(det))

@@ -39,6 +39,29 @@ def test_oracle_reproduces_reference_trajectory(oracle, mols, name):
             assert golden_io.vec_hash(d, v) == row["hash"], (name, row["it"])
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["mpi_runs"]))
+def test_oracle_ranks_reproduce_reference_under_mpiexec(oracle, mols, name):
+    """The multi-rank oracle (P in-process ranks) against what every rank of the real reference logged under
+    `mpiexec -n P`: bit-for-bit scalars, shard sizes and shard digests."""
+    r = golden_io.manifest()["mpi_runs"][name]
+    P = r["n_ranks"]
+    g = [golden_io.read_traj(name, rank=k) for k in range(P)]
+    orc = oracle.OracleRanks(P, mols(r["shape"]), **_run_params(r))
+    assert orc.hf_proc == g[0]["hf_proc"] and orc.htrial()[0].size == g[0]["n_htrial"]
+    assert orc.p_doub() == g[0]["p_doub"]
+    n_it = len(g[0]["rows"])
+    logs = orc.iterate(n_it)
+    for k in range(P):
+        for i, row in enumerate(g[k]["rows"]):
+            lg = logs[k, i]
+            for f in ("numer", "denom", "norm", "shift"):
+                assert float(lg[f]) == row[f], (name, k, i, f)
+            for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+                assert int(lg[f]) == row[f], (name, k, i, f)
+        d, v = orc.vector(k)
+        assert golden_io.vec_hash(d, v) == g[k]["rows"][-1]["hash"], (name, k)
+
+
 def test_oracle_snapshot_matches_reference(oracle, mols):
     name = "ne_m2000_unnorm"
     r = golden_io.manifest()["runs"][name]
