@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # V = 8 B value, D = 8 B determinant, 8 B = parent index + orbital code).
 ALG_BYTES = {
     # one replay of find_keep_sub over a stage: read value + (parent idx, code) + parent determinant
-    "k_fks_iter": lambda units: 24.0 * units,
+    "k_fks_sweep": lambda units: 24.0 * units,
     "k_sys_count": lambda units: 24.0 * units,
     "k_sys_write": lambda units: 40.0 * units,
     "k_prep": lambda units: 40.0 * units,
@@ -146,12 +146,9 @@ def main():
         name, (ms, calls) = dom
         avg_s = ms / calls * 1e-3
         stage_elems = (cB["stage_elems"] - cA["stage_elems"]) / args.profile_steps      # elements over the five stages, per iteration
-        units = None
-        if name == "k_fks_iter":
-            units = stage_elems / 5.0           # elements one launch sweeps (stage average)
-        elif name in ("k_sys_count", "k_sys_write", "k_prep"):
-            units = stage_elems / 5.0
-        ach = ALG_BYTES[name](units) / avg_s / 1e9 if (units and name in ALG_BYTES) else None
+        base = next((k for k in ALG_BYTES if name.startswith(k)), None)
+        units = stage_elems / 5.0 if base else None      # elements one launch passes over (stage average)
+        ach = ALG_BYTES[base](units) / avg_s / 1e9 if base else None
         result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
                               "avg_launch_us": avg_s * 1e6, "calls_per_iter": calls / args.profile_steps,

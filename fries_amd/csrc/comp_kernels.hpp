@@ -168,33 +168,6 @@ __device__ __forceinline__ unsigned fr_row_len(const HbTables &T, uint32_t nsub_
     return nsub_stored;
 }
 
-// ------------------------------------------------------------------ find_keep_sub replay
-struct FksPass { double G; uint32_t n; };
-
-// Sweep bookkeeping of compress_utils.cpp:153-158, 251-265 from the totals of a previous replay.
-// Every lane of every workgroup runs this on identical inputs.  Returns the number of sweeps.
-__device__ __forceinline__ int fr_fks_passes(const double *totG, const uint32_t *totK, const double *totW, double G0, uint32_t n0,
-                                             FksPass *ps, double *G_last, uint32_t *n_last) {
-    uint32_t n = n0;
-    double G = G0;
-    int last_pass = 0, p = 0;
-    for (; p < FR_FKS_PMAX; p++) {
-        ps[p].G = G; ps[p].n = n;
-        if (G < 0) break;
-        uint32_t K = totK[p];
-        n -= K;
-        uint32_t gs = K;
-        if (last_pass && gs) last_pass = 0;
-        double Gn = G - totG[p];
-        if (gs == 0 && !last_pass) { last_pass = 1; gs = 1; Gn = totW[p]; }
-        if (gs == 0) { p++; break; }
-        G = Gn;
-    }
-    *G_last = ps[p > 0 ? p - 1 : 0].G;
-    *n_last = n;
-    return p;
-}
-
 // ------------------------------------------------------------------ replay of sys_sub for one element
 // Returns the number of emissions; *k advances over consumed teeth.  When EMIT, writes
 // (wi, sub, value) triples starting at slot `out`.

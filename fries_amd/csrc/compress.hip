@@ -60,7 +60,21 @@ void fr_death_clone(FriesCtx *c, uint32_t vec_size_before) {
 
 // One round of the exact-preservation fixed point: keep every element with
 // |v| >= remaining_norm / remaining_samples (compress_utils.cpp:58).
-__global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int round) {
+struct FpMsg { double G; uint32_t kept, pad; };     // a rank's unkept norm and the elements it preserved in the last round
+
+// this rank's totals of the previous round, for the all-gather (n_ranks > 1)
+__global__ void __launch_bounds__(FR_BLOCK) k_fp_reduce(VcompBuf B, int round, FpMsg *msg) {
+    __shared__ double shd[12];
+    __shared__ uint32_t shu[4];
+    const CompState prev = B.state[round - 1];
+    const unsigned nblk = (prev.n_in + FR_TILE - 1) / FR_TILE;
+    const int pin = (round - 1) & 1;
+    double G = fr_sum_partials(B.psum[pin], nblk, shd);
+    uint32_t k = fr_sum_partials_u32(B.pcnt[pin], nblk, shu);
+    if (threadIdx.x == 0) { msg->G = G; msg->kept = k; msg->pad = 0; }
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int round, const FpMsg *all, int n_ranks) {
     __shared__ double shd[12];
     __shared__ uint32_t shu[4];
     const CompState prev = B.state[round - 1];
@@ -69,10 +83,17 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
     if (prev.done) { if (blockIdx.x == 0 && threadIdx.x == 0) B.state[round] = prev; return; }
     if (blockIdx.x >= nblk && blockIdx.x != 0) return;
     const int pin = (round - 1) & 1, pout = round & 1;
-    double G = fr_sum_partials(B.psum[pin], nblk, shd);
-    uint32_t kept_prev = fr_sum_partials_u32(B.pcnt[pin], nblk, shu);
+    double G; uint32_t kept_prev;
+    if (n_ranks == 1) {
+        G = fr_sum_partials(B.psum[pin], nblk, shd);
+        kept_prev = fr_sum_partials_u32(B.pcnt[pin], nblk, shu);
+    }
+    else {      // sum_mpi: rank order (compress_utils.cpp:53, :76)
+        G = 0; kept_prev = 0;
+        for (int p = 0; p < n_ranks; p++) { G += all[p].G; kept_prev += all[p].kept; }
+    }
     uint32_t n_rem = prev.n_rem - kept_prev;
-    bool done = (round > 1 && kept_prev == 0) || nblk == 0;
+    bool done = (round > 1 && kept_prev == 0) || (n_ranks == 1 && nblk == 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CompState s = prev;
         if (round == 1) s.loc_norm = G;          // *global_norm (compress_utils.cpp:50)
@@ -103,9 +124,25 @@ template <class Acc>
 static void run_seq(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound) {
     unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, 0.0);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, 0.0);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, fr_seq_from_zero());
+}
+// the chain again, starting from the lbound this rank inherits (classification and maps depend on the running sum's binade)
+template <class Acc>
+static void run_seq_from(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound, SeqStart from) {
+    unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, from);
+}
+
+static __global__ void k_put_double(const double *src, double *dst) { *dst = *src; }
+// sum_mpi of one double: 0 + x_0 + x_1 + ... in rank order (compress_utils.hpp:177-187)
+static __global__ void k_sum_ranks(const double *all, int n_ranks, double *out) {
+    double g = 0;
+    for (int p = 0; p < n_ranks; p++) g += all[p];
+    *out = g;
 }
 
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
@@ -117,6 +154,12 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
     AccAbs aa{c->vec.v0, c->vec.st};
     SeqWork Qg = B.seq; Qg.total = B.gnorm;
     run_seq(c, Qg, aa, bound);
+    const int P = c->n_ranks;
+    if (P > 1) {
+        FR_LAUNCH(c, "k_put_double", k_put_double, dim3(1), dim3(1), B.gnorm, (double *)c->comm.small_send);
+        const double *all = (const double *)fr_allgather(c, sizeof(double));
+        FR_LAUNCH(c, "k_sum_ranks", k_sum_ranks, dim3(1), dim3(1), all, P, B.gnorm);
+    }
     int r = 0, batch = c->rounds_hint[6] + 1;
     CompState hs{};
     hs.done = 0;
@@ -125,7 +168,12 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
         if (batch <= 0) throw FriesError("find_preserve did not converge within FR_MAX_ROUNDS rounds");
         for (int k = 0; k < batch; k++) {
             r++;
-            FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r);
+            const FpMsg *all = nullptr;
+            if (P > 1) {
+                FR_LAUNCH(c, "k_fp_reduce", k_fp_reduce, dim3(1), dim3(FR_BLOCK), B, r, (FpMsg *)c->comm.small_send);
+                all = (const FpMsg *)fr_allgather(c, sizeof(FpMsg));
+            }
+            FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r, all, P);
         }
         FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
         FR_HIP(hipMemcpyAsync(glob_norm, B.gnorm, 8, hipMemcpyDeviceToHost, st));
@@ -139,11 +187,16 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
     *n_samp_io = n_rem;
 }
 
-__global__ void k_vc_teeth(VcompBuf B, int last_round, uint32_t n_samp, double rn, double lbound0, double norm_after) {
+// norms: every rank's find_preserve result in rank order (frisys_mol.cpp:529, compress_utils.cpp:293-300);
+// keep receives a copy that outlives the staging block (zeros when no samples are left: every lbound then starts at 0)
+__global__ void k_vc_teeth(VcompBuf B, int last_round, uint32_t n_samp, double rn, const double *norms, int rank, int n_ranks, double *keep) {
     CompState s = B.state[last_round];
     const double loc_norm = n_samp ? *B.seq.total : 0.0;      // exact in-order sum of the non-preserved |v|
     s.n_rem = n_samp; s.loc_norm = loc_norm; s.n_fix = 0; s.n_out = 0;
-    double glob = lbound0 + loc_norm + norm_after;
+    double lbound0 = 0;
+    for (int p = 0; p < rank; p++) { double x = n_samp ? norms[p] : 0.0; lbound0 += x; keep[p] = x; }
+    double glob = lbound0;
+    for (int p = rank; p < n_ranks; p++) glob += (p == rank) ? loc_norm : (n_samp ? norms[p] : 0.0);
     double unit = 0, r0 = INFINITY;
     if (n_samp > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_samp, &unit);
     s.unit = glob / n_samp;
@@ -229,6 +282,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sc_write(VecDev V, VcompBuf B, con
     fr_sc_element(V, B, B.teeth, i, B.S[i], &k, fin->unit, true);
 }
 
+// find_preserve returns 0 when the budget is spent (compress_utils.cpp:94-96)
+static __global__ void k_put_norm_vc(const double *total, uint32_t n_samp, double *out) { *out = n_samp ? *total : 0.0; }
+
 void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     VcompBuf &B = c->vc;
     hipStream_t st = c->stream;
@@ -236,7 +292,18 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     uint32_t *kin = c->W.kin;      // HB-PP scratch is idle here
     AccUnkept au{c->vec.v0, B.keep, c->vec.st};
     run_seq(c, B.seq, au, bound);
-    FR_LAUNCH(c, "k_vc_teeth", k_vc_teeth, dim3(1), dim3(1), B, c->rounds_hint[7], n_samp, rn, 0.0, 0.0);
+    const int P = c->n_ranks;
+    const double *norms = B.seq.total;
+    if (P > 1) {
+        FR_LAUNCH(c, "k_put_norm", k_put_norm_vc, dim3(1), dim3(1), B.seq.total, n_samp, (double *)c->comm.small_send);
+        norms = (const double *)fr_allgather(c, sizeof(double));
+    }
+    FR_LAUNCH(c, "k_vc_teeth", k_vc_teeth, dim3(1), dim3(1), B, c->rounds_hint[7], n_samp, rn, norms, c->rank, P, c->d_norms_keep);
+    if (c->rank > 0) {
+        SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
+        SeqWork Q2 = B.seq; Q2.total = c->d_seq_scratch;
+        run_seq_from(c, Q2, au, bound, from);
+    }
     FR_LAUNCH(c, "k_sc_apply", k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, kin);
     FR_LAUNCH(c, "k_sc_fixup", k_sc_fixup, dim3(1), dim3(1), c->vec, B, kin, c->d_err);
     FR_LAUNCH(c, "k_sc_write", k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, kin);
@@ -260,8 +327,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, co
 
 void fr_dots(FriesCtx *c, double *numer, double *denom) {
     FR_LAUNCH(c, "k_dots", k_dots, dim3(2), dim3(FR_BLOCK), c->vec, c->htr_det, c->htr_val, c->n_htrial, c->tr_det, c->tr_val, c->n_trial, c->vc.dots);
-    double h[2];
-    FR_HIP(hipMemcpyAsync(h, c->vc.dots, 16, hipMemcpyDeviceToHost, c->stream));
+    const int P = c->n_ranks;
+    double h[2 * FR_MAX_RANKS];
+    const double *src = c->vc.dots;
+    if (P > 1) {
+        FR_HIP(hipMemcpyAsync(c->comm.small_send, c->vc.dots, 16, hipMemcpyDeviceToDevice, c->stream));
+        src = (const double *)fr_allgather(c, 16);
+    }
+    FR_HIP(hipMemcpyAsync(h, src, 16 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
     FR_HIP(hipStreamSynchronize(c->stream));
-    *numer = h[0]; *denom = h[1];
+    double nu = 0, de = 0;          // sum_mpi in rank order (frisys_mol.cpp:512-517)
+    for (int p = 0; p < P; p++) { nu += h[2 * p]; de += h[2 * p + 1]; }
+    *numer = nu; *denom = de;
 }

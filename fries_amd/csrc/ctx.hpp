@@ -44,6 +44,8 @@ struct SpawnBuf {
     uint32_t *hist;                            // digit histograms
     uint32_t *pcnt;                            // block partial counts
     uint32_t *n_spawn;                         // device scalar: list length
+    // exchange between ranks (n_ranks > 1)
+    uint8_t *xkey; uint32_t *xcnt, *xoff, *xbucket;
 };
 
 // vector-compression scratch (compress.hip)
@@ -72,9 +74,27 @@ struct AccUnkept {          // compress_utils.cpp:98-101 and the lbound of sys_c
     __device__ double get(size_t i) const { return keep[i] ? 0.0 : fabs(v[i]); }
 };
 
+// ranks (include/fries_hip.h: fries_comm).  size == 1: no callbacks, the "gathered" block is the send block.
+struct fries_comm_ops {
+    void *user; int32_t rank, size;
+    void *small_send, *small_recv, *big_send, *big_recv; uint64_t big_bytes;
+    int (*allgather)(void *, uint64_t, void *);
+    int (*alltoallv)(void *, const uint64_t *, const uint64_t *, void *);
+};
+struct FriesCtx;
+// gathers c->comm.small_send[0, bytes) of every rank; returns the device address of the rank-ordered blocks
+const void *fr_allgather(FriesCtx *c, size_t bytes);
+
 struct FriesCtx {
     int device = 0;
     hipStream_t stream = nullptr;
+    fries_comm_ops comm{};
+    int rank = 0, n_ranks = 1, hf_proc = 0;
+    uint32_t *d_proc_scr = nullptr;          // proc_hash_ scrambler on the device
+    void *own_small = nullptr;               // size == 1: engine-owned small_send
+    double *d_norms_keep = nullptr, *d_seq_scratch = nullptr;
+    uint32_t adder_cap = 0;                  // the reference's Adder capacity per destination (frisys_mol.cpp:109-110)
+    uint64_t n_collectives = 0;
     // system
     uint32_t n_orb = 0, n_elec = 0;
     double *d_h = nullptr, *d_eris = nullptr;
@@ -125,6 +145,8 @@ void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool same_colu
 void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n);
 void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap);
+void fr_xch_alloc(FriesCtx *c, uint32_t cap);
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local);
 // hbpp.hip
 void fr_hbpp_alloc(FriesCtx *c, uint32_t cap);
 void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]);

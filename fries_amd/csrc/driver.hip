@@ -81,6 +81,29 @@ static void check_dev_err(FriesCtx *c) {
     throw FriesError(m);
 }
 
+const void *fr_allgather(FriesCtx *c, size_t bytes) {
+    if (c->n_ranks == 1) return c->comm.small_send;
+    if (bytes > 2048) throw FriesError("all-gather block exceeds FRIES_COMM_SMALL_BYTES");
+    if (c->comm.allgather(c->comm.user, bytes, (void *)c->stream)) throw FriesError("fries_comm.allgather failed");
+    c->n_collectives++;
+    return c->comm.small_recv;
+}
+
+// DistVec::idx_to_proc (vec_utils.hpp:360-379): hash_fxn over the occupied orbitals with the proc scrambler, mod n_procs
+static int host_idx_to_proc(const FriesCtx *c, det_t d) {
+    if (c->n_ranks == 1) return 0;
+    uint64_t hash = 0;
+    uint32_t i = 0;
+    while (d) {
+        unsigned orb = (unsigned)__builtin_ctzll(d);
+        d &= d - 1;
+        uint32_t term = (i + 1u) * c->proc_scr[orb];
+        hash = 1099511628211ULL * hash + term;
+        i++;
+    }
+    return (int)(hash % (uint64_t)c->n_ranks);
+}
+
 static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
     c->eps = p->epsilon; c->target_norm = p->target_norm; c->init_thresh = p->initiator;
@@ -91,19 +114,30 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     c->proc_scr.resize(2 * c->n_orb); c->vec_scr.resize(2 * c->n_orb);
     for (auto &x : c->proc_scr) x = c->mt();        // frisys_mol.cpp:133-135
     for (auto &x : c->vec_scr) x = c->mt();         // :142-144
+    // A shard can in principle emit the whole (global) sample budget, so the work arrays are sized for it; the
+    // reference sizes them mat_nonz * 4 / n_procs and throws when a shard outgrows that (:109, heat_bathPP.cpp:700-704).
     uint32_t wcap = p->max_dets > p->mat_nonz + 4096 ? p->max_dets : p->mat_nonz + 4096;
+    uint32_t spawn_length = (uint32_t)((uint64_t)p->mat_nonz * 4 / c->n_ranks);
+    c->adder_cap = spawn_length > 1000000u ? 1000000u : spawn_length;        // :109-110
+    if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
+    if (!c->d_proc_scr) c->d_proc_scr = fr_alloc<uint32_t>(64);
+    FR_HIP(hipMemcpyAsync(c->d_proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size(), hipMemcpyHostToDevice, c->stream));
+    c->hf_proc = host_idx_to_proc(c, c->hf_det);
     fr_vec_alloc(c, &c->vec, p->max_dets);
     fr_hbpp_alloc(c, wcap);
     fr_spawn_alloc(c, p->mat_nonz + 4096);
+    fr_xch_alloc(c, p->mat_nonz + 4096);
     fr_vcomp_alloc(c, p->max_dets);
-    fr_h_trial_setup(c);
-    // start from 100 * |HF>  (:277-281)
-    double v = 100; uint8_t one = 1; uint32_t n1 = 1;
-    FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
-    FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
-    FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
-    FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
-    fr_vec_merge(c, &c->vec, 1, true);               // perform_add(0) into column 0
+    fr_h_trial_setup(c);        // replicated: every rank enumerates H|HF> (the reference gathers the shards, vec_utils.hpp:920-952)
+    // start from 100 * |HF> on the rank that owns it (:277-281)
+    if (c->rank == c->hf_proc) {
+        double v = 100; uint8_t one = 1; uint32_t n1 = 1;
+        FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
+        fr_vec_merge(c, &c->vec, 1, true);               // perform_add(0) into column 0
+    }
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     check_dev_err(c);
 }
@@ -121,10 +155,10 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     uint32_t vec_size = c->h_vst.curr_size;
     // spawning + annihilation (:429-471)
     if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
-    if (c->num_success) {
-        FR_LAUNCH(c, "k_spawn_build", k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
-        fr_vec_merge(c, &c->vec, c->num_success, false);
-    }
+    if (c->num_success) FR_LAUNCH(c, "k_spawn_build", k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
+    uint32_t n_merge = c->num_success;
+    if (c->n_ranks > 1) n_merge = fr_spawn_exchange(c, c->num_success);      // every rank takes part, also with nothing to send
+    if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false);
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) check_dev_err(c);
     // death / cloning, column add (:487-499)
@@ -209,6 +243,28 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
     if (h->c.stream) hipStreamDestroy(h->c.stream);
     delete h;
+}
+
+extern "C" int fries_set_comm(fries_ctx *h, const fries_comm *cm) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (c->vec.dets) throw FriesError("fries_set_comm must be called before fries_frisys_setup");
+    if (!cm || cm->size < 1 || cm->size > FR_MAX_RANKS || cm->rank < 0 || cm->rank >= cm->size) throw FriesError("bad rank / size");
+    if (cm->size > 1 && (!cm->allgather || !cm->alltoallv || !cm->small_send || !cm->small_recv || !cm->big_send || !cm->big_recv))
+        throw FriesError("fries_comm needs both collectives and all four staging buffers");
+    c->comm.user = cm->user; c->comm.rank = cm->rank; c->comm.size = cm->size;
+    c->comm.small_send = cm->small_send; c->comm.small_recv = cm->small_recv; c->comm.big_send = cm->big_send; c->comm.big_recv = cm->big_recv;
+    c->comm.big_bytes = cm->big_bytes; c->comm.allgather = cm->allgather; c->comm.alltoallv = cm->alltoallv;
+    c->rank = cm->rank; c->n_ranks = cm->size;
+    FR_API_END
+}
+extern "C" void *fries_stream(fries_ctx *h) { return (void *)h->c.stream; }
+extern "C" int fries_idx_to_proc(fries_ctx *h, const uint64_t *dets, size_t n, int32_t *proc) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (c->proc_scr.empty()) throw FriesError("fries_frisys_setup must be called first");
+    for (size_t i = 0; i < n; i++) proc[i] = host_idx_to_proc(c, dets[i]);
+    FR_API_END
 }
 
 extern "C" int fries_set_molecule(fries_ctx *h, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris) {
@@ -338,6 +394,7 @@ extern "C" int fries_vec_add(fries_ctx *h, const uint64_t *dets, const double *v
     FriesCtx *c = &h->c;
     FR_HIP(hipSetDevice(c->device));
     if (n > c->sp.cap) throw FriesError("Too many elements added to Adder - must call perform_add() more frequently.");
+    if (c->n_ranks > 1) throw FriesError("fries_vec_add is a one-rank entry point; with ranks, adds travel inside fries_frisys_iterate");
     // DistVec::add drops zero values before they reach the adder (vec_utils.hpp:418-423)
     std::vector<det_t> d; std::vector<double> v; std::vector<uint8_t> f;
     for (size_t i = 0; i < n; i++) if (vals[i] != 0) { d.push_back(dets[i]); v.push_back(vals[i]); f.push_back(ini[i]); }
@@ -468,10 +525,13 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     FR_HIP(hipMemcpy(da, vals, 8 * (size_t)n, hipMemcpyHostToDevice));
     FR_HIP(hipMemset(Q.subs, 0, sizeof(SeqRec) * (size_t)ntile * FR_SUBS_PER_TILE));
     AccArr acc{da, n};
+    double *dstart = fr_alloc<double>(1);
+    FR_HIP(hipMemcpy(dstart, &start, 8, hipMemcpyHostToDevice));
+    SeqStart from; from.norms = dstart; from.n = 1;      // 0 + start == start
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, start);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccArr>), dim3(1), dim3(64), Q, acc, start);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccArr>), dim3(1), dim3(64), Q, acc, from);
     FR_LAUNCH(c, "k_test_seq_apply", k_test_seq_apply, dim3(ntile), dim3(FR_BLOCK), Q, acc, dout);
     FR_HIP(hipStreamSynchronize(c->stream));
     FR_HIP(hipMemcpy(out_prefix, dout, 8 * (size_t)n, hipMemcpyDeviceToHost));
@@ -483,7 +543,7 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     for (unsigned t = 0; t < ntile; t++) if (tl[t].dirty) { dt++; for (int j = 0; j < FR_SUBS_PER_TILE; j++) if (sb[(size_t)t * FR_SUBS_PER_TILE + j].dirty) ds++; }
     if (n_dirty_tiles) *n_dirty_tiles = dt;
     if (n_dirty_subs) *n_dirty_subs = ds;
-    hipFree(Q.tiles); hipFree(Q.subs); hipFree(Q.total); hipFree(da); hipFree(dout);
+    hipFree(Q.tiles); hipFree(Q.subs); hipFree(Q.total); hipFree(da); hipFree(dout); hipFree(dstart);
     FR_API_END
 }
 

@@ -20,8 +20,6 @@
 struct FksScal {
     double psG[FR_FKS_PMAX];        // norm at the start of sweep p
     uint32_t psN[FR_FKS_PMAX];      // sample budget at the start of sweep p
-    double totG[FR_FKS_PMAX], totW[FR_FKS_PMAX];
-    uint32_t totK[FR_FKS_PMAX];
     int n_pass;
     uint32_t zero_prefix;           // 1: replay 0, every prefix is zero
     double G0, G_last;
@@ -44,28 +42,66 @@ struct Fks2Work {
 #define FR_FKS_CHUNK 2048                   // groups per scan workgroup
 #define FR_FKS_MAXCHUNK 1024
 
-__device__ __forceinline__ void fr_fks2_passes(FksScal *S) {
-    FksPass ps[FR_FKS_PMAX];
-    double G_last; uint32_t n_last;
-    S->n_pass = fr_fks_passes(S->totG, S->totK, S->totW, S->G0, S->n0, ps, &G_last, &n_last);
-    if (S->n_pass >= FR_FKS_PMAX) S->overflow = 1;
-    for (int p = 0; p < FR_FKS_PMAX; p++) { S->psG[p] = ps[p].G; S->psN[p] = ps[p].n; }
-    S->G_last = G_last; S->n_last = n_last;
+// What a rank tells the others about its shard: the norm entering sweep 0 and, per sweep of the replay that just
+// ran, how many samples it preserved, by how much its norm dropped and what its wt_remain re-sums to.
+struct FksMsg {
+    double L0;
+    uint32_t changed, pad;
+    uint32_t totK[FR_FKS_PMAX];
+    double totG[FR_FKS_PMAX], totW[FR_FKS_PMAX];
+};
+static_assert(sizeof(FksMsg) <= 2048, "FksMsg must fit FRIES_COMM_SMALL_BYTES");
+#define FR_MAX_RANKS 64
+
+// Sweep bookkeeping of compress_utils.cpp:153-158, 251-265 for the next replay from every rank's totals:
+// glob_one_norm = sum_mpi(loc_one_norm) and glob_sampled = sum_mpi(loc_sampled), added in rank order.
+__device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, int n_ranks, uint32_t *hist_it) {
+    double L[FR_MAX_RANKS];
+    uint32_t ch = 0;
+    for (int r = 0; r < n_ranks; r++) { L[r] = msgs[r].L0; ch |= msgs[r].changed; }
+    if (hist_it) *hist_it = ch;
+    uint32_t n = S->n0;
+    int last_pass = 0, p = 0;
+    for (; p < FR_FKS_PMAX; p++) {
+        double G = 0;
+        for (int r = 0; r < n_ranks; r++) G += L[r];
+        S->psG[p] = G; S->psN[p] = n;
+        if (G < 0) break;
+        uint32_t K = 0;
+        for (int r = 0; r < n_ranks; r++) K += msgs[r].totK[p];
+        n -= K;
+        uint32_t gs = K;
+        if (last_pass && gs) last_pass = 0;
+        if (gs == 0 && !last_pass) { last_pass = 1; gs = 1; for (int r = 0; r < n_ranks; r++) L[r] = msgs[r].totW[p]; }
+        else for (int r = 0; r < n_ranks; r++) L[r] = L[r] - msgs[r].totG[p];
+        if (gs == 0) { p++; break; }
+    }
+    S->n_pass = p;
+    if (p >= FR_FKS_PMAX) S->overflow = 1;
+    S->G_last = S->psG[p > 0 ? p - 1 : 0]; S->n_last = n;
 }
 
 // sets up replay 0: "nothing kept anywhere" (the stage's input norm comes from the prep kernel's tile partials)
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Work F) {
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Work F, FksMsg *msg, int n_ranks) {
     __shared__ double shd[4];
     const CompState st0 = W.state[0];
     const double G0 = fr_sum_partials(W.psum[0], (st0.n_in + FR_TILE - 1) / FR_TILE, shd);
     if (threadIdx.x == 0) {
         FksScal *S = F.scal;
         S->G0 = G0; S->n0 = st0.n_rem; S->n_in = st0.n_in;
-        for (int p = 0; p < FR_FKS_PMAX; p++) { S->totG[p] = 0; S->totK[p] = 0; S->totW[p] = G0; }
-        fr_fks2_passes(S);
+        msg->L0 = G0; msg->changed = 0; msg->pad = 0;
+        for (int p = 0; p < FR_FKS_PMAX; p++) { msg->totG[p] = 0; msg->totK[p] = 0; msg->totW[p] = G0; }
         S->zero_prefix = 1; S->changed = 0; S->done_ctr = 0; S->overflow = 0; S->valid_upto = -1;
         for (int k = 0; k < FR_MAX_ROUNDS + 2; k++) F.hist[k] = 0;
+        if (n_ranks == 1) fr_fks2_passes(S, msg, 1, nullptr);
     }
+}
+
+// after the all-gather of every rank's FksMsg (n_ranks > 1)
+static __global__ void k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks, int it, uint32_t *err) {
+    FksScal *S = F.scal;
+    fr_fks2_passes(S, msgs, n_ranks, it >= 0 ? &F.hist[it] : nullptr);
+    if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
 }
 
 // One sub-weight row against a threshold: keeps, remaining weight, and the bounds needed to tell whether the
@@ -295,8 +331,8 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
     }
 }
 
-// Sweep totals from the chunk totals, then the sweep scalars of the next replay (one workgroup)
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err) {
+// Sweep totals from the chunk totals into this rank's FksMsg; with one rank, also the sweep scalars of the next replay
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int n_ranks, int it) {
     __shared__ double shd[4];
     __shared__ uint32_t shu[4];
     FksScal *S = F.scal;
@@ -305,19 +341,22 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
     const int n_pass = S->n_pass;
     for (int q = 0; q < FR_FKS_PMAX; q++) {
         uint32_t k = 0; double g = 0, w = 0;
-        if (q > n_pass + 1) { if (threadIdx.x == 0) { S->totK[q] = 0; S->totG[q] = 0; S->totW[q] = 0; } continue; }
+        if (q > n_pass + 1) { if (threadIdx.x == 0) { msg->totK[q] = 0; msg->totG[q] = 0; msg->totW[q] = 0; } continue; }
         if (q <= n_pass) {
             k = fr_sum_partials_u32(F.ck + (size_t)q * FR_FKS_MAXCHUNK, nchunk, shu);
             g = fr_sum_partials(F.cg + (size_t)q * FR_FKS_MAXCHUNK, nchunk, shd);
             w = fr_sum_partials(F.cw + (size_t)q * FR_FKS_MAXCHUNK, nchunk, shd);
         }
-        if (threadIdx.x == 0) { S->totK[q] = k; S->totG[q] = g; S->totW[q] = w; }
+        if (threadIdx.x == 0) { msg->totK[q] = k; msg->totG[q] = g; msg->totW[q] = w; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         S->zero_prefix = 0;
         S->valid_upto = n_pass;         // k_fks_scan covered sweeps 0..n_pass of the replay that just ran
-        fr_fks2_passes(S);
-        if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
+        msg->L0 = S->G0; msg->changed = F.hist[it]; msg->pad = 0;
+        if (n_ranks == 1) {
+            fr_fks2_passes(S, msg, 1, nullptr);
+            if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
+        }
     }
 }

@@ -213,7 +213,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_compact(CompWork W, int prev
 }
 
 // find_keep_sub's epilogue (compress_utils.cpp:266-275), seed_sys and the comb, from the settled replay
-static __global__ void k_comp_finalize2(CompWork W, Fks2Work F, double rn, double lbound0, double norm_others_after) {
+// norms: every rank's find_keep_sub result in rank order (compress_utils.cpp:817-818); norms[rank] == *W.seq.total
+static __global__ void k_comp_finalize2(CompWork W, Fks2Work F, double rn, const double *norms, int rank, int n_ranks) {
     const FksScal *S = F.scal;
     CompState s = W.state[0];
     double G = S->G_last;
@@ -223,7 +224,12 @@ static __global__ void k_comp_finalize2(CompWork W, Fks2Work F, double rn, doubl
     if (G / n_rem < 1e-8) n_rem = 0;
     else loc_norm = *W.seq.total;
     s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
-    double glob = lbound0 + loc_norm + norm_others_after;     // sum in rank order (seed_sys)
+    // seed_sys (compress_utils.cpp:113-120): lbound over the ranks before me, then the rest on top of it, in rank order.
+    // n_rem == 0 is decided from replicated scalars, so every rank then reports a zero norm.
+    double lbound0 = 0;
+    for (int p = 0; p < rank; p++) lbound0 += n_rem ? norms[p] : 0.0;
+    double glob = lbound0;
+    for (int p = rank; p < n_ranks; p++) glob += (p == rank) ? loc_norm : (n_rem ? norms[p] : 0.0);
     double unit = 0, r0 = INFINITY;
     if (n_rem > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_rem, &unit);
     s.unit = glob / n_rem;
@@ -231,6 +237,18 @@ static __global__ void k_comp_finalize2(CompWork W, Fks2Work F, double rn, doubl
     W.state[FR_MAX_ROUNDS + 1] = s;
     if (n_rem > 0) fr_build_teeth(W.teeth, r0, unit, n_rem + 2, lbound0);
     else { W.teeth->nseg = 0; W.teeth->kmax = 0; W.teeth->unit = 0; W.teeth->lbound0 = lbound0; }
+}
+
+// this rank's find_keep_sub result, as the reference returns it (0 when the budget is spent, compress_utils.cpp:267-269)
+static __global__ void k_put_norm(CompWork W, Fks2Work F, double *out) {
+    const FksScal *S = F.scal;
+    *out = (S->G_last / S->n_last < 1e-8) ? 0.0 : *W.seq.total;
+}
+// copies the gathered norms out of the staging block (the next collective overwrites it)
+// (all zero when no samples are left: sys_sub then starts every rank's lbound at 0, compress_utils.cpp:720-726)
+static __global__ void k_keep_norms(const double *norms, int n, double *keep, CompWork W, Fks2Work F) {
+    const bool any = W.state[FR_MAX_ROUNDS + 1].n_rem > 0;
+    for (int p = threadIdx.x; p < n; p += blockDim.x) keep[p] = any ? norms[p] : 0.0;
 }
 
 // ------------------------------------------------------------------ host orchestration
@@ -261,6 +279,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         FR_HIP(hipMemset(F.hist, 0, 4 * (FR_MAX_ROUNDS + 2)));
         FR_HIP(hipMemset(F.scal, 0, sizeof(FksScal)));
     }
+    c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1);
     c->c_pos = fr_alloc<uint32_t>(cap); c->c_orbs = fr_alloc<uint32_t>(cap); c->c_val = fr_alloc<double>(cap);
     c->d_nsucc = fr_alloc<uint32_t>(1);
     FR_HIP(hipMemset(W.state, 0, sizeof(CompState) * (FR_MAX_ROUNDS + 2)));
@@ -279,7 +298,13 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
     unsigned nchunk = fr_blocks((size_t)n_bound / 8 + 1, FR_FKS_CHUNK);
     if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
-    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F);
+    const int P = c->n_ranks;
+    FksMsg *msg = (FksMsg *)c->comm.small_send;
+    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F, msg, P);
+    if (P > 1) {
+        const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
+        FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, -1, c->d_err);
+    }
     int it = 0, batch = c->rounds_hint[STAGE];
     uint32_t changed = 1;
     while (changed) {
@@ -288,7 +313,11 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         for (int k = 0; k < batch; k++) {
             FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it);
-            FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err);
+            FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, P, it);
+            if (P > 1) {
+                const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
+                FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, it, c->d_err);
+            }
             it++;
         }
         FR_HIP(hipMemcpyAsync(&changed, &F.hist[it - 1], 4, hipMemcpyDeviceToHost, st));
@@ -301,10 +330,25 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
     AccWt acc{W.wt_remain, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, 0.0);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, 0.0);
-    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(1), W, F, rn, 0.0, 0.0);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, fr_seq_from_zero());
+    const double *norms = W.seq.total;
+    if (P > 1) {
+        // every rank's remaining norm (compress_utils.cpp:817-818), then the in-order lbound chain again from this
+        // rank's offset: a floating-point running sum depends on where it starts
+        FR_LAUNCH(c, "k_put_norm", k_put_norm, dim3(1), dim3(1), W, F, (double *)c->comm.small_send);
+        norms = (const double *)fr_allgather(c, sizeof(double));
+    }
+    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(1), W, F, rn, norms, c->rank, P);
+    if (c->rank > 0) {
+        SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
+        SeqWork Q2 = W.seq; Q2.total = c->d_seq_scratch;
+        FR_LAUNCH(c, "k_keep_norms", k_keep_norms, dim3(1), dim3(64), norms, P, c->d_norms_keep, W, F);
+        FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
+        FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc);
+        FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), Q2, acc, from);
+    }
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
     FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
@@ -320,11 +364,25 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     uint32_t bound1 = c->h_vst.curr_size;
     uint32_t bound = n_samp + 64 < W.cap ? n_samp + 64 : W.cap;     // a stage never emits more than n_samp entries
     if (bound1 > W.cap) throw FriesError("vector larger than HB-PP work capacity");
+    // with ranks, n_samp is the global budget and a shard usually emits ~1/n_ranks of it: size the next stage's
+    // launches from the emission count (one host sync per stage; the replay loop syncs anyway)
+    const uint32_t bound_max = bound;
+    auto next_bound = [&](int k) {
+        if (c->n_ranks == 1) return bound_max;
+        FR_HIP(hipStreamSynchronize(st));
+        uint32_t b = c->comp_len[k] + 64;
+        return b < bound_max ? b : bound_max;
+    };
     run_stage<1, NEW_HB>(c, 0, bound1, n_samp, rn[0], &c->comp_len[0]);
+    bound = next_bound(0);
     run_stage<2, NEW_HB>(c, 1, bound, n_samp, rn[1], &c->comp_len[1]);
+    bound = next_bound(1);
     run_stage<3, NEW_HB>(c, 0, bound, n_samp, rn[2], &c->comp_len[2]);
+    bound = next_bound(2);
     run_stage<4, NEW_HB>(c, 1, bound, n_samp, rn[3], &c->comp_len[3]);
+    bound = next_bound(3);
     run_stage<5, NEW_HB>(c, 0, bound, n_samp, rn[4], &c->comp_len[4]);
+    bound = next_bound(4);
     unsigned grid = fr_blocks(bound, FR_TILE);
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     // f_val / f_orbs reuse the S / kin arrays of the (finished) last stage

@@ -35,6 +35,14 @@ struct SeqWork {
     double *total;      // [1] exact sum of everything (+ start)
 };
 
+// where a chain starts: 0 + norms[0] + ... + norms[n-1], added left to right -- the lbound a rank inherits from the
+// ranks before it (seed_sys, compress_utils.cpp:113-116).  n == 0: the chain starts at 0.
+struct SeqStart {
+    const double *norms; int n;
+    __device__ double value() const { double s = 0; for (int p = 0; p < n; p++) s += norms[p]; return s; }
+};
+static inline SeqStart fr_seq_from_zero() { SeqStart s; s.norms = nullptr; s.n = 0; return s; }
+
 struct PMap { long long d0, d1; };
 __device__ __forceinline__ PMap fr_pm_id() { PMap m; m.d0 = 0; m.d1 = 0; return m; }
 // g first, then f
@@ -98,7 +106,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seq_sums(SeqWork Q, Acc acc) {
 
 // ---- S2: approximate carries per tile, clean / dirty classification (one workgroup)
 template <class Acc>
-__global__ void __launch_bounds__(FR_BLOCK) k_seq_classify(SeqWork Q, Acc acc, double start) {
+__global__ void __launch_bounds__(FR_BLOCK) k_seq_classify(SeqWork Q, Acc acc, SeqStart st) {
+    const double start = st.value();
     __shared__ double shd[12];
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
@@ -236,8 +245,8 @@ __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double s
 }
 
 template <class Acc>
-__global__ void __launch_bounds__(64) k_seq_chain(SeqWork Q, Acc acc, double start) {
-    double tot = fr_seq_chain_wave(Q, acc, start);
+__global__ void __launch_bounds__(64) k_seq_chain(SeqWork Q, Acc acc, SeqStart st) {
+    double tot = fr_seq_chain_wave(Q, acc, st.value());
     if (threadIdx.x == 0) *Q.total = tot;
 }
 

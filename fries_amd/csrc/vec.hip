@@ -399,3 +399,164 @@ void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v) {
     FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)v->hcap, c->stream));
     FR_LAUNCH(c, "k_hash_reinsert", k_hash_reinsert, dim3(fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK)), dim3(FR_BLOCK), *v);
 }
+
+// ------------------------------------------------------------------ spawn exchange between ranks
+// Adder::add routes every pending element to idx_to_proc(det) (vec_utils.hpp:418-423, 360-379) and
+// perform_add ships them with MPI_Alltoallv; the receiver walks its receive buffer source rank by
+// source rank, each source's elements in the order of its add() calls (:991-1019, :606-641).
+// frisys_mol calls this twice per iteration, first for the non-initiator spawns and then for the
+// initiator ones (frisys_mol.cpp:430-471).  Here one exchange carries both: a source's segment for
+// a destination is [non-initiators in spawn order | initiators in spawn order] as 16-byte
+// (determinant, value) records, and the merge's stable (position, pass) sort restores the
+// reference's accumulation order (pass 0 of every source before pass 1 of any).
+#define FR_XCH_MAXB (2 * FR_MAX_RANKS)
+
+__device__ __forceinline__ uint32_t fr_proc_of(det_t d, const uint32_t *scr, uint32_t n_ranks) {
+    unsigned long long hash = 0;
+    uint32_t i = 0;
+    while (d) {
+        unsigned orb = __ffsll((long long)d) - 1;
+        d &= d - 1;
+        uint32_t term = (i + 1u) * scr[orb];             // unsigned int * uint32_t: wraps at 32 bits (det_hash.hpp:160-170)
+        hash = 1099511628211ULL * hash + term;
+        i++;
+    }
+    return (uint32_t)(hash % n_ranks);
+}
+
+// bucket = 2 * destination + initiator flag; counts per 256-element tile
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt) {
+    __shared__ uint32_t wcnt[4][FR_XCH_MAXB];
+    const uint32_t n = *S.n_spawn;
+    const uint32_t nb = 2 * n_ranks;
+    const uint32_t ntile = (n + FR_BLOCK - 1) / FR_BLOCK;
+    if (blockIdx.x >= ntile) return;
+    uint32_t j = blockIdx.x * FR_BLOCK + threadIdx.x;
+    uint32_t k = 0xFFu;
+    if (j < n) { k = 2 * fr_proc_of(S.det[j], scr, n_ranks) + (S.ini[j] ? 1u : 0u); key[j] = (uint8_t)k; }
+    const int w = threadIdx.x >> 6;
+    for (uint32_t b = 0; b < nb; b++) {
+        unsigned long long m = __ballot(k == b);
+        if (fr_lane() == 0) wcnt[w][b] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += FR_BLOCK) tile_cnt[(size_t)blockIdx.x * nb + b] = wcnt[0][b] + wcnt[1][b] + wcnt[2][b] + wcnt[3][b];
+}
+
+// exclusive prefix of every bucket over the tiles, bucket totals, bucket bases (one workgroup)
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_scan(SpawnBuf S, uint32_t n_ranks, const uint32_t *tile_cnt, uint32_t *tile_off, uint32_t *bucket /* [2][nb]: totals, bases */, uint32_t *msg) {
+    __shared__ uint32_t shu[4];
+    __shared__ uint32_t s_tot[FR_XCH_MAXB];
+    const uint32_t n = *S.n_spawn;
+    const uint32_t nb = 2 * n_ranks;
+    const uint32_t ntile = (n + FR_BLOCK - 1) / FR_BLOCK;
+    for (uint32_t b = 0; b < nb; b++) {
+        uint32_t run = 0;
+        for (uint32_t t0 = 0; t0 < ntile; t0 += FR_BLOCK) {
+            uint32_t t = t0 + threadIdx.x;
+            uint32_t x = t < ntile ? tile_cnt[(size_t)t * nb + b] : 0u;
+            uint32_t tot;
+            uint32_t incl = fr_block_scan_u32(x, shu, &tot);
+            if (t < ntile) tile_off[(size_t)t * nb + b] = run + incl - x;
+            run += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) s_tot[b] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t base = 0;
+        for (uint32_t b = 0; b < nb; b++) { bucket[b] = s_tot[b]; bucket[nb + b] = base; msg[b] = s_tot[b]; base += s_tot[b]; }
+    }
+}
+
+struct XchRec { det_t det; double val; };
+
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n_ranks, const uint8_t *key, const uint32_t *tile_off, const uint32_t *bucket, XchRec *out, uint32_t cap_recs, uint32_t *err) {
+    __shared__ uint32_t wcnt[4][FR_XCH_MAXB];
+    const uint32_t n = *S.n_spawn;
+    const uint32_t nb = 2 * n_ranks;
+    const uint32_t ntile = (n + FR_BLOCK - 1) / FR_BLOCK;
+    if (blockIdx.x >= ntile) return;
+    uint32_t j = blockIdx.x * FR_BLOCK + threadIdx.x;
+    uint32_t k = j < n ? key[j] : 0xFFu;
+    const int w = threadIdx.x >> 6, lane = fr_lane();
+    uint32_t my_rank = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        unsigned long long m = __ballot(k == b);
+        if (lane == 0) wcnt[w][b] = (uint32_t)__popcll(m);
+        if (k == b) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (j < n) {
+        for (int ww = 0; ww < w; ww++) my_rank += wcnt[ww][k];
+        uint32_t o = bucket[nb + k] + tile_off[(size_t)blockIdx.x * nb + k] + my_rank;
+        if (o < cap_recs) { XchRec r; r.det = S.det[j]; r.val = S.val[j]; out[o] = r; }
+        else atomicOr(err, FR_ERR_SPAWN_CAP);
+    }
+}
+
+// seg[s] = {first record, number of pass-0 records, number of records} of source s in the receive buffer
+struct XchSegs { uint32_t n_src; uint32_t first[FR_MAX_RANKS], n0[FR_MAX_RANKS], cnt[FR_MAX_RANKS]; };
+
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_unpack(SpawnBuf S, const XchRec *in, XchSegs G, uint32_t n_recv) {
+    uint32_t j = blockIdx.x * FR_BLOCK + threadIdx.x;
+    if (j == 0) *S.n_spawn = n_recv;
+    if (j >= n_recv) return;
+    uint32_t s = 0;
+    while (s + 1 < G.n_src && j >= G.first[s + 1]) s++;
+    XchRec r = in[j];
+    S.det[j] = r.det; S.val[j] = r.val; S.ini[j] = (j - G.first[s]) >= G.n0[s] ? 1 : 0;
+}
+
+void fr_xch_alloc(FriesCtx *c, uint32_t cap) {
+    SpawnBuf &S = c->sp;
+    if (c->n_ranks == 1) return;
+    uint32_t ntile = fr_blocks(cap, FR_BLOCK) + 1;
+    S.xkey = fr_alloc<uint8_t>(cap);
+    S.xcnt = fr_alloc<uint32_t>((size_t)ntile * 2 * c->n_ranks);
+    S.xoff = fr_alloc<uint32_t>((size_t)ntile * 2 * c->n_ranks);
+    S.xbucket = fr_alloc<uint32_t>(4 * (size_t)c->n_ranks);
+    if ((uint64_t)cap * sizeof(XchRec) > c->comm.big_bytes) throw FriesError("fries_comm.big_bytes is smaller than 16 bytes x (mat_nonz + 4096)");
+    if ((size_t)2 * c->n_ranks * 4 > 2048) throw FriesError("too many ranks");
+}
+
+// Ships the n_local spawns in c->sp to their owners; on return c->sp holds what this rank received, in the
+// reference's arrival order.  Returns the number received.
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local) {
+    SpawnBuf &S = c->sp;
+    hipStream_t st = c->stream;
+    const int P = c->n_ranks;
+    const uint32_t nb = 2 * P;
+    if (n_local > S.cap) throw FriesError("spawn list exceeds spawn buffer capacity");
+    unsigned g = fr_blocks(n_local ? n_local : 1, FR_BLOCK);
+    uint32_t cap_recs = (uint32_t)(c->comm.big_bytes / sizeof(XchRec));
+    if (n_local == 0) FR_HIP(hipMemsetAsync(S.n_spawn, 0, 4, st));
+    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt);
+    FR_LAUNCH(c, "k_xch_scan", k_xch_scan, dim3(1), dim3(FR_BLOCK), S, (uint32_t)P, S.xcnt, S.xoff, S.xbucket, (uint32_t *)c->comm.small_send);
+    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err);
+    const uint32_t *all = (const uint32_t *)fr_allgather(c, nb * 4);
+    std::vector<uint32_t> cnt((size_t)P * nb);
+    FR_HIP(hipMemcpyAsync(cnt.data(), all, cnt.size() * 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> sb(P), rb(P);
+    XchSegs G{};
+    G.n_src = (uint32_t)P;
+    uint64_t n_recv = 0;
+    for (int p = 0; p < P; p++) {
+        const uint32_t *mine = &cnt[(size_t)c->rank * nb], *theirs = &cnt[(size_t)p * nb];
+        sb[p] = (uint64_t)sizeof(XchRec) * ((uint64_t)mine[2 * p] + mine[2 * p + 1]);
+        uint32_t n0 = theirs[2 * c->rank], n1 = theirs[2 * c->rank + 1];
+        // Adder::add refuses more than adder_size_ pending elements per destination (vec_utils.hpp:957-971); the reference
+        // then flushes early, which would reorder arrivals.  mat_nonz * 4 / n_ranks (capped at 1e6) per pass is that limit.
+        if (n0 >= c->adder_cap || n1 >= c->adder_cap) throw FriesError("a rank has more pending adds for one destination than the reference's Adder holds (early perform_add flushes are not reproduced)");
+        G.first[p] = (uint32_t)n_recv; G.n0[p] = n0; G.cnt[p] = n0 + n1;
+        rb[p] = (uint64_t)sizeof(XchRec) * ((uint64_t)n0 + n1);
+        n_recv += (uint64_t)n0 + n1;
+    }
+    if (n_recv > S.cap || n_recv > cap_recs) throw FriesError("received spawns exceed the spawn buffer");
+    if (c->comm.alltoallv(c->comm.user, sb.data(), rb.data(), (void *)st)) throw FriesError("fries_comm.alltoallv failed");
+    c->n_collectives++;
+    FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv);
+    return (uint32_t)n_recv;
+}

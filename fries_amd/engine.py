@@ -22,6 +22,7 @@ EXPORTS = [
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
+    "fries_set_comm", "fries_stream", "fries_idx_to_proc",
 ]
 
 
@@ -82,6 +83,10 @@ def load_library() -> C.CDLL:
     lib.fries_prof_count.argtypes = [C.c_void_p]
     lib.fries_prof_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fries_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
+    lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fries_stream.restype = C.c_void_p
+    lib.fries_stream.argtypes = [C.c_void_p]
+    lib.fries_idx_to_proc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     _lib = lib
     return lib
 
@@ -91,9 +96,10 @@ def _ptr(a):
 
 
 class FriEngine:
-    """One MI355X running the FRI iteration for one molecular Hamiltonian."""
+    """One MI355X running the FRI iteration for one molecular Hamiltonian -- or, with ``comm`` (fries_amd.comm.TorchComm),
+    one rank of a hash-sharded run: vec_nonz / mat_nonz / target_norm are then global, max_dets is per rank."""
 
-    def __init__(self, mol, device: int = 0):
+    def __init__(self, mol, device: int = 0, comm=None):
         self.lib = load_library()
         if self.lib.fries_device_count() <= 0:
             raise RuntimeError("no HIP device visible: the FRI engine runs on MI355X only (no CPU fallback)")
@@ -105,6 +111,9 @@ class FriEngine:
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
         self._ck(self.lib.fries_set_molecule(self.h, mol.n_orb, mol.n_elec, _ptr(irr), _ptr(hc), _ptr(er)))
         self.max_dets = 0
+        self.comm = comm
+        if comm is not None:
+            self._ck(self.lib.fries_set_comm(self.h, C.byref(comm.struct)))
 
     def _ck(self, rc):
         if rc != 0:
@@ -157,9 +166,18 @@ class FriEngine:
     def setup(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm"):
         if distribution not in ("HB", "HB_unnorm"):
             raise RuntimeError('"dist_str" argument must be either "HB" or "HB_unnorm"')
+        if self.comm is not None and self.comm.big_bytes < 16 * (mat_nonz + 4096):
+            raise RuntimeError("TorchComm was sized for a smaller mat_nonz")
         p = FrisysParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
         self._ck(self.lib.fries_frisys_setup(self.h, C.byref(p)))
         self.max_dets = max_dets
+
+    def idx_to_proc(self, dets) -> np.ndarray:
+        """DistVec::idx_to_proc: the rank that owns each determinant."""
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        out = np.zeros(d.size, dtype=np.int32)
+        self._ck(self.lib.fries_idx_to_proc(self.h, _ptr(d), d.size, _ptr(out)))
+        return out
 
     def iterate(self, n_iter: int, want_logs: bool = True):
         logs = np.zeros(n_iter, dtype=ITERLOG_DTYPE) if want_logs else None

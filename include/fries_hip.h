@@ -46,6 +46,40 @@ double fries_hf_energy(fries_ctx *ctx);     /* diag_matrel of the HF determinant
 int fries_matrel_batch(fries_ctx *ctx, int kind, const uint64_t *dets, const uint8_t *orbs, size_t n,
                        double *out, int32_t *sign);
 
+/* ---- ranks ------------------------------------------------------------------------------------
+ * The reference shards the solution vector over MPI ranks by determinant hash (DistVec::idx_to_proc,
+ * FRIES/vec_utils.hpp:360-379) and synchronises with blocking collectives on MPI_COMM_WORLD:
+ * sum_mpi = MPI_Allgather + a sum in rank order (compress_utils.hpp:170-231), MPI_Alltoallv of the
+ * pending adds (Adder::perform_add, vec_utils.hpp:991-1019), MPI_Allgather of the local norms
+ * (compress_utils.cpp:326, :818), MPI_Bcast of rank 0's uniform (:291, :806).
+ * The engine does the same with ONE process per GPU and two caller-supplied collectives that run
+ * on caller-owned DEVICE staging buffers, stream-ordered like an RCCL call: when the callback
+ * returns, the collective must be ordered after everything already enqueued on `stream`, and work
+ * enqueued on `stream` afterwards must see its result.  fries_amd/comm.py implements them with
+ * torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for tests); INTEGRATION.md shows the
+ * GPU-aware-MPI version a FRIES maintainer would write. */
+#define FRIES_COMM_SMALL_BYTES 2048
+#define FRIES_COMM_MAX_RANKS 64
+typedef struct {
+    void *user;
+    int32_t rank, size;
+    void *small_send;       /* device, FRIES_COMM_SMALL_BYTES */
+    void *small_recv;       /* device, size * FRIES_COMM_SMALL_BYTES */
+    void *big_send;         /* device, big_bytes: all-to-all segments, contiguous in destination order */
+    void *big_recv;         /* device, big_bytes: received segments, contiguous in source order */
+    uint64_t big_bytes;
+    /* every rank contributes small_send[0, bytes); rank p's block lands at small_recv + p * bytes */
+    int (*allgather)(void *user, uint64_t bytes, void *stream);
+    /* send_bytes[d] bytes of big_send go to rank d, recv_bytes[s] bytes arrive from rank s (host arrays of `size`) */
+    int (*alltoallv)(void *user, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *stream);
+} fries_comm;
+/* call between fries_set_molecule and fries_frisys_setup; without it the context is one rank */
+int fries_set_comm(fries_ctx *ctx, const fries_comm *comm);
+/* the HIP stream (hipStream_t) every kernel of this context is launched on */
+void *fries_stream(fries_ctx *ctx);
+/* DistVec::idx_to_proc (vec_utils.hpp:360-379) for n determinants; valid after fries_frisys_setup */
+int fries_idx_to_proc(fries_ctx *ctx, const uint64_t *dets, size_t n, int32_t *proc);
+
 /* frisys_mol's run parameters (FRIES_bin/frisys_mol.cpp:16-33) plus the seed the reference takes
  * from the wall clock (:104-106). */
 typedef struct {
@@ -66,7 +100,9 @@ typedef struct {
     uint32_t err;
 } fries_iter_log;
 
-/* frisys_mol.cpp:76-346: scramblers, solution vector, HF trial vector and H*trial, p_doub, HF start */
+/* frisys_mol.cpp:76-346: scramblers, solution vector, HF trial vector and H*trial, p_doub, HF start.
+ * With ranks: vec_nonz / mat_nonz / target_norm are the GLOBAL budgets, max_dets is per rank, and every rank
+ * must pass the same seed (the reference broadcasts rank 0's scramblers and uniforms). */
 int fries_frisys_setup(fries_ctx *ctx, const fries_frisys_params *p);
 /* frisys_mol.cpp:405-552, n_iter times; logs may be NULL or hold n_iter entries */
 int fries_frisys_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);

@@ -1,0 +1,75 @@
+"""One rank of a hash-sharded FRI run (launched by torch.distributed.run from test_gpu_ranks.py / by hand).
+
+Runs the golden configuration `name` (tests/golden/manifest.json "mpi_runs") with as many ranks as the reference
+was run with under mpiexec, and compares what THIS rank logs with what the same rank of the reference logged:
+scalars bit for bit, shard sizes, and the digest of the shard (position, determinant, value).
+All ranks may share one GPU (backend gloo) -- the point is the exchange logic, not bandwidth.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import golden_io
+    from fries_amd import fcidump
+    from fries_amd.comm import TorchComm
+    from fries_amd.engine import FriEngine
+
+    name, backend, out_dir = sys.argv[1], sys.argv[2], sys.argv[3]
+    n_check = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"]); local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev = local % max(ndev, 1)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend)
+    r = golden_io.manifest()["mpi_runs"][name]
+    assert r["n_ranks"] == world, (r["n_ranks"], world)
+    g = golden_io.read_traj(name, rank=rank)
+    mol = fcidump.synthetic(r["shape"])
+    comm = TorchComm(r["mat_nonz"], torch.device("cuda", dev))
+    eng = FriEngine(mol, device=dev, comm=comm)
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    res = dict(rank=rank, ok=True, fails=[])
+    if eng.p_doub != g["p_doub"]:
+        res["fails"].append(("p_doub", eng.p_doub, g["p_doub"]))
+    rows = g["rows"][:n_check] if n_check else g["rows"]
+    for row in rows:
+        lg = eng.iterate(1)[0]
+        for f in ("norm", "shift"):
+            if float(lg[f]) != row[f]:
+                res["fails"].append((row["it"], f, float(lg[f]), row[f]))
+        for f in ("numer", "denom"):       # block-parallel dot products: 1e-10 relative, not bit-exact
+            if abs(float(lg[f]) - row[f]) > 1e-10 * max(1.0, abs(row[f])):
+                res["fails"].append((row["it"], f, float(lg[f]), row[f]))
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            if int(lg[f]) != row[f]:
+                res["fails"].append((row["it"], f, int(lg[f]), row[f]))
+        if int(lg["err"]):
+            res["fails"].append((row["it"], "err", int(lg["err"])))
+        if len(res["fails"]) > 8:
+            break
+    d, v = eng.vector()
+    if not res["fails"] and golden_io.vec_hash(d, v) != rows[-1]["hash"]:
+        res["fails"].append(("digest",))
+    res["ok"] = not res["fails"]
+    res["n_allgather"] = comm.n_allgather; res["n_alltoallv"] = comm.n_alltoallv; res["iters"] = len(rows)
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f, default=str)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+    sys.exit(0 if res["ok"] else 1)
+
+
+if __name__ == "__main__":
+    main()
