@@ -38,21 +38,30 @@ ALG_BYTES = {
 }
 
 
-def build_state(mol, m, seed):
-    """Filler run (initiator 0) -> a vector with ~m determinants at norm ~ m."""
+def build_state(mol, m_glob, max_dets, seed, device, comm, dist):
+    """Filler run (initiator 0) -> this rank's shard of a vector with ~m_glob determinants at norm ~ m_glob."""
     from fries_amd.engine import FriEngine
-    eng = FriEngine(mol)
-    eng.setup(epsilon=0.01, vec_nonz=m, mat_nonz=m, max_dets=4 * m, target_norm=0.0, initiator=0.0, seed=seed, distribution="HB_unnorm")
+    eng = FriEngine(mol, device=device, comm=comm)
+    eng.setup(epsilon=0.01, vec_nonz=m_glob, mat_nonz=m_glob, max_dets=max_dets, target_norm=0.0, initiator=0.0, seed=seed, distribution="HB_unnorm")
+
+    def glob(x):
+        if dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        return float(t.item())
+
     for _ in range(200):
         lg = eng.iterate(5)
-        if lg["n_nonz"][-1] >= m:
+        if glob(lg["n_nonz"][-1]) >= m_glob:
             break
     eng.iterate(10)
     dets, vals = eng.vector()
     eng.close()
     keep = vals != 0
     dets, vals = dets[keep], vals[keep]
-    vals = vals * (float(m) / np.abs(vals).sum())       # norm == target: about half the elements are initiators
+    vals = vals * (float(m_glob) / glob(np.abs(vals).sum()))       # norm == target: about half the elements are initiators
     return dets, vals
 
 
@@ -61,10 +70,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--m", type=int, default=1_000_000)
+    ap.add_argument("--m", type=int, default=int(os.environ.get("FRIES_BENCH_M", "1000000")), help="nonzeros per GPU")
     ap.add_argument("--shape", default="N2")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: sized to ~20 s; 0: skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--backend", default=os.environ.get("FRIES_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,10 +83,12 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        device = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(device)
+        dist.init_process_group(args.backend)
     else:
         dist = None
+        device = 0
 
     from fries_amd import fcidump
     from fries_amd.engine import FriEngine
@@ -84,14 +96,20 @@ def main():
     m = args.m
     mol = fcidump.synthetic(args.shape)
     seed = 20250215
-    # every rank builds the same restart state; with N > 1 each rank advances an independent
-    # replica from its own seed (hash-sharded exchange is the next row of SURVEY.md section 8(e))
-    dets, vals = build_state(mol, m, seed)
-    par = dict(epsilon=0.01, vec_nonz=m, mat_nonz=m, max_dets=4 * m, target_norm=float(m), initiator=1.0, seed=seed, distribution="HB_unnorm")
-    eng = FriEngine(mol, device=local_rank if world > 1 else 0)
+    # Weak scaling: m determinants PER GPU.  N ranks hold one hash-sharded vector with vec_nonz = mat_nonz = target = N * m
+    # (determinants routed by the reference's proc hash, spawns exchanged with an RCCL all-to-all, every sum_mpi an
+    # all-gather added in rank order) -- the run `mpiexec -n N frisys_mol` would do, one rank per MI355X.
+    m_glob = world * m
+    comm = None
+    if world > 1:
+        from fries_amd.comm import TorchComm
+        comm = TorchComm(m_glob, torch.device("cuda", device))
+    dets, vals = build_state(mol, m_glob, 4 * m, seed, device, comm, dist)
+    par = dict(epsilon=0.01, vec_nonz=m_glob, mat_nonz=m_glob, max_dets=4 * m, target_norm=float(m_glob), initiator=1.0, seed=seed, distribution="HB_unnorm")
+    eng = FriEngine(mol, device=device, comm=comm)
     eng.setup(**par)
-    eng.vec_load(dets, vals)
-    run_seed = 777 + rank
+    eng.vec_load(dets, vals)            # this rank's shard
+    run_seed = 777                      # every rank draws the same uniforms (the reference broadcasts rank 0's)
     eng.restart(run_seed, 0.0, 0.0, 0)
 
     def barrier():
@@ -119,28 +137,35 @@ def main():
         spawns = float(sp.item())
     else:
         spawns = float(c1["spawns"] - c0["spawns"])
+    # whole-job rate in units of "one iteration of an m-determinant shard": N shards advance per global iteration
     iters_per_s = world * args.steps / dt
+    n_coll = (comm.n_allgather + comm.n_alltoallv) if comm is not None else 0
     result = {
         "metric": "fri_iterations_per_s", "value": iters_per_s, "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.shape} cc-pVDZ-shaped synthetic FCIDUMP, frisys_mol HB_unnorm, vec_nonz=mat_nonz=target={m}, initiator 1, eps 0.01, restart from a full vector",
-                   "m": m, "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (hash-sharded exchange not built yet)"},
+                   "m": m, "m_global": m_glob,
+                   "parallelism": "1 GPU" if world == 1 else f"{world} ranks, one hash-sharded vector of {m_glob} nonzeros ({m} per GPU), {args.backend} all-to-all + rank-ordered all-gathers; value = ranks x global iterations/s"},
+        "global_iterations_per_s": args.steps / dt,
         "spawns_per_s": spawns / dt,
         "kernel_launches_per_iter": (c1["launches"] - c0["launches"]) / args.steps,
         "fks_replays_per_iter": (c1["fks_replays"] - c0["fks_replays"]) / args.steps,
     }
 
+    # ---- roofline of the dominant kernel, HIP events on the engine's stream (rank 0 times; every rank iterates)
+    info = eng.vec_info()
+    cA = eng.counters()
     if rank == 0:
-        # ---- roofline of the dominant kernel, HIP events on the engine's stream
-        info = eng.vec_info()
-        cA = eng.counters()
         eng.prof_enable(True)
-        eng.iterate(args.profile_steps, want_logs=False)
-        eng.vec_info()
+    eng.iterate(args.profile_steps, want_logs=False)
+    eng.vec_info()
+    if rank == 0:
         rep = eng.prof_report()
         eng.prof_enable(False)
         cB = eng.counters()
+        if comm is not None:
+            result["collectives_per_iter"] = n_coll / max(1, args.warmup + args.steps)
         tot_ms = sum(v[0] for v in rep.values())
         dom = max(rep.items(), key=lambda kv: kv[1][0])
         name, (ms, calls) = dom
@@ -157,10 +182,10 @@ def main():
         result["top_kernels"] = {k: {"ms_per_iter": v[0] / args.profile_steps, "calls_per_iter": v[1] / args.profile_steps}
                                  for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])[:8]}
         # whole-iteration algorithmic traffic (~312 B per nonzero per iteration)
-        result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9
+        result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9      # per GPU
 
         # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores
-        if args.cpu_iters != 0:
+        if args.cpu_iters != 0 and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
             orc = oracle_lib.OracleFrisys(mol, **par)

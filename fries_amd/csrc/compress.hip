@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
     if (blockIdx.x >= nblk && blockIdx.x != 0) return;
     const int pin = (round - 1) & 1, pout = round & 1;
     double G; uint32_t kept_prev;
-    if (n_ranks == 1) {
+    if (!all) {
         G = fr_sum_partials(B.psum[pin], nblk, shd);
         kept_prev = fr_sum_partials_u32(B.pcnt[pin], nblk, shu);
     }
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
         for (int p = 0; p < n_ranks; p++) { G += all[p].G; kept_prev += all[p].kept; }
     }
     uint32_t n_rem = prev.n_rem - kept_prev;
-    bool done = (round > 1 && kept_prev == 0) || (n_ranks == 1 && nblk == 0);
+    bool done = (round > 1 && kept_prev == 0) || (!all && nblk == 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CompState s = prev;
         if (round == 1) s.loc_norm = G;          // *global_norm (compress_utils.cpp:50)
@@ -155,7 +155,7 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
     SeqWork Qg = B.seq; Qg.total = B.gnorm;
     run_seq(c, Qg, aa, bound);
     const int P = c->n_ranks;
-    if (P > 1) {
+    if (c->use_comm) {
         FR_LAUNCH(c, "k_put_double", k_put_double, dim3(1), dim3(1), B.gnorm, (double *)c->comm.small_send);
         const double *all = (const double *)fr_allgather(c, sizeof(double));
         FR_LAUNCH(c, "k_sum_ranks", k_sum_ranks, dim3(1), dim3(1), all, P, B.gnorm);
@@ -169,7 +169,7 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
         for (int k = 0; k < batch; k++) {
             r++;
             const FpMsg *all = nullptr;
-            if (P > 1) {
+            if (c->use_comm) {
                 FR_LAUNCH(c, "k_fp_reduce", k_fp_reduce, dim3(1), dim3(FR_BLOCK), B, r, (FpMsg *)c->comm.small_send);
                 all = (const FpMsg *)fr_allgather(c, sizeof(FpMsg));
             }
@@ -294,7 +294,7 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     run_seq(c, B.seq, au, bound);
     const int P = c->n_ranks;
     const double *norms = B.seq.total;
-    if (P > 1) {
+    if (c->use_comm) {
         FR_LAUNCH(c, "k_put_norm", k_put_norm_vc, dim3(1), dim3(1), B.seq.total, n_samp, (double *)c->comm.small_send);
         norms = (const double *)fr_allgather(c, sizeof(double));
     }
@@ -330,7 +330,7 @@ void fr_dots(FriesCtx *c, double *numer, double *denom) {
     const int P = c->n_ranks;
     double h[2 * FR_MAX_RANKS];
     const double *src = c->vc.dots;
-    if (P > 1) {
+    if (c->use_comm) {
         FR_HIP(hipMemcpyAsync(c->comm.small_send, c->vc.dots, 16, hipMemcpyDeviceToDevice, c->stream));
         src = (const double *)fr_allgather(c, 16);
     }

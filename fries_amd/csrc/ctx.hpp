@@ -90,6 +90,7 @@ struct FriesCtx {
     hipStream_t stream = nullptr;
     fries_comm_ops comm{};
     int rank = 0, n_ranks = 1, hf_proc = 0;
+    bool use_comm = false;
     uint32_t *d_proc_scr = nullptr;          // proc_hash_ scrambler on the device
     void *own_small = nullptr;               // size == 1: engine-owned small_send
     double *d_norms_keep = nullptr, *d_seq_scratch = nullptr;

@@ -82,7 +82,7 @@ static void check_dev_err(FriesCtx *c) {
 }
 
 const void *fr_allgather(FriesCtx *c, size_t bytes) {
-    if (c->n_ranks == 1) return c->comm.small_send;
+    if (!c->use_comm) return c->comm.small_send;
     if (bytes > 2048) throw FriesError("all-gather block exceeds FRIES_COMM_SMALL_BYTES");
     if (c->comm.allgather(c->comm.user, bytes, (void *)c->stream)) throw FriesError("fries_comm.allgather failed");
     c->n_collectives++;
@@ -157,7 +157,7 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
     if (c->num_success) FR_LAUNCH(c, "k_spawn_build", k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
     uint32_t n_merge = c->num_success;
-    if (c->n_ranks > 1) n_merge = fr_spawn_exchange(c, c->num_success);      // every rank takes part, also with nothing to send
+    if (c->use_comm) n_merge = fr_spawn_exchange(c, c->num_success);      // every rank takes part, also with nothing to send
     if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false);
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) check_dev_err(c);
@@ -250,12 +250,14 @@ extern "C" int fries_set_comm(fries_ctx *h, const fries_comm *cm) {
     FriesCtx *c = &h->c;
     if (c->vec.dets) throw FriesError("fries_set_comm must be called before fries_frisys_setup");
     if (!cm || cm->size < 1 || cm->size > FR_MAX_RANKS || cm->rank < 0 || cm->rank >= cm->size) throw FriesError("bad rank / size");
+    const bool have = cm->allgather && cm->alltoallv && cm->small_send && cm->small_recv && cm->big_send && cm->big_recv;
     if (cm->size > 1 && (!cm->allgather || !cm->alltoallv || !cm->small_send || !cm->small_recv || !cm->big_send || !cm->big_recv))
         throw FriesError("fries_comm needs both collectives and all four staging buffers");
     c->comm.user = cm->user; c->comm.rank = cm->rank; c->comm.size = cm->size;
     c->comm.small_send = cm->small_send; c->comm.small_recv = cm->small_recv; c->comm.big_send = cm->big_send; c->comm.big_recv = cm->big_recv;
     c->comm.big_bytes = cm->big_bytes; c->comm.allgather = cm->allgather; c->comm.alltoallv = cm->alltoallv;
     c->rank = cm->rank; c->n_ranks = cm->size;
+    c->use_comm = cm->size > 1 || have;      // a one-rank communicator still routes everything through the callbacks
     FR_API_END
 }
 extern "C" void *fries_stream(fries_ctx *h) { return (void *)h->c.stream; }
@@ -394,7 +396,7 @@ extern "C" int fries_vec_add(fries_ctx *h, const uint64_t *dets, const double *v
     FriesCtx *c = &h->c;
     FR_HIP(hipSetDevice(c->device));
     if (n > c->sp.cap) throw FriesError("Too many elements added to Adder - must call perform_add() more frequently.");
-    if (c->n_ranks > 1) throw FriesError("fries_vec_add is a one-rank entry point; with ranks, adds travel inside fries_frisys_iterate");
+    if (c->use_comm) throw FriesError("fries_vec_add is a one-rank entry point; with ranks, adds travel inside fries_frisys_iterate");
     // DistVec::add drops zero values before they reach the adder (vec_utils.hpp:418-423)
     std::vector<det_t> d; std::vector<double> v; std::vector<uint8_t> f;
     for (size_t i = 0; i < n; i++) if (vals[i] != 0) { d.push_back(dets[i]); v.push_back(vals[i]); f.push_back(ini[i]); }

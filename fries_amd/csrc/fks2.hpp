@@ -82,7 +82,7 @@ __device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, i
 }
 
 // sets up replay 0: "nothing kept anywhere" (the stage's input norm comes from the prep kernel's tile partials)
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Work F, FksMsg *msg, int n_ranks) {
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Work F, FksMsg *msg, int inline_passes) {
     __shared__ double shd[4];
     const CompState st0 = W.state[0];
     const double G0 = fr_sum_partials(W.psum[0], (st0.n_in + FR_TILE - 1) / FR_TILE, shd);
@@ -93,7 +93,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Wo
         for (int p = 0; p < FR_FKS_PMAX; p++) { msg->totG[p] = 0; msg->totK[p] = 0; msg->totW[p] = G0; }
         S->zero_prefix = 1; S->changed = 0; S->done_ctr = 0; S->overflow = 0; S->valid_upto = -1;
         for (int k = 0; k < FR_MAX_ROUNDS + 2; k++) F.hist[k] = 0;
-        if (n_ranks == 1) fr_fks2_passes(S, msg, 1, nullptr);
+        if (inline_passes) fr_fks2_passes(S, msg, 1, nullptr);
     }
 }
 
@@ -332,7 +332,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
 }
 
 // Sweep totals from the chunk totals into this rank's FksMsg; with one rank, also the sweep scalars of the next replay
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int n_ranks, int it) {
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
     __shared__ double shd[4];
     __shared__ uint32_t shu[4];
     FksScal *S = F.scal;
@@ -354,7 +354,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
         S->zero_prefix = 0;
         S->valid_upto = n_pass;         // k_fks_scan covered sweeps 0..n_pass of the replay that just ran
         msg->L0 = S->G0; msg->changed = F.hist[it]; msg->pad = 0;
-        if (n_ranks == 1) {
+        if (inline_passes) {
             fr_fks2_passes(S, msg, 1, nullptr);
             if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
         }

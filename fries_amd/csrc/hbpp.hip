@@ -300,8 +300,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
     const int P = c->n_ranks;
     FksMsg *msg = (FksMsg *)c->comm.small_send;
-    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F, msg, P);
-    if (P > 1) {
+    const bool xr = c->use_comm;        // totals travel through the all-gather (also with one rank, when a comm was given)
+    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F, msg, xr ? 0 : 1);
+    if (xr) {
         const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
         FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, -1, c->d_err);
     }
@@ -313,8 +314,8 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         for (int k = 0; k < batch; k++) {
             FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it);
-            FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, P, it);
-            if (P > 1) {
+            FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
+            if (xr) {
                 const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
                 FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, it, c->d_err);
             }
@@ -334,7 +335,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, fr_seq_from_zero());
     const double *norms = W.seq.total;
-    if (P > 1) {
+    if (xr) {
         // every rank's remaining norm (compress_utils.cpp:817-818), then the in-order lbound chain again from this
         // rank's offset: a floating-point running sum depends on where it starts
         FR_LAUNCH(c, "k_put_norm", k_put_norm, dim3(1), dim3(1), W, F, (double *)c->comm.small_send);
@@ -368,7 +369,7 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     // launches from the emission count (one host sync per stage; the replay loop syncs anyway)
     const uint32_t bound_max = bound;
     auto next_bound = [&](int k) {
-        if (c->n_ranks == 1) return bound_max;
+        if (!c->use_comm) return bound_max;
         FR_HIP(hipStreamSynchronize(st));
         uint32_t b = c->comp_len[k] + 64;
         return b < bound_max ? b : bound_max;

@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_unpack(SpawnBuf S, const XchRe
 
 void fr_xch_alloc(FriesCtx *c, uint32_t cap) {
     SpawnBuf &S = c->sp;
-    if (c->n_ranks == 1) return;
+    if (!c->use_comm) return;
     uint32_t ntile = fr_blocks(cap, FR_BLOCK) + 1;
     S.xkey = fr_alloc<uint8_t>(cap);
     S.xcnt = fr_alloc<uint32_t>((size_t)ntile * 2 * c->n_ranks);

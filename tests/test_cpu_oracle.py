@@ -62,6 +62,33 @@ def test_oracle_ranks_reproduce_reference_under_mpiexec(oracle, mols, name):
         assert golden_io.vec_hash(d, v) == g[k]["rows"][-1]["hash"], (name, k)
 
 
+def test_comm_layer_world_size_2_gloo(tmp_path):
+    """fries_amd.comm.TorchComm under torch.distributed (gloo, 2 ranks, CPU tensors), driven through the fries_comm
+    function pointers like the engine drives it."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "comm_worker.py")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "comm ok 0" in res.stdout and "comm ok 1" in res.stdout
+
+
+def test_sharding_hash_matches_reference_ranks(oracle, mols):
+    """idx_to_proc of the oracle (checked against the reference's hf_proc and shard sizes through the rank goldens)
+    partitions a vector the way the shards of a 4-rank run hold it."""
+    name = "n2_m10000_unnorm_p4"
+    r = golden_io.manifest()["mpi_runs"][name]
+    orc = oracle.OracleRanks(4, mols(r["shape"]), **_run_params(r))
+    orc.iterate(5)
+    for k in range(4):
+        d, v = orc.vector(k)
+        nz = d[v != 0]
+        assert nz.size > 0 and all(orc.idx_to_proc(x) == k for x in nz[:200])
+
+
 def test_oracle_snapshot_matches_reference(oracle, mols):
     name = "ne_m2000_unnorm"
     r = golden_io.manifest()["runs"][name]

@@ -1,0 +1,57 @@
+"""-m gpu: the hash-sharded engine with 2, 3 and 4 ranks against what every rank of the real reference logged
+under `mpiexec -n P` (tests/golden/*.traj.r<rank>).  The ranks are separate processes sharing this box's GPU and
+talking through torch.distributed (gloo here; bench.py uses nccl = RCCL with one GPU per rank)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import golden_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["mpi_runs"]))
+def test_sharded_engine_matches_reference_ranks(name, tmp_path):
+    r = golden_io.manifest()["mpi_runs"][name]
+    P = r["n_ranks"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "gloo", str(tmp_path)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    reports = []
+    for k in range(P):
+        fn = tmp_path / f"rank{k}.json"
+        assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+        reports.append(json.loads(fn.read_text()))
+    for rep in reports:
+        assert rep["ok"], rep["fails"]
+        assert rep["iters"] == r["n_iter"] and rep["n_alltoallv"] == r["n_iter"]
+    assert res.returncode == 0, res.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_one_rank_communicator_over_rccl(tmp_path):
+    """backend "nccl" (RCCL) with a world of one: every all-gather and the spawn all-to-all run as real RCCL
+    collectives enqueued under the engine's stream, and the run must still equal the one-rank golden."""
+    name = "n2_m10000_unnorm_ini0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "nccl", str(tmp_path)]
+    res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    fn = tmp_path / "rank0.json"
+    assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+    rep = json.loads(fn.read_text())
+    assert rep["ok"], rep["fails"]
+    assert rep["n_alltoallv"] == rep["iters"] and rep["n_allgather"] > 10 * rep["iters"]
