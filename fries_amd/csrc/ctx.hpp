@@ -109,6 +109,8 @@ struct FriesCtx {
     // HB-PP work arrays
     CompWork W{};
     Fks2Work F2{};
+    FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr; double *fks_wg = nullptr;    // per-stage warm-start records
+    bool warm_start = true;
     uint32_t *c_pos = nullptr, *c_orbs = nullptr; double *c_val = nullptr;   // compacted apply_HBPP_sys output
     uint32_t *d_nsucc = nullptr;
     SpawnBuf sp{};

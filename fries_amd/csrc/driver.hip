@@ -212,6 +212,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     fries_ctx *h = new fries_ctx();
     h->c.device = device;
     if (getenv("FRIES_DBG")) h->c.dbg = atoi(getenv("FRIES_DBG"));
+    if (getenv("FRIES_NO_WARM")) h->c.warm_start = false;
     FR_HIP(hipStreamCreate(&h->c.stream));
     h->c.d_err = fr_alloc<uint32_t>(1);
     FR_HIP(hipMemset(h->c.d_err, 0, 4));

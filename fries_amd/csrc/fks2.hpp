@@ -29,6 +29,19 @@ struct FksScal {
     uint32_t n_in;
     uint32_t overflow;              // the reference would run more sweeps than FR_FKS_PMAX
     int valid_upto;                 // sweeps 0..valid_upto have prefixes / chunk totals from the previous replay
+    uint32_t warm;                  // replay 0 starts from the previous iteration's sweep structure (FksSaved)
+    double warm_scale;              // this stage's norm / the saved stage's norm
+};
+
+// What the settled replay of this stage looked like in the previous FRI iteration: the sweep scalars and, per sweep,
+// how many samples / how much norm each chunk of 2048 blocks consumed.  The walk is statistically stationary and vector
+// positions persist, so this is a close first guess; any guess converges to the same (unique) consistent assignment.
+struct FksSaved {
+    int valid, n_pass;
+    uint32_t n0, nchunk;
+    double G0;
+    double psG[FR_FKS_PMAX];
+    uint32_t psN[FR_FKS_PMAX];
 };
 
 struct Fks2Work {
@@ -38,6 +51,8 @@ struct Fks2Work {
     uint32_t *ck; double *cg, *cw;          // [FR_FKS_PMAX][FR_FKS_MAXCHUNK] totals per chunk of 2048 groups
     FksScal *scal;
     uint32_t *hist;                         // [FR_MAX_ROUNDS] changed flag per replay, for the host
+    uint32_t *dbg_cnt;                      // [FR_MAX_ROUNDS][4] FRIES_DBG=3 statistics
+    FksSaved *saved; uint32_t *wk; double *wg;      // this stage's warm-start record and saved chunk totals (same shape as ck / cg)
 };
 #define FR_FKS_CHUNK 2048                   // groups per scan workgroup
 #define FR_FKS_MAXCHUNK 1024
@@ -81,8 +96,18 @@ __device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, i
     S->G_last = S->psG[p > 0 ? p - 1 : 0]; S->n_last = n;
 }
 
+// Replay 0 from the previous iteration's record instead of "nothing kept anywhere" (psG[0] is already this stage's norm)
+__device__ __forceinline__ void fr_fks2_warm(FksScal *S, const FksSaved *Wv, int enable) {
+    S->warm = 0; S->warm_scale = 1.0;
+    if (!enable || !Wv->valid || Wv->n0 != S->n0 || !(Wv->G0 > 0) || !(S->psG[0] > 0) || Wv->n_pass < 1) return;
+    const double sc = S->psG[0] / Wv->G0;
+    for (int p = 0; p < Wv->n_pass; p++) { S->psG[p] = Wv->psG[p] * sc; S->psN[p] = Wv->psN[p]; }
+    S->n_pass = Wv->n_pass;
+    S->warm = 1; S->warm_scale = sc;
+}
+
 // sets up replay 0: "nothing kept anywhere" (the stage's input norm comes from the prep kernel's tile partials)
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Work F, FksMsg *msg, int inline_passes) {
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Work F, FksMsg *msg, int inline_passes, int warm) {
     __shared__ double shd[4];
     const CompState st0 = W.state[0];
     const double G0 = fr_sum_partials(W.psum[0], (st0.n_in + FR_TILE - 1) / FR_TILE, shd);
@@ -93,14 +118,16 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Wo
         for (int p = 0; p < FR_FKS_PMAX; p++) { msg->totG[p] = 0; msg->totK[p] = 0; msg->totW[p] = G0; }
         S->zero_prefix = 1; S->changed = 0; S->done_ctr = 0; S->overflow = 0; S->valid_upto = -1;
         for (int k = 0; k < FR_MAX_ROUNDS + 2; k++) F.hist[k] = 0;
-        if (inline_passes) fr_fks2_passes(S, msg, 1, nullptr);
+        S->warm = 0; S->warm_scale = 1.0;
+        if (inline_passes) { fr_fks2_passes(S, msg, 1, nullptr); fr_fks2_warm(S, F.saved, warm); }
     }
 }
 
 // after the all-gather of every rank's FksMsg (n_ranks > 1)
-static __global__ void k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks, int it, uint32_t *err) {
+static __global__ void k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks, int it, uint32_t *err, int warm) {
     FksScal *S = F.scal;
     fr_fks2_passes(S, msgs, n_ranks, it >= 0 ? &F.hist[it] : nullptr);
+    if (it < 0) fr_fks2_warm(S, F.saved, warm);
     if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
 }
 
@@ -133,19 +160,30 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     }
     if (STAGE != 1) fr_stage_tables(&T, Tg); else __syncthreads();
     // offsets of my chunk of groups: sums of the earlier chunks' totals, sweep by sweep (one wave per sweep, round robin)
-    __shared__ uint32_t s_offK[FR_FKS_PMAX];
-    __shared__ double s_offG[FR_FKS_PMAX];
+    __shared__ uint32_t s_offK[FR_FKS_PMAX], s_inK[FR_FKS_PMAX];
+    __shared__ double s_offG[FR_FKS_PMAX], s_inG[FR_FKS_PMAX];
+    const bool warm0 = !final && S.zero_prefix && S.warm;      // replay 0 of a warm start: prefixes from the saved chunk totals
+    const unsigned my_chunk = (unsigned)(((size_t)blockIdx.x * FR_BLOCK / 8) / FR_FKS_CHUNK);
     {
-        const unsigned my_chunk = (unsigned)(((size_t)blockIdx.x * FR_BLOCK / 8) / FR_FKS_CHUNK);
         const int ln = fr_lane(), wv_ = threadIdx.x >> 6;
-        const int p_hi = (S.zero_prefix || S.valid_upto < 0) ? -1 : (S.valid_upto < FR_FKS_PMAX - 1 ? S.valid_upto : FR_FKS_PMAX - 1);
+        int p_hi = (S.zero_prefix || S.valid_upto < 0) ? -1 : (S.valid_upto < FR_FKS_PMAX - 1 ? S.valid_upto : FR_FKS_PMAX - 1);
+        const uint32_t *srck = F.ck; const double *srcg = F.cg;
+        unsigned c_hi = my_chunk;
+        if (warm0) { p_hi = S.n_pass - 1; srck = F.wk; srcg = F.wg; const unsigned nc = F.saved->nchunk; if (c_hi > nc) c_hi = nc; }
         for (int p = wv_; p <= p_hi; p += 4) {
             uint32_t k = 0; double g = 0;
             {
-                for (unsigned c = ln; c < my_chunk; c += 64) { k += F.ck[(size_t)p * FR_FKS_MAXCHUNK + c]; g += F.cg[(size_t)p * FR_FKS_MAXCHUNK + c]; }
+                for (unsigned c = ln; c < c_hi; c += 64) { k += srck[(size_t)p * FR_FKS_MAXCHUNK + c]; g += srcg[(size_t)p * FR_FKS_MAXCHUNK + c]; }
             }
             k = fr_wave_sum_u32(k); g = fr_wave_sum(g);
-            if (ln == 0) { s_offK[p] = k; s_offG[p] = g; }
+            if (ln == 0) {
+                s_offK[p] = k; s_offG[p] = warm0 ? g * S.warm_scale : g;
+                if (warm0) {
+                    const bool in = my_chunk < F.saved->nchunk;
+                    s_inK[p] = in ? srck[(size_t)p * FR_FKS_MAXCHUNK + my_chunk] : 0u;
+                    s_inG[p] = in ? srcg[(size_t)p * FR_FKS_MAXCHUNK + my_chunk] * S.warm_scale : 0.0;
+                }
+            }
         }
         __syncthreads();
     }
@@ -207,6 +245,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         const bool pv = !zp && in_grp && p <= S.valid_upto;
         double xg = pv ? s_offG[p] + F.xg8[(size_t)p * stride + b] : 0.0;
         uint32_t xk = pv ? s_offK[p] + F.xk8[(size_t)p * stride + b] : 0u;
+        if (warm0) {        // chunk offsets of the previous iteration, linear inside the chunk
+            const double fr = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
+            xg = s_offG[p] + s_inG[p] * fr;
+            xk = s_offK[p] + (uint32_t)((double)s_inK[p] * fr);
+            if (xk >= S.psN[p]) xk = S.psN[p] - 1;
+        }
         const double glob0 = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
         // flags are taken against the group's start norm (compress_utils.cpp:172-180)
         double cw = v * wf;
@@ -224,6 +268,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         bool need_eval = flagged && nd == 0 && !skipped && dbg != 2;
         double gl_mine = glob0;
         for (int round = 0; round < 9; round++) {
+            if (dbg == 3) {
+                if (need_eval) atomicAdd(&F.hist[FR_MAX_ROUNDS], 1u);
+                if (__any(need_eval) && lane == 0) atomicAdd(&F.hist[FR_MAX_ROUNDS + 1], 1u);
+            }
             if (need_eval) {
                 fetch_row();
                 unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
@@ -268,6 +316,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         if (f == 0 && in_grp) {
             size_t ix = (size_t)p * stride + b;
             if (zp || p > S.valid_upto || F.dk8[ix] != gk || __double_as_longlong(F.dg8[ix]) != __double_as_longlong(gg) || __double_as_longlong(F.ws8[ix]) != __double_as_longlong(gw)) diff = 1;
+            if (dbg == 3 && !zp && p <= S.valid_upto) {
+                if (F.dk8[ix] != gk) atomicAdd(&F.dbg_cnt[it * 4 + 0], 1u);
+                else if (__double_as_longlong(F.dg8[ix]) != __double_as_longlong(gg)) {
+                    atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u);
+                    if (fabs(F.dg8[ix] - gg) > 1e-9 * fabs(gg)) atomicAdd(&F.dbg_cnt[it * 4 + 3], 1u);
+                }
+                else if (__double_as_longlong(F.ws8[ix]) != __double_as_longlong(gw)) atomicAdd(&F.dbg_cnt[it * 4 + 2], 1u);
+            }
             F.dk8[ix] = gk; F.dg8[ix] = gg; F.ws8[ix] = gw;
         }
     }
@@ -358,5 +414,24 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
             fr_fks2_passes(S, msg, 1, nullptr);
             if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
         }
+    }
+}
+
+// records the settled replay for the next iteration's warm start (one workgroup)
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
+    const FksScal *S = F.scal;
+    const unsigned nb8 = S->n_in / 8 + 1;
+    const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
+    const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
+    for (int p = 0; p < n_pass; p++)
+        for (unsigned c = threadIdx.x; c < nchunk; c += blockDim.x) {
+            F.wk[(size_t)p * FR_FKS_MAXCHUNK + c] = F.ck[(size_t)p * FR_FKS_MAXCHUNK + c];
+            F.wg[(size_t)p * FR_FKS_MAXCHUNK + c] = F.cg[(size_t)p * FR_FKS_MAXCHUNK + c];
+        }
+    if (threadIdx.x == 0) {
+        FksSaved *V = F.saved;
+        V->n_pass = n_pass; V->n0 = S->n0; V->nchunk = nchunk; V->G0 = S->psG[0];
+        for (int p = 0; p < n_pass; p++) { V->psG[p] = S->psG[p]; V->psN[p] = S->psN[p]; }
+        V->valid = (S->overflow || !(S->psG[0] > 0)) ? 0 : 1;
     }
 }

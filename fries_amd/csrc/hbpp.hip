@@ -277,6 +277,11 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
         F.ck = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cg = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cw = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
         FR_HIP(hipMemset(F.hist, 0, 4 * (FR_MAX_ROUNDS + 2)));
+        F.dbg_cnt = fr_alloc<uint32_t>((size_t)FR_MAX_ROUNDS * 4);
+        FR_HIP(hipMemset(F.dbg_cnt, 0, (size_t)FR_MAX_ROUNDS * 16));
+        c->fks_saved = fr_alloc<FksSaved>(8);
+        FR_HIP(hipMemset(c->fks_saved, 0, 8 * sizeof(FksSaved)));
+        c->fks_wk = fr_alloc<uint32_t>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK); c->fks_wg = fr_alloc<double>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK);
         FR_HIP(hipMemset(F.scal, 0, sizeof(FksScal)));
     }
     c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1);
@@ -294,39 +299,60 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (grid == 0) grid = 1;
     if (STAGE == 1) FR_LAUNCH(c, "k_prep1", k_prep1, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
     else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
-    Fks2Work &F = c->F2;
+    Fks2Work F = c->F2;
+    F.saved = c->fks_saved + STAGE; F.wk = c->fks_wk + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wg = c->fks_wg + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
+    const int warm = c->warm_start ? 1 : 0;
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
     unsigned nchunk = fr_blocks((size_t)n_bound / 8 + 1, FR_FKS_CHUNK);
     if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
     const int P = c->n_ranks;
     FksMsg *msg = (FksMsg *)c->comm.small_send;
     const bool xr = c->use_comm;        // totals travel through the all-gather (also with one rank, when a comm was given)
-    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F, msg, xr ? 0 : 1);
+    FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F, msg, xr ? 0 : 1, warm);
     if (xr) {
         const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
-        FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, -1, c->d_err);
+        FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, -1, c->d_err, warm);
     }
-    int it = 0, batch = c->rounds_hint[STAGE];
-    uint32_t changed = 1;
-    while (changed) {
+    // Replays are enqueued in batches (a host round trip costs a fraction of a replay); the per-replay "changed" flags tell
+    // afterwards which replay was the first to reproduce its predecessor, and that count is the next iteration's first batch.
+    int it = 0, batch = c->rounds_hint[STAGE], needed = 0;
+    uint32_t hh[FR_MAX_ROUNDS];
+    while (!needed) {
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
         if (batch <= 0) throw FriesError("find_keep_sub replay did not settle within FR_MAX_ROUNDS iterations");
         for (int k = 0; k < batch; k++) {
+            if (c->dbg == 4) FR_LAUNCH(c, "k_fks_prologue", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, 1);
             FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it);
             FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
             if (xr) {
                 const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
-                FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, it, c->d_err);
+                FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, it, c->d_err, 0);
             }
             it++;
         }
-        FR_HIP(hipMemcpyAsync(&changed, &F.hist[it - 1], 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipMemcpyAsync(hh, F.hist, 4 * (size_t)it, hipMemcpyDeviceToHost, st));
         FR_HIP(hipStreamSynchronize(st));
-        batch = 2;
+        for (int j = 1; j < it && !needed; j++) if (hh[j] == 0) needed = j + 1;      // replay 0 always counts as changed
+        batch = 1;
     }
-    c->rounds_hint[STAGE] = it > 2 ? it : 2;
+    c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
     c->fks_iters[STAGE] = it;
+    if (c->dbg == 3) {
+        FksScal hs; uint32_t hh[FR_MAX_ROUNDS + 2];
+        FR_HIP(hipMemcpy(&hs, F.scal, sizeof(hs), hipMemcpyDeviceToHost));
+        FR_HIP(hipMemcpy(hh, F.hist, sizeof(hh), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[fks] stage %d n_in %u replays %d needed %d n_pass %d lane_evals %u wave_eval_rounds %u (per replay %.0f / %.0f) psN:", STAGE, hs.n_in, it, needed, hs.n_pass,
+                hh[FR_MAX_ROUNDS], hh[FR_MAX_ROUNDS + 1], hh[FR_MAX_ROUNDS] / (double)it, hh[FR_MAX_ROUNDS + 1] / (double)it);
+        for (int p = 0; p < hs.n_pass; p++) fprintf(stderr, " %u", hs.psN[p]);
+        fprintf(stderr, "\n   groups changed per replay (dk | dg only | ws only | dg>1e-9):");
+        std::vector<uint32_t> dc((size_t)FR_MAX_ROUNDS * 4);
+        FR_HIP(hipMemcpy(dc.data(), F.dbg_cnt, dc.size() * 4, hipMemcpyDeviceToHost));
+        for (int k = 1; k < it; k++) fprintf(stderr, "  [%d] %u|%u|%u|%u", k, dc[k * 4], dc[k * 4 + 1], dc[k * 4 + 2], dc[k * 4 + 3]);
+        fprintf(stderr, "\n");
+        FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
+    }
+    FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
     // settled: recompute every wt_remain with the budget of its last flagged sweep
     FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
     AccWt acc{W.wt_remain, &W.state[0]};
