@@ -109,7 +109,8 @@ struct FriesCtx {
     // HB-PP work arrays
     CompWork W{};
     Fks2Work F2{};
-    FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr; double *fks_wg = nullptr;    // per-stage warm-start records
+    FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
+    unsigned fks_grid = 1280;
     bool warm_start = true;
     uint32_t *c_pos = nullptr, *c_orbs = nullptr; double *c_val = nullptr;   // compacted apply_HBPP_sys output
     uint32_t *d_nsucc = nullptr;

@@ -213,6 +213,12 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     h->c.device = device;
     if (getenv("FRIES_DBG")) h->c.dbg = atoi(getenv("FRIES_DBG"));
     if (getenv("FRIES_NO_WARM")) h->c.warm_start = false;
+    {
+        hipDeviceProp_t pr;
+        FR_HIP(hipGetDeviceProperties(&pr, device));
+        h->c.fks_grid = 5u * (unsigned)pr.multiProcessorCount;      // k_fks_sweep: <= 92 VGPRs -> 5 waves/SIMD = 5 workgroups per CU
+        if (getenv("FRIES_FKS_GRID")) h->c.fks_grid = (unsigned)atoi(getenv("FRIES_FKS_GRID"));
+    }
     FR_HIP(hipStreamCreate(&h->c.stream));
     h->c.d_err = fr_alloc<uint32_t>(1);
     FR_HIP(hipMemset(h->c.d_err, 0, 4));

@@ -1,17 +1,21 @@
 // find_keep_sub replay, lane-per-element formulation (see comp_kernels.hpp for the idea).
 //
-// One replay = k_fks_sweep + k_fks_scan.
+// One replay = k_fks_sweep + k_fks_scan + k_fks_totals.
 //   k_fks_sweep: lane <-> element, 8 consecutive lanes <-> one 8-block of the reference's sweep
 //     (compress_utils.cpp:159-250).  For every sweep p the group's start state comes from the
-//     previous replay's exclusive prefixes (xk8, xg8) and the sweep scalars; inside the group the
-//     reference's order (element 0 updates the running norm before element 1 is examined, ...) is
-//     reproduced by speculate-and-validate: every flagged lane decides with the group's start
-//     norm, the exact running norm of each lane is then rebuilt from its predecessors' changes in
-//     order with shuffles, and lanes whose decision could differ under their exact norm redo it.
-//     Group deltas (dk8, dg8, ws8) are updated in place; any change raises the replay's flag.
-//   k_fks_scan: per sweep, exclusive prefixes of (dk8, dg8) over the 8-blocks and the totals; the
-//     last workgroup to finish turns the totals into the sweep scalars of the next replay
-//     (compress_utils.cpp:153-158, 251-265).
+//     previous replay's exclusive prefixes (chunk offset + xk8 / xg8) and the sweep scalars; inside
+//     the group the reference's order (element 0 updates the running norm before element 1 is
+//     examined, ...) is reproduced by speculate-and-validate: every flagged lane decides with the
+//     group's start norm, the running norm of each lane is then rebuilt from its predecessors'
+//     changes in order (DPP row shifts), and lanes whose decision could differ under it redo it.
+//     Workgroups are persistent (the 17.5 KB table block is staged into LDS once per workgroup) and
+//     the prefixes of sweep p + 1 are fetched while sweep p is evaluated: the kernel is bound by
+//     dependent global-load latency at 2 waves/SIMD, not by bandwidth.
+//   k_fks_scan: per (sweep, chunk of 2048 groups) exclusive prefixes of the deltas and the chunk
+//     totals; compares the deltas with the previous replay's (double-buffered) and raises the
+//     replay's "changed" flag.
+//   k_fks_totals: exclusive prefixes over the chunks, sweep totals, and (one rank) the sweep scalars
+//     of the next replay (compress_utils.cpp:153-158, 251-265).
 // After the replay has settled, k_fks_sweep in final mode recomputes every wt_remain with the
 // budget of the last sweep that flagged the element (compress_utils.cpp:243-245), bit for bit.
 #pragma once
@@ -46,13 +50,14 @@ struct FksSaved {
 
 struct Fks2Work {
     uint32_t nb8_cap;
-    uint32_t *dk8; double *dg8, *ws8;       // [FR_FKS_PMAX][nb8_cap] group deltas (in place)
-    uint32_t *xk8; double *xg8;             // exclusive prefixes over groups, same shape
+    uint32_t *dk8[2]; double *dg8[2], *ws8[2];   // [FR_FKS_PMAX][nb8_cap] group deltas; replay `it` writes buffer it & 1
+    uint32_t *xk8; double *xg8;             // exclusive prefixes over the groups of a chunk, same shape
     uint32_t *ck; double *cg, *cw;          // [FR_FKS_PMAX][FR_FKS_MAXCHUNK] totals per chunk of 2048 groups
+    uint32_t *ckx; double *cgx;             // exclusive prefixes of (ck, cg) over the chunks
     FksScal *scal;
     uint32_t *hist;                         // [FR_MAX_ROUNDS] changed flag per replay, for the host
     uint32_t *dbg_cnt;                      // [FR_MAX_ROUNDS][4] FRIES_DBG=3 statistics
-    FksSaved *saved; uint32_t *wk; double *wg;      // this stage's warm-start record and saved chunk totals (same shape as ck / cg)
+    FksSaved *saved; uint32_t *wk, *wkx; double *wg, *wgx;     // this stage's warm-start record: saved ck / cg / ckx / cgx
 };
 #define FR_FKS_CHUNK 2048                   // groups per scan workgroup
 #define FR_FKS_MAXCHUNK 1024
@@ -131,6 +136,45 @@ static __global__ void k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks,
     if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
 }
 
+// ------------------------------------------------------------------ 8-lane group primitives (DPP, no LDS traffic)
+#define FR_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define FR_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define FR_DPP_HMIRROR 0x141      // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
+template <int CTRL> __device__ __forceinline__ uint32_t fr_dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ double fr_dpp_f64(double v) {
+    long long b = __double_as_longlong(v);
+    uint32_t lo = fr_dpp_u32<CTRL>((uint32_t)b), hi = fr_dpp_u32<CTRL>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the 8 lanes of a group; every lane gets the same bits (pairs (i, 7-i), then the quad butterfly)
+__device__ __forceinline__ double fr_grp8_sum(double v) {
+    v = v + fr_dpp_f64<FR_DPP_HMIRROR>(v);
+    v = v + fr_dpp_f64<FR_DPP_XOR1>(v);
+    v = v + fr_dpp_f64<FR_DPP_XOR2>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t fr_grp8_sum_u32(uint32_t v) {
+    v += fr_dpp_u32<FR_DPP_HMIRROR>(v);
+    v += fr_dpp_u32<FR_DPP_XOR1>(v);
+    v += fr_dpp_u32<FR_DPP_XOR2>(v);
+    return v;
+}
+// start - (c of lane 0) - (c of lane 1) - ... - (c of lane f-1), subtracted in that order (f = lane & 7)
+__device__ __forceinline__ double fr_grp8_running(double start, double c, int f) {
+    double g = start;
+    double t;
+    t = fr_dpp_f64<0x117>(c); if (f >= 7) g -= t;        // row_shr:7 -> lane f-7
+    t = fr_dpp_f64<0x116>(c); if (f >= 6) g -= t;
+    t = fr_dpp_f64<0x115>(c); if (f >= 5) g -= t;
+    t = fr_dpp_f64<0x114>(c); if (f >= 4) g -= t;
+    t = fr_dpp_f64<0x113>(c); if (f >= 3) g -= t;
+    t = fr_dpp_f64<0x112>(c); if (f >= 2) g -= t;
+    t = fr_dpp_f64<0x111>(c); if (f >= 1) g -= t;
+    return g;
+}
+
 // One sub-weight row against a threshold: keeps, remaining weight, and the bounds needed to tell whether the
 // decision would differ under a slightly smaller threshold.
 template <int STAGE, bool NEW_HB>
@@ -149,6 +193,8 @@ __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32
     *kp_out = kk; *add = a; *sub_remain = rem; *max_unkept = mu;
 }
 
+#define FR_FKS_TILES_PER_CHUNK (FR_FKS_CHUNK * 8 / FR_BLOCK)
+
 template <int STAGE, bool NEW_HB>
 __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, VecDev V, const HbTables *Tg, int cur, int it, double p_doub, int final, int dbg = 0) {
     __shared__ HbTables T;
@@ -159,200 +205,164 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         for (unsigned i = threadIdx.x; i < sizeof(FksScal) / 4; i += blockDim.x) dst[i] = src[i];
     }
     if (STAGE != 1) fr_stage_tables(&T, Tg); else __syncthreads();
-    // offsets of my chunk of groups: sums of the earlier chunks' totals, sweep by sweep (one wave per sweep, round robin)
-    __shared__ uint32_t s_offK[FR_FKS_PMAX], s_inK[FR_FKS_PMAX];
-    __shared__ double s_offG[FR_FKS_PMAX], s_inG[FR_FKS_PMAX];
-    const bool warm0 = !final && S.zero_prefix && S.warm;      // replay 0 of a warm start: prefixes from the saved chunk totals
-    const unsigned my_chunk = (unsigned)(((size_t)blockIdx.x * FR_BLOCK / 8) / FR_FKS_CHUNK);
-    {
-        const int ln = fr_lane(), wv_ = threadIdx.x >> 6;
-        int p_hi = (S.zero_prefix || S.valid_upto < 0) ? -1 : (S.valid_upto < FR_FKS_PMAX - 1 ? S.valid_upto : FR_FKS_PMAX - 1);
-        const uint32_t *srck = F.ck; const double *srcg = F.cg;
-        unsigned c_hi = my_chunk;
-        if (warm0) { p_hi = S.n_pass - 1; srck = F.wk; srcg = F.wg; const unsigned nc = F.saved->nchunk; if (c_hi > nc) c_hi = nc; }
-        for (int p = wv_; p <= p_hi; p += 4) {
-            uint32_t k = 0; double g = 0;
-            {
-                for (unsigned c = ln; c < c_hi; c += 64) { k += srck[(size_t)p * FR_FKS_MAXCHUNK + c]; g += srcg[(size_t)p * FR_FKS_MAXCHUNK + c]; }
-            }
-            k = fr_wave_sum_u32(k); g = fr_wave_sum(g);
-            if (ln == 0) {
-                s_offK[p] = k; s_offG[p] = warm0 ? g * S.warm_scale : g;
-                if (warm0) {
-                    const bool in = my_chunk < F.saved->nchunk;
-                    s_inK[p] = in ? srck[(size_t)p * FR_FKS_MAXCHUNK + my_chunk] : 0u;
-                    s_inG[p] = in ? srcg[(size_t)p * FR_FKS_MAXCHUNK + my_chunk] * S.warm_scale : 0.0;
-                }
-            }
-        }
-        __syncthreads();
-    }
     const unsigned n_in = S.n_in;
-    const size_t e = (size_t)blockIdx.x * FR_BLOCK + threadIdx.x;
-    const unsigned nb8 = n_in / 8 + 1;
-    const size_t b = e >> 3;
-    const int f = (int)(e & 7), lane = fr_lane(), gbase = lane & ~7;
-    const bool in_grp = b < nb8;                 // the reference also visits the (possibly empty) tail group
-    const bool live = e < n_in;
+    const unsigned nb8 = n_in / 8 + 1;                       // the reference also visits the (possibly empty) tail group
+    const unsigned ntile = (unsigned)(((size_t)nb8 * 8 + FR_BLOCK - 1) / FR_BLOCK);
     const size_t stride = F.nb8_cap;
     const StageElems E = W.el[cur];
     const int n_pass = S.n_pass;
     const bool zp = S.zero_prefix != 0;
-    // my element
-    double v = live ? E.val[e] : 0.0;
-    uint32_t nd = live ? E.ndiv[e] : 1u;
-    double wr = v;
-    uint32_t kp = (final && live) ? W.keep[e] : 0u;
-    // could any sweep ever flag it?  the threshold never drops below G_last / n0-ish; be generous
-    det_t det = 0; uint32_t code = 0; RowInfo ri; ri.inv_norm = 1; ri.aux = 0; ri.nsub = 2; ri.tot = 0;
-    bool have_row = false;
-    auto fetch_row = [&]() {
-        if (have_row) return;
-        have_row = true;
-        if (STAGE != 1) { code = E.code[e]; det = V.dets[E.pos[e]]; ri = fr_row_cached(E, e); }
-    };
-    if (final) {
-        double lastwf = 0;
-        for (int p = 0; p < n_pass; p++) {
-            const bool pv = !zp && in_grp && p <= S.valid_upto;
-            double xg = pv ? s_offG[p] + F.xg8[(size_t)p * stride + b] : 0.0;
-            uint32_t xk = pv ? s_offK[p] + F.xk8[(size_t)p * stride + b] : 0u;
-            double glob = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
-            if (live && nd == 0 && v > 0 && v * wf >= glob) lastwf = wf;
-        }
-        if (live) {
-            double out = v;
-            if (nd > 0) { if (kp & 1u) out = 0; }
-            else if (lastwf > 0) {
-                fetch_row();
-                unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
-                const double cwf = v * lastwf;
-                double rem = 0;
-                fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
-                    if (s >= n_sub || ((kp >> s) & 1u)) return;
-                    rem += cwf * w;
-                });
-                out = rem / lastwf;
-            }
-            W.wt_remain[e] = out;
-        }
-        return;
-    }
-    if (dbg == 1) return;
-    float wmax = -1.0f;         // upper bound of the largest unpreserved normalised weight; < 0: row not looked at yet
-    uint32_t diff = 0;
-    for (int p = 0; p < n_pass; p++) {
-        const bool pv = !zp && in_grp && p <= S.valid_upto;
-        double xg = pv ? s_offG[p] + F.xg8[(size_t)p * stride + b] : 0.0;
-        uint32_t xk = pv ? s_offK[p] + F.xk8[(size_t)p * stride + b] : 0u;
-        if (warm0) {        // chunk offsets of the previous iteration, linear inside the chunk
-            const double fr = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
-            xg = s_offG[p] + s_inG[p] * fr;
-            xk = s_offK[p] + (uint32_t)((double)s_inK[p] * fr);
-            if (xk >= S.psN[p]) xk = S.psN[p] - 1;
-        }
-        const double glob0 = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
-        // flags are taken against the group's start norm (compress_utils.cpp:172-180)
-        double cw = v * wf;
-        if (nd > 0) cw /= nd;
-        const bool flagged = live && wr > 0 && cw >= glob0;
-        // --- speculate with the start norm, then validate against the exact running norm
-        double change = 0, new_wr = wr, mu = 0;
-        uint32_t add = 0, new_kp = kp;
-        bool evaluated = false, skipped = false;
-        double used_gl = glob0;
-        if (flagged) {
-            if (nd > 0) { new_kp = kp | 1u; new_wr = 0; add = nd; change = v; }
-            else if (wmax >= 0 && cw * (double)wmax < glob0) skipped = true;
-        }
-        bool need_eval = flagged && nd == 0 && !skipped && dbg != 2;
-        double gl_mine = glob0;
-        for (int round = 0; round < 9; round++) {
-            if (dbg == 3) {
-                if (need_eval) atomicAdd(&F.hist[FR_MAX_ROUNDS], 1u);
-                if (__any(need_eval) && lane == 0) atomicAdd(&F.hist[FR_MAX_ROUNDS + 1], 1u);
-            }
-            if (need_eval) {
-                fetch_row();
-                unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
-                double rem;
-                fr_fks2_row<STAGE, NEW_HB>(T, det, code, ri, n_sub, p_doub, cw, gl_mine, kp, &new_kp, &add, &rem, &mu);
-                new_wr = rem / wf;
-                change = wr - new_wr;
-                evaluated = true; used_gl = gl_mine; skipped = false;
-            }
-            // exact running norm of each lane: start norm minus the changes of the flagged lanes before it, in order
-            double g = glob0;
-            for (int j = 0; j < 7; j++) {
-                double cj = __shfl(change, gbase + j);
-                int fj = __shfl((int)(flagged && !skipped), gbase + j);
-                if (j < f && fj) g -= cj;
-            }
-            gl_mine = g;
-            // would my decision differ under gl_mine?
-            need_eval = false;
-            if (flagged && nd == 0) {
-                if (skipped) { if (cw * (double)wmax >= gl_mine) need_eval = true; }
-                else if (evaluated && used_gl != gl_mine && mu >= gl_mine) need_eval = true;
-            }
-            if (!__any(need_eval)) break;
-        }
-        // commit
-        if (flagged && !skipped) {
-            if (evaluated) {
-                // largest unpreserved normalised weight, rounded up
-                wmax = (cw > 0) ? (float)((mu / cw) * 1.000002) : 0.0f;
-            }
-            kp = new_kp; wr = new_wr;
-        }
-        else { add = 0; change = 0; }
-        // group totals in element order
-        uint32_t gk = 0; double gg = 0, gw = 0;
-        for (int j = 0; j < 8; j++) {
-            gk += (uint32_t)__shfl((int)add, gbase + j);
-            gg += __shfl(change, gbase + j);
-            gw += __shfl(live ? wr : 0.0, gbase + j);
-        }
-        if (f == 0 && in_grp) {
-            size_t ix = (size_t)p * stride + b;
-            if (zp || p > S.valid_upto || F.dk8[ix] != gk || __double_as_longlong(F.dg8[ix]) != __double_as_longlong(gg) || __double_as_longlong(F.ws8[ix]) != __double_as_longlong(gw)) diff = 1;
-            if (dbg == 3 && !zp && p <= S.valid_upto) {
-                if (F.dk8[ix] != gk) atomicAdd(&F.dbg_cnt[it * 4 + 0], 1u);
-                else if (__double_as_longlong(F.dg8[ix]) != __double_as_longlong(gg)) {
-                    atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u);
-                    if (fabs(F.dg8[ix] - gg) > 1e-9 * fabs(gg)) atomicAdd(&F.dbg_cnt[it * 4 + 3], 1u);
+    const bool warm0 = !final && zp && S.warm;               // replay 0 of a warm start: prefixes from the saved chunk totals
+    const int vup = S.valid_upto;
+    const unsigned n_chunk_saved = warm0 ? F.saved->nchunk : 0u;
+    const double wsc = S.warm_scale;
+    uint32_t *const dk8 = F.dk8[it & 1];
+    double *const dg8 = F.dg8[it & 1], *const ws8 = F.ws8[it & 1];
+    const int lane = fr_lane(), f = lane & 7;
+
+    for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const size_t e = (size_t)tile * FR_BLOCK + threadIdx.x;
+        const size_t b = e >> 3;
+        const bool in_grp = b < nb8;
+        const bool live = e < n_in;
+        const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
+        const double chunk_frac = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
+        // group start state of sweep p: what the groups before mine removed (norm) and used (samples) in that sweep
+        auto prefix = [&](int p, double *xg, uint32_t *xk) {
+            *xg = 0.0; *xk = 0u;
+            if (warm0) {        // previous iteration's chunk profile, linear inside the chunk
+                if (my_chunk < n_chunk_saved) {
+                    const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
+                    *xg = (F.wgx[cx] + F.wg[cx] * chunk_frac) * wsc;
+                    *xk = F.wkx[cx] + (uint32_t)((double)F.wk[cx] * chunk_frac);
                 }
-                else if (__double_as_longlong(F.ws8[ix]) != __double_as_longlong(gw)) atomicAdd(&F.dbg_cnt[it * 4 + 2], 1u);
+                else if (n_chunk_saved) {
+                    const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + n_chunk_saved - 1;
+                    *xg = (F.wgx[cx] + F.wg[cx]) * wsc; *xk = F.wkx[cx] + F.wk[cx];
+                }
+                if (*xk >= S.psN[p]) *xk = S.psN[p] - 1;
             }
-            F.dk8[ix] = gk; F.dg8[ix] = gg; F.ws8[ix] = gw;
+            else if (!zp && in_grp && p <= vup) {
+                const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
+                *xg = F.cgx[cx] + F.xg8[(size_t)p * stride + b];
+                *xk = F.ckx[cx] + F.xk8[(size_t)p * stride + b];
+            }
+        };
+        // my element
+        double v = live ? E.val[e] : 0.0;
+        uint32_t nd = live ? E.ndiv[e] : 1u;
+        double wr = v;
+        uint32_t kp = (final && live) ? W.keep[e] : 0u;
+        det_t det = 0; uint32_t code = 0; RowInfo ri; ri.inv_norm = 1; ri.aux = 0; ri.nsub = 2; ri.tot = 0;
+        if (STAGE != 1 && live && nd == 0 && v > 0) { code = E.code[e]; det = V.dets[E.pos[e]]; ri = fr_row_cached(E, e); }
+        if (final) {
+            double lastwf = 0;
+            double xg_n; uint32_t xk_n;
+            if (n_pass > 0) prefix(0, &xg_n, &xk_n);
+            for (int p = 0; p < n_pass; p++) {
+                const double xg = xg_n; const uint32_t xk = xk_n;
+                if (p + 1 < n_pass) prefix(p + 1, &xg_n, &xk_n);
+                double glob = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
+                if (live && nd == 0 && v > 0 && v * wf >= glob) lastwf = wf;
+            }
+            if (live) {
+                double out = v;
+                if (nd > 0) { if (kp & 1u) out = 0; }
+                else if (lastwf > 0) {
+                    unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
+                    const double cwf = v * lastwf;
+                    double rem = 0;
+                    fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
+                        if (s >= n_sub || ((kp >> s) & 1u)) return;
+                        rem += cwf * w;
+                    });
+                    out = rem / lastwf;
+                }
+                W.wt_remain[e] = out;
+            }
+            continue;
         }
-    }
-    // one sweep beyond: keeps nothing, but its wt_remain sum is what a re-summed norm would be
-    if (n_pass < FR_FKS_PMAX) {
-        double gw = 0;
-        for (int j = 0; j < 8; j++) gw += __shfl(live ? wr : 0.0, gbase + j);
-        if (f == 0 && in_grp) {
-            size_t ix = (size_t)n_pass * stride + b;
-            if (zp || n_pass > S.valid_upto || F.dk8[ix] != 0 || __double_as_longlong(F.ws8[ix]) != __double_as_longlong(gw)) diff = 1;
-            F.dk8[ix] = 0; F.dg8[ix] = 0; F.ws8[ix] = gw;
+        if (dbg == 1) continue;
+        float wmax = -1.0f;         // upper bound of the largest unpreserved normalised weight; < 0: row not looked at yet
+        double xg_n; uint32_t xk_n;
+        if (n_pass > 0) prefix(0, &xg_n, &xk_n);
+        for (int p = 0; p < n_pass; p++) {
+            const double xg = xg_n; const uint32_t xk = xk_n;
+            if (p + 1 < n_pass) prefix(p + 1, &xg_n, &xk_n);       // in flight while this sweep is evaluated
+            const double glob0 = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
+            // flags are taken against the group's start norm (compress_utils.cpp:172-180)
+            double cw = v * wf;
+            if (nd > 0) cw /= nd;
+            const bool flagged = live && wr > 0 && cw >= glob0;
+            // --- speculate with the start norm, then validate against the running norm
+            double change = 0, new_wr = wr, mu = 0;
+            uint32_t add = 0, new_kp = kp;
+            bool evaluated = false, skipped = false;
+            double used_gl = glob0;
+            if (flagged) {
+                if (nd > 0) { new_kp = kp | 1u; new_wr = 0; add = nd; change = v; }
+                else if (wmax >= 0 && cw * (double)wmax < glob0) skipped = true;
+            }
+            bool need_eval = flagged && nd == 0 && !skipped && dbg != 2;
+            double gl_mine = glob0;
+            if (__any(flagged)) {
+                for (int round = 0; round < 9; round++) {
+                    if (dbg == 3) {
+                        if (need_eval) atomicAdd(&F.hist[FR_MAX_ROUNDS], 1u);
+                        if (__any(need_eval) && lane == 0) atomicAdd(&F.hist[FR_MAX_ROUNDS + 1], 1u);
+                    }
+                    if (need_eval) {
+                        unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
+                        double rem;
+                        fr_fks2_row<STAGE, NEW_HB>(T, det, code, ri, n_sub, p_doub, cw, gl_mine, kp, &new_kp, &add, &rem, &mu);
+                        new_wr = rem / wf;
+                        change = wr - new_wr;
+                        evaluated = true; used_gl = gl_mine; skipped = false;
+                    }
+                    // running norm of each lane: start norm minus the changes of the flagged lanes before it, in order
+                    gl_mine = fr_grp8_running(glob0, (flagged && !skipped) ? change : 0.0, f);
+                    // would my decision differ under gl_mine?
+                    need_eval = false;
+                    if (flagged && nd == 0) {
+                        if (skipped) { if (cw * (double)wmax >= gl_mine) need_eval = true; }
+                        else if (evaluated && used_gl != gl_mine && mu >= gl_mine) need_eval = true;
+                    }
+                    if (!__any(need_eval)) break;
+                }
+            }
+            // commit
+            if (flagged && !skipped) {
+                if (evaluated) wmax = (cw > 0) ? (float)((mu / cw) * 1.000002) : 0.0f;     // largest unpreserved normalised weight, rounded up
+                kp = new_kp; wr = new_wr;
+            }
+            else { add = 0; change = 0; }
+            // group totals
+            const uint32_t gk = fr_grp8_sum_u32(add);
+            const double gg = fr_grp8_sum(change);
+            const double gw = fr_grp8_sum(live ? wr : 0.0);
+            if (f == 0 && in_grp) {
+                size_t ix = (size_t)p * stride + b;
+                dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw;
+            }
         }
+        // one sweep beyond: keeps nothing, but its wt_remain sum is what a re-summed norm would be
+        if (n_pass < FR_FKS_PMAX) {
+            const double gw = fr_grp8_sum(live ? wr : 0.0);
+            if (f == 0 && in_grp) {
+                size_t ix = (size_t)n_pass * stride + b;
+                dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw;
+            }
+        }
+        if (live) { W.keep[e] = kp; W.wt_remain[e] = wr; }
     }
-    if (live) { W.keep[e] = kp; W.wt_remain[e] = wr; }
-    __shared__ uint32_t s_any;
-    if (threadIdx.x == 0) s_any = 0;
-    __syncthreads();
-    if (__any(diff) && lane == 0) s_any = 1;
-    __syncthreads();
-    if (threadIdx.x == 0 && s_any && F.hist[it] == 0) atomicOr(&F.hist[it], 1u);
 }
 
 // Exclusive prefixes over the 8-blocks inside chunks of 2048 groups (grid: chunks x sweeps); chunk totals go to
-// (ck, cg, cw).  The last workgroup to finish sums them into the sweep totals and derives the sweep scalars of the
-// next replay (compress_utils.cpp:153-158, 251-265).
+// (ck, cg, cw).  Also compares this replay's deltas with the previous replay's and raises hist[it] on any difference.
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it) {
     __shared__ double shd[12];
     __shared__ uint32_t shu[4];
-    FksScal *S = F.scal;
+    const FksScal *S = F.scal;
     const int p = blockIdx.y;
     const unsigned c = blockIdx.x;
     const unsigned nb8 = S->n_in / 8 + 1;
@@ -360,15 +370,24 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
     const int n_pass = S->n_pass;
     const size_t stride = F.nb8_cap;
     if (c < nchunk && p <= n_pass && p < FR_FKS_PMAX) {
+        const uint32_t *dk = F.dk8[it & 1], *dkp = F.dk8[(it & 1) ^ 1];
+        const double *dg = F.dg8[it & 1], *dgp = F.dg8[(it & 1) ^ 1], *ws = F.ws8[it & 1], *wsp = F.ws8[(it & 1) ^ 1];
+        const bool fresh = S->zero_prefix || p > S->valid_upto;      // nothing to compare with
         const size_t base = (size_t)p * stride + (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8;
         const size_t lim = (size_t)p * stride + nb8;
         uint32_t k[8]; double g[8];
         uint32_t tk = 0; double tg = 0, tw = 0;
+        bool diff = fresh;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             bool ok = base + j < lim;
-            k[j] = ok ? F.dk8[base + j] : 0u; g[j] = ok ? F.dg8[base + j] : 0.0;
-            tk += k[j]; tg += g[j]; tw += ok ? F.ws8[base + j] : 0.0;
+            k[j] = ok ? dk[base + j] : 0u; g[j] = ok ? dg[base + j] : 0.0;
+            double w = ok ? ws[base + j] : 0.0;
+            if (ok && !fresh) {
+                if (dkp[base + j] != k[j] || __double_as_longlong(dgp[base + j]) != __double_as_longlong(g[j]) ||
+                    __double_as_longlong(wsp[base + j]) != __double_as_longlong(w)) diff = true;
+            }
+            tk += k[j]; tg += g[j]; tw += w;
         }
         uint32_t totk;
         uint32_t ik = fr_block_scan_u32(tk, shu, &totk);
@@ -384,26 +403,35 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
         if (threadIdx.x == 0) {
             F.ck[(size_t)p * FR_FKS_MAXCHUNK + c] = totk; F.cg[(size_t)p * FR_FKS_MAXCHUNK + c] = totg; F.cw[(size_t)p * FR_FKS_MAXCHUNK + c] = totw;
         }
+        if (__any(diff) && fr_lane() == 0 && F.hist[it] == 0) atomicOr(&F.hist[it], 1u);
     }
 }
 
-// Sweep totals from the chunk totals into this rank's FksMsg; with one rank, also the sweep scalars of the next replay
+// Exclusive prefixes over the chunks and sweep totals (one wave per sweep) into this rank's FksMsg; with one rank,
+// also the sweep scalars of the next replay
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
-    __shared__ double shd[4];
-    __shared__ uint32_t shu[4];
     FksScal *S = F.scal;
     const unsigned nb8 = S->n_in / 8 + 1;
     const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
     const int n_pass = S->n_pass;
-    for (int q = 0; q < FR_FKS_PMAX; q++) {
-        uint32_t k = 0; double g = 0, w = 0;
-        if (q > n_pass + 1) { if (threadIdx.x == 0) { msg->totK[q] = 0; msg->totG[q] = 0; msg->totW[q] = 0; } continue; }
+    const int lane = fr_lane(), wv = threadIdx.x >> 6;
+    for (int q = wv; q < FR_FKS_PMAX; q += 4) {
+        uint32_t rk = 0; double rg = 0, rw = 0;
         if (q <= n_pass) {
-            k = fr_sum_partials_u32(F.ck + (size_t)q * FR_FKS_MAXCHUNK, nchunk, shu);
-            g = fr_sum_partials(F.cg + (size_t)q * FR_FKS_MAXCHUNK, nchunk, shd);
-            w = fr_sum_partials(F.cw + (size_t)q * FR_FKS_MAXCHUNK, nchunk, shd);
+            for (unsigned c0 = 0; c0 < nchunk; c0 += 64) {
+                unsigned c = c0 + lane;
+                size_t ix = (size_t)q * FR_FKS_MAXCHUNK + c;
+                uint32_t k = c < nchunk ? F.ck[ix] : 0u;
+                double g = c < nchunk ? F.cg[ix] : 0.0, w = c < nchunk ? F.cw[ix] : 0.0;
+                uint32_t tk; double tg, tw;
+                uint32_t ek = fr_wave_excl_u32(k, &tk);
+                double eg = fr_wave_excl_f64(g, &tg);
+                fr_wave_excl_f64(w, &tw);
+                if (c < nchunk) { F.ckx[ix] = rk + ek; F.cgx[ix] = rg + eg; }
+                rk += tk; rg += tg; rw += tw;
+            }
         }
-        if (threadIdx.x == 0) { msg->totK[q] = k; msg->totG[q] = g; msg->totW[q] = w; }
+        if (lane == 0) { msg->totK[q] = rk; msg->totG[q] = rg; msg->totW[q] = rw; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -425,8 +453,8 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
     const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
     for (int p = 0; p < n_pass; p++)
         for (unsigned c = threadIdx.x; c < nchunk; c += blockDim.x) {
-            F.wk[(size_t)p * FR_FKS_MAXCHUNK + c] = F.ck[(size_t)p * FR_FKS_MAXCHUNK + c];
-            F.wg[(size_t)p * FR_FKS_MAXCHUNK + c] = F.cg[(size_t)p * FR_FKS_MAXCHUNK + c];
+            const size_t ix = (size_t)p * FR_FKS_MAXCHUNK + c;
+            F.wk[ix] = F.ck[ix]; F.wg[ix] = F.cg[ix]; F.wkx[ix] = F.ckx[ix]; F.wgx[ix] = F.cgx[ix];
         }
     if (threadIdx.x == 0) {
         FksSaved *V = F.saved;

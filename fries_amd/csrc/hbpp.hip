@@ -272,10 +272,12 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         Fks2Work &F = c->F2;
         F.nb8_cap = cap / 8 + 2;
         size_t n8 = (size_t)FR_FKS_PMAX * F.nb8_cap;
-        F.dk8 = fr_alloc<uint32_t>(n8); F.dg8 = fr_alloc<double>(n8); F.ws8 = fr_alloc<double>(n8);
+        for (int h = 0; h < 2; h++) { F.dk8[h] = fr_alloc<uint32_t>(n8); F.dg8[h] = fr_alloc<double>(n8); F.ws8[h] = fr_alloc<double>(n8); }
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
         F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
         F.ck = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cg = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cw = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
+        F.ckx = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cgx = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
+        c->fks_wkx = fr_alloc<uint32_t>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK); c->fks_wgx = fr_alloc<double>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK);
         FR_HIP(hipMemset(F.hist, 0, 4 * (FR_MAX_ROUNDS + 2)));
         F.dbg_cnt = fr_alloc<uint32_t>((size_t)FR_MAX_ROUNDS * 4);
         FR_HIP(hipMemset(F.dbg_cnt, 0, (size_t)FR_MAX_ROUNDS * 16));
@@ -301,8 +303,10 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
     Fks2Work F = c->F2;
     F.saved = c->fks_saved + STAGE; F.wk = c->fks_wk + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wg = c->fks_wg + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
+    F.wkx = c->fks_wkx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wgx = c->fks_wgx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
     const int warm = c->warm_start ? 1 : 0;
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
+    if (gridE > c->fks_grid) gridE = c->fks_grid;          // persistent workgroups (5 per CU), each strides over the tiles
     unsigned nchunk = fr_blocks((size_t)n_bound / 8 + 1, FR_FKS_CHUNK);
     if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
     const int P = c->n_ranks;
