@@ -65,6 +65,59 @@ def build_state(mol, m_glob, max_dets, seed, device, comm, dist):
     return dets, vals
 
 
+def cpu_baseline(args, mol, par, dets, vals, run_seed, m):
+    """-> (cpu_baseline dict, per-iteration log of the CPU run).  Bounded to roughly 20 s of CPU work."""
+    import struct
+    import subprocess
+    import tempfile
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    from fries_amd import fcidump
+    n_cpu = args.cpu_iters if args.cpu_iters > 0 else max(4, min(40, int(14.0 * 1.0e6 / m)))
+    if os.path.exists(harness):
+        try:
+            tmp = tempfile.mkdtemp(prefix="fries_bench_")
+            fc = os.path.join(tmp, "mol.FCIDUMP")
+            fcidump.write_fcidump(fc, mol)
+            st = os.path.join(tmp, "state.bin")
+            with open(st, "wb") as f:
+                f.write(struct.pack("<Q", dets.size)); f.write(dets.astype("<u8").tobytes()); f.write(vals.astype("<f8").tobytes())
+            log = os.path.join(tmp, "log.txt")
+            base = [fc, mol.point_group, str(n_cpu), str(par["seed"]), repr(par["epsilon"]), str(par["vec_nonz"]), str(par["mat_nonz"]), str(par["max_dets"]),
+                    repr(par["initiator"]), repr(par["target_norm"]), par["distribution"], st, str(run_seed)]
+            out = subprocess.run([harness, "restart"] + base + [log], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+            r = json.loads(line)
+            rows = [ln.split() for ln in open(log)]
+            ref_log = {"numer": [float.fromhex(t[1]) for t in rows], "denom": [float.fromhex(t[2]) for t in rows], "norm": [float.fromhex(t[3]) for t in rows],
+                       "nkept": [int(t[5]) for t in rows], "n_nonz": [int(t[6]) for t in rows], "curr_size": [int(t[7]) for t in rows], "num_success": [int(t[8]) for t in rows]}
+            cb = {"value": r["iters_per_s"], "unit": "iterations/s", "cores": 1, "kind": "reference",
+                  "sample": f"{n_cpu} iterations of the reference's frisys_mol loop (oracle/_ref/ref_harness restart, 1 MPI rank) from the same restart state and seed"}
+            # the reference under MPI on this box's cores (its only parallelism), same state: reported beside, not as `value`
+            mpiexec = "/opt/conda/bin/mpiexec"
+            ncore = min(8, os.cpu_count() or 1)
+            if os.path.exists(mpiexec) and ncore > 1:
+                try:
+                    o2 = subprocess.run([mpiexec, "-n", str(ncore), harness, "restart"] + base, capture_output=True, text=True, timeout=600)
+                    r2 = json.loads([ln for ln in o2.stdout.splitlines() if ln.startswith("{")][-1])
+                    cb["mpi"] = {"value": r2["iters_per_s"], "cores": ncore, "sample": f"mpiexec -n {ncore}, {n_cpu} iterations, same state"}
+                except Exception as e:       # MPI launcher unusable on this box: keep the 1-rank figure
+                    cb["mpi"] = {"value": None, "error": str(e)[:200]}
+            return cb, ref_log
+        except Exception as e:
+            sys.stderr.write(f"reference harness unusable here ({e}); timing the oracle port instead\n")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.OracleFrisys(mol, **par)
+    orc.vec_load(dets, vals)
+    orc.restart(run_seed, 0.0, 0.0, 0)
+    t0 = time.perf_counter()
+    lo = orc.iterate(n_cpu)
+    cpu_dt = time.perf_counter() - t0
+    cb = {"value": n_cpu / cpu_dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+          "sample": f"{n_cpu} iterations of the same restart state and seed (oracle/fries_oracle.cpp, 1 thread)"}
+    return cb, {f: [x for x in lo[f]] for f in ("numer", "denom", "norm", "nkept", "n_nonz", "curr_size", "num_success")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,8 +236,19 @@ def main():
         base = next((k for k in ALG_BYTES if name.startswith(k)), None)
         units = stage_elems / 5.0 if base else None      # elements one launch passes over (stage average)
         ach = ALG_BYTES[base](units) / avg_s / 1e9 if base else None
+        # HBM bytes per launch from the PMC passes kept under profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+        # command, corrected as MI355X_MICROARCH.md prescribes); mean over the stage instantiations of the kernel
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                tk = json.load(f)["kernels"]
+            vals_t = [v["bytes_per_launch"] for k, v in tk.items() if k.startswith(name + "<") or k == name]
+            if vals_t and m == 1_000_000 and world == 1:
+                traffic = float(np.mean(vals_t))
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                              "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                               "avg_launch_us": avg_s * 1e6, "calls_per_iter": calls / args.profile_steps,
                               "share_of_kernel_time": ms / tot_ms, "n_nonz": info[1]}
         result["kernel_time_ms_per_iter"] = tot_ms / args.profile_steps
@@ -193,31 +257,19 @@ def main():
         # whole-iteration algorithmic traffic (~312 B per nonzero per iteration)
         result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9      # per GPU
 
-        # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores
+        # ---- CPU baseline on this box's host cores: the REAL reference (oracle/_ref, built from /root/reference by
+        # oracle/Makefile and shipped as a binary) advanced from the same restart state and seed; the oracle port is the
+        # fallback where that binary cannot run.  Either way it is a checker / yardstick, never the product path.
         if args.cpu_iters != 0 and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib
-            orc = oracle_lib.OracleFrisys(mol, **par)
-            orc.vec_load(dets, vals)
-            orc.restart(run_seed, 0.0, 0.0, 0)
-            n_cpu = args.cpu_iters
-            t0 = time.perf_counter()
-            lo1 = orc.iterate(1)
-            one = time.perf_counter() - t0
-            if n_cpu < 0:
-                n_cpu = max(2, min(40, int(20.0 / max(one, 1e-3))))
-            t0 = time.perf_counter()
-            lo = orc.iterate(n_cpu - 1)
-            cpu_dt = one + (time.perf_counter() - t0)
-            result["cpu_baseline"] = {"value": n_cpu / cpu_dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-                                      "sample": f"{n_cpu} iterations of the same restart state and seed (oracle/fries_oracle.cpp, 1 thread)"}
-            # the GPU's first iterations ran from the same state and seed: compare what they logged
-            if first_logs is not None:
-                k = min(n_cpu, args.warmup)
-                olog = np.concatenate([lo1, lo])[:k]
-                same = all(int(first_logs[f][i]) == int(olog[f][i]) for i in range(k) for f in ("num_success", "n_nonz", "curr_size", "nkept"))
-                num_ok = bool(np.all(np.abs(first_logs["numer"][:k] / first_logs["denom"][:k] - olog["numer"] / olog["denom"]) < 1e-10))
-                result["parity"] = {"iterations_compared": k, "counts_identical": bool(same), "energy_within_1e-10": num_ok}
+            result["cpu_baseline"], ref_log = cpu_baseline(args, mol, par, dets, vals, run_seed, m)
+            if first_logs is not None and ref_log is not None:
+                k = min(len(ref_log["numer"]), args.warmup)
+                same = all(int(first_logs[f][i]) == int(ref_log[f][i]) for i in range(k) for f in ("num_success", "n_nonz", "curr_size", "nkept"))
+                en_g = first_logs["numer"][:k] / first_logs["denom"][:k]
+                en_r = np.asarray(ref_log["numer"][:k]) / np.asarray(ref_log["denom"][:k])
+                result["parity"] = {"against": result["cpu_baseline"]["kind"], "iterations_compared": k, "counts_identical": bool(same),
+                                    "energy_within_1e-10": bool(np.all(np.abs(en_g - en_r) < 1e-10)),
+                                    "norm_bit_identical": bool(all(float(first_logs["norm"][i]) == float(ref_log["norm"][i]) for i in range(k)))}
         print(json.dumps(result))
     eng.close()
     if dist is not None:

@@ -557,6 +557,62 @@ static int run_frisys_mpi(int argc, char **argv) {
     return 0;
 }
 
+// [mpiexec -n P] ref_harness restart <fcidump> <pg> <n_iter> <seed> <eps> <vnz> <mnz> <max_dets> <ini> <tgt> <dist> <state.bin> <run_seed> [log]
+// The REAL reference advanced from a given vector: state.bin = u64 n, u64 dets[n], f64 vals[n] (storage order).  Every rank keeps
+// the determinants it owns (idx_to_proc), in file order, so that positions equal what DistVec::load / fries_vec_load produce.
+// Prints one JSON line with the timing of the iteration loop (rank 0); `log` receives rank 0's per-iteration scalars.
+static int run_restart(int argc, char **argv) {
+    if (argc < 15) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10), mnz = strtoul(argv[8], 0, 10);
+    size_t max_dets = strtoull(argv[9], 0, 10); double ini = atof(argv[10]), tgt = atof(argv[11]);
+    int nhb = !strcmp(argv[12], "HB_unnorm");
+    uint32_t run_seed = strtoul(argv[14], 0, 10);
+    RefRun rr;
+    rr.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
+    // empty the vector (setup left 100 |HF> on its owner), then add the state in file order
+    DistVec<double> &sv = *rr.sol;
+    for (size_t i = 0; i < sv.curr_size(); i++) if (*sv[i] != 0) { *sv[i] = 0; sv.del_at_pos(i); }
+    FILE *f = fopen(argv[13], "rb");
+    if (!f) { fprintf(stderr, "cannot open state\n"); return 2; }
+    uint64_t n = 0;
+    if (fread(&n, 8, 1, f) != 1) return 2;
+    std::vector<uint64_t> dets(n); std::vector<double> vals(n);
+    if (fread(dets.data(), 8, n, f) != n || fread(vals.data(), 8, n, f) != n) return 2;
+    fclose(f);
+    size_t i = 0;
+    int more = 1;
+    while (more) {
+        while (i < n) {
+            uint8_t d[8]; memcpy(d, &dets[i], 8);
+            bool mine = sv.idx_to_proc(d) == (unsigned)rr.proc_rank;
+            i++;
+            if (mine && !sv.add(d, vals[i - 1], 1)) break;
+        }
+        sv.perform_add(0);
+        more = sum_mpi((int)(i < n), rr.proc_rank, rr.n_procs);
+    }
+    rr.mt.seed(run_seed); rr.en_shift = 0; rr.last_one_norm = 0; rr.iterat = 0;
+    FILE *lg = (argc > 15 && rr.proc_rank == 0) ? fopen(argv[15], "w") : NULL;
+    MPI_Barrier(MPI_COMM_WORLD);
+    auto t0 = std::chrono::steady_clock::now();
+    size_t spawns = 0;
+    for (unsigned it = 0; it < n_iter; it++) {
+        rr.iterate();
+        spawns += rr.num_success;
+        if (lg) fprintf(lg, "%u %a %a %a %a %u %d %zu %zu\n", it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success);
+    }
+    MPI_Barrier(MPI_COMM_WORLD);
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (lg) fclose(lg);
+    int nn = sum_mpi(rr.sol->n_nonz(), rr.proc_rank, rr.n_procs);
+    int sp = sum_mpi((int)(spawns / (n_iter ? n_iter : 1)), rr.proc_rank, rr.n_procs);
+    if (rr.proc_rank == 0)
+        printf("{\"kind\": \"reference\", \"ranks\": %d, \"iters\": %u, \"seconds\": %.6f, \"iters_per_s\": %.6f, \"spawns_per_iter\": %d, \"n_nonz\": %d}\n", rr.n_procs, n_iter, s, n_iter / s, sp, nn);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     MPI_Init(NULL, NULL);
     int rc = 2;
@@ -565,6 +621,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
     else fprintf(stderr, "unknown command\n");
     MPI_Finalize();
