@@ -32,10 +32,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
         B.state[0] = s;
     }
     if (blockIdx.x >= nblk) return;
-    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     double sum = 0;
     for (int it = 0; it < FR_ITEMS; it++) {
-        size_t i = base + it;
+        size_t i = base + (size_t)it * FR_BLOCK;
         if (i >= n) break;
         double v = V.v0[i];
         if (i < vec_size_before && v != 0) {
@@ -84,29 +84,26 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
     if (blockIdx.x >= nblk && blockIdx.x != 0) return;
     const int pin = (round - 1) & 1, pout = round & 1;
     double G; uint32_t kept_prev;
-    if (!all) {
-        G = fr_sum_partials(B.psum[pin], nblk, shd);
-        kept_prev = fr_sum_partials_u32(B.pcnt[pin], nblk, shu);
-    }
-    else {      // sum_mpi: rank order (compress_utils.cpp:53, :76)
+    {      // sum_mpi: rank order (compress_utils.cpp:53, :76)
         G = 0; kept_prev = 0;
         for (int p = 0; p < n_ranks; p++) { G += all[p].G; kept_prev += all[p].kept; }
     }
     uint32_t n_rem = prev.n_rem - kept_prev;
-    bool done = (round > 1 && kept_prev == 0) || (!all && nblk == 0);
+    bool done = (round > 1 && kept_prev == 0) || (n_ranks == 1 && nblk == 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CompState s = prev;
         if (round == 1) s.loc_norm = G;          // *global_norm (compress_utils.cpp:50)
         s.G = G; s.n_rem = n_rem; s.done = done; s.pbuf = pin;
+        if (done) s.n_pass = round;          // the round that found nothing left to preserve (later rounds copy this state)
         B.state[round] = s;
     }
     if (done || blockIdx.x >= nblk) return;
     const double thr = G / n_rem;
-    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     double sum = 0;
     uint32_t kept = 0;
     for (int it = 0; it < FR_ITEMS; it++) {
-        size_t i = base + it;
+        size_t i = base + (size_t)it * FR_BLOCK;
         if (i >= n) break;
         double a = fabs(V.v0[i]);
         if (!B.keep[i] && a != 0) {
@@ -168,11 +165,9 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
         if (batch <= 0) throw FriesError("find_preserve did not converge within FR_MAX_ROUNDS rounds");
         for (int k = 0; k < batch; k++) {
             r++;
-            const FpMsg *all = nullptr;
-            if (c->use_comm) {
-                FR_LAUNCH(c, "k_fp_reduce", k_fp_reduce, dim3(1), dim3(FR_BLOCK), B, r, (FpMsg *)c->comm.small_send);
-                all = (const FpMsg *)fr_allgather(c, sizeof(FpMsg));
-            }
+            // one workgroup reduces the previous round's partials (every workgroup of the round would otherwise redo it)
+            FR_LAUNCH(c, "k_fp_reduce", k_fp_reduce, dim3(1), dim3(FR_BLOCK), B, r, (FpMsg *)c->comm.small_send);
+            const FpMsg *all = (const FpMsg *)fr_allgather(c, sizeof(FpMsg));
             FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r, all, P);
         }
         FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
@@ -180,7 +175,7 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
         FR_HIP(hipStreamSynchronize(st));
         batch = 2;
     }
-    c->rounds_hint[6] = r > 2 ? r - 1 : 2;
+    c->rounds_hint[6] = hs.n_pass > 3 ? (int)hs.n_pass - 1 : 2;     // next iteration's first batch = the rounds this one needed
     c->rounds_hint[7] = r;      // state slot sys_comp reads
     uint32_t n_rem = hs.n_rem;
     if (hs.G < 1e-9) n_rem = 0;     // compress_utils.cpp:94-96

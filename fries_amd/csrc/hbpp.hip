@@ -17,10 +17,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep1(CompWork W, VecDev V, int cu
     }
     if (blockIdx.x >= nblk) return;
     const StageElems E = W.el[cur];
-    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     double sum = 0;
     for (int it = 0; it < FR_ITEMS; it++) {
-        size_t e = base + it;
+        size_t e = base + (size_t)it * FR_BLOCK;
         if (e >= n_in) break;
         double w = fabs(V.v0[e]);
         E.val[e] = w; E.pos[e] = (uint32_t)e; E.code[e] = 0; E.ndiv[e] = (w > 0) ? 0u : 1u; E.nsub[e] = 2; E.rinv[e] = 1.0; E.raux[e] = 0;
@@ -49,10 +49,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const H
     fr_stage_tables(&T, Tg);
     const StageElems E = W.el[cur], P = W.el[cur ^ 1];
     const unsigned n_elec = T.n_elec, n_orb = T.n_orb;
-    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     double sum = 0;
     for (int it = 0; it < FR_ITEMS; it++) {
-        size_t e = base + it;
+        size_t e = base + (size_t)it * FR_BLOCK;
         if (e >= n_in) break;
         uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
         double val = W.e_val[e];
@@ -142,10 +142,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_eval(CompWork W, VecDev V, S
     fr_stage_tables(&T, S.hb);
     const StageElems P = W.el[prev];
     const unsigned n_orb = T.n_orb;
-    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     uint32_t cnt = 0;
     for (int it = 0; it < FR_ITEMS; it++) {
-        size_t e = base + it;
+        size_t e = base + (size_t)it * FR_BLOCK;
         if (e >= n_in) break;
         uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
         double val = W.e_val[e];
