@@ -129,8 +129,9 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Wo
 }
 
 // after the all-gather of every rank's FksMsg (n_ranks > 1)
-static __global__ void k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks, int it, uint32_t *err, int warm) {
+static __global__ void __launch_bounds__(64) k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks, int it, uint32_t *err, int warm) {
     FksScal *S = F.scal;
+    if (threadIdx.x != 0) return;
     fr_fks2_passes(S, msgs, n_ranks, it >= 0 ? &F.hist[it] : nullptr);
     if (it < 0) fr_fks2_warm(S, F.saved, warm);
     if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
@@ -368,26 +369,39 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
     const unsigned nb8 = S->n_in / 8 + 1;
     const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
     const int n_pass = S->n_pass;
-    const size_t stride = F.nb8_cap;
+    const size_t stride = F.nb8_cap;            // a multiple of FR_FKS_CHUNK: every chunk of a sweep's row is fully addressable
     if (c < nchunk && p <= n_pass && p < FR_FKS_PMAX) {
-        const uint32_t *dk = F.dk8[it & 1], *dkp = F.dk8[(it & 1) ^ 1];
-        const double *dg = F.dg8[it & 1], *dgp = F.dg8[(it & 1) ^ 1], *ws = F.ws8[it & 1], *wsp = F.ws8[(it & 1) ^ 1];
         const bool fresh = S->zero_prefix || p > S->valid_upto;      // nothing to compare with
+        // thread t owns groups [8t, 8t + 8) of the chunk: 32 / 64 contiguous bytes per array, fetched as 16-byte vectors
         const size_t base = (size_t)p * stride + (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8;
-        const size_t lim = (size_t)p * stride + nb8;
-        uint32_t k[8]; double g[8];
-        uint32_t tk = 0; double tg = 0, tw = 0;
+        const unsigned left = (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8 < nb8 ? (unsigned)(nb8 - ((size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8)) : 0u;   // valid groups of mine
+        uint32_t k[8]; double g[8], w[8];
+        {
+            const uint4 *pk = (const uint4 *)(F.dk8[it & 1] + base);
+            uint4 a = pk[0], bq = pk[1];
+            k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = bq.x; k[5] = bq.y; k[6] = bq.z; k[7] = bq.w;
+            const double2 *pg = (const double2 *)(F.dg8[it & 1] + base), *pw = (const double2 *)(F.ws8[it & 1] + base);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { double2 x = pg[j], y = pw[j]; g[2 * j] = x.x; g[2 * j + 1] = x.y; w[2 * j] = y.x; w[2 * j + 1] = y.y; }
+        }
         bool diff = fresh;
+        if (!fresh) {
+            const uint4 *pk = (const uint4 *)(F.dk8[(it & 1) ^ 1] + base);
+            uint4 a = pk[0], bq = pk[1];
+            uint32_t kp[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+            const double2 *pg = (const double2 *)(F.dg8[(it & 1) ^ 1] + base), *pw = (const double2 *)(F.ws8[(it & 1) ^ 1] + base);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double2 x = pg[j], y = pw[j];
+                if ((unsigned)(2 * j) < left && (kp[2 * j] != k[2 * j] || __double_as_longlong(x.x) != __double_as_longlong(g[2 * j]) || __double_as_longlong(y.x) != __double_as_longlong(w[2 * j]))) diff = true;
+                if ((unsigned)(2 * j + 1) < left && (kp[2 * j + 1] != k[2 * j + 1] || __double_as_longlong(x.y) != __double_as_longlong(g[2 * j + 1]) || __double_as_longlong(y.y) != __double_as_longlong(w[2 * j + 1]))) diff = true;
+            }
+        }
+        uint32_t tk = 0; double tg = 0, tw = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            bool ok = base + j < lim;
-            k[j] = ok ? dk[base + j] : 0u; g[j] = ok ? dg[base + j] : 0.0;
-            double w = ok ? ws[base + j] : 0.0;
-            if (ok && !fresh) {
-                if (dkp[base + j] != k[j] || __double_as_longlong(dgp[base + j]) != __double_as_longlong(g[j]) ||
-                    __double_as_longlong(wsp[base + j]) != __double_as_longlong(w)) diff = true;
-            }
-            tk += k[j]; tg += g[j]; tw += w;
+            if ((unsigned)j >= left) { k[j] = 0; g[j] = 0; w[j] = 0; }
+            tk += k[j]; tg += g[j]; tw += w[j];
         }
         uint32_t totk;
         uint32_t ik = fr_block_scan_u32(tk, shu, &totk);
@@ -395,10 +409,15 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
         double eg = fr_block_excl_f64(tg, shd, &totg);
         fr_block_excl_f64(tw, shd, &totw);
         uint32_t ek = ik - tk;
+        uint32_t xk[8]; double xg[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (base + j < lim) { F.xk8[base + j] = ek; F.xg8[base + j] = eg; }
-            ek += k[j]; eg += g[j];
+        for (int j = 0; j < 8; j++) { xk[j] = ek; xg[j] = eg; ek += k[j]; eg += g[j]; }
+        {
+            uint4 *qk = (uint4 *)(F.xk8 + base);
+            qk[0] = make_uint4(xk[0], xk[1], xk[2], xk[3]); qk[1] = make_uint4(xk[4], xk[5], xk[6], xk[7]);
+            double2 *qg = (double2 *)(F.xg8 + base);
+#pragma unroll
+            for (int j = 0; j < 4; j++) qg[j] = make_double2(xg[2 * j], xg[2 * j + 1]);
         }
         if (threadIdx.x == 0) {
             F.ck[(size_t)p * FR_FKS_MAXCHUNK + c] = totk; F.cg[(size_t)p * FR_FKS_MAXCHUNK + c] = totg; F.cw[(size_t)p * FR_FKS_MAXCHUNK + c] = totw;
@@ -410,6 +429,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
 // Exclusive prefixes over the chunks and sweep totals (one wave per sweep) into this rank's FksMsg; with one rank,
 // also the sweep scalars of the next replay
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
+    __shared__ FksMsg sm;        // the bookkeeping below is one thread chasing ~20 values per sweep: keep them in LDS
     FksScal *S = F.scal;
     const unsigned nb8 = S->n_in / 8 + 1;
     const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
@@ -431,15 +451,17 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
                 rk += tk; rg += tg; rw += tw;
             }
         }
-        if (lane == 0) { msg->totK[q] = rk; msg->totG[q] = rg; msg->totW[q] = rw; }
+        if (lane == 0) { msg->totK[q] = rk; msg->totG[q] = rg; msg->totW[q] = rw; sm.totK[q] = rk; sm.totG[q] = rg; sm.totW[q] = rw; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         S->zero_prefix = 0;
         S->valid_upto = n_pass;         // k_fks_scan covered sweeps 0..n_pass of the replay that just ran
-        msg->L0 = S->G0; msg->changed = F.hist[it]; msg->pad = 0;
+        const double L0 = S->G0; const uint32_t ch = F.hist[it];
+        msg->L0 = L0; msg->changed = ch; msg->pad = 0;
+        sm.L0 = L0; sm.changed = ch;
         if (inline_passes) {
-            fr_fks2_passes(S, msg, 1, nullptr);
+            fr_fks2_passes(S, &sm, 1, nullptr);
             if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
         }
     }

@@ -270,7 +270,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
     {
         Fks2Work &F = c->F2;
-        F.nb8_cap = cap / 8 + 2;
+        F.nb8_cap = (uint32_t)(((size_t)cap / 8 + 2 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK * FR_FKS_CHUNK);     // whole chunks: k_fks_scan uses unguarded vector loads
         size_t n8 = (size_t)FR_FKS_PMAX * F.nb8_cap;
         for (int h = 0; h < 2; h++) { F.dk8[h] = fr_alloc<uint32_t>(n8); F.dg8[h] = fr_alloc<double>(n8); F.ws8[h] = fr_alloc<double>(n8); }
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);

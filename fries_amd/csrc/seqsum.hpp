@@ -188,58 +188,126 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seq_maps(SeqWork Q, Acc acc) {
     }
 }
 
-// ---- S4: the chain.  One wave; lane-parallel over runs of clean same-binade tiles.
+// ---- S4: the chain.  One wave.  Tile records are fetched 64 at a time (the next batch is in flight while the
+// current one is consumed); inside a batch, runs of clean same-binade tiles are resolved by an ordered scan of parity
+// maps over lanes, a tile that may straddle a power of two is walked through its 16 sub-tiles (fetched together), and a
+// sub-tile that may straddle one is added element by element from registers (v_readlane broadcasts).
+__device__ __forceinline__ double fr_bcast_f64(double v, int src_lane /* wave-uniform */) {
+    long long b = __double_as_longlong(v);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ long long fr_bcast_i64(long long b, int src_lane) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// inclusive prefix sum of one int64 per lane over the wave: Kogge-Stone inside rows of 16 lanes (DPP row shifts, zeros
+// shifted in), then the row totals are broadcast down (row_bcast15 / row_bcast31) -- no LDS crossbar traffic
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ long long fr_dpp_i64z(long long v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, true);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xf, true);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long fr_wave_incl_i64(long long v) {
+    v += fr_dpp_i64z<0x111, 0xf>(v);       // row_shr:1
+    v += fr_dpp_i64z<0x112, 0xf>(v);       // row_shr:2
+    v += fr_dpp_i64z<0x114, 0xf>(v);       // row_shr:4
+    v += fr_dpp_i64z<0x118, 0xf>(v);       // row_shr:8
+    v += fr_dpp_i64z<0x142, 0xa>(v);       // row_bcast15 -> rows 1 and 3
+    v += fr_dpp_i64z<0x143, 0xc>(v);       // row_bcast31 -> rows 2 and 3
+    return v;
+}
+
 template <class Acc>
 __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start) {
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
     const int lane = fr_lane();
     double carry = start;
-    unsigned t = 0;
-    while (t < ntile) {
-        unsigned mine = t + lane;
-        SeqRec r;
-        bool have = mine < ntile;
-        if (have) r = Q.tiles[mine]; else { r.dirty = 1; r.e = 0; r.d0 = r.d1 = 0; }
-        int e0 = __shfl(r.e, 0);
-        unsigned d0flag = __shfl((int)r.dirty, 0);
-        if (d0flag) {
-            // tile t may straddle a power of two: walk its sub-tiles (the whole wave follows lane 0)
-            if (lane == 0) Q.tiles[t].carry = carry;
-            for (unsigned j = 0; j < FR_SUBS_PER_TILE; j++) {
-                size_t sidx = (size_t)t * FR_SUBS_PER_TILE + j;
-                size_t e_lo = (size_t)t * FR_SEQ_TILE + (size_t)j * 64;
-                if (e_lo >= n) { if (lane == 0) Q.subs[sidx].carry = carry; continue; }
-                SeqRec s = Q.subs[sidx];
-                if (lane == 0) Q.subs[sidx].carry = carry;
-                if (!s.dirty) carry = fr_seq_apply_map(carry, s.e, s.d0, s.d1);
+    SeqRec nxt;
+    nxt.dirty = 1; nxt.e = 0; nxt.d0 = nxt.d1 = 0;
+    if ((unsigned)lane < ntile) nxt = Q.tiles[lane];
+    for (unsigned t0 = 0; t0 < ntile; t0 += 64) {
+        SeqRec r = nxt;
+        if (t0 + 64 + lane < ntile) nxt = Q.tiles[t0 + 64 + lane];          // in flight while this batch is consumed
+        const int n_here = (ntile - t0) < 64u ? (int)(ntile - t0) : 64;
+        // sub-tile records of the first four dirty tiles of the batch, fetched now (16 lanes each) so that their latency
+        // overlaps the clean runs before them
+        const unsigned long long dirty_mask = __ballot(lane < n_here && r.dirty != 0);
+        SeqRec pre;
+        pre.dirty = 1; pre.e = 0; pre.d0 = pre.d1 = 0;
+        {
+            unsigned long long dm = dirty_mask;
+            const int grp = lane >> 4;
+            for (int k = 0; k < grp && dm; k++) dm &= dm - 1;
+            if (dm) { const unsigned tt = t0 + (unsigned)(__ffsll((long long)dm) - 1); pre = Q.subs[(size_t)tt * FR_SUBS_PER_TILE + (lane & 15)]; }
+        }
+        int pos = 0, n_dirty_seen = 0;
+        while (pos < n_here) {
+            const int e0 = __builtin_amdgcn_readlane(r.e, pos);
+            const unsigned dflag = (unsigned)__builtin_amdgcn_readlane((int)r.dirty, pos);
+            const unsigned t = t0 + pos;
+            if (dflag) {
+                // tile t may straddle a power of two: walk its sub-tiles (records fetched by lanes 0..15 at once)
+                SeqRec sr;
+                int src0 = 0;           // lane holding sub-tile 0's record
+                if (n_dirty_seen < 4) { sr = pre; src0 = 16 * n_dirty_seen; }
                 else {
-                    size_t e_hi = e_lo + 64 < n ? e_lo + 64 : n;
-                    double mine_a = (e_lo + lane < e_hi) ? acc.get(e_lo + lane) : 0.0;
-                    for (int k = 0; k < 64; k++) { double ak = __shfl(mine_a, k); carry = carry + ak; }
+                    sr.dirty = 1; sr.e = 0; sr.d0 = sr.d1 = 0;
+                    if (lane < FR_SUBS_PER_TILE) sr = Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane];
                 }
+                n_dirty_seen++;
+                if (lane == 0) Q.tiles[t].carry = carry;
+                for (int j = 0; j < FR_SUBS_PER_TILE; j++) {
+                    const size_t sidx = (size_t)t * FR_SUBS_PER_TILE + j;
+                    const size_t e_lo = (size_t)t * FR_SEQ_TILE + (size_t)j * 64;
+                    if (lane == 0) Q.subs[sidx].carry = carry;
+                    if (e_lo >= n) continue;
+                    const unsigned sd = (unsigned)__builtin_amdgcn_readlane((int)sr.dirty, src0 + j);
+                    if (!sd) {
+                        const int se = __builtin_amdgcn_readlane(sr.e, src0 + j);
+                        carry = fr_seq_apply_map(carry, se, fr_bcast_i64(sr.d0, src0 + j), fr_bcast_i64(sr.d1, src0 + j));
+                    }
+                    else {
+                        const size_t e_hi = e_lo + 64 < n ? e_lo + 64 : n;
+                        const double mine_a = (e_lo + lane < e_hi) ? acc.get(e_lo + lane) : 0.0;
+#pragma unroll
+                        for (int k = 0; k < 64; k++) carry = carry + fr_bcast_f64(mine_a, k);
+                    }
+                }
+                pos++;
+                continue;
             }
-            t++;
-            continue;
+            // run of clean tiles in binade e0 starting at lane `pos`
+            const unsigned long long ok = __ballot(lane >= pos && lane < n_here && !r.dirty && r.e == e0);
+            const unsigned long long sh = ok >> pos;
+            int run = (~sh == 0ull) ? 64 : (__ffsll((long long)~sh) - 1);        // lanes pos .. pos+run-1 (run >= 1)
+            PMap m; m.d0 = r.d0; m.d1 = r.d1;
+            if (lane < pos || lane >= pos + run) m = fr_pm_id();
+            PMap ex;                                                             // exclusive map of my tile
+            if (!__any(m.d0 != m.d1)) {
+                // no exact tie anywhere in the run: every map is "add d", composition is integer addition
+                const long long own = m.d0;
+                const long long inc = fr_wave_incl_i64(own);
+                m.d0 = m.d1 = inc;
+                ex.d0 = ex.d1 = inc - own;
+            }
+            else {
+                for (int off = 1; off < 64; off <<= 1) {                         // inclusive ordered scan of maps over lanes
+                    PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
+                    if (lane >= off) m = fr_pm_compose(o, m);
+                }
+                ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
+                if (lane == 0 || lane == pos) ex = fr_pm_id();
+            }
+            if (lane >= pos && lane < pos + run) Q.tiles[t0 + lane].carry = fr_seq_apply_map(carry, e0, ex.d0, ex.d1);
+            const int last = pos + run - 1;
+            carry = fr_seq_apply_map(carry, e0, fr_bcast_i64(m.d0, last), fr_bcast_i64(m.d1, last));
+            pos += run;
         }
-        // run of clean tiles in binade e0 starting at t
-        unsigned long long ok = __ballot(have && !r.dirty && r.e == e0);
-        unsigned run = __ffsll((long long)~ok) - 1;       // lanes 0..run-1 form the run (run >= 1)
-        if (run > 64) run = 64;
-        PMap m; m.d0 = r.d0; m.d1 = r.d1;
-        if ((unsigned)lane >= run) m = fr_pm_id();
-        // inclusive ordered scan of maps over lanes
-        for (int off = 1; off < 64; off <<= 1) {
-            PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
-            if (lane >= off) m = fr_pm_compose(o, m);
-        }
-        // exclusive map for my tile = inclusive of the previous lane
-        PMap ex; ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
-        if (lane == 0) ex = fr_pm_id();
-        if ((unsigned)lane < run) Q.tiles[mine].carry = fr_seq_apply_map(carry, e0, ex.d0, ex.d1);
-        PMap last; last.d0 = __shfl(m.d0, (int)run - 1); last.d1 = __shfl(m.d1, (int)run - 1);
-        carry = fr_seq_apply_map(carry, e0, last.d0, last.d1);
-        t += run;
     }
     return carry;
 }

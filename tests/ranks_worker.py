@@ -30,7 +30,8 @@ def main():
     ndev = torch.cuda.device_count()
     dev = local % max(ndev, 1)
     torch.cuda.set_device(dev)
-    dist.init_process_group(backend)
+    import datetime
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180))     # a dead peer must surface as an error, not a hang
     man = golden_io.manifest()
     if name in man["mpi_runs"]:
         r = man["mpi_runs"][name]

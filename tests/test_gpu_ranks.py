@@ -14,6 +14,20 @@ import golden_io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run_ranks(cmd, env, timeout):
+    """Runs the launcher in its own process group and kills the whole group on timeout (a stuck rank must fail the
+    test, never hang it)."""
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail(f"ranks did not finish within {timeout} s\n" + out[-2000:] + err[-4000:])
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -30,7 +44,7 @@ def test_sharded_engine_matches_reference_ranks(name, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "gloo", str(tmp_path)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = _run_ranks(cmd, env, 300)
     reports = []
     for k in range(P):
         fn = tmp_path / f"rank{k}.json"
@@ -49,7 +63,7 @@ def test_one_rank_communicator_over_rccl(tmp_path):
     name = "n2_m10000_unnorm_ini0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "nccl", str(tmp_path)]
-    res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    res = _run_ranks(cmd, dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), 300)
     fn = tmp_path / "rank0.json"
     assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
     rep = json.loads(fn.read_text())
