@@ -67,6 +67,7 @@ struct CompWork {
     Teeth *teeth;
     uint32_t *fix_list;           // elements with a tooth backlog (rare)
     SeqWork seq;                  // exact in-order sum of wt_remain
+    double row1[2];               // stage-1 sub-weights (fr_row1)
 };
 
 // wt_remain of the current stage as the addend sequence of sys_sub's lbound (compress_utils.cpp:739)
@@ -142,7 +143,7 @@ __device__ __forceinline__ RowInfo fr_row_setup(const HbTables &T, det_t det, ui
 
 template <int STAGE, bool NEW_HB, class F>
 __device__ __forceinline__ void fr_row_visit(const HbTables &T, det_t det, uint32_t code, const RowInfo &ri, double p_doub, F f) {
-    if (STAGE == 1) { f(0u, p_doub); f(1u, 1 - p_doub); }
+    if (STAGE == 1) { f(0u, ri.inv_norm); f(1u, ri.tot); }        // the two first-level weights travel in the RowInfo (fr_row1)
     else if (STAGE == 2) fr_row2_visit<NEW_HB>(T, det, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
     else if (STAGE == 3) {
         if (NEW_HB) fr_row3h_visit(T, det, fr_c(code, 1), ri.aux, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
@@ -151,6 +152,10 @@ __device__ __forceinline__ void fr_row_visit(const HbTables &T, det_t det, uint3
     else if (STAGE == 4) fr_row4_visit(T, det, ri.aux & 0xffu, (ri.aux & 0x100u) != 0, [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
     else fr_row5_visit<NEW_HB>(T, det, ri.aux & 0xffu, (ri.aux >> 8) & 0xffu, fr_c(code, 3), [&](unsigned s, double w) { f(s, w * ri.inv_norm); });
 }
+
+// Stage 1 has one row for every element: {p_doub, 1 - p_doub} for molecules (heat_bathPP.cpp:714-727), {t, g} for
+// Hubbard-Holstein (frisys_hh.cpp:191-194)
+__device__ __forceinline__ RowInfo fr_row1(const double w[2]) { RowInfo r; r.inv_norm = w[0]; r.tot = w[1]; r.nsub = 2; r.aux = 0; return r; }
 
 // RowInfo of a stored element: the prep kernel cached what the visit needs
 __device__ __forceinline__ RowInfo fr_row_cached(const StageElems &E, size_t e) {
@@ -206,7 +211,7 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const VecD
             double sub_lbound = lbound - wr;
             uint32_t code = STAGE == 1 ? 0u : E.code[e];
             det_t det = STAGE == 1 ? 0ull : V.dets[E.pos[e]];
-            RowInfo ri = fr_row_cached(E, e);
+            RowInfo ri = STAGE == 1 ? fr_row1(W.row1) : fr_row_cached(E, e);
             unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
             fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
                 if (s >= n_sub) return;

@@ -302,6 +302,7 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     FR_LAUNCH(c, "k_sc_apply", k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, kin);
     FR_LAUNCH(c, "k_sc_fixup", k_sc_fixup, dim3(1), dim3(1), c->vec, B, kin, c->d_err);
     FR_LAUNCH(c, "k_sc_write", k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, kin);
+    if (c->hh_keep0) fr_hh_clear_pos0(c);        // frisys_hh.cpp:356
     fr_vec_delete_flagged(c, &c->vec, B.del, bound);
 }
 

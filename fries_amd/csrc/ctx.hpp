@@ -4,6 +4,7 @@
 #include "fries_dev.hpp"
 #include "comp_kernels.hpp"
 #include "fks2.hpp"
+#include "../../include/fries_hip.h"
 #include <string>
 #include <vector>
 #include <random>
@@ -94,6 +95,11 @@ struct FriesCtx {
     uint32_t *d_proc_scr = nullptr;          // proc_hash_ scrambler on the device
     void *own_small = nullptr;               // size == 1: engine-owned small_send
     double *d_norms_keep = nullptr, *d_seq_scratch = nullptr;
+    // Hubbard-Holstein driver (hh.hip)
+    bool hh_mode = false, hh_keep0 = false;
+    fries_hh_params hh{};
+    uint32_t *d_vec_scr = nullptr;
+    det_t *hh_fdet = nullptr; double *hh_ovlp = nullptr;
     uint32_t adder_cap = 0;                  // the reference's Adder capacity per destination (frisys_mol.cpp:109-110)
     uint64_t n_collectives = 0;
     // system
@@ -161,6 +167,12 @@ void fr_death_clone(FriesCtx *c, uint32_t vec_size_before);
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm);
 void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
+// hh.hip
+void fr_hh_setup(FriesCtx *c, const fries_hh_params *p);
+void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg);
+void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]);
+void fr_hh_clear_pos0(FriesCtx *c);
+int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 // system.hip
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);

@@ -90,10 +90,17 @@ const void *fr_allgather(FriesCtx *c, size_t bytes) {
 }
 
 // DistVec::idx_to_proc (vec_utils.hpp:360-379): hash_fxn over the occupied orbitals with the proc scrambler, mod n_procs
-static int host_idx_to_proc(const FriesCtx *c, det_t d) {
+int fr_host_idx_to_proc(const FriesCtx *c, det_t d) {
     if (c->n_ranks == 1) return 0;
     uint64_t hash = 0;
     uint32_t i = 0;
+    if (c->hh_mode) {       // HubHolVec::idx_to_proc (hh_vec.hpp:56-66): occupied orbitals, then every site's phonon number
+        const unsigned L = c->hh.n_sites;
+        for (det_t a = d & ((1ull << (2 * L)) - 1ull); a; a &= a - 1, i++)
+            hash = 1099511628211ULL * hash + (uint32_t)((i + 1u) * c->proc_scr[(unsigned)__builtin_ctzll(a)]);
+        for (unsigned s = 0; s < L; s++) hash = 1099511628211ULL * hash + (uint32_t)((s + 1u) * c->proc_scr[(d >> (2 * L + 3 * s)) & 7u]);
+        return (int)(hash % (uint64_t)c->n_ranks);
+    }
     while (d) {
         unsigned orb = (unsigned)__builtin_ctzll(d);
         d &= d - 1;
@@ -122,7 +129,7 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
     if (!c->d_proc_scr) c->d_proc_scr = fr_alloc<uint32_t>(64);
     FR_HIP(hipMemcpyAsync(c->d_proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size(), hipMemcpyHostToDevice, c->stream));
-    c->hf_proc = host_idx_to_proc(c, c->hf_det);
+    c->hf_proc = fr_host_idx_to_proc(c, c->hf_det);
     fr_vec_alloc(c, &c->vec, p->max_dets);
     fr_hbpp_alloc(c, wcap);
     fr_spawn_alloc(c, p->mat_nonz + 4096);
@@ -272,7 +279,7 @@ extern "C" int fries_idx_to_proc(fries_ctx *h, const uint64_t *dets, size_t n, i
     FR_API_BEGIN
     FriesCtx *c = &h->c;
     if (c->proc_scr.empty()) throw FriesError("fries_frisys_setup must be called first");
-    for (size_t i = 0; i < n; i++) proc[i] = host_idx_to_proc(c, dets[i]);
+    for (size_t i = 0; i < n; i++) proc[i] = fr_host_idx_to_proc(c, dets[i]);
     FR_API_END
 }
 
@@ -358,7 +365,25 @@ extern "C" int fries_frisys_setup(fries_ctx *h, const fries_frisys_params *p) {
 extern "C" int fries_frisys_iterate(fries_ctx *h, uint32_t n_iter, fries_iter_log *logs) {
     FR_API_BEGIN
     FR_HIP(hipSetDevice(h->c.device));
+    if (h->c.hh_mode) throw FriesError("this context runs frisys_hh: use fries_hh_iterate");
     for (uint32_t i = 0; i < n_iter; i++) frisys_iterate(&h->c, logs ? &logs[i] : nullptr);
+    check_dev_err(&h->c);
+    FR_API_END
+}
+
+extern "C" int fries_hh_setup(fries_ctx *h, const fries_hh_params *p) {
+    FR_API_BEGIN
+    FR_HIP(hipSetDevice(h->c.device));
+    if (h->c.vec.dets) throw FriesError("this context already holds a run");
+    fr_hh_setup(&h->c, p);
+    check_dev_err(&h->c);
+    FR_API_END
+}
+extern "C" int fries_hh_iterate(fries_ctx *h, uint32_t n_iter, fries_iter_log *logs) {
+    FR_API_BEGIN
+    FR_HIP(hipSetDevice(h->c.device));
+    if (!h->c.hh_mode) throw FriesError("fries_hh_setup must be called first");
+    for (uint32_t i = 0; i < n_iter; i++) fr_hh_iterate(&h->c, logs ? &logs[i] : nullptr);
     check_dev_err(&h->c);
     FR_API_END
 }

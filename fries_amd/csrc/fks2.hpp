@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         uint32_t nd = live ? E.ndiv[e] : 1u;
         double wr = v;
         uint32_t kp = (final && live) ? W.keep[e] : 0u;
-        det_t det = 0; uint32_t code = 0; RowInfo ri; ri.inv_norm = 1; ri.aux = 0; ri.nsub = 2; ri.tot = 0;
+        det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
         if (STAGE != 1 && live && nd == 0 && v > 0) { code = E.code[e]; det = V.dets[E.pos[e]]; ri = fr_row_cached(E, e); }
         if (final) {
             double lastwf = 0;

@@ -63,7 +63,11 @@ struct VecDev {
     det_t *hkeys;           // open addressing, linear probing
     uint32_t *hvals;        // position; FR_NOPOS while empty; FR_NEWBIT|j while being created
     VecState *st;
+    // Hubbard-Holstein indices (hh_vec.hpp): electrons in the low 2 * hh_sites bits, 3 bits per phonon above them
+    uint32_t hh_sites, hh_nelec, hh_buckets;
+    const uint32_t *hh_scr;     // the reference's vec_hash_ scrambler (device)
 };
+#define FR_HH_PH_BITS 3
 
 enum { FR_ERR_CAP = 1, FR_ERR_SPAWN_CAP = 2, FR_ERR_NELEC = 4, FR_ERR_HASH_FULL = 8, FR_ERR_ROUNDS = 16, FR_ERR_BACKLOG = 32 };
 
@@ -247,9 +251,34 @@ __device__ __forceinline__ uint32_t fr_sum_partials_u32(const uint32_t *p, unsig
 }
 
 // ------------------------------------------------------------------ hash table
+// hash_fxn with phonon numbers (det_hash.hpp:160-170): occupied orbitals, then the phonon number of every site
+__device__ __forceinline__ unsigned long long fr_hh_hash(det_t d, const uint32_t *scr, uint32_t n_sites) {
+    unsigned long long hash = 0;
+    uint32_t i = 0;
+    for (det_t a = d & ((1ull << (2 * n_sites)) - 1ull); a; a &= a - 1, i++) {
+        unsigned orb = __ffsll((long long)a) - 1;
+        hash = 1099511628211ULL * hash + (uint32_t)((i + 1u) * scr[orb]);
+    }
+    for (uint32_t s = 0; s < n_sites; s++) {
+        uint32_t ph = (uint32_t)(d >> (2 * n_sites + FR_HH_PH_BITS * s)) & ((1u << FR_HH_PH_BITS) - 1u);
+        hash = 1099511628211ULL * hash + (uint32_t)((s + 1u) * scr[ph]);
+    }
+    return hash;
+}
+// What identifies a stored index.  Molecules: the determinant.  Hubbard-Holstein: what the reference's HashTable can tell
+// apart -- the bucket (hash % table size) and the first ceil(2 n_sites / 8) bytes (det_hash.hpp:47, :60-94): states with
+// the same electrons, different phonons and the same bucket share one entry there, and so they do here.
+__device__ __forceinline__ det_t fr_vec_key(const VecDev &v, det_t d) {
+    if (!v.hh_sites) return d;
+    unsigned long long bucket = fr_hh_hash(d, v.hh_scr, v.hh_sites) % v.hh_buckets;
+    unsigned key_bytes = (2 * v.hh_sites + 7) / 8;
+    det_t tmask = (1ull << (8 * key_bytes)) - 1ull;        // key_bytes <= 3
+    return (bucket << 24) | (d & tmask);
+}
 __device__ __forceinline__ uint32_t fr_hash_slot(det_t d, uint32_t hcap) { return (uint32_t)fr_mix64(d) & (hcap - 1); }
-// returns slot holding d or FR_NOPOS
-__device__ __forceinline__ uint32_t fr_hash_find(const VecDev &v, det_t d) {
+// returns the slot holding determinant dd's entry or FR_NOPOS
+__device__ __forceinline__ uint32_t fr_hash_find(const VecDev &v, det_t dd) {
+    const det_t d = fr_vec_key(v, dd);
     uint32_t s = fr_hash_slot(d, v.hcap);
     for (uint32_t probe = 0; probe < v.hcap; probe++) {
         det_t k = v.hkeys[s];

@@ -293,13 +293,54 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     if (fr_blocks(cap, FR_TILE) > FR_MAX_PART) throw FriesError("work capacity exceeds FR_MAX_PART tiles");
 }
 
+// Stage 2 of frisys_hh (frisys_hh.cpp:209-220): element e comes from emission e of stage 1; sub 0 = electron hop (uniform over
+// the possible hops), sub 1 = phonon move (uniform over 2 n_elec choices); the value is multiplied by the subdivision count.
+__global__ void __launch_bounds__(FR_BLOCK) k_prep_hh2(CompWork W, VecDev V, int cur, uint32_t n_samp) {
+    __shared__ double shd[12];
+    const unsigned n_in = W.state[FR_MAX_ROUNDS + 1].n_out;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CompState s{};
+        s.n_rem = n_samp; s.n_in = n_in; s.done = 0; s.pbuf = 0;
+        W.state[0] = s;
+    }
+    if (blockIdx.x >= nblk) return;
+    const StageElems E = W.el[cur], P = W.el[cur ^ 1];
+    const unsigned L = V.hh_sites;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;
+    double sum = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + (size_t)it * FR_BLOCK;
+        if (e >= n_in) break;
+        uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
+        double val = W.e_val[e];
+        uint32_t pos = P.pos[wi];
+        uint32_t ndiv;
+        if (sub) ndiv = 2 * V.hh_nelec;
+        else {
+            const det_t El = V.dets[pos] & ((1ull << (2 * L)) - 1ull);
+            det_t r0 = El & ~(El >> 1); r0 &= ~(1ull << (L - 1)); r0 &= ~(1ull << (2 * L - 1));      // hh_vec.hpp:139-175
+            det_t r1 = El & (~El << 1); r1 &= ~(1ull << L);
+            ndiv = (uint32_t)__popcll(r0) + (uint32_t)__popcll(r1);
+        }
+        val *= ndiv;
+        E.val[e] = val; E.pos[e] = pos; E.code[e] = sub; E.ndiv[e] = ndiv; E.nsub[e] = 0; E.rinv[e] = 1.0; E.raux[e] = 0;
+        W.wt_remain[e] = val; W.keep[e] = 0;
+        sum += val;
+    }
+    double bs;
+    fr_block_excl_f64(sum, shd, &bs);
+    if (threadIdx.x == 0) { W.psum[0][blockIdx.x] = bs; W.pcnt[0][blockIdx.x] = 0; }
+}
+
 template <int STAGE, bool NEW_HB>
-static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, double rn, uint32_t *n_out_host) {
+static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, double rn, uint32_t *n_out_host, bool hh_stage2 = false) {
     CompWork &W = c->W;
     hipStream_t st = c->stream;
     unsigned grid = fr_blocks(n_bound, FR_TILE);
     if (grid == 0) grid = 1;
     if (STAGE == 1) FR_LAUNCH(c, "k_prep1", k_prep1, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
+    else if (hh_stage2) FR_LAUNCH(c, "k_prep_hh2", k_prep_hh2, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
     else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
     Fks2Work F = c->F2;
     F.saved = c->fks_saved + STAGE; F.wk = c->fks_wk + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wg = c->fks_wg + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
@@ -431,4 +472,17 @@ void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]) {
 void fr_hbpp_apply_unit(FriesCtx *c, uint32_t n_samp, const double rn[5]) {
     if (c->new_hb) hbpp_apply_t<true>(c, n_samp, rn, 1);
     else hbpp_apply_t<false>(c, n_samp, rn, 1);
+}
+
+// frisys_hh.cpp:187-224: hop-vs-phonon (two sub-weights per element), then which hop / which phonon move (uniform)
+void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]) {
+    CompWork &W = c->W;
+    uint32_t bound1 = c->h_vst.curr_size;
+    uint32_t bound = n_samp + 64 < W.cap ? n_samp + 64 : W.cap;
+    if (bound1 > W.cap) throw FriesError("vector larger than the compression work capacity");
+    run_stage<1, true>(c, 0, bound1, n_samp, rn[0], &c->comp_len[0]);
+    if (c->use_comm) { FR_HIP(hipStreamSynchronize(c->stream)); uint32_t b = c->comp_len[0] + 64; if (b < bound) bound = b; }
+    run_stage<2, true>(c, 1, bound, n_samp, rn[1], &c->comp_len[1], true);
+    FR_HIP(hipStreamSynchronize(c->stream));
+    c->num_success = c->comp_len[1];
 }

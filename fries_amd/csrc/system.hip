@@ -254,6 +254,7 @@ void fr_h_trial_setup(FriesCtx *c) {
     uint32_t n_sing = 0, n_doub = 0;
     fr_h_apply_list(c, src, val, od, ov, &n_sing, &n_doub);
     c->p_doub = (double)n_doub / (n_sing + n_doub);        // frisys_mol.cpp:216-220
+    c->W.row1[0] = c->p_doub; c->W.row1[1] = 1 - c->p_doub;    // heat_bathPP.cpp:714-727
     c->n_trial = 1; c->n_htrial = (uint32_t)od.size();
     c->tr_det = fr_alloc<det_t>(1); c->tr_val = fr_alloc<double>(1);
     c->htr_det = fr_alloc<det_t>(od.size()); c->htr_val = fr_alloc<double>(od.size());

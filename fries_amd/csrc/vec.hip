@@ -56,10 +56,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
     const uint32_t n = *S.n_spawn;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    det_t d = S.det[j];
+    const det_t dd = S.det[j];
     bool ini = S.ini[j];
     if ((mode == 1 && !ini) || (mode == 2 && ini)) return;
-    if ((uint32_t)__popcll(d) != n_elec) { atomicOr(&V.st->err, FR_ERR_NELEC); S.slot[j] = FR_NOPOS; return; }
+    const det_t emask = V.hh_sites ? (1ull << (2 * V.hh_sites)) - 1ull : ~0ull;
+    if ((uint32_t)__popcll(dd & emask) != n_elec) { atomicOr(&V.st->err, FR_ERR_NELEC); S.slot[j] = FR_NOPOS; return; }
+    const det_t d = fr_vec_key(V, dd);
     uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS;
     bool created = false;
     for (uint32_t probe = 0; probe < V.hcap; probe++) {
@@ -382,7 +384,7 @@ __global__ void k_hash_reinsert(VecDev V) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { V.st->n_tomb = 0; V.st->n_used = (uint32_t)V.st->n_nonz; }
     if (i >= n || !V.active[i]) return;
-    det_t d = V.dets[i];
+    det_t d = fr_vec_key(V, V.dets[i]);
     uint32_t s = fr_hash_slot(d, V.hcap);
     for (uint32_t probe = 0; probe < V.hcap; probe++) {
         det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
@@ -425,7 +427,7 @@ __device__ __forceinline__ uint32_t fr_proc_of(det_t d, const uint32_t *scr, uin
 }
 
 // bucket = 2 * destination + initiator flag; counts per 256-element tile
-__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt) {
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt, uint32_t hh_sites) {
     __shared__ uint32_t wcnt[4][FR_XCH_MAXB];
     const uint32_t n = *S.n_spawn;
     const uint32_t nb = 2 * n_ranks;
@@ -433,7 +435,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_
     if (blockIdx.x >= ntile) return;
     uint32_t j = blockIdx.x * FR_BLOCK + threadIdx.x;
     uint32_t k = 0xFFu;
-    if (j < n) { k = 2 * fr_proc_of(S.det[j], scr, n_ranks) + (S.ini[j] ? 1u : 0u); key[j] = (uint8_t)k; }
+    if (j < n) {
+        uint32_t owner = hh_sites ? (uint32_t)(fr_hh_hash(S.det[j], scr, hh_sites) % n_ranks) : fr_proc_of(S.det[j], scr, n_ranks);
+        k = 2 * owner + (S.ini[j] ? 1u : 0u); key[j] = (uint8_t)k;
+    }
     const int w = threadIdx.x >> 6;
     for (uint32_t b = 0; b < nb; b++) {
         unsigned long long m = __ballot(k == b);
@@ -532,7 +537,7 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local) {
     unsigned g = fr_blocks(n_local ? n_local : 1, FR_BLOCK);
     uint32_t cap_recs = (uint32_t)(c->comm.big_bytes / sizeof(XchRec));
     if (n_local == 0) FR_HIP(hipMemsetAsync(S.n_spawn, 0, 4, st));
-    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt);
+    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites);
     FR_LAUNCH(c, "k_xch_scan", k_xch_scan, dim3(1), dim3(FR_BLOCK), S, (uint32_t)P, S.xcnt, S.xoff, S.xbucket, (uint32_t *)c->comm.small_send);
     FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err);
     const uint32_t *all = (const uint32_t *)fr_allgather(c, nb * 4);

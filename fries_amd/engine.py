@@ -22,7 +22,7 @@ EXPORTS = [
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
-    "fries_set_comm", "fries_stream", "fries_idx_to_proc",
+    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate",
 ]
 
 
@@ -30,6 +30,13 @@ class FrisysParams(C.Structure):
     _fields_ = [("epsilon", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double),
                 ("vec_nonz", C.c_uint32), ("mat_nonz", C.c_uint32), ("max_dets", C.c_uint32),
                 ("seed", C.c_uint32), ("hb_unnorm", C.c_int32)]
+
+
+class HHParams(C.Structure):
+    """struct fries_hh_params"""
+    _fields_ = [("n_elec", C.c_uint32), ("n_sites", C.c_uint32), ("eps", C.c_double), ("U", C.c_double), ("omega", C.c_double), ("g", C.c_double),
+                ("gs_energy", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double), ("vec_nonz", C.c_uint32), ("max_dets", C.c_uint32),
+                ("seed", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class IterLog(C.Structure):
@@ -83,6 +90,8 @@ def load_library() -> C.CDLL:
     lib.fries_prof_count.argtypes = [C.c_void_p]
     lib.fries_prof_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fries_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
+    lib.fries_hh_setup.argtypes = [C.c_void_p, C.POINTER(HHParams)]
+    lib.fries_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]
     lib.fries_stream.restype = C.c_void_p
     lib.fries_stream.argtypes = [C.c_void_p]
@@ -106,10 +115,11 @@ class FriEngine:
         self.h = C.c_void_p()
         self._ck(self.lib.fries_ctx_create(C.byref(self.h), device))
         self.mol = mol
-        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
-        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
-        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
-        self._ck(self.lib.fries_set_molecule(self.h, mol.n_orb, mol.n_elec, _ptr(irr), _ptr(hc), _ptr(er)))
+        if mol is not None:         # mol=None: a lattice-model run (setup_hh) needs no integrals
+            irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+            hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+            er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+            self._ck(self.lib.fries_set_molecule(self.h, mol.n_orb, mol.n_elec, _ptr(irr), _ptr(hc), _ptr(er)))
         self.max_dets = 0
         self.comm = comm
         if comm is not None:
@@ -171,6 +181,18 @@ class FriEngine:
         p = FrisysParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
         self._ck(self.lib.fries_frisys_setup(self.h, C.byref(p)))
         self.max_dets = max_dets
+
+    # ---- frisys_hh
+    def setup_hh(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0):
+        """frisys_hh (FRIES_bin/frisys_hh.cpp): 1-D Hubbard-Holstein chain, open boundaries, t = 1, start from 100 x Neel."""
+        p = HHParams(n_elec, n_sites, eps, U, omega, g, gs_energy, target_norm, initiator, vec_nonz, max_dets, seed, 0)
+        self._ck(self.lib.fries_hh_setup(self.h, C.byref(p)))
+        self.max_dets = max_dets
+
+    def iterate_hh(self, n_iter: int, want_logs: bool = True):
+        logs = np.zeros(n_iter, dtype=ITERLOG_DTYPE) if want_logs else None
+        self._ck(self.lib.fries_hh_iterate(self.h, n_iter, _ptr(logs) if want_logs else None))
+        return logs
 
     def idx_to_proc(self, dets) -> np.ndarray:
         """DistVec::idx_to_proc: the rank that owns each determinant."""

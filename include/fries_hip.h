@@ -109,6 +109,21 @@ int fries_frisys_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
 double fries_p_doub(fries_ctx *ctx);
 uint64_t fries_kernel_launches(fries_ctx *ctx);
 
+/* ---- frisys_hh: FRI with systematic matrix compression for the 1-D Hubbard-Holstein model (FRIES_bin/frisys_hh.cpp),
+ * open boundaries, hopping t = 1, 3 bits per phonon (:96).  Parameters are those of the reference's params file
+ * (parse_hh_input, FRIES/io_utils.cpp:320-405: n_elec, lat_len, eps, U, omega, g, gs_energy) and command line (:15-23),
+ * plus the seed.  Index = [alpha sites | beta sites | 3 bits per site] in one uint64_t (FRIES/hh_vec.hpp), n_sites <= 12.
+ * Start: 100 x the Neel state (:113-117).  Logs: numer / denom are what projnum.txt / projden.txt receive on the rank that
+ * owns the Neel state (:338-347) and 0 elsewhere; num_success = samples after the second compression.
+ * Shares the vector accessors, fries_set_comm and fries_frisys_restart with frisys_mol. */
+typedef struct {
+    uint32_t n_elec, n_sites;
+    double eps, U, omega, g, gs_energy, target_norm, initiator;
+    uint32_t vec_nonz, max_dets, seed, pad;
+} fries_hh_params;
+int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
+int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
+
 /* DistVec accessors (FRIES/vec_utils.hpp:506-535): positions [0, curr_size) incl. holes (value 0) */
 int fries_vec_info(fries_ctx *ctx, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free);
 int fries_vec_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);

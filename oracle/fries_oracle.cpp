@@ -853,10 +853,26 @@ void Vec::init(size_t size, size_t add_size, unsigned n_el, unsigned nv, const C
     add_det.assign(cm.size, {}); add_val.assign(cm.size, {}); add_ini.assign(cm.size, {});
 }
 
+det_t Vec::key_of(det_t det) const {
+    if (!hh_sites) return det;
+    uint8_t o[64], ph[64];
+    occ_list(det & elec_mask(), o);
+    decode_phonons(det, hh_sites, hh_ph_bits, ph);
+    uint64_t bucket = hash_fxn_hh(o, n_elec, ph, hh_sites, vec_scr) % (uint64_t)n_buckets;
+    unsigned key_bytes = (2 * hh_sites + 7) / 8;
+    det_t tmask = key_bytes >= 8 ? ~(det_t)0 : (((det_t)1 << (8 * key_bytes)) - 1);
+    return (bucket << 24) | (det & tmask);
+}
+
 int Vec::idx_to_proc(det_t det) const {
     if (cm.size == 1) return 0;
     uint8_t o[64];
-    unsigned n = (unsigned)occ_list(det, o);
+    unsigned n = (unsigned)occ_list(det & elec_mask(), o);
+    if (hh_sites) {         // HubHolVec::idx_to_proc, hh_vec.hpp:56-66
+        uint8_t ph[64];
+        decode_phonons(det, hh_sites, hh_ph_bits, ph);
+        return (int)(hash_fxn_hh(o, n_elec, ph, hh_sites, proc_scr) % (uint64_t)cm.size);
+    }
     return (int)(hash_fxn(o, n, proc_scr) % (uint64_t)cm.size);
 }
 
@@ -911,11 +927,12 @@ void Vec::perform_add(size_t origin) {
     for (size_t e = 0; e < rdet.size(); e++) {
         det_t d = rdet[e];
         int ini = rini[e];
-        if ((unsigned)occ_list(d, tmp_occ) != n_elec) throw std::runtime_error("Determinant created with an incorrect number of electrons");
+        if ((unsigned)occ_list(d & elec_mask(), tmp_occ) != n_elec) throw std::runtime_error("Determinant created with an incorrect number of electrons");
         ptrdiff_t *ptr = nullptr;
-        auto it = table.find(d);
+        const det_t key = key_of(d);
+        auto it = table.find(key);
         if (it != table.end()) ptr = &it->second;
-        else if (ini) ptr = &table.emplace(d, (ptrdiff_t)-1).first->second;
+        else if (ini) ptr = &table.emplace(key, (ptrdiff_t)-1).first->second;
         if (ptr && *ptr == -1) {
             if (!free_stack.empty()) { *ptr = (ptrdiff_t)free_stack.back(); free_stack.pop_back(); }
             else {
@@ -948,7 +965,7 @@ void Vec::del_at_pos(size_t pos) {
     for (unsigned v = 0; v < n_vecs; v++) if (vals[v][pos] != 0) all_zero = false;
     if (all_zero) {
         free_stack.push_back(pos);
-        table.erase(dets[pos]);
+        table.erase(key_of(dets[pos]));
         n_nonz--;
         active[pos] = 0;
     }
@@ -963,7 +980,7 @@ double Vec::local_norm() const {
 double Vec::dot(const std::vector<det_t> &d2, const std::vector<double> &v2) const {
     double numer = 0;
     for (size_t k = 0; k < d2.size(); k++) {
-        auto it = table.find(d2[k]);
+        auto it = table.find(key_of(d2[k]));
         if (it != table.end()) numer += v2[k] * vals[cur][(size_t)it->second];
     }
     return numer;
@@ -1348,6 +1365,250 @@ void Frisys::iterate(unsigned n_iter) {
         sys_comp(sol.vals[0].data(), sol.curr_size, loc_norms.data(), n_samp, keep, rn_sys, cm);
         for (size_t i = 0; i < sol.curr_size; i++) {
             if (keep[i]) { sol.del_at_pos(i); keep[i] = 0; }
+        }
+        lg.n_nonz = sol.n_nonz; lg.curr_size = sol.curr_size;
+        log.push_back(lg);
+    }
+}
+
+
+// ------------------------------------------------------------------ Hubbard-Holstein
+uint64_t hash_fxn_hh(const uint8_t *occ, unsigned n_elec, const uint8_t *ph, unsigned n_sites, const uint32_t *scr) {
+    uint64_t hash = 0;
+    for (unsigned i = 0; i < n_elec; i++) hash = 1099511628211ULL * hash + (uint32_t)((i + 1) * scr[occ[i]]);
+    for (unsigned i = 0; i < n_sites; i++) hash = 1099511628211ULL * hash + (uint32_t)((i + 1) * scr[ph[i]]);
+    return hash;
+}
+
+unsigned hub_diag(det_t det, unsigned L) {          // doubly occupied sites
+    det_t m = ((det_t)1 << L) - 1;
+    return (unsigned)__builtin_popcountll(det & (det >> L) & m);
+}
+
+det_t gen_neel_det_1D(unsigned L, unsigned n_elec) {
+    // alpha electrons on the even sites 0, 2, ..., beta electrons on the odd sites 1, 3, ... (n_elec / 2 of each); no phonons
+    det_t d = 0;
+    for (unsigned k = 0; k < n_elec / 2; k++) { d |= (det_t)1 << (2 * k); d |= (det_t)1 << (L + 2 * k + 1); }
+    return d;
+}
+
+void find_neighbors_1D(det_t det, unsigned L, unsigned n_elec, uint8_t *nb) {
+    const det_t E = det & (((det_t)1 << (2 * L)) - 1);
+    // row 0: occupied orbitals whose right neighbour (orbital + 1) is empty; the last site of each spin chain cannot hop right
+    det_t r0 = E & ~(E >> 1);
+    r0 &= ~((det_t)1 << (L - 1)); r0 &= ~((det_t)1 << (2 * L - 1));
+    // row 1: occupied orbitals whose left neighbour (orbital - 1) is empty; site 0 of each chain cannot hop left
+    det_t r1 = E & (~E << 1);
+    r1 &= ~((det_t)1 << L);
+    nb[0] = (uint8_t)occ_list(r0, nb + 1);
+    nb[n_elec + 1] = (uint8_t)occ_list(r1, nb + n_elec + 2);
+}
+
+void decode_phonons(det_t det, unsigned L, unsigned ph_bits, uint8_t *numbers) {
+    for (unsigned s = 0; s < L; s++) numbers[s] = (uint8_t)((det >> (2 * L + s * ph_bits)) & (((det_t)1 << ph_bits) - 1));
+}
+
+bool det_from_ph(det_t det, det_t *out, unsigned L, unsigned ph_bits, unsigned site, int change) {
+    unsigned sh = 2 * L + site * ph_bits;
+    det_t mask = (((det_t)1 << ph_bits) - 1) << sh;
+    unsigned num = (unsigned)((det & mask) >> sh);
+    if (change == 1 && num == (1u << ph_bits) - 1) return false;
+    if (change == -1 && num == 0) return false;
+    num += change;
+    *out = (det & ~mask) | ((det_t)num << sh);
+    return true;
+}
+
+// hub_holstein.hpp:93-186 restated on one 64-bit word.  The reference walks the electron part byte by byte; two of its
+// byte-level details are behaviour and are kept: (1) "the orbital to my right is empty" is taken as true for bit 7 of
+// every byte (integer promotion of ~byte >> 1, :150), (2) the open-boundary mask is applied to byte ceil(L / 8) (:165-167).
+double calc_ref_ovlp(const det_t *dets, const double *vals, size_t n, det_t ref, unsigned n_elec, unsigned L, unsigned ph_bits, double g_over_t) {
+    double result = 0;
+    const unsigned nbytes = (2 * L + 7) / 8;
+    const det_t emask = ((det_t)1 << (2 * L)) - 1;
+    const det_t byte_mask = nbytes >= 8 ? ~(det_t)0 : (((det_t)1 << (8 * nbytes)) - 1);
+    for (size_t i = 0; i < n; i++) {
+        det_t cur = dets[i];
+        uint8_t ph[64];
+        decode_phonons(cur, L, ph_bits, ph);
+        if (((cur ^ ref) & emask) == 0) {
+            unsigned found = 0, site_elecs = 0;
+            for (unsigned s = 0; s < L && found < 2; s++) {
+                unsigned n_occ = (unsigned)((ref >> s) & 1) + (unsigned)((ref >> (s + L)) & 1);
+                if (ph[s] > 1 || (ph[s] == 1 && n_occ == 0)) { site_elecs = 0; break; }
+                else if (ph[s] == 1) { site_elecs = n_occ; found++; }
+            }
+            if (found == 2) site_elecs = 0;
+            result -= vals[i] * g_over_t * site_elecs;
+        }
+        else {
+            unsigned num_ph = 0;
+            for (unsigned s = 0; s < L; s++) num_ph += ph[s];
+            if (num_ph != 0) continue;
+            // the reference compares whole bytes, so phonon bits sharing the last electron byte take part (they are zero here)
+            det_t c = cur & byte_mask, r = ref & byte_mask;
+            det_t not_occ = c & ~r;
+            det_t ref_left = c & (r >> 1);
+            det_t not_occ_left = ((~c & byte_mask) >> 1) | 0x8080808080808080ULL;
+            det_t ref_right = c & (r << 1);
+            det_t not_occ_right = (~c << 1);
+            // last byte: nothing chains in from a following byte for ref_left (zero), handled by byte_mask above
+            unsigned ob = (L + 7) / 8;       // byte the open-boundary mask lands in
+            if (ob < nbytes) ref_left &= ~((det_t)1 << (8 * ob + (L - 1) % 8));
+            det_t mask = not_occ & ((ref_left & not_occ_left) | (ref_right & not_occ_right)) & byte_mask;
+            if ((2 * L) % 8 != 0) mask &= ~(((det_t)0xff << (8 * (nbytes - 1))) & ~emask);      // last byte keeps only electron bits
+            // the reference stops at the first byte that brings n_hop above 1, before counting that byte's common bits
+            unsigned n_hop = 0, n_common = 0;
+            for (unsigned b = 0; b < nbytes && n_hop <= 1; b++) {
+                n_hop += (unsigned)__builtin_popcountll((mask >> (8 * b)) & 0xff);
+                if (n_hop > 1) break;
+                n_common += (unsigned)__builtin_popcountll(((r & c) >> (8 * b)) & 0xff);
+            }
+            if (n_hop == 1 && n_common == n_elec - 1) result += vals[i];
+        }
+    }
+    return result;
+}
+
+void FrisysHH::setup() {
+    const unsigned L = par.n_sites, n_elec = par.n_elec;
+    mt.seed(par.seed);
+    proc_scr.resize(2 * L); vec_scr.resize(2 * L);
+    for (auto &x : proc_scr) x = mt();     // frisys_hh.cpp:80-83
+    for (auto &x : vec_scr) x = mt();      // :88-91
+    unsigned spawn_length = par.vec_nonz * 4 / cm.size;     // :94
+    sol.hh_sites = L; sol.hh_ph_bits = par.ph_bits; sol.vec_scr = vec_scr.data(); sol.n_buckets = par.max_dets;
+    sol.init(par.max_dets, spawn_length, n_elec, 2, cm, proc_scr.data());      // the Adder gets spawn_length here (:100), not adder_size
+    neel = gen_neel_det_1D(L, n_elec);
+    ref_proc = sol.idx_to_proc(neel);
+    if (ref_proc == cm.rank) sol.add(neel, 100, 1);       // :113-117
+    sol.perform_add(0);
+    comp1.assign(spawn_length, 0); comp2.assign(spawn_length, 0); wt_remain.assign(spawn_length, 0);
+    ndiv.assign(spawn_length, 0); comp_idx.assign(2 * (size_t)spawn_length, 0); det_indices.assign(spawn_length, 0); ph_ex.assign(spawn_length, 0);
+    sw.cols = 2; sw.w.assign((size_t)spawn_length * 2, 0); sw.keep.assign(spawn_length, 0);
+    srt.assign(sol.max_size, 0); keep.assign(sol.max_size, 0);
+    en_shift = 0; last_one_norm = 0; iterat = 0;
+}
+
+void FrisysHH::iterate(unsigned n_iter) {
+    const unsigned L = par.n_sites, n_elec = par.n_elec;
+    const double hub_t = 1, eps = par.eps;
+    const unsigned shift_interval = 10;
+    const double shift_damping = 0.05;
+    size_t (*cidx)[2] = (size_t (*)[2])comp_idx.data();
+    uint8_t nb[2 * 65];
+    for (unsigned it = 0; it < n_iter; it++, iterat++) {
+        HHLog lg{};
+        // :187-204 electron hop vs phonon
+        for (size_t i = 0; i < sol.curr_size; i++) {
+            double w = fabs(sol.vals[0][i]);
+            comp1[i] = w;
+            if (w > 0) { sw.row(i)[0] = hub_t; sw.row(i)[1] = par.g; ndiv[i] = 0; }
+            else ndiv[i] = 1;
+        }
+        double rn = mt() / (1. + UINT32_MAX);
+        size_t comp_len = comp_sub(comp1.data(), sol.curr_size, ndiv.data(), sw, nullptr, par.vec_nonz, wt_remain.data(), rn, comp2.data(), cidx, cm);
+        // :209-220 which hop / which phonon move
+        for (size_t s = 0; s < comp_len; s++) {
+            size_t d = cidx[s][0];
+            det_indices[s] = d;
+            ph_ex[s] = (uint8_t)cidx[s][1];
+            if (ph_ex[s]) ndiv[s] = 2 * n_elec;
+            else { find_neighbors_1D(sol.dets[d], L, n_elec, nb); ndiv[s] = nb[0] + nb[n_elec + 1]; }
+            comp2[s] *= ndiv[s];
+        }
+        rn = mt() / (1. + UINT32_MAX);
+        comp_len = comp_sub(comp2.data(), comp_len, ndiv.data(), sw, nullptr, par.vec_nonz, wt_remain.data(), rn, comp1.data(), cidx, cm);
+        lg.num_success = comp_len;
+
+        std::vector<double> &before = sol.vals[0];
+        sol.cur = 1;
+        sol.zero_cur();
+        size_t vec_size = sol.curr_size;
+        for (int add_ini = 0; add_ini < 2; add_ini++) {       // :233-300
+            int num_added = 1;
+            size_t s = 0;
+            while (num_added > 0) {
+                num_added = 0;
+                while (s < comp_len) {
+                    size_t prev = cidx[s][0];
+                    size_t d = det_indices[prev];
+                    double cv = before[d];
+                    uint8_t ini = fabs(cv) >= par.init_thresh;
+                    if (ini != add_ini) { s++; continue; }
+                    unsigned exc = (unsigned)(cidx[s][1] & 0xff);
+                    det_t cur = sol.dets[d], nd = cur;
+                    double el = comp1[s] * -eps;
+                    if (cv < 0) el *= -1;
+                    if (ph_ex[prev]) {
+                        uint8_t ph[64];
+                        decode_phonons(cur, L, par.ph_bits, ph);
+                        const uint8_t *occ = sol.orbs_at(d);
+                        unsigned site = occ[exc % n_elec] % L;
+                        unsigned pn = ph[site];
+                        if (exc < n_elec && pn > 0) { det_from_ph(cur, &nd, L, par.ph_bits, site, -1); el *= sqrt((double)pn); }
+                        else if (exc >= n_elec && pn + 1 < (1u << par.ph_bits)) { det_from_ph(cur, &nd, L, par.ph_bits, site, +1); el *= sqrt((double)(pn + 1)); }
+                        else el = 0;
+                    }
+                    else {
+                        find_neighbors_1D(cur, L, n_elec, nb);
+                        unsigned orig, dest;
+                        if (exc < nb[0]) { orig = nb[exc + 1]; dest = orig + 1; }
+                        else { orig = nb[n_elec + 1 + exc - nb[0] + 1]; dest = orig - 1; }
+                        nd = (cur & ~((det_t)1 << orig)) | ((det_t)1 << dest);
+                        el *= -1;      // hub_t
+                    }
+                    s++;
+                    if (fabs(el) > 1e-9) {
+                        num_added++;
+                        if (!sol.add(nd, el, ini)) break;
+                    }
+                }
+                sol.perform_add(0);
+                num_added = cm.sum(num_added);
+            }
+        }
+        if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
+        // diagonal :311-320
+        sol.cur = 0;
+        for (size_t i = 0; i < vec_size; i++) {
+            double &cv = sol.vals[0][i];
+            if (cv != 0) {
+                if (std::isnan(sol.diag[i])) sol.diag[i] = hub_diag(sol.dets[i], L);
+                uint8_t ph[64];
+                decode_phonons(sol.dets[i], L, par.ph_bits, ph);
+                unsigned tot = 0;
+                for (unsigned k = 0; k < L; k++) tot += ph[k];
+                double phonon_diag = tot * par.omega;
+                cv *= 1 - eps * (sol.diag[i] * par.U + phonon_diag - par.hf_en - en_shift);
+            }
+        }
+        sol.add_vecs(0, 1);
+        // compression :323-361
+        unsigned n_samp = par.vec_nonz;
+        double glob_norm;
+        std::vector<double> loc_norms(cm.size);
+        double mine = find_preserve(sol.vals[0].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm, cm);
+        lg.nkept = par.vec_nonz - n_samp;
+        if ((iterat + 1) % shift_interval == 0)
+            adjust_shift(&en_shift, glob_norm, &last_one_norm, par.target_norm, shift_damping / shift_interval / eps);
+        double numer = calc_ref_ovlp(sol.dets.data(), sol.vals[0].data(), sol.curr_size, neel, n_elec, L, par.ph_bits, par.g / hub_t);
+        std::vector<double> recv(cm.size);
+        cm.allgather(&numer, recv.data(), sizeof(double));      // MPI_Gather to ref_proc (:337)
+        lg.numer = 0; lg.denom = 0;
+        if (cm.rank == ref_proc) {
+            if (std::isnan(sol.diag[0])) sol.diag[0] = hub_diag(sol.dets[0], L);
+            double ref_el = sol.vals[0][0];
+            double nu = (sol.diag[0] * par.U - par.hf_en) * ref_el;
+            for (int p = 0; p < cm.size; p++) nu += recv[p] * -hub_t;
+            lg.numer = nu; lg.denom = ref_el;
+        }
+        lg.shift = en_shift; lg.norm = glob_norm;
+        double rn_sys = mt() / (1. + UINT32_MAX);
+        cm.allgather(&mine, loc_norms.data(), sizeof(double));
+        sys_comp(sol.vals[0].data(), sol.curr_size, loc_norms.data(), n_samp, keep, rn_sys, cm);
+        for (size_t i = 0; i < sol.curr_size; i++) {
+            if (keep[i] && !(cm.rank == 0 && i == 0)) { sol.del_at_pos(i); keep[i] = 0; }      // :356 (rank 0, not ref_proc)
         }
         lg.n_nonz = sol.n_nonz; lg.curr_size = sol.curr_size;
         log.push_back(lg);

@@ -180,6 +180,16 @@ struct Vec {
     std::vector<std::vector<det_t>> add_det; std::vector<std::vector<double>> add_val; std::vector<std::vector<uint8_t>> add_ini;
     Comm cm;                                 // ranks this vector is sharded over
     const uint32_t *proc_scr = nullptr;      // proc_hash_ scrambler (vec_utils.hpp:137)
+    // Hubbard-Holstein indices (HubHolVec, hh_vec.hpp:10-262): electrons live in the low 2 * hh_sites bits, hh_ph_bits per phonon above
+    unsigned hh_sites = 0, hh_ph_bits = 0;
+    const uint32_t *vec_scr = nullptr;       // vec_hash_ scrambler, only needed for key_of() below
+    size_t n_buckets = 0;
+    det_t elec_mask() const { return hh_sites ? ((det_t)1 << (2 * hh_sites)) - 1 : ~(det_t)0; }
+    // What the reference's HashTable can tell apart (det_hash.hpp:47, :60-94): entries live in bucket hash % n_buckets and are
+    // compared over ceil(scrambler.size() / 8) bytes.  For molecules that is the whole determinant.  For Hubbard-Holstein the
+    // scrambler has 2 * n_sites entries, so only the first ceil(2 n_sites / 8) bytes are compared: two states with the same
+    // electrons, different phonons and the same bucket ARE one entry there (the later one adds into the earlier one's slot).
+    det_t key_of(det_t det) const;
 
     void init(size_t size, size_t add_size, unsigned n_el, unsigned nv, const Comm &c = Comm::self(), const uint32_t *pscr = nullptr);
     int idx_to_proc(det_t det) const;         // vec_utils.hpp:360-379
@@ -255,6 +265,48 @@ struct Frisys {
     void setup();
     void iterate(unsigned n);
 };
+// ---------------------------------------------------------------- Hubbard-Holstein (frisys_hh)
+// bit string = [alpha sites | beta sites | ph_bits per site] (hh_vec.hpp:22, hub_holstein.cpp:139-171)
+struct HHParams {
+    unsigned n_elec = 0, n_sites = 0, ph_bits = 3;      // ph_bits: frisys_hh.cpp:96
+    double eps = 0, U = 0, omega = 0, g = 0, hf_en = 0; // parse_hh_input, io_utils.cpp:320-405
+    double target_norm = 0, init_thresh = 0;
+    uint32_t vec_nonz = 0; size_t max_dets = 0;
+    uint32_t seed = 0;
+};
+// FRIES/Hamiltonians/hub_holstein.cpp:101-136 / 139-171; FRIES/hh_vec.hpp:139-175 / 185-197 / 207-233
+unsigned hub_diag(det_t det, unsigned n_sites);
+det_t gen_neel_det_1D(unsigned n_sites, unsigned n_elec);
+void find_neighbors_1D(det_t det, unsigned n_sites, unsigned n_elec, uint8_t *neighbors /* 2 (n_elec + 1) */);
+void decode_phonons(det_t det, unsigned n_sites, unsigned ph_bits, uint8_t *numbers);
+bool det_from_ph(det_t det, det_t *out, unsigned n_sites, unsigned ph_bits, unsigned site, int change);
+// FRIES/Hamiltonians/hub_holstein.hpp:93-186
+double calc_ref_ovlp(const det_t *dets, const double *vals, size_t n, det_t ref, unsigned n_elec, unsigned n_sites, unsigned ph_bits, double g_over_t);
+uint64_t hash_fxn_hh(const uint8_t *occ, unsigned n_elec, const uint8_t *ph, unsigned n_sites, const uint32_t *scr);   // det_hash.hpp:160-170
+
+struct HHLog { double numer, denom, shift, norm; uint32_t nkept; int n_nonz; size_t curr_size, num_success; };
+// FRIES_bin/frisys_hh.cpp:27-380, seed injected instead of the wall clock (:66-68)
+struct FrisysHH {
+    HHParams par;
+    std::mt19937 mt;
+    std::vector<uint32_t> proc_scr, vec_scr;
+    Vec sol;
+    det_t neel = 0;
+    int ref_proc = 0;
+    double en_shift = 0, last_one_norm = 0;
+    unsigned iterat = 0;
+    std::vector<double> comp1, comp2, wt_remain;
+    std::vector<uint32_t> ndiv;
+    std::vector<size_t> comp_idx, det_indices;
+    std::vector<uint8_t> ph_ex;
+    SubWts sw;
+    std::vector<size_t> srt; std::vector<uint8_t> keep;
+    std::vector<HHLog> log;
+    Comm cm;
+    void setup();
+    void iterate(unsigned n);
+};
+
 // runs fn(rank) on `size` in-process ranks that share one communicator (fn receives its Comm)
 void run_ranks(int size, const std::function<void(const Comm &)> &fn);
 

@@ -32,6 +32,14 @@ MPI_RUNS = {
 }
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
+# frisys_hh (1-D Hubbard-Holstein): name -> (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, initiator, target)
+HH_RUNS = {
+    "hh_l6_m2000": (1, 60, 5, 6, 6, 0.01, 2.0, 0.5, 0.3, -3.0, 2000, 20000, 1.0, 1000.0),
+    "hh_l8_m5000": (1, 40, 7, 8, 8, 0.01, 4.0, 1.0, 0.5, -2.0, 5000, 50000, 1.0, 2500.0),
+    "hh_l10_m8000_ini0": (1, 40, 9, 10, 10, 0.005, 4.0, 1.0, 0.7, -4.0, 8000, 80000, 0.0, 4000.0),
+    "hh_l8_m5000_p3": (3, 40, 7, 8, 8, 0.01, 4.0, 1.0, 0.5, -2.0, 5000, 50000, 1.0, 2500.0),
+}
+
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
@@ -66,6 +74,16 @@ def main():
             subprocess.run(cmd, check=True)
             manifest["mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz,
                                               max_dets=maxd, initiator=ini, target_norm=tgt, distribution=dist)
+        manifest["hh_runs"] = {}
+        for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HH_RUNS.items():
+            out = os.path.join(GOLD, name + ".traj")
+            cmd = [HARNESS, "hh", str(n_iter), str(seed), str(n_elec), str(n_sites), repr(eps), repr(U), repr(omega), repr(g), repr(gs), str(vnz), str(maxd),
+                   repr(ini), repr(tgt), out]
+            if n_ranks > 1:
+                cmd = [MPIEXEC, "-n", str(n_ranks)] + cmd
+            subprocess.run(cmd, check=True)
+            manifest["hh_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
+                                             gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

@@ -197,4 +197,53 @@ void *fo_ranks_get(void *h, uint32_t rank) { return ((OracleRanks *)h)->fr[rank]
 int fo_ranks_hf_proc(void *h) { return ((OracleRanks *)h)->fr[0]->hf_proc; }
 int fo_idx_to_proc(void *h, uint64_t det) { return ((Frisys *)h)->sol.idx_to_proc(det); }
 
+
+// ---- frisys_hh: P in-process ranks (P = 1: plain)
+struct OracleHH { std::vector<std::unique_ptr<FrisysHH>> fr; };
+void *fo_hh_create(uint32_t n_ranks, uint32_t n_elec, uint32_t n_sites, double eps, double U, double omega, double g, double gs_energy,
+                   double target, double init, uint32_t vec_nonz, uint32_t max_dets, uint32_t seed) {
+    OracleHH *R = new OracleHH();
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        FrisysHH *f = new FrisysHH();
+        f->par.n_elec = n_elec; f->par.n_sites = n_sites; f->par.eps = eps; f->par.U = U; f->par.omega = omega; f->par.g = g; f->par.hf_en = gs_energy;
+        f->par.target_norm = target; f->par.init_thresh = init; f->par.vec_nonz = vec_nonz; f->par.max_dets = max_dets; f->par.seed = seed;
+        R->fr.emplace_back(f);
+    }
+    try {
+        run_ranks((int)n_ranks, [&](const Comm &c) { FrisysHH &f = *R->fr[c.rank]; f.cm = c; f.setup(); });
+    } catch (std::exception &e) { fprintf(stderr, "fo_hh_create: %s\n", e.what()); delete R; return nullptr; }
+    return R;
+}
+void fo_hh_destroy(void *h) { delete (OracleHH *)h; }
+int fo_hh_iterate(void *h, uint32_t n, OracleLog *logs) {
+    OracleHH *R = (OracleHH *)h;
+    int P = (int)R->fr.size();
+    try {
+        run_ranks(P, [&](const Comm &c) {
+            FrisysHH &f = *R->fr[c.rank];
+            f.cm = c; f.sol.cm = c;
+            for (uint32_t i = 0; i < n; i++) {
+                f.iterate(1);
+                if (logs) {
+                    const HHLog &l = f.log.back();
+                    OracleLog &o = logs[(size_t)c.rank * n + i];
+                    o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.nkept = l.nkept; o.n_nonz = l.n_nonz;
+                    o.curr_size = (uint32_t)l.curr_size; o.num_success = (uint32_t)l.num_success;
+                    for (int k = 0; k < 5; k++) o.comp_len[k] = 0;
+                    o.err = 0;
+                }
+            }
+        });
+    } catch (std::exception &e) { fprintf(stderr, "fo_hh_iterate: %s\n", e.what()); return 1; }
+    return 0;
+}
+size_t fo_hh_vec(void *h, uint32_t rank, uint64_t *dets, double *vals, size_t cap) {
+    FrisysHH *f = ((OracleHH *)h)->fr[rank].get();
+    size_t n = f->sol.curr_size;
+    if (dets && vals && cap >= n) for (size_t i = 0; i < n; i++) { dets[i] = f->sol.dets[i]; vals[i] = f->sol.vals[0][i]; }
+    return n;
+}
+int fo_hh_ref_proc(void *h) { return ((OracleHH *)h)->fr[0]->ref_proc; }
+uint64_t fo_hh_neel(void *h) { return ((OracleHH *)h)->fr[0]->neel; }
+
 }  // extern "C"

@@ -16,6 +16,8 @@
 #include <FRIES/Hamiltonians/heat_bathPP.hpp>
 #include <FRIES/Hamiltonians/molecule.hpp>
 #include <FRIES/vec_utils.hpp>
+#include <FRIES/hh_vec.hpp>
+#include <FRIES/Hamiltonians/hub_holstein.hpp>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -613,6 +615,240 @@ static int run_restart(int argc, char **argv) {
     return 0;
 }
 
+
+// ------------------------------------------------------------------ Hubbard-Holstein: reference frisys_hh loop vs the oracle
+// [mpiexec -n P] ref_harness hh <n_iter> <seed> <n_elec> <n_sites> <eps> <U> <omega> <g> <gs_energy> <vec_nonz> <max_dets> <initiator> <target> <out>
+// One rank: lockstep against fo::FrisysHH + unit checks of the bit-string helpers, writes <out>.  P ranks: every rank writes <out>.r<rank>.
+static int run_hh(int argc, char **argv) {
+    if (argc < 16) { fprintf(stderr, "usage: see header\n"); return 2; }
+    unsigned n_iter = atoi(argv[2]); uint32_t seed = strtoul(argv[3], 0, 10);
+    unsigned n_elec = atoi(argv[4]), hub_len = atoi(argv[5]);
+    double eps = atof(argv[6]), hub_u = atof(argv[7]), ph_freq = atof(argv[8]), elec_ph = atof(argv[9]), hf_en = atof(argv[10]);
+    uint32_t target_nonz = strtoul(argv[11], 0, 10); size_t max_n_dets = strtoull(argv[12], 0, 10);
+    double init_thresh = atof(argv[13]), target_norm = atof(argv[14]);
+    const double hub_t = 1;
+    int n_procs = 1, proc_rank = 0;
+    MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
+    MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
+    unsigned n_orb = hub_len;
+    std::mt19937 mt_obj(seed);
+    std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
+    for (auto &x : proc_scrambler) x = mt_obj();
+    for (auto &x : vec_scrambler) x = mt_obj();
+    unsigned spawn_length = target_nonz * 4 / n_procs;
+    uint8_t ph_bits = 3;
+    std::function<double(const uint8_t *)> diag_shortcut = [hub_len](const uint8_t *det) { return hub_diag((uint8_t *)det, hub_len); };
+    HubHolVec<double> sol_vec(max_n_dets, spawn_length, hub_len, ph_bits, n_elec, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    size_t det_size = CEILING(2 * n_orb + ph_bits * n_orb, 8);
+    uint8_t neel_det[16] = {0};
+    gen_neel_det_1D(n_orb, n_elec, ph_bits, neel_det);
+    unsigned ref_proc = sol_vec.idx_to_proc(neel_det);
+    uint8_t neel_occ[64];
+    sol_vec.gen_orb_list(neel_det, neel_occ);
+    if ((int)ref_proc == proc_rank) sol_vec.add(neel_det, 100, 1);
+    sol_vec.perform_add(0);
+    double en_shift = 0, last_one_norm = 0, glob_norm = 0;
+    double loc_norms[64]; double rn_sys = 0;
+    std::vector<size_t> srt_arr(max_n_dets); std::vector<bool> keep_exact(max_n_dets, false);
+    Matrix<double> subwt_mem(spawn_length, 2); Matrix<bool> keep_idx(spawn_length, 2);
+    std::vector<double> wt_remain(spawn_length, 0);
+    std::vector<unsigned int> ndiv_vec(spawn_length);
+    std::vector<double> comp_vec1(spawn_length), comp_vec2(spawn_length);
+    std::vector<size_t> comp_idx_v(2 * (size_t)spawn_length), det_indices(spawn_length);
+    size_t (*comp_idx)[2] = (size_t (*)[2])comp_idx_v.data();
+    std::vector<bool> ph_ex(spawn_length, false);
+    uint8_t new_det[16] = {0};
+    double recv_nums[64];
+    Matrix<uint8_t> &neighb_orbs = sol_vec.neighb();
+
+    // oracle twin (one rank only)
+    fo::FrisysHH fr;
+    const bool lock = n_procs == 1;
+    if (lock) {
+        fr.par.n_elec = n_elec; fr.par.n_sites = hub_len; fr.par.ph_bits = ph_bits; fr.par.eps = eps; fr.par.U = hub_u; fr.par.omega = ph_freq; fr.par.g = elec_ph;
+        fr.par.hf_en = hf_en; fr.par.target_norm = target_norm; fr.par.init_thresh = init_thresh; fr.par.vec_nonz = target_nonz; fr.par.max_dets = max_n_dets; fr.par.seed = seed;
+        fr.setup();
+        CHECK(fr.neel == to_u64(neel_det, det_size), "neel det %" PRIx64 " %" PRIx64, (uint64_t)fr.neel, (uint64_t)to_u64(neel_det, det_size));
+        // helper functions on random bit strings
+        std::mt19937 rg(12345 + seed);
+        for (int trial = 0; trial < 20000; trial++) {
+            fo::det_t d = 0;
+            for (int sp = 0; sp < 2; sp++) { unsigned placed = 0; while (placed < n_elec / 2) { unsigned o = rg() % hub_len; if (!((d >> (o + sp * hub_len)) & 1)) { d |= (fo::det_t)1 << (o + sp * hub_len); placed++; } } }
+            bool with_ph = (trial % 3) != 0;
+            if (with_ph) for (unsigned st = 0; st < hub_len; st++) if (rg() % 4 == 0) d |= (fo::det_t)(rg() % 8) << (2 * hub_len + 3 * st);
+            uint8_t db[16] = {0}; memcpy(db, &d, 8);
+            CHECK(hub_diag(db, hub_len) == fo::hub_diag(d, hub_len), "hub_diag %" PRIx64, (uint64_t)d);
+            uint8_t nb_r[2 * 65] = {0}, nb_o[2 * 65] = {0};
+            sol_vec.find_neighbors_1D(db, nb_r);
+            fo::find_neighbors_1D(d, hub_len, n_elec, nb_o);
+            bool same = nb_r[0] == nb_o[0] && nb_r[n_elec + 1] == nb_o[n_elec + 1];
+            for (unsigned k = 0; same && k < nb_r[0]; k++) same = nb_r[1 + k] == nb_o[1 + k];
+            for (unsigned k = 0; same && k < nb_r[n_elec + 1]; k++) same = nb_r[n_elec + 2 + k] == nb_o[n_elec + 2 + k];
+            CHECK(same, "neighbors %" PRIx64, (uint64_t)d);
+            uint8_t ph_r[64], ph_o[64];
+            sol_vec.decode_phonons(db, ph_r); fo::decode_phonons(d, hub_len, ph_bits, ph_o);
+            CHECK(!memcmp(ph_r, ph_o, hub_len), "phonons %" PRIx64, (uint64_t)d);
+            unsigned st = rg() % hub_len; int chg = (rg() & 1) ? 1 : -1;
+            uint8_t nd_r[16] = {0}; fo::det_t nd_o = 0;
+            bool ok_o = fo::det_from_ph(d, &nd_o, hub_len, ph_bits, st, chg);
+            bool at_max = ph_r[st] == 7 && chg == 1;
+            if (!at_max) { int ok_r = sol_vec.det_from_ph(db, nd_r, st, chg); CHECK((ok_r != 0) == ok_o && (!ok_o || to_u64(nd_r, det_size) == nd_o), "det_from_ph"); }
+            else CHECK(!ok_o, "det_from_ph at max");
+            // reference overlap of a single element
+            Matrix<uint8_t> dm(1, det_size); memcpy(dm[0], db, det_size);
+            Matrix<uint8_t> pm(1, hub_len); memcpy(pm[0], ph_r, hub_len);
+            double v1 = 1.25;
+            double r_ref = calc_ref_ovlp(dm, &v1, pm, 1, neel_det, neel_occ, n_elec, hub_len, elec_ph / hub_t);
+            double r_orc = fo::calc_ref_ovlp(&d, &v1, 1, fr.neel, n_elec, hub_len, ph_bits, elec_ph / hub_t);
+            CHECK(same_bits(r_ref, r_orc), "calc_ref_ovlp %" PRIx64 " %a %a", (uint64_t)d, r_ref, r_orc);
+            if (trial < 2000) {      // states one hop / one phonon away from the Neel state exercise the non-zero branches
+                fo::det_t e = fr.neel;
+                uint8_t nbn[2 * 65]; fo::find_neighbors_1D(e, hub_len, n_elec, nbn);
+                if (trial & 1) { unsigned tot = nbn[0] + nbn[n_elec + 1]; if (tot) { unsigned x = rg() % tot; unsigned og, ds; if (x < nbn[0]) { og = nbn[1 + x]; ds = og + 1; } else { og = nbn[n_elec + 2 + x - nbn[0]]; ds = og - 1; } e = (e & ~((fo::det_t)1 << og)) | ((fo::det_t)1 << ds); } }
+                else { e |= (fo::det_t)(1 + rg() % 2) << (2 * hub_len + 3 * (rg() % hub_len)); if (rg() & 1) e |= (fo::det_t)1 << (2 * hub_len + 3 * (rg() % hub_len)); }
+                uint8_t eb[16] = {0}; memcpy(eb, &e, 8);
+                uint8_t phe[64]; sol_vec.decode_phonons(eb, phe);
+                memcpy(dm[0], eb, det_size); memcpy(pm[0], phe, hub_len);
+                double a = calc_ref_ovlp(dm, &v1, pm, 1, neel_det, neel_occ, n_elec, hub_len, elec_ph / hub_t);
+                double b = fo::calc_ref_ovlp(&e, &v1, 1, fr.neel, n_elec, hub_len, ph_bits, elec_ph / hub_t);
+                CHECK(same_bits(a, b), "calc_ref_ovlp near neel %" PRIx64 " %a %a", (uint64_t)e, a, b);
+            }
+        }
+    }
+    char fn[1024];
+    if (lock) snprintf(fn, sizeof fn, "%s", argv[15]); else snprintf(fn, sizeof fn, "%s.r%d", argv[15], proc_rank);
+    FILE *f = fopen(fn, "w");
+    fprintf(f, "# golden trajectory from the reference (frisys_hh.cpp loop, %d rank(s), rank %d); cols: it numer denom norm shift nkept n_nonz curr_size num_success digest\n", n_procs, proc_rank);
+    fprintf(f, "# ref_proc %u neel %016" PRIx64 "\n", ref_proc, (uint64_t)to_u64(neel_det, det_size));
+    for (unsigned iterat = 0; iterat < n_iter; iterat++) {
+        size_t det_idx;
+        for (det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
+            double *curr_el = sol_vec[det_idx];
+            double weight = fabs(*curr_el);
+            comp_vec1[det_idx] = weight;
+            if (weight > 0) { subwt_mem(det_idx, 0) = hub_t; subwt_mem(det_idx, 1) = elec_ph; ndiv_vec[det_idx] = 0; }
+            else ndiv_vec[det_idx] = 1;
+        }
+        if (proc_rank == 0) rn_sys = mt_obj() / (1. + UINT32_MAX);
+        size_t comp_len = comp_sub(comp_vec1.data(), sol_vec.curr_size(), ndiv_vec.data(), subwt_mem, keep_idx, NULL, target_nonz, wt_remain.data(), rn_sys, comp_vec2.data(), comp_idx);
+        for (size_t samp_idx = 0; samp_idx < comp_len; samp_idx++) {
+            det_idx = comp_idx[samp_idx][0];
+            det_indices[samp_idx] = det_idx;
+            ph_ex[samp_idx] = comp_idx[samp_idx][1];
+            if (ph_ex[samp_idx]) ndiv_vec[samp_idx] = 2 * n_elec;
+            else ndiv_vec[samp_idx] = neighb_orbs(det_idx, 0) + neighb_orbs(det_idx, n_elec + 1);
+            comp_vec2[samp_idx] *= ndiv_vec[samp_idx];
+        }
+        if (proc_rank == 0) rn_sys = mt_obj() / (1. + UINT32_MAX);
+        comp_len = comp_sub(comp_vec2.data(), comp_len, ndiv_vec.data(), subwt_mem, keep_idx, NULL, target_nonz, wt_remain.data(), rn_sys, comp_vec1.data(), comp_idx);
+        size_t num_success = comp_len;
+        double *vals_before_mult = sol_vec.values();
+        sol_vec.set_curr_vec_idx(1);
+        sol_vec.zero_vec();
+        size_t vec_size = sol_vec.curr_size();
+        for (int add_ini = 0; add_ini < 2; add_ini++) {
+            int num_added = 1;
+            size_t samp_idx = 0;
+            while (num_added > 0) {
+                num_added = 0;
+                while (samp_idx < comp_len) {
+                    size_t prev_idx = comp_idx[samp_idx][0];
+                    size_t d_idx = det_indices[prev_idx];
+                    double curr_val = vals_before_mult[d_idx];
+                    uint8_t ini_flag = fabs(curr_val) >= init_thresh;
+                    if (ini_flag != add_ini) { samp_idx++; continue; }
+                    uint8_t exc_idx = comp_idx[samp_idx][1];
+                    uint8_t *curr_det = sol_vec.indices()[d_idx];
+                    double matr_el = comp_vec1[samp_idx] * -eps;
+                    if (curr_val < 0) matr_el *= -1;
+                    if (ph_ex[prev_idx]) {
+                        uint8_t *curr_ph = sol_vec.phonons_at_pos(d_idx);
+                        uint8_t *curr_occ = sol_vec.orbs_at_pos(d_idx);
+                        uint8_t site = curr_occ[exc_idx % n_elec] % hub_len;
+                        uint8_t phonon_num = curr_ph[site];
+                        if (exc_idx < n_elec && phonon_num > 0) { sol_vec.det_from_ph(curr_det, new_det, site, -1); matr_el *= sqrt(phonon_num); }
+                        else if (exc_idx >= n_elec && phonon_num + 1 < (1 << ph_bits)) { sol_vec.det_from_ph(curr_det, new_det, site, +1); matr_el *= sqrt(phonon_num + 1); }
+                        else matr_el = 0;
+                    }
+                    else {
+                        std::copy(curr_det, curr_det + det_size, new_det);
+                        uint8_t *curr_neighb = neighb_orbs[d_idx];
+                        uint8_t orig_orb, dest_orb;
+                        if (exc_idx < curr_neighb[0]) { orig_orb = curr_neighb[exc_idx + 1]; dest_orb = orig_orb + 1; }
+                        else { orig_orb = curr_neighb[n_elec + 1 + exc_idx - curr_neighb[0] + 1]; dest_orb = orig_orb - 1; }
+                        zero_bit(new_det, orig_orb);
+                        set_bit(new_det, dest_orb);
+                        matr_el *= -1;
+                    }
+                    samp_idx++;
+                    if (fabs(matr_el) > 1e-9) { num_added++; if (!sol_vec.add(new_det, matr_el, ini_flag)) break; }
+                }
+                sol_vec.perform_add(0);
+                sol_vec.set_curr_vec_idx(0);
+                vals_before_mult = sol_vec.values();
+                sol_vec.set_curr_vec_idx(1);
+                num_added = sum_mpi(num_added, proc_rank, n_procs);
+            }
+        }
+        size_t new_max_dets = sol_vec.max_size();
+        if (new_max_dets > max_n_dets) { keep_exact.resize(new_max_dets, false); srt_arr.resize(new_max_dets); max_n_dets = new_max_dets; }
+        sol_vec.set_curr_vec_idx(0);
+        for (det_idx = 0; det_idx < vec_size; det_idx++) {
+            double *curr_el = sol_vec[det_idx];
+            if (*curr_el != 0) {
+                double diag_el = sol_vec.matr_el_at_pos(det_idx);
+                double phonon_diag = sol_vec.total_ph(det_idx) * ph_freq;
+                *curr_el *= 1 - eps * (diag_el * hub_u + phonon_diag - hf_en - en_shift);
+            }
+        }
+        sol_vec.add_vecs(0, 1);
+        unsigned int n_samp = target_nonz;
+        loc_norms[proc_rank] = find_preserve(sol_vec.values(), srt_arr, keep_exact, sol_vec.curr_size(), &n_samp, &glob_norm);
+        unsigned nkept = target_nonz - n_samp;
+        if ((iterat + 1) % 10 == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, target_norm, 0.05 / 10 / eps);
+        double numer = calc_ref_ovlp(sol_vec.indices(), sol_vec.values(), sol_vec.phonon_nums(), sol_vec.curr_size(), neel_det, neel_occ, n_elec, hub_len, elec_ph / hub_t);
+        MPI_Gather(&numer, 1, MPI_DOUBLE, recv_nums, 1, MPI_DOUBLE, ref_proc, MPI_COMM_WORLD);
+        double ref_element = 0;
+        numer = 0;
+        if (proc_rank == (int)ref_proc) {
+            double diag_el = sol_vec.matr_el_at_pos(0);
+            ref_element = *(sol_vec[0]);
+            numer = (diag_el * hub_u - hf_en) * ref_element;
+            for (int proc_idx = 0; proc_idx < n_procs; proc_idx++) numer += recv_nums[proc_idx] * -hub_t;
+        }
+        if (proc_rank == 0) rn_sys = mt_obj() / (1. + UINT32_MAX);
+        MPI_Allgather(MPI_IN_PLACE, 0, MPI_DOUBLE, loc_norms, 1, MPI_DOUBLE, MPI_COMM_WORLD);
+        sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, keep_exact, rn_sys);
+        for (det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
+            if (keep_exact[det_idx] && !(proc_rank == 0 && det_idx == 0)) { sol_vec.del_at_pos(det_idx); keep_exact[det_idx] = 0; }
+        }
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < sol_vec.curr_size(); i++) {
+            double rv = sol_vec.values()[i];
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol_vec.indices()[i], det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", iterat, numer, ref_element, glob_norm, en_shift, nkept, sol_vec.n_nonz(), (size_t)sol_vec.curr_size(), num_success, hsh);
+        if (lock) {
+            fr.iterate(1);
+            const fo::HHLog &lg = fr.log.back();
+            CHECK(same_bits(lg.numer, numer) && same_bits(lg.denom, ref_element), "hh it %u numer/denom %a %a | %a %a", iterat, lg.numer, numer, lg.denom, ref_element);
+            CHECK(same_bits(lg.norm, glob_norm) && same_bits(lg.shift, en_shift), "hh it %u norm/shift", iterat);
+            CHECK(lg.nkept == nkept && lg.n_nonz == sol_vec.n_nonz() && lg.curr_size == sol_vec.curr_size() && lg.num_success == num_success, "hh it %u counts nkept %u/%u nnz %d/%d size %zu/%zu succ %zu/%zu",
+                  iterat, lg.nkept, nkept, lg.n_nonz, sol_vec.n_nonz(), lg.curr_size, (size_t)sol_vec.curr_size(), lg.num_success, num_success);
+            size_t bad = 0, nmin = std::min(lg.curr_size, (size_t)sol_vec.curr_size());
+            for (size_t i = 0; i < nmin; i++) {
+                double rv = sol_vec.values()[i];
+                if (!same_bits(rv, fr.sol.vals[0][i])) bad++;
+                if (rv != 0 && to_u64(sol_vec.indices()[i], det_size) != fr.sol.dets[i]) bad++;
+            }
+            CHECK(bad == 0, "hh it %u vector mismatch in %zu slots", iterat, bad);
+        }
+    }
+    fclose(f);
+    if (proc_rank == 0) printf("HH ranks=%d iters=%u checks=%d fails=%d final n_nonz=%d\n", n_procs, n_iter, n_chk, n_fail, sol_vec.n_nonz());
+    return n_fail != 0;
+}
+
 int main(int argc, char **argv) {
     MPI_Init(NULL, NULL);
     int rc = 2;
@@ -622,6 +858,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "hh")) rc = run_hh(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
     else fprintf(stderr, "unknown command\n");
     MPI_Finalize();

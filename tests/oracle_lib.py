@@ -62,6 +62,15 @@ def load():
         lib.fo_ranks_get.argtypes = [C.c_void_p, C.c_uint32]
         lib.fo_ranks_hf_proc.argtypes = [C.c_void_p]
         lib.fo_idx_to_proc.argtypes = [C.c_void_p, C.c_uint64]
+        lib.fo_hh_create.restype = C.c_void_p
+        lib.fo_hh_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_double] * 7 + [C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.fo_hh_destroy.argtypes = [C.c_void_p]
+        lib.fo_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_hh_vec.restype = C.c_size_t
+        lib.fo_hh_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_hh_ref_proc.argtypes = [C.c_void_p]
+        lib.fo_hh_neel.restype = C.c_uint64
+        lib.fo_hh_neel.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -225,3 +234,40 @@ class OracleRanks:
 
     def idx_to_proc(self, det):
         return self.lib.fo_idx_to_proc(self._rank(0), int(det))
+
+
+class OracleHH:
+    """fo::FrisysHH -- the CPU restatement of frisys_hh (1-D Hubbard-Holstein), on n_ranks in-process ranks."""
+
+    def __init__(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, n_ranks=1):
+        self.lib = load()
+        self.n_ranks = n_ranks
+        self.h = self.lib.fo_hh_create(n_ranks, n_elec, n_sites, eps, U, omega, g, gs_energy, target_norm, initiator, vec_nonz, max_dets, seed)
+        if not self.h:
+            raise RuntimeError("oracle HH setup failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.fo_hh_destroy(self.h)
+            self.h = None
+
+    def iterate(self, n):
+        logs = np.zeros((self.n_ranks, n), dtype=LOG_DTYPE)
+        if self.lib.fo_hh_iterate(self.h, n, _p(logs)):
+            raise RuntimeError("oracle HH failed")
+        return logs if self.n_ranks > 1 else logs[0]
+
+    def vector(self, rank=0):
+        n = self.lib.fo_hh_vec(self.h, rank, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_hh_vec(self.h, rank, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
+
+    @property
+    def ref_proc(self):
+        return self.lib.fo_hh_ref_proc(self.h)
+
+    @property
+    def neel(self):
+        return int(self.lib.fo_hh_neel(self.h))

@@ -33,7 +33,12 @@ def main():
     import datetime
     dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180))     # a dead peer must surface as an error, not a hang
     man = golden_io.manifest()
-    if name in man["mpi_runs"]:
+    hh = name in man.get("hh_runs", {})
+    if hh:
+        r = man["hh_runs"][name]
+        assert r["n_ranks"] == world, (r["n_ranks"], world)
+        g = golden_io.read_traj(name, rank=rank if world > 1 else None)
+    elif name in man["mpi_runs"]:
         r = man["mpi_runs"][name]
         assert r["n_ranks"] == world, (r["n_ranks"], world)
         g = golden_io.read_traj(name, rank=rank)
@@ -41,17 +46,25 @@ def main():
         r = man["runs"][name]
         assert world == 1
         g = golden_io.read_traj(name)
-    mol = fcidump.synthetic(r["shape"])
-    comm = TorchComm(r["mat_nonz"], torch.device("cuda", dev))
-    eng = FriEngine(mol, device=dev, comm=comm)
-    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
-              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
     res = dict(rank=rank, ok=True, fails=[])
-    if eng.p_doub != g["p_doub"]:
-        res["fails"].append(("p_doub", eng.p_doub, g["p_doub"]))
+    if hh:
+        comm = TorchComm(r["vec_nonz"], torch.device("cuda", dev))
+        eng = FriEngine(None, device=dev, comm=comm)
+        eng.setup_hh(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
+                     vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
+        step = eng.iterate_hh
+    else:
+        mol = fcidump.synthetic(r["shape"])
+        comm = TorchComm(r["mat_nonz"], torch.device("cuda", dev))
+        eng = FriEngine(mol, device=dev, comm=comm)
+        eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+                  initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+        step = eng.iterate
+        if eng.p_doub != g["p_doub"]:
+            res["fails"].append(("p_doub", eng.p_doub, g["p_doub"]))
     rows = g["rows"][:n_check] if n_check else g["rows"]
     for row in rows:
-        lg = eng.iterate(1)[0]
+        lg = step(1)[0]
         for f in ("norm", "shift"):
             if float(lg[f]) != row[f]:
                 res["fails"].append((row["it"], f, float(lg[f]), row[f]))

@@ -73,7 +73,7 @@ def test_comm_layer_world_size_2_gloo(tmp_path):
            os.path.join(ROOT, "tests", "comm_worker.py")]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert "comm ok 0" in res.stdout and "comm ok 1" in res.stdout
+    assert res.stdout.count("comm ok") == 2, res.stdout[-2000:]        # the two ranks' lines may interleave
 
 
 def test_sharding_hash_matches_reference_ranks(oracle, mols):
@@ -87,6 +87,33 @@ def test_sharding_hash_matches_reference_ranks(oracle, mols):
         d, v = orc.vector(k)
         nz = d[v != 0]
         assert nz.size > 0 and all(orc.idx_to_proc(x) == k for x in nz[:200])
+
+
+def _hh_params(r):
+    return dict(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
+                vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["hh_runs"]))
+def test_oracle_hubbard_holstein_reproduces_reference(oracle, name):
+    """frisys_hh (1-D Hubbard-Holstein) restatement against the reference's own loop, one rank and under mpiexec -n 3:
+    every logged scalar bit for bit and the digest of every shard."""
+    r = golden_io.manifest()["hh_runs"][name]
+    P = r["n_ranks"]
+    orc = oracle.OracleHH(n_ranks=P, **_hh_params(r))
+    logs = orc.iterate(r["n_iter"])
+    if P == 1:
+        logs = logs[None, :]
+    for k in range(P):
+        g = golden_io.read_traj(name, rank=None if P == 1 else k)
+        for i, row in enumerate(g["rows"]):
+            lg = logs[k, i]
+            for f in ("numer", "denom", "norm", "shift"):
+                assert float(lg[f]) == row[f], (name, k, i, f)
+            for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+                assert int(lg[f]) == row[f], (name, k, i, f)
+        d, v = orc.vector(k)
+        assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"], (name, k)
 
 
 def test_oracle_snapshot_matches_reference(oracle, mols):

@@ -36,10 +36,13 @@ def _free_port():
     return p
 
 
+_RANK_RUNS = dict(golden_io.manifest()["mpi_runs"], **{k: v for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] > 1})
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(golden_io.manifest()["mpi_runs"]))
+@pytest.mark.parametrize("name", sorted(_RANK_RUNS))
 def test_sharded_engine_matches_reference_ranks(name, tmp_path):
-    r = golden_io.manifest()["mpi_runs"][name]
+    r = _RANK_RUNS[name]
     P = r["n_ranks"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
