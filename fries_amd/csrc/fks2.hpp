@@ -180,18 +180,18 @@ __device__ __forceinline__ double fr_grp8_running(double start, double c, int f)
 // decision would differ under a slightly smaller threshold.
 template <int STAGE, bool NEW_HB>
 __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32_t code, const RowInfo &ri, unsigned n_sub, double p_doub,
-                                            double cwf, double gl, uint32_t kp_in, uint32_t *kp_out, uint32_t *add, double *sub_remain, double *max_unkept) {
+                                            double cwf, double gl, uint32_t kp_in, uint32_t *kp_out, uint32_t *add, double *unkept_wt, double *max_unkept) {
     unsigned full = (n_sub / 8) * 8;
     uint32_t kk = kp_in, a = 0;
-    double rem = 0, mu = 0;
+    double wsum = 0, mu = 0;
     fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
         if (s >= n_sub || ((kk >> s) & 1u)) return;
         double sub_magn = cwf * w;
         double thr = s < full ? 1e-12 : 1e-10;      // compress_utils.cpp:213 / :233
         if (sub_magn >= gl && fabs(sub_magn) > thr) { kk |= 1u << s; a++; }
-        else { rem += sub_magn; mu = sub_magn > mu ? sub_magn : mu; }
+        else { wsum += w; mu = sub_magn > mu ? sub_magn : mu; }
     });
-    *kp_out = kk; *add = a; *sub_remain = rem; *max_unkept = mu;
+    *kp_out = kk; *add = a; *unkept_wt = wsum; *max_unkept = mu;
 }
 
 #define FR_FKS_TILES_PER_CHUNK (FR_FKS_CHUNK * 8 / FR_BLOCK)
@@ -314,9 +314,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                     }
                     if (need_eval) {
                         unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
-                        double rem;
-                        fr_fks2_row<STAGE, NEW_HB>(T, det, code, ri, n_sub, p_doub, cw, gl_mine, kp, &new_kp, &add, &rem, &mu);
-                        new_wr = rem / wf;
+                        double uw;
+                        fr_fks2_row<STAGE, NEW_HB>(T, det, code, ri, n_sub, p_doub, cw, gl_mine, kp, &new_kp, &add, &uw, &mu);
+                        // Remaining weight of the row inside the replay: value x (sum of the unpreserved normalised sub-weights).  The
+                        // reference forms sum(value * budget * w_s) / budget (compress_utils.cpp:243-245), the same number up to rounding
+                        // but dependent on the budget; that form is used for the final wt_remain (final pass, bit for bit), while the
+                        // replay's running norms only steer comparisons and use the budget-free form so that they stop moving as soon as
+                        // the decisions do (<= 1e-16 relative, inside the tolerance the tree-summed norms already have).
+                        new_wr = v * uw;
                         change = wr - new_wr;
                         evaluated = true; used_gl = gl_mine; skipped = false;
                     }
