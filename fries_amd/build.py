@@ -53,7 +53,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_drivers(force)
     return LIB
+
+
+DRIVER = os.path.join(HERE, "frisys_mol_hip")
+
+
+def build_drivers(force: bool = False) -> str:
+    """The C++ command-line driver (host side in the reference's language) linked against libfries_hip.so."""
+    src = os.path.join(HERE, "drivers", "frisys_mol_hip.cpp")
+    hdr = os.path.join(HERE, "..", "include", "fries_hip.h")
+    if force or _stale(DRIVER, [src, hdr, LIB]):
+        cmd = ["g++", "-std=c++17", "-O2", "-o", DRIVER, src, "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
+               "-Wl,-rpath-link,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed on frisys_mol_hip.cpp:\n{r.stdout}\n{r.stderr}")
+    return DRIVER
 
 
 if __name__ == "__main__":

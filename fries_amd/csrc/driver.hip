@@ -326,6 +326,15 @@ extern "C" int fries_set_hb_tensor(fries_ctx *h, int which, const double *in, si
 
 extern "C" double fries_hf_energy(fries_ctx *h) { return h->c.hf_en; }
 extern "C" double fries_p_doub(fries_ctx *h) { return h->c.p_doub; }
+extern "C" int fries_get_scramblers(fries_ctx *h, uint32_t *proc_scr, uint32_t *vec_scr, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (c->proc_scr.empty()) throw FriesError("no run has been set up");
+    if (n < c->proc_scr.size()) throw FriesError("scrambler buffer too small");
+    if (proc_scr) memcpy(proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size());
+    if (vec_scr) memcpy(vec_scr, c->vec_scr.data(), 4 * c->vec_scr.size());
+    FR_API_END
+}
 extern "C" uint64_t fries_kernel_launches(fries_ctx *h) { return h->c.n_kernel_launch; }
 
 __global__ void k_matrel_batch(int kind, const det_t *dets, const uint8_t *orbs, size_t n, const double *hc, const double *eris, unsigned n_orb, double *out, int32_t *sign) {

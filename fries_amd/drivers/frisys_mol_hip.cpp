@@ -1,0 +1,225 @@
+// frisys_mol on the MI355X engine: the reference driver's command line, inputs and output files
+// (FRIES_bin/frisys_mol.cpp) over the C ABI of libfries_hip.so (include/fries_hip.h).
+//
+//   frisys_mol_hip --fcidump_path F --point_group D2h --distribution HB_unnorm --vec_nonz N --mat_nonz N --max_dets N
+//                  [--target T] [--initiator I] [--epsilon E] [--max_iter K] [--result_dir DIR/] [--load_dir DIR/] [--seed S] [--device D]
+//
+// Host side only: option parsing (argparse there, a loop here), the FCIDUMP reader (parse_fcidump / convert_symm,
+// FRIES/io_utils.cpp:189-318), the text outputs projnum.txt / projden.txt / S.txt / norm.txt / nkept.txt / params.txt
+// (frisys_mol.cpp:288-345, 505-531) and the binary checkpoint dets0.dat / vals0.dat / dense.txt / hash.dat
+// (DistVec::save / load, FRIES/vec_utils.hpp:703-844; save_proc_hash, io_utils.cpp:589-606).  Everything numeric runs on
+// the GPU.  One rank; ranks are driven through fries_set_comm.
+#include "../../include/fries_hip.h"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+static void ck(int rc) { if (rc) throw std::runtime_error(fries_last_error()); }
+
+struct Fcidump { uint32_t n_orb = 0, n_elec = 0; double core_en = 0; std::vector<uint8_t> symm; std::vector<double> hcore, eris; };
+
+// io_utils.cpp:189-239
+static void convert_symm(std::vector<uint8_t> &irreps, const std::string &pg_in) {
+    std::string pg = pg_in;
+    for (auto &ch : pg) ch = (char)tolower(ch);
+    std::vector<uint8_t> map;
+    unsigned max_label;
+    if (pg == "d2h") { map = {0, 7, 6, 1, 5, 2, 3, 4}; max_label = 8; }
+    else if (pg == "c2v" || pg == "c2h") { map = {0, 2, 3, 1}; max_label = 4; }
+    else if (pg == "d2") { map = {0, 3, 2, 1}; max_label = 4; }
+    else if (pg == "cs" || pg == "c2" || pg == "ci" || pg == "c1") { map = {0, 1}; max_label = 2; }
+    else throw std::runtime_error("Point group " + pg_in + " not recognized");
+    for (auto &ir : irreps) {
+        if (ir > max_label || ir == 0) {
+            std::stringstream msg;
+            msg << "irrep index " << (unsigned)ir << " read from the FCIDUMP file exceeds the maximum allowed irrep index (" << max_label << ") for point group " << pg_in;
+            throw std::runtime_error(msg.str());
+        }
+        ir = map[ir - 1];
+    }
+}
+
+static size_t tri(size_t i, size_t j) { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
+
+// io_utils.cpp:241-318: line 1 NORB / NELEC / MS2, line 2 ORBSYM, two more header lines, then "value i j k l" records
+static Fcidump parse_fcidump(const std::string &path, const std::string &point_group) {
+    std::ifstream in(path);
+    if (!in.is_open()) throw std::runtime_error("Could not open FCIDUMP file " + path);
+    std::string line;
+    std::getline(in, line);
+    auto field = [&](const char *key) {
+        size_t p = line.find(key);
+        if (p == std::string::npos) throw std::runtime_error(std::string("FCIDUMP header lacks ") + key);
+        size_t e = line.find(",", p);
+        return std::stoi(line.substr(p + strlen(key), e - (p + strlen(key))));
+    };
+    Fcidump f;
+    f.n_orb = (uint32_t)field("NORB="); f.n_elec = (uint32_t)field("NELEC=");
+    if (field("MS2=") != 0) throw std::runtime_error("MS2 is not zero in FCIDUMP file.");
+    std::getline(in, line);
+    size_t op = line.find("ORBSYM=");
+    if (op == std::string::npos) throw std::runtime_error("ORBSYM missing on line 2 of the FCIDUMP file");
+    std::stringstream ss(line.substr(op + 7));
+    std::string tok;
+    while (std::getline(ss, tok, ',')) { try { if (!tok.empty()) f.symm.push_back((uint8_t)std::stoi(tok)); } catch (std::invalid_argument &) {} }
+    if (f.symm.size() != f.n_orb) throw std::runtime_error("Number of irrep labels read in after ORBSYM in FCIDUMP file does not equal number of orbitals");
+    convert_symm(f.symm, point_group);
+    std::getline(in, line);     // ISYM
+    std::getline(in, line);     // &END
+    const size_t n = f.n_orb, np = n * (n + 1) / 2;
+    f.hcore.assign(n * n, 0.0); f.eris.assign(np * (np + 1) / 2, 0.0);
+    double v; unsigned o[4];
+    while (in >> v >> o[0] >> o[1] >> o[2] >> o[3]) {
+        if (!o[0] && !o[1] && !o[2] && !o[3]) f.core_en = v;
+        else if (!o[1] && !o[2] && !o[3]) continue;                  // orbital energy
+        else if (!o[2] && !o[3]) f.hcore[(o[0] - 1) * n + (o[1] - 1)] = f.hcore[(o[1] - 1) * n + (o[0] - 1)] = v;
+        else { size_t p1 = tri(o[0] - 1, o[1] - 1), p2 = tri(o[2] - 1, o[3] - 1); f.eris[tri(p1, p2)] = v; }     // 8-fold packed, ndarr.hpp:206-244
+    }
+    return f;
+}
+
+struct Args {
+    std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir;
+    double target = 0, initiator = 0, epsilon = 0.01;
+    uint32_t max_iter = 1000000, vec_nonz = 0, mat_nonz = 0, max_dets = 0, seed = 0, device = 0;
+    bool have_seed = false;
+};
+
+static Args parse_args(int argc, char **argv) {
+    std::map<std::string, std::string> kv;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) != 0 || i + 1 >= argc) throw std::runtime_error("expected --option value pairs, got " + a);
+        kv[a.substr(2)] = argv[++i];
+    }
+    Args r;
+    auto need = [&](const char *k) { if (!kv.count(k)) throw std::runtime_error(std::string("missing required option --") + k); return kv[k]; };
+    r.fcidump_path = need("fcidump_path"); r.vec_nonz = (uint32_t)std::stoul(need("vec_nonz")); r.mat_nonz = (uint32_t)std::stoul(need("mat_nonz"));
+    r.max_dets = (uint32_t)std::stoul(need("max_dets"));
+    if (kv.count("point_group")) r.point_group = kv["point_group"];
+    if (kv.count("distribution")) r.dist = kv["distribution"];
+    if (kv.count("result_dir")) r.result_dir = kv["result_dir"];
+    if (kv.count("load_dir")) r.load_dir = kv["load_dir"];
+    if (kv.count("target")) r.target = std::stod(kv["target"]);
+    if (kv.count("initiator")) r.initiator = std::stod(kv["initiator"]);
+    if (kv.count("epsilon")) r.epsilon = std::stod(kv["epsilon"]);
+    if (kv.count("max_iter")) r.max_iter = (uint32_t)std::stoul(kv["max_iter"]);
+    if (kv.count("seed")) { r.seed = (uint32_t)std::stoul(kv["seed"]); r.have_seed = true; }
+    if (kv.count("device")) r.device = (uint32_t)std::stoul(kv["device"]);
+    return r;
+}
+
+// DistVec::save (vec_utils.hpp:703-737): raw index bytes, then the value columns; dense.txt; hash.dat is written by the caller
+static void save_vector(fries_ctx *ctx, const std::string &dir, unsigned n_orb) {
+    uint32_t n = 0; int32_t nz; uint32_t nf;
+    ck(fries_vec_info(ctx, &n, &nz, &nf));
+    std::vector<uint64_t> dets(n ? n : 1); std::vector<double> vals(n ? n : 1);
+    size_t m = 0;
+    ck(fries_vec_download(ctx, dets.data(), vals.data(), dets.size(), &m));
+    const size_t n_bytes = (2 * n_orb + 7) / 8;
+    std::ofstream fd(dir + "dets0.dat", std::ios::binary);
+    for (size_t i = 0; i < m; i++) fd.write((const char *)&dets[i], (std::streamsize)n_bytes);     // little-endian byte string, det_store.h:23-26
+    std::ofstream fv(dir + "vals0.dat", std::ios::binary);
+    fv.write((const char *)vals.data(), (std::streamsize)(8 * m));
+    std::vector<double> zeros(m, 0.0);                                  // column 1 is zero between iterations (frisys_mol.cpp:498)
+    fv.write((const char *)zeros.data(), (std::streamsize)(8 * m));
+    std::ofstream fx(dir + "dense.txt");
+    fx << 0 << '\n';
+}
+
+// DistVec::load (:739-844): positions 0.. hold the stored elements with |value| > 1e-9, in file order
+static size_t load_vector(fries_ctx *ctx, const std::string &dir, unsigned n_orb) {
+    const size_t n_bytes = (2 * n_orb + 7) / 8;
+    std::ifstream fd(dir + "dets0.dat", std::ios::binary | std::ios::ate);
+    if (!fd.is_open()) throw std::runtime_error("Could not open saved binary vector file at path " + dir + "dets0.dat");
+    size_t n = (size_t)fd.tellg() / n_bytes;
+    fd.seekg(0);
+    std::vector<uint64_t> dets(n, 0); std::vector<double> vals(n);
+    for (size_t i = 0; i < n; i++) fd.read((char *)&dets[i], (std::streamsize)n_bytes);
+    std::ifstream fv(dir + "vals0.dat", std::ios::binary);
+    if (!fv.is_open()) throw std::runtime_error("Could not open saved binary vector file at path " + dir + "vals0.dat");
+    fv.read((char *)vals.data(), (std::streamsize)(8 * n));
+    std::vector<uint64_t> d2; std::vector<double> v2;
+    for (size_t i = 0; i < n; i++) if (fabs(vals[i]) > 1e-9) { d2.push_back(dets[i]); v2.push_back(vals[i]); }
+    ck(fries_vec_load(ctx, d2.data(), v2.data(), d2.size()));
+    return d2.size();
+}
+
+static bool load_last_line(const std::string &path, double *out) {
+    std::ifstream f(path);
+    double v; bool any = false;
+    while (f >> v) { *out = v; any = true; }
+    return any;
+}
+
+int main(int argc, char **argv) {
+    Args args;
+    try { args = parse_args(argc, argv); if (args.dist != "HB" && args.dist != "HB_unnorm") throw std::runtime_error("\"dist_str\" argument must be either \"HB\" or \"HB_unnorm\""); }
+    catch (std::exception &ex) { std::cerr << "\nError parsing command line: " << ex.what() << "\n\n"; return 1; }
+    try {
+        Fcidump in = parse_fcidump(args.fcidump_path, args.point_group);
+        fries_ctx *ctx = nullptr;
+        ck(fries_ctx_create(&ctx, (int)args.device));
+        ck(fries_set_molecule(ctx, in.n_orb, in.n_elec, in.symm.data(), in.hcore.data(), in.eris.data()));
+        uint32_t seed = args.seed;
+        if (!args.have_seed) seed = (uint32_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();      // frisys_mol.cpp:104-106
+        std::cout << "seed on process 0 is " << seed << std::endl;
+        fries_frisys_params p{args.epsilon, args.target, args.initiator, args.vec_nonz, args.mat_nonz, args.max_dets, seed, args.dist == "HB_unnorm" ? 1 : 0};
+        ck(fries_frisys_setup(ctx, &p));
+        double en_shift = 0, last_norm = 0;
+        if (!args.load_dir.empty()) {                       // :257-263, :284-286
+            load_vector(ctx, args.load_dir, in.n_orb);
+            load_last_line(args.load_dir + "S.txt", &en_shift);
+            uint32_t n; int32_t nz; uint32_t nf;
+            ck(fries_vec_info(ctx, &n, &nz, &nf));
+            std::vector<uint64_t> d(n ? n : 1); std::vector<double> v(n ? n : 1); size_t m;
+            ck(fries_vec_download(ctx, d.data(), v.data(), d.size(), &m));
+            for (size_t i = 0; i < m; i++) last_norm += fabs(v[i]);
+            ck(fries_frisys_restart(ctx, seed, en_shift, last_norm, 0));
+        }
+        const std::string &rd = args.result_dir;
+        std::ofstream num_file(rd + "projnum.txt", std::ofstream::app), den_file(rd + "projden.txt", std::ofstream::app),
+            shift_file(rd + "S.txt", std::ofstream::app), norm_file(rd + "norm.txt", std::ofstream::app), nkept_file(rd + "nkept.txt", std::ofstream::app);
+        if (!num_file.is_open()) throw std::runtime_error("Could not open file for writing in directory " + rd);
+        num_file.precision(17); den_file.precision(17); shift_file.precision(17); norm_file.precision(17);
+        {
+            std::ofstream param_f(rd + "params.txt");
+            param_f << "FRI calculation\nFCIDUMP path: " << args.fcidump_path << "\nepsilon (imaginary time step): " << args.epsilon << "\nTarget norm " << args.target
+                    << "\nInitiator threshold: " << args.initiator << "\nMatrix nonzero: " << args.mat_nonz << "\nVector nonzero: " << args.vec_nonz << "\n";
+            if (!args.load_dir.empty()) param_f << "Restarting calculation from " << args.load_dir << "\n";
+            else param_f << "Initializing calculation from HF unit vector\n";
+        }
+        {   // hash.dat: the proc scrambler (io_utils.cpp:589-606); one rank never uses it, but a restart on several ranks would
+            std::vector<uint32_t> scr(2 * in.n_orb);
+            ck(fries_get_scramblers(ctx, scr.data(), nullptr, scr.size()));
+            std::ofstream fh(rd + "hash.dat", std::ios::binary);
+            fh.write((const char *)scr.data(), (std::streamsize)(4 * scr.size()));
+        }
+        const unsigned shift_interval = 10, save_interval = 100;
+        for (uint32_t it = 0; it < args.max_iter; it++) {
+            fries_iter_log lg;
+            ck(fries_frisys_iterate(ctx, 1, &lg));
+            num_file << lg.numer << '\n'; den_file << lg.denom << '\n'; nkept_file << lg.nkept << '\n';
+            if ((it + 1) % shift_interval == 0) { shift_file << lg.shift << '\n'; norm_file << lg.norm << '\n'; }
+            std::cout << it << ", en est: " << lg.numer / lg.denom << ", shift: " << lg.shift << ", norm: " << lg.norm << '\n';      // :518-520
+            if ((it + 1) % save_interval == 0) {
+                save_vector(ctx, rd, in.n_orb);
+                num_file.flush(); den_file.flush(); shift_file.flush(); nkept_file.flush();
+            }
+        }
+        save_vector(ctx, rd, in.n_orb);
+        fries_ctx_destroy(ctx);
+    } catch (std::exception &ex) {
+        std::cerr << "\nException : " << ex.what() << "\n";       // the reference prints and exits 0 (frisys_mol.cpp:562-566)
+    }
+    return 0;
+}

@@ -22,7 +22,7 @@ EXPORTS = [
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
-    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate",
+    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers",
 ]
 
 
@@ -90,6 +90,7 @@ def load_library() -> C.CDLL:
     lib.fries_prof_count.argtypes = [C.c_void_p]
     lib.fries_prof_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fries_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
+    lib.fries_get_scramblers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.fries_hh_setup.argtypes = [C.c_void_p, C.POINTER(HHParams)]
     lib.fries_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]

@@ -107,6 +107,9 @@ int fries_frisys_setup(fries_ctx *ctx, const fries_frisys_params *p);
 /* frisys_mol.cpp:405-552, n_iter times; logs may be NULL or hold n_iter entries */
 int fries_frisys_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
 double fries_p_doub(fries_ctx *ctx);
+/* the proc / vec hash scramblers drawn at setup (frisys_mol.cpp:132-145; hash.dat holds the first, io_utils.cpp:589-606).
+ * Either pointer may be NULL; n = 2 * n_orb entries each. */
+int fries_get_scramblers(fries_ctx *ctx, uint32_t *proc_scrambler, uint32_t *vec_scrambler, size_t n);
 uint64_t fries_kernel_launches(fries_ctx *ctx);
 
 /* ---- frisys_hh: FRI with systematic matrix compression for the 1-D Hubbard-Holstein model (FRIES_bin/frisys_hh.cpp),

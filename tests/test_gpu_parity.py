@@ -2,6 +2,8 @@
 on the same seeded inputs and against the golden vectors the real reference produced.
 Bar: integers (positions, determinants, counts) and stored doubles bit-exact; projected energy
 numer/denom within 1e-10 (their mixed-sign dot products are summed in a tree on the GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -293,3 +295,61 @@ def test_hubbard_holstein_matches_reference(name):
     d, v = eng.vector()
     assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"]
     eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_driver_reproduces_reference_outputs(tmp_path):
+    """fries_amd/frisys_mol_hip (C++ host driver over the C ABI) with the reference's command line: projnum / projden /
+    nkept / S / norm files against the golden trajectory, then the binary checkpoint through --load_dir."""
+    import subprocess
+    from fries_amd import build
+    name = "ne_m2000_unnorm"
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out1 = str(tmp_path / "run1") + "/"
+    os.makedirs(out1)
+    exe = build.DRIVER
+    assert os.path.exists(exe), "frisys_mol_hip has not been built"
+    n_it = 40
+    cmd = [exe, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--vec_nonz", str(r["vec_nonz"]),
+           "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--initiator", repr(r["initiator"]),
+           "--epsilon", repr(r["epsilon"]), "--max_iter", str(n_it), "--result_dir", out1, "--seed", str(r["seed"])]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out1 + "projnum.txt"); den = np.loadtxt(out1 + "projden.txt"); nk = np.loadtxt(out1 + "nkept.txt")
+    sh = np.loadtxt(out1 + "S.txt"); nm = np.loadtxt(out1 + "norm.txt")
+    assert num.size == n_it and sh.size == n_it // 10
+    for i in range(n_it):
+        row = g["rows"][i]
+        assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10
+        assert int(nk[i]) == row["nkept"]
+    for k in range(n_it // 10):
+        row = g["rows"][10 * k + 9]
+        assert sh[k] == row["shift"] and nm[k] == row["norm"]        # written with 17 significant digits
+    # checkpoint: dets0.dat holds ceil(2 n_orb / 8) bytes per stored index, vals0.dat two value columns (DistVec::save)
+    nb = (2 * mol.n_orb + 7) // 8
+    raw = np.fromfile(out1 + "dets0.dat", dtype=np.uint8)
+    n_saved = raw.size // nb
+    assert n_saved == g["rows"][n_it - 1]["curr_size"]
+    vals = np.fromfile(out1 + "vals0.dat", dtype=np.float64)
+    assert vals.size == 2 * n_saved and np.all(vals[n_saved:] == 0)
+    dets = np.zeros(n_saved, dtype=np.uint64)
+    for b in range(nb):
+        dets |= raw.reshape(n_saved, nb)[:, b].astype(np.uint64) << np.uint64(8 * b)
+    assert golden_io.vec_hash(dets, vals[:n_saved]) == g["rows"][n_it - 1]["hash"]
+    assert np.fromfile(out1 + "hash.dat", dtype=np.uint32).size == 2 * mol.n_orb
+    # --load_dir: the stored non-zeros come back in file order (DistVec::load) and the run continues
+    out2 = str(tmp_path / "run2") + "/"
+    os.makedirs(out2)
+    cmd2 = cmd[:]
+    cmd2[cmd2.index("--result_dir") + 1] = out2
+    cmd2[cmd2.index("--max_iter") + 1] = "5"
+    cmd2 += ["--load_dir", out1]
+    res2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=300)
+    assert res2.returncode == 0 and "Exception" not in res2.stderr, res2.stderr[-2000:]
+    assert np.loadtxt(out2 + "projnum.txt").size == 5
+    keep = vals[:n_saved] != 0
+    assert np.fromfile(out2 + "dets0.dat", dtype=np.uint8).size // nb > 0 and int(keep.sum()) > 0
