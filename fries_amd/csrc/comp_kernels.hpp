@@ -174,17 +174,41 @@ __device__ __forceinline__ unsigned fr_row_len(const HbTables &T, uint32_t nsub_
 }
 
 // ------------------------------------------------------------------ replay of sys_sub for one element
+// Everything one element contributes to sys_sub.  The kernels fetch these for their four elements in one batch (independent
+// loads, one wait) before any element is evaluated: evaluated one after the other, each element costs three dependent
+// global-load latencies (value -> parent position -> determinant) and the kernels were bound by exactly that.
+struct ElemIn {
+    double v, wr, rinv;
+    uint32_t nd, kp, code, pos, nsub, raux;
+    det_t det;
+};
+template <int STAGE, int N>
+__device__ __forceinline__ void fr_load_elems(const CompWork &W, const VecDev &V, int cur, size_t base, unsigned n_in, ElemIn (&x)[N]) {
+    const StageElems &E = W.el[cur];
+    const size_t last = n_in ? n_in - 1 : 0;
+#pragma unroll
+    for (int it = 0; it < N; it++) {
+        const size_t e = base + it;
+        const size_t ec = e < n_in ? e : last;          // clamped: the loads stay unconditional
+        x[it].v = E.val[ec]; x[it].nd = E.ndiv[ec]; x[it].wr = W.wt_remain[ec]; x[it].kp = W.keep[ec];
+        if (STAGE != 1) { x[it].code = E.code[ec]; x[it].pos = E.pos[ec]; x[it].nsub = E.nsub[ec]; x[it].raux = E.raux[ec]; x[it].rinv = E.rinv[ec]; }
+        else { x[it].code = 0; x[it].pos = 0; x[it].nsub = 2; x[it].raux = 0; x[it].rinv = 1.0; }
+        if (e >= n_in) x[it].v = 0;
+    }
+#pragma unroll
+    for (int it = 0; it < N; it++) x[it].det = (STAGE != 1 && x[it].nd == 0 && x[it].v != 0) ? V.dets[x[it].pos] : 0ull;
+}
+
 // Returns the number of emissions; *k advances over consumed teeth.  When EMIT, writes
 // (wi, sub, value) triples starting at slot `out`.
 template <int STAGE, bool NEW_HB, bool EMIT>
-__device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const VecDev &V, const HbTables &T, const Teeth *th, int cur,
+__device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTables &T, const Teeth *th, const ElemIn &x,
                                                    size_t e, double lbound, uint32_t *k, double unit, double p_doub, size_t out) {
-    const StageElems &E = W.el[cur];
-    double v = E.val[e];
+    const double v = x.v;
     if (v == 0) return 0;
-    uint32_t nd = E.ndiv[e], n = 0;
-    double wr = W.wt_remain[e];
-    uint32_t kp = W.keep[e];
+    const uint32_t nd = x.nd, kp = x.kp;
+    uint32_t n = 0;
+    const double wr = x.wr;
     auto emit = [&](uint32_t sub, double val) {
         if (EMIT) { size_t o = out + n; if (o < W.cap) { W.e_wi[o] = (uint32_t)e; W.e_sub[o] = sub; W.e_val[o] = val; } }
         n++;
@@ -209,11 +233,11 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const VecD
         double rn = fr_tooth(th, *k);
         if (wr < v || rn < lbound) {
             double sub_lbound = lbound - wr;
-            uint32_t code = STAGE == 1 ? 0u : E.code[e];
-            det_t det = STAGE == 1 ? 0ull : V.dets[E.pos[e]];
-            RowInfo ri = STAGE == 1 ? fr_row1(W.row1) : fr_row_cached(E, e);
+            RowInfo ri;
+            if (STAGE == 1) ri = fr_row1(W.row1);
+            else { ri.inv_norm = x.rinv; ri.aux = x.raux; ri.nsub = x.nsub; ri.tot = 0; }
             unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
-            fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
+            fr_row_visit<STAGE, NEW_HB>(T, x.det, x.code, ri, p_doub, [&](unsigned s, double w) {
                 if (s >= n_sub) return;
                 if (((kp >> s) & 1u) && w != 0) emit(s, v * w);
                 else {
@@ -237,12 +261,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
     if (STAGE != 1) fr_stage_tables(&T, Tg);
-    const Teeth *th = W.teeth;
+    __shared__ Teeth Tsh;
+    fr_stage_teeth(&Tsh, W.teeth);
+    const Teeth *th = &Tsh;
     const double unit = fin->unit;
     AccWt acc{W.wt_remain, &W.state[0]};
     double Sx[4], Sprev;
     fr_seq_prefix4(W.seq, acc, blockIdx.x, &seqsh, Sx, &Sprev);
     size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    ElemIn x[FR_ITEMS];
+    fr_load_elems<STAGE, FR_ITEMS>(W, V, cur, base, n_in, x);
     uint32_t cnt_t = 0;
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
@@ -251,7 +279,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
         double Se = Sx[it];
         uint32_t kin = (e == 0) ? 0u : fr_teeth_below(th, Sprev);
         uint32_t k = kin;
-        uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e, Se, &k, unit, p_doub, 0);
+        uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x[it], e, Se, &k, unit, p_doub, 0);
         W.S[e] = Se; W.kin[e] = kin; W.cnt[e] = c;
         cnt_t += c;
         if (k != fr_teeth_below(th, Se)) {      // tooth backlog: repaired by k_sys_fixup
@@ -282,10 +310,13 @@ __global__ void k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, d
         size_t e = W.fix_list[i];
         if (e < done_upto) continue;
         uint32_t k = W.kin[e];
-        fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e, W.S[e], &k, fin->unit, p_doub, 0);
+        ElemIn x1[1];
+        fr_load_elems<STAGE, 1>(W, V, cur, e, n_in, x1);
+        fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x1[0], e, W.S[e], &k, fin->unit, p_doub, 0);
         for (size_t e2 = e + 1; e2 < n_in; e2++) {
             uint32_t kin = k;
-            uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, V, T, th, cur, e2, W.S[e2], &k, fin->unit, p_doub, 0);
+            fr_load_elems<STAGE, 1>(W, V, cur, e2, n_in, x1);
+            uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x1[0], e2, W.S[e2], &k, fin->unit, p_doub, 0);
             uint32_t old = W.cnt[e2];
             W.kin[e2] = kin; W.cnt[e2] = c;
             W.pcnt[1][e2 / FR_TILE] += c - old;
@@ -304,7 +335,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
     if (STAGE != 1) fr_stage_tables(&T, Tg);
-    const Teeth *th = W.teeth;
+    __shared__ Teeth Tsh;
+    fr_stage_teeth(&Tsh, W.teeth);
+    const Teeth *th = &Tsh;
     const uint32_t *pc = W.pcnt[1];
     uint32_t off;
     {
@@ -319,13 +352,18 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     uint32_t tot;
     uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
     size_t o = (size_t)off + (incl - tsum);
+    ElemIn x[FR_ITEMS];
+    fr_load_elems<STAGE, FR_ITEMS>(W, V, cur, base, n_in, x);
+    uint32_t kin4[FR_ITEMS]; double S4[FR_ITEMS];
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { size_t e = base + it; size_t ec = e < n_in ? e : (n_in ? n_in - 1 : 0); kin4[it] = W.kin[ec]; S4[it] = W.S[ec]; }
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + it;
         if (e >= n_in) break;
         if (c[it]) {
-            uint32_t k = W.kin[e];
-            fr_sys_element<STAGE, NEW_HB, true>(W, V, T, th, cur, e, W.S[e], &k, fin->unit, p_doub, o);
+            uint32_t k = kin4[it];
+            fr_sys_element<STAGE, NEW_HB, true>(W, T, th, x[it], e, S4[it], &k, fin->unit, p_doub, o);
         }
         W.keep[e] = 0;
         o += c[it];

@@ -218,7 +218,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sc_apply(VecDev V, VcompBuf B, uin
     const unsigned n = fin->n_in;
     const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
-    const Teeth *th = B.teeth;
+    __shared__ Teeth Tsh;
+    fr_stage_teeth(&Tsh, B.teeth);
+    const Teeth *th = &Tsh;
     AccUnkept acc{V.v0, B.keep, V.st};
     double Sx[4], Sprev;
     fr_seq_prefix4(B.seq, acc, blockIdx.x, &seqsh, Sx, &Sprev);
@@ -269,12 +271,14 @@ __global__ void k_sc_fixup(VecDev V, VcompBuf B, uint32_t *kin, uint32_t *err) {
 }
 
 __global__ void __launch_bounds__(FR_BLOCK) k_sc_write(VecDev V, VcompBuf B, const uint32_t *kin) {
+    __shared__ Teeth Tsh;
+    fr_stage_teeth(&Tsh, B.teeth);
     CompState *fin = &B.state[FR_MAX_ROUNDS + 1];
     const unsigned n = fin->n_in;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k = kin[i];
-    fr_sc_element(V, B, B.teeth, i, B.S[i], &k, fin->unit, true);
+    fr_sc_element(V, B, &Tsh, i, B.S[i], &k, fin->unit, true);
 }
 
 // find_preserve returns 0 when the budget is spent (compress_utils.cpp:94-96)

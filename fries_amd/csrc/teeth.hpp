@@ -9,6 +9,7 @@
 // segments per binade, and tooth k can be evaluated in O(log #segments) by any lane.
 #pragma once
 #include "fries_dev.hpp"
+#include <cstddef>
 
 #define FR_MAX_SEG 320
 
@@ -54,6 +55,17 @@ __device__ inline void fr_build_teeth(Teeth *t, double r0, double u, uint32_t km
     // teeth below k are tabulated
     t->nseg = ns;
     t->kmax = k < kmax ? k : kmax;
+}
+
+// Copies the table into LDS (all threads of the workgroup call it; ends with a barrier).  A lookup is a binary search
+// over ~60 segments: from global memory that is ~7 dependent L2 round trips per call, three calls per element.
+__device__ __forceinline__ void fr_stage_teeth(Teeth *dst, const Teeth *src) {
+    const uint32_t nseg = src->nseg < FR_MAX_SEG ? src->nseg : FR_MAX_SEG;
+    const uint32_t ndw = (uint32_t)((offsetof(Teeth, seg) + (size_t)nseg * sizeof(TeethSeg)) / 4);
+    const uint32_t *s = (const uint32_t *)src;
+    uint32_t *d = (uint32_t *)dst;
+    for (uint32_t i = threadIdx.x; i < ndw; i += blockDim.x) d[i] = s[i];
+    __syncthreads();
 }
 
 // position of tooth k (k < kmax)
