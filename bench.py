@@ -253,7 +253,7 @@ def main():
                               "share_of_kernel_time": ms / tot_ms, "n_nonz": info[1]}
         result["kernel_time_ms_per_iter"] = tot_ms / args.profile_steps
         result["top_kernels"] = {k: {"ms_per_iter": v[0] / args.profile_steps, "calls_per_iter": v[1] / args.profile_steps}
-                                 for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])[:8]}
+                                 for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("FRIES_BENCH_TOPK", "8"))]}
         # whole-iteration algorithmic traffic (~312 B per nonzero per iteration)
         result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9      # per GPU
 

@@ -116,13 +116,13 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Wo
     __shared__ double shd[4];
     const CompState st0 = W.state[0];
     const double G0 = fr_sum_partials(W.psum[0], (st0.n_in + FR_TILE - 1) / FR_TILE, shd);
+    for (int k = threadIdx.x; k < FR_MAX_ROUNDS + 2; k += blockDim.x) F.hist[k] = 0;
     if (threadIdx.x == 0) {
         FksScal *S = F.scal;
         S->G0 = G0; S->n0 = st0.n_rem; S->n_in = st0.n_in;
         msg->L0 = G0; msg->changed = 0; msg->pad = 0;
         for (int p = 0; p < FR_FKS_PMAX; p++) { msg->totG[p] = 0; msg->totK[p] = 0; msg->totW[p] = G0; }
         S->zero_prefix = 1; S->changed = 0; S->done_ctr = 0; S->overflow = 0; S->valid_upto = -1;
-        for (int k = 0; k < FR_MAX_ROUNDS + 2; k++) F.hist[k] = 0;
         S->warm = 0; S->warm_scale = 1.0;
         if (inline_passes) { fr_fks2_passes(S, msg, 1, nullptr); fr_fks2_warm(S, F.saved, warm); }
     }

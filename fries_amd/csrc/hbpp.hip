@@ -214,29 +214,37 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_compact(CompWork W, int prev
 
 // find_keep_sub's epilogue (compress_utils.cpp:266-275), seed_sys and the comb, from the settled replay
 // norms: every rank's find_keep_sub result in rank order (compress_utils.cpp:817-818); norms[rank] == *W.seq.total
-static __global__ void k_comp_finalize2(CompWork W, Fks2Work F, double rn, const double *norms, int rank, int n_ranks) {
-    const FksScal *S = F.scal;
-    CompState s = W.state[0];
-    double G = S->G_last;
-    uint32_t n_rem = S->n_last;
-    s.n_pass = S->n_pass;
-    double loc_norm = 0;
-    if (G / n_rem < 1e-8) n_rem = 0;
-    else loc_norm = *W.seq.total;
-    s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
-    // seed_sys (compress_utils.cpp:113-120): lbound over the ranks before me, then the rest on top of it, in rank order.
-    // n_rem == 0 is decided from replicated scalars, so every rank then reports a zero norm.
-    double lbound0 = 0;
-    for (int p = 0; p < rank; p++) lbound0 += n_rem ? norms[p] : 0.0;
-    double glob = lbound0;
-    for (int p = rank; p < n_ranks; p++) glob += (p == rank) ? loc_norm : (n_rem ? norms[p] : 0.0);
-    double unit = 0, r0 = INFINITY;
-    if (n_rem > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_rem, &unit);
-    s.unit = glob / n_rem;
-    s.n_out = 0; s.n_fix = 0;
-    W.state[FR_MAX_ROUNDS + 1] = s;
-    if (n_rem > 0) fr_build_teeth(W.teeth, r0, unit, n_rem + 2, lbound0);
-    else { W.teeth->nseg = 0; W.teeth->kmax = 0; W.teeth->unit = 0; W.teeth->lbound0 = lbound0; }
+static __global__ void __launch_bounds__(64) k_comp_finalize2(CompWork W, Fks2Work F, double rn, const double *norms, int rank, int n_ranks) {
+    __shared__ Teeth Tsh;           // the comb is tabulated in LDS by one lane and copied out by the wave
+    if (threadIdx.x == 0) {
+        const FksScal *S = F.scal;
+        CompState s = W.state[0];
+        double G = S->G_last;
+        uint32_t n_rem = S->n_last;
+        s.n_pass = S->n_pass;
+        double loc_norm = 0;
+        if (G / n_rem < 1e-8) n_rem = 0;
+        else loc_norm = *W.seq.total;
+        s.n_rem = n_rem; s.loc_norm = loc_norm; s.G = G; s.pbuf = 0;
+        // seed_sys (compress_utils.cpp:113-120): lbound over the ranks before me, then the rest on top of it, in rank order.
+        // n_rem == 0 is decided from replicated scalars, so every rank then reports a zero norm.
+        double lbound0 = 0;
+        for (int p = 0; p < rank; p++) lbound0 += n_rem ? norms[p] : 0.0;
+        double glob = lbound0;
+        for (int p = rank; p < n_ranks; p++) glob += (p == rank) ? loc_norm : (n_rem ? norms[p] : 0.0);
+        double unit = 0, r0 = INFINITY;
+        if (n_rem > 0) r0 = fr_seed_sys(rn, lbound0, glob, n_rem, &unit);
+        s.unit = glob / n_rem;
+        s.n_out = 0; s.n_fix = 0;
+        W.state[FR_MAX_ROUNDS + 1] = s;
+        if (n_rem > 0) fr_build_teeth(&Tsh, r0, unit, n_rem + 2, lbound0);
+        else { Tsh.nseg = 0; Tsh.kmax = 0; Tsh.unit = 0; Tsh.lbound0 = lbound0; }
+    }
+    __syncthreads();
+    const uint32_t ndw = (uint32_t)((offsetof(Teeth, seg) + (size_t)Tsh.nseg * sizeof(TeethSeg)) / 4);
+    const uint32_t *src = (const uint32_t *)&Tsh;
+    uint32_t *dst = (uint32_t *)W.teeth;
+    for (uint32_t i = threadIdx.x; i < ndw; i += blockDim.x) dst[i] = src[i];
 }
 
 // this rank's find_keep_sub result, as the reference returns it (0 when the budget is spent, compress_utils.cpp:267-269)
@@ -412,7 +420,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_LAUNCH(c, "k_put_norm", k_put_norm, dim3(1), dim3(1), W, F, (double *)c->comm.small_send);
         norms = (const double *)fr_allgather(c, sizeof(double));
     }
-    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(1), W, F, rn, norms, c->rank, P);
+    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(64), W, F, rn, norms, c->rank, P);
     if (c->rank > 0) {
         SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
         SeqWork Q2 = W.seq; Q2.total = c->d_seq_scratch;

@@ -55,45 +55,57 @@ void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
 __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec, int mode) {
     const uint32_t n = *S.n_spawn;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const det_t dd = S.det[j];
-    bool ini = S.ini[j];
-    if ((mode == 1 && !ini) || (mode == 2 && ini)) return;
-    const det_t emask = V.hh_sites ? (1ull << (2 * V.hh_sites)) - 1ull : ~0ull;
-    if ((uint32_t)__popcll(dd & emask) != n_elec) { atomicOr(&V.st->err, FR_ERR_NELEC); S.slot[j] = FR_NOPOS; return; }
-    const det_t d = fr_vec_key(V, dd);
-    uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS;
-    bool created = false;
-    for (uint32_t probe = 0; probe < V.hcap; probe++) {
-        det_t k = V.hkeys[s];
-        if (k == d) { found = s; break; }
-        if (k == FR_EMPTY_KEY) {
-            if (!ini) break;
-            det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
-            if (old == FR_EMPTY_KEY) { found = s; created = true; break; }
-            if (old == d) { found = s; break; }
-            // another determinant took the slot: keep probing from the next one
+    bool created = false, counted = false;          // counters are bumped once per wave at the end (one address, ~1e6 lanes)
+    bool bad_nelec = false, hash_full = false;
+    if (j < n) {
+        const det_t dd = S.det[j];
+        bool ini = S.ini[j];
+        if (!((mode == 1 && !ini) || (mode == 2 && ini))) {
+            const det_t emask = V.hh_sites ? (1ull << (2 * V.hh_sites)) - 1ull : ~0ull;
+            if ((uint32_t)__popcll(dd & emask) != n_elec) { bad_nelec = true; S.slot[j] = FR_NOPOS; }
+            else {
+                const det_t d = fr_vec_key(V, dd);
+                uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS;
+                for (uint32_t probe = 0; probe < V.hcap; probe++) {
+                    det_t k = V.hkeys[s];
+                    if (k == d) { found = s; break; }
+                    if (k == FR_EMPTY_KEY) {
+                        if (!ini) break;
+                        det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
+                        if (old == FR_EMPTY_KEY) { found = s; created = true; break; }
+                        if (old == d) { found = s; break; }
+                        // another determinant took the slot: keep probing from the next one
+                    }
+                    s = (s + 1) & (V.hcap - 1);
+                }
+                if (found == FR_NOPOS) {
+                    if (ini) hash_full = true;
+                    S.slot[j] = FR_NOPOS;
+                }
+                else {
+                    uint32_t hv = V.hvals[found];
+                    if (ini) {
+                        if (hv & FR_NEWBIT) atomicMin(&V.hvals[found], FR_NEWBIT | j);   // being created in this merge
+                        S.slot[j] = found;
+                    }
+                    else if (mode == 0) {
+                        // non-initiator spawns only reach determinants that were present before this merge and are
+                        // non-zero in the origin column (vec_utils.hpp:617, 632-637)
+                        if ((hv & FR_NEWBIT) || V.v0[hv] == 0) S.slot[j] = FR_NOPOS;
+                        else { S.slot[j] = found; counted = true; }
+                    }
+                    else S.slot[j] = found;     // decided in arrival order by k_seg_sum
+                }
+            }
         }
-        s = (s + 1) & (V.hcap - 1);
     }
-    if (created) atomicAdd(&V.st->n_used, 1u);
-    if (found == FR_NOPOS) {
-        if (ini) atomicOr(&V.st->err, FR_ERR_HASH_FULL);
-        S.slot[j] = FR_NOPOS;
-        return;
+    const unsigned long long mc = __ballot(created), mn = __ballot(counted);
+    if (fr_lane() == 0) {
+        if (mc) atomicAdd(&V.st->n_used, (uint32_t)__popcll(mc));
+        if (mn) atomicAdd(&V.st->nonini_occ_add, (unsigned long long)__popcll(mn));
     }
-    uint32_t hv = V.hvals[found];
-    if (ini) {
-        if (hv & FR_NEWBIT) atomicMin(&V.hvals[found], FR_NEWBIT | j);   // being created in this merge
-        S.slot[j] = found;
-    }
-    else if (mode == 0) {
-        // non-initiator spawns only reach determinants that were present before this merge and are
-        // non-zero in the origin column (vec_utils.hpp:617, 632-637)
-        if ((hv & FR_NEWBIT) || V.v0[hv] == 0) S.slot[j] = FR_NOPOS;
-        else { S.slot[j] = found; atomicAdd(&V.st->nonini_occ_add, 1ull); }
-    }
-    else S.slot[j] = found;     // decided in arrival order by k_seg_sum
+    if (__any(bad_nelec) && fr_lane() == 0) atomicOr(&V.st->err, FR_ERR_NELEC);
+    if (__any(hash_full) && fr_lane() == 0) atomicOr(&V.st->err, FR_ERR_HASH_FULL);
 }
 
 // M2: flag the first arrival of every new determinant
