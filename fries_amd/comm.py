@@ -54,6 +54,8 @@ class TorchComm:
         self.big_send = torch.zeros(self.big_bytes, **u8)
         self.big_recv = torch.zeros(self.big_bytes, **u8)
         self._ext = {}
+        self._bound = None          # engine stream made torch's current stream (see _enter)
+        self._views = {}            # byte count -> (recv view, send view): slicing costs microseconds per call otherwise
         self.n_allgather = 0
         self.n_alltoallv = 0
         self.error = None
@@ -63,23 +65,36 @@ class TorchComm:
         self.struct = CommStruct(None, self.rank, self.size, self.small_send.data_ptr(), self.small_recv.data_ptr(),
                                  self.big_send.data_ptr(), self.big_recv.data_ptr(), self.big_bytes, self._ag, self._a2a)
 
-    # the engine's stream as a torch stream, so that collectives order themselves after the engine's kernels
-    def _stream_ctx(self, stream_ptr):
+    # The engine's stream as torch's current stream, so that collectives order themselves after the engine's kernels.  The
+    # callbacks run on the thread that called into the engine, ~50 times per iteration: the stream is made current once per
+    # engine stream instead of entering a context manager on every call.
+    def _enter(self, stream_ptr):
+        if self.device.type != "cuda" or not stream_ptr or self._bound == stream_ptr:
+            return
         torch = self.torch
-        if self.device.type != "cuda" or not stream_ptr:
-            import contextlib
-            return contextlib.nullcontext()
         ext = self._ext.get(stream_ptr)
         if ext is None:
             ext = torch.cuda.ExternalStream(stream_ptr, device=self.device)
             self._ext[stream_ptr] = ext
-        return torch.cuda.stream(ext)
+        torch.cuda.set_stream(ext)
+        self._bound = stream_ptr
+
+    def release(self):
+        """Called before the engine's stream is destroyed: torch must not keep it as its current stream."""
+        if self._bound is not None and self.device.type == "cuda":
+            self.torch.cuda.set_stream(self.torch.cuda.default_stream(self.device))
+        self._bound = None
+        self._ext.clear()
 
     def _allgather(self, user, nbytes, stream):
         try:
             n = int(nbytes)
-            with self._stream_ctx(stream):
-                self.dist.all_gather_into_tensor(self.small_recv[:n * self.size], self.small_send[:n], group=self.group)
+            self._enter(stream)
+            v = self._views.get(n)
+            if v is None:
+                v = (self.small_recv[:n * self.size], self.small_send[:n])
+                self._views[n] = v
+            self.dist.all_gather_into_tensor(v[0], v[1], group=self.group)
             self.n_allgather += 1
             return 0
         except Exception as e:       # an exception must not unwind through the C frames
@@ -91,8 +106,8 @@ class TorchComm:
         try:
             sb = [int(send_bytes[i]) for i in range(self.size)]
             rb = [int(recv_bytes[i]) for i in range(self.size)]
-            with self._stream_ctx(stream):
-                self.dist.all_to_all_single(self.big_recv[:sum(rb)], self.big_send[:sum(sb)], rb, sb, group=self.group)
+            self._enter(stream)
+            self.dist.all_to_all_single(self.big_recv[:sum(rb)], self.big_send[:sum(sb)], rb, sb, group=self.group)
             self.n_alltoallv += 1
             return 0
         except Exception as e:

@@ -132,6 +132,8 @@ class FriEngine:
 
     def close(self):
         if self.h:
+            if self.comm is not None:
+                self.comm.release()
             self.lib.fries_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
