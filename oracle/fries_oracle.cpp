@@ -1615,4 +1615,277 @@ void FrisysHH::iterate(unsigned n_iter) {
     }
 }
 
+
+// ------------------------------------------------------------------ FCIQMC, near-uniform
+uint64_t Rng::mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+void Rng::begin(uint64_t iter, det_t det, uint32_t attempt, uint32_t purpose) {
+    if (mt) return;
+    uint64_t h = mix(seed ^ 0x9e3779b97f4a7c15ULL);
+    h = mix(h ^ (iter * 0xd1b54a32d192ed03ULL));
+    h = mix(h ^ det);
+    h = mix(h ^ (((uint64_t)attempt << 8) | purpose));
+    key = h; ctr = 0;
+}
+double Rng::uni() {
+    if (mt) return (*mt)() / (1. + UINT32_MAX);
+    uint64_t h = mix(key + (uint64_t)(++ctr) * 0x9e3779b97f4a7c15ULL);
+    return (uint32_t)(h >> 32) / (1. + UINT32_MAX);
+}
+
+unsigned bin_sample(unsigned n, double p, Rng &rng) {
+    unsigned success = 0;
+    for (unsigned i = 0; i < n; i++) success += rng.uni() < p;
+    return success;
+}
+int round_binomially(double p, unsigned n, Rng &rng) {
+    int flr = (int)floor(p);
+    double prob = p - flr;
+    int ret = flr * (int)n;
+    for (unsigned i = 0; i < n; i++) ret += rng.uni() < prob;
+    return ret;
+}
+static inline unsigned choose_uint(Rng &rng, unsigned nmax) { return (unsigned)(rng.uni() * nmax); }   // near_uniform.cpp:41-44
+
+bool nu_doub_sample(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &sy, unsigned counts[][2], Rng &rng, uint8_t orbs[4], double *prob) {
+    const unsigned n_orb = sy.n_orb;
+    // _choose_occ_pair / _tri_to_occ_pair (:46-64)
+    unsigned tri = choose_uint(rng, n_elec * (n_elec - 1) / 2);
+    unsigned i1 = (unsigned)((sqrt(tri * 8. + 1) - 1) / 2);
+    unsigned i2 = (unsigned)(tri - i1 * (i1 + 1.) / 2);
+    i1 += 1;
+    unsigned orb1 = occ[i1], orb2 = occ[i2];
+    unsigned spin1 = i1 / (n_elec / 2), spin2 = i2 / (n_elec / 2);
+    unsigned sym_prod = sy.irrep[orb1 % n_orb] ^ sy.irrep[orb2 % n_orb];
+    // _count_doub_virt (:66-87)
+    int same_symm = sym_prod == 0 && spin1 == spin2;
+    unsigned n_allow = spin1 == spin2 ? n_orb - n_elec / 2 : 2 * n_orb - n_elec;
+    for (unsigned i = 0; i < N_IRREPS; i++) {
+        if (counts[i ^ sym_prod][spin2] == (unsigned)same_symm) n_allow -= counts[i][spin1];
+        if (spin1 != spin2 && counts[i ^ sym_prod][spin1] == (unsigned)same_symm) n_allow -= counts[i][spin2];
+    }
+    if (n_allow == 0) return false;
+    // _doub_choose_virt1 (:89-173)
+    int virt_choice;
+    unsigned a_spin, b_spin, n_virt2, orbital;
+    if (n_allow <= 3) {
+        virt_choice = (int)choose_uint(rng, n_allow);
+        if (spin1 == spin2) { a_spin = spin1; b_spin = a_spin; } else { a_spin = 0; b_spin = 1; }
+        orbital = 0;
+        while (virt_choice >= 0 && orbital < n_orb) {
+            if (!((det >> (orbital + a_spin * n_orb)) & 1)) {
+                unsigned a_symm = sy.irrep[orbital];
+                n_virt2 = counts[sym_prod ^ a_symm][b_spin] - (sym_prod == 0 && a_spin == b_spin);
+                if (n_virt2 != 0) virt_choice -= 1;
+            }
+            orbital += 1;
+        }
+        if (virt_choice >= 0) {
+            a_spin = 1; b_spin = 0;
+            while (virt_choice >= 0 && orbital < 2 * n_orb) {
+                if (!((det >> orbital) & 1)) {
+                    unsigned a_symm = sy.irrep[orbital - n_orb];
+                    n_virt2 = counts[sym_prod ^ a_symm][b_spin] - (sym_prod == 0 && a_spin == b_spin);
+                    if (n_virt2 != 0) virt_choice -= 1;
+                }
+                orbital += 1;
+            }
+            orbital -= n_orb;
+        }
+        virt_choice = (int)(orbital - 1 + a_spin * n_orb);
+    }
+    else {
+        n_virt2 = 0;
+        while (n_virt2 == 0) {
+            if (spin1 == spin2) { a_spin = spin1; b_spin = a_spin; virt_choice = (int)(choose_uint(rng, n_orb) + a_spin * n_orb); }
+            else { virt_choice = (int)choose_uint(rng, 2 * n_orb); a_spin = virt_choice / n_orb; b_spin = 1 - a_spin; }
+            if (!((det >> virt_choice) & 1)) {
+                unsigned a_symm = sy.irrep[virt_choice % n_orb];
+                n_virt2 = counts[sym_prod ^ a_symm][b_spin] - (sym_prod == 0 && a_spin == b_spin);
+            }
+        }
+    }
+    unsigned unocc1 = (unsigned)virt_choice;
+    a_spin = unocc1 / n_orb;
+    b_spin = spin1 ^ spin2 ^ a_spin;
+    unsigned a_symm = sy.irrep[unocc1 % n_orb], b_symm = sym_prod ^ a_symm;
+    unsigned m_a_b = counts[b_symm][b_spin] - (sym_prod == 0 && a_spin == b_spin);
+    // _doub_choose_virt2 (:176-191)
+    int orb_idx = (int)choose_uint(rng, m_a_b);
+    unsigned unocc2 = 0, symm_idx = 1;
+    while (orb_idx >= 0) {
+        unocc2 = sy.lk(b_symm, symm_idx) + b_spin * n_orb;
+        if (!((det >> unocc2) & 1) && unocc2 != unocc1) orb_idx -= 1;
+        symm_idx += 1;
+    }
+    unsigned m_b_a = counts[a_symm][a_spin] - (sym_prod == 0 && a_spin == b_spin);
+    *prob = 2. / n_elec / (n_elec - 1) / n_allow * (1. / m_a_b + 1. / m_b_a);
+    orbs[0] = (uint8_t)orb2; orbs[1] = (uint8_t)orb1;
+    if (unocc1 < unocc2) { orbs[2] = (uint8_t)unocc1; orbs[3] = (uint8_t)unocc2; } else { orbs[2] = (uint8_t)unocc2; orbs[3] = (uint8_t)unocc1; }
+    return true;
+}
+
+void nu_sing_setup(const uint8_t *occ, unsigned n_elec, const Symm &sy, unsigned counts[][2], unsigned *m_allow, unsigned *delta_s) {
+    unsigned ds = 0;
+    for (unsigned e = 0; e < n_elec; e++) {
+        unsigned na = counts[sy.irrep[occ[e] % sy.n_orb]][e / (n_elec / 2)];
+        m_allow[e] = na;
+        if (na == 0) ds++;
+    }
+    *delta_s = ds;
+}
+void nu_sing_sample(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &sy, const unsigned *m_allow, unsigned delta_s, Rng &rng, uint8_t orbs[2], double *prob) {
+    unsigned elec = 0, na = 0;
+    while (na == 0) { elec = choose_uint(rng, n_elec); na = m_allow[elec]; }        // _sing_choose_occ (:248-257)
+    unsigned occ_orb = occ[elec], occ_symm = sy.irrep[occ_orb % sy.n_orb], spin = occ_orb / sy.n_orb;
+    int symm_idx = -1;
+    unsigned orbital = 0;
+    while (symm_idx == -1) {                                                          // _sing_choose_virt (:260-274)
+        symm_idx = (int)choose_uint(rng, sy.lk(occ_symm, 0));
+        orbital = spin * sy.n_orb + sy.lk(occ_symm, symm_idx + 1);
+        if ((det >> orbital) & 1) symm_idx = -1;
+    }
+    *prob = 1. / m_allow[elec] / (n_elec - delta_s);
+    orbs[0] = (uint8_t)occ_orb; orbs[1] = (uint8_t)orbital;
+}
+
+void Fciqmc::setup() {
+    const unsigned n_orb = sys.n_orb, n_elec = sys.n_elec;
+    uint8_t tmp[64];
+    hf_det = gen_hf_det(n_orb, n_elec);
+    occ_list(hf_det, tmp);
+    sys.hf_en = diag_matrel(tmp, sys.ints, n_elec);
+    mt.seed(par.seed);
+    proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
+    for (auto &x : proc_scr) x = mt();     // fciqmc_mol.cpp:126-128
+    for (auto &x : vec_scr) x = mt();      // :134-136
+    if (par.counter_rng) { rng.mt = nullptr; rng.seed = par.seed; } else rng.mt = &mt;
+    unsigned spawn_length = par.target_walkers * 2;      // / n_procs^2, one rank (:107)
+    sol.init(par.max_dets, spawn_length, n_elec, 1);
+    // trial = HF, H trial by enumeration (:148-191), as in frisys_mol
+    trial_det = {hf_det}; trial_val = {1.0};
+    {
+        size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
+        Vec ht; ht.init(2 * n_ex, 2 * n_ex, n_elec, 2);
+        ht.add(hf_det, 1, 1); ht.perform_add(0);
+        std::vector<uint8_t> ex;
+        ht.cur = 1;
+        size_t n_sing = sing_ex_symm(hf_det, tmp, n_elec, n_orb, ex, sys.symm.irrep.data());
+        for (size_t e = 0; e < n_sing; e++) {
+            double m = sing_matrel_nosgn(&ex[2 * e], tmp, sys.ints, n_elec);
+            det_t nd = hf_det;
+            m *= sing_det_parity(&nd, &ex[2 * e]);
+            ht.add(nd, m * 1.0, 1);
+        }
+        ht.perform_add(0);
+        size_t n_doub = doub_ex_symm(hf_det, tmp, n_elec, n_orb, ex, sys.symm.irrep.data());
+        for (size_t e = 0; e < n_doub; e++) {
+            double m = doub_matrel_nosgn(&ex[4 * e], sys.ints);
+            det_t nd = hf_det;
+            m *= doub_det_parity(&nd, &ex[4 * e]);
+            ht.add(nd, m * 1.0, 1);
+        }
+        ht.perform_add(0);
+        for (size_t i = 0; i < ht.curr_size; i++) {
+            double cv = ht.vals[0][i];
+            if (cv != 0) ht.vals[0][i] = cv * (diag_matrel(ht.orbs_at(i), sys.ints, n_elec) - sys.hf_en);
+        }
+        ht.add_vecs(0, 1);
+        htrial_det.assign(ht.dets.begin(), ht.dets.begin() + ht.curr_size);
+        htrial_val.assign(ht.vals[0].begin(), ht.vals[0].begin() + ht.curr_size);
+        size_t n_sing2 = count_singex(hf_det, tmp, n_elec, sys.symm);
+        p_doub = (double)n_doub / (n_sing2 + n_doub);
+    }
+    sol.add(hf_det, 100, 1);      // :239-243
+    sol.perform_add(0);
+    en_shift = 0; last_norm = 0; iterat = 0;
+}
+
+void Fciqmc::iterate(unsigned n_iter) {
+    const unsigned n_elec = sys.n_elec;
+    const double eps = par.eps;
+    const unsigned shift_interval = 10;
+    const double shift_damping = 0.05;
+    std::vector<uint8_t> orbs; std::vector<double> probs;
+    for (unsigned it = 0; it < n_iter; it++, iterat++) {
+        FciqmcLog lg{};
+        int n_nonz = 0; uint32_t n_ini = 0; size_t n_spawn = 0;
+        for (size_t d = 0; d < sol.curr_size; d++) {          // :331-411
+            double &cur = sol.vals[0][d];
+            int cur_i = (int)cur;
+            unsigned n_walk = (unsigned)abs(cur_i);
+            if (n_walk == 0) continue;
+            n_nonz++;
+            int ini = n_walk > par.init_thresh;
+            n_ini += ini;
+            int sign = cur_i < 0 ? -1 : 1;
+            const det_t det = sol.dets[d];
+            const uint8_t *occ = sol.orbs_at(d);
+            unsigned counts[N_IRREPS][2];
+            count_symm_virt(counts, occ, n_elec, sys.symm);
+            rng.begin(iterat, det, 0, RNG_BIN);
+            unsigned n_doub = bin_sample(n_walk, p_doub, rng);
+            unsigned n_sing = n_walk - n_doub;
+            // doubles: all samples first (doub_multin), then the rounding draws (:363-378)
+            if (orbs.size() < 4 * (size_t)n_walk) { orbs.resize(4 * (size_t)n_walk); probs.resize(n_walk); }
+            unsigned nn = 0;
+            std::vector<uint32_t> att(n_doub);       // which attempt produced sample w: counter mode keys the rounding draw by it
+            for (unsigned i = 0; i < n_doub; i++) {
+                rng.begin(iterat, det, i, RNG_DOUB);
+                if (nu_doub_sample(det, occ, n_elec, sys.symm, counts, rng, &orbs[4 * nn], &probs[nn])) { att[nn] = i; nn++; }
+            }
+            for (unsigned w = 0; w < nn; w++) {
+                double m = doub_matrel_nosgn(&orbs[4 * w], sys.ints);
+                m *= eps / probs[w] / p_doub;
+                rng.begin(iterat, det, att[w], RNG_ROUND_D);
+                int sp = round_binomially(m, 1, rng);
+                if (sp != 0) {
+                    det_t nd = det;
+                    sp *= -doub_det_parity(&nd, &orbs[4 * w]) * sign;
+                    if (!sol.add(nd, sp, (uint8_t)ini)) throw std::runtime_error("Insufficient memory allocated in adder");
+                    n_spawn++;
+                }
+            }
+            // singles (:380-394)
+            unsigned m_allow[64], delta_s;
+            nu_sing_setup(occ, n_elec, sys.symm, counts, m_allow, &delta_s);
+            unsigned ns = delta_s == n_elec ? 0 : n_sing;
+            for (unsigned j = 0; j < ns; j++) {
+                rng.begin(iterat, det, j, RNG_SING);
+                nu_sing_sample(det, occ, n_elec, sys.symm, m_allow, delta_s, rng, &orbs[2 * j], &probs[j]);
+            }
+            for (unsigned w = 0; w < ns; w++) {
+                double m = sing_matrel_nosgn(&orbs[2 * w], occ, sys.ints, n_elec);
+                m *= eps / probs[w] / (1 - p_doub);
+                rng.begin(iterat, det, w, RNG_ROUND_S);
+                int sp = round_binomially(m, 1, rng);
+                if (sp != 0) {
+                    det_t nd = det;
+                    sp *= -sing_det_parity(&nd, &orbs[2 * w]) * sign;
+                    if (!sol.add(nd, sp, (uint8_t)ini)) throw std::runtime_error("Insufficient memory allocated in adder");
+                    n_spawn++;
+                }
+            }
+            // death / cloning (:396-402).  The reference calls del_at_pos BEFORE it stores the new value (:400-403), while the
+            // old one is still non-zero, so del_at_pos declines: a determinant left without walkers keeps its slot and its
+            // hash entry with value 0 (only initiator spawns can revive it).  Reproduced: nothing is deleted here.
+            if (std::isnan(sol.diag[d])) sol.diag[d] = diag_matrel(occ, sys.ints, n_elec) - sys.hf_en;
+            double m = (1 - eps * (sol.diag[d] - en_shift)) * sign;
+            rng.begin(iterat, det, 0, RNG_DEATH);
+            int new_val = round_binomially(m, n_walk, rng);
+            if (new_val == 0) sol.del_at_pos(d);      // value still non-zero: no effect, as in the reference
+            cur = new_val;
+        }
+        sol.perform_add(0);
+        double glob_norm = 0;
+        if ((iterat + 1) % shift_interval == 0) {          // :415-427
+            glob_norm = sol.local_norm();
+            adjust_shift(&en_shift, glob_norm, &last_norm, par.target_walkers, shift_damping / eps / shift_interval);
+        }
+        lg.numer = sol.dot(htrial_det, htrial_val);
+        lg.denom = sol.dot(trial_det, trial_val);
+        lg.shift = en_shift; lg.norm = glob_norm; lg.n_nonz = n_nonz; lg.n_ini = n_ini; lg.curr_size = sol.curr_size; lg.n_spawn = n_spawn;
+        log.push_back(lg);
+    }
+}
+
 }  // namespace fo

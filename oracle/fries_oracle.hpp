@@ -307,6 +307,56 @@ struct FrisysHH {
     void iterate(unsigned n);
 };
 
+// ---------------------------------------------------------------- FCIQMC (fciqmc_mol, near-uniform excitation generator)
+// The reference draws every uniform from ONE sequential mt19937 stream, and how many draws a determinant consumes depends
+// on the values drawn (rejection loops): a parallel sampler cannot replay that stream.  Rng therefore has two modes.
+//   mt mode      -- the reference's stream: used to pin every function and the whole loop against the reference.
+//   counter mode -- uniform = hash(seed, iteration, determinant, attempt, purpose, n-th draw of that attempt): the draws
+//                   of different determinants / attempts are independent of each other, so the GPU can reproduce the
+//                   oracle bit for bit.  Same distribution (i.i.d. uniforms), different stream.
+struct Rng {
+    std::mt19937 *mt = nullptr;
+    uint64_t seed = 0, key = 0;
+    uint32_t ctr = 0;
+    void begin(uint64_t iter, det_t det, uint32_t attempt, uint32_t purpose);
+    double uni();
+    static uint64_t mix(uint64_t x);
+};
+enum { RNG_BIN = 0, RNG_DOUB = 1, RNG_SING = 2, RNG_ROUND_D = 3, RNG_ROUND_S = 4, RNG_DEATH = 5 };
+// FRIES/Hamiltonians/near_uniform.cpp:31-39, compress_utils.cpp:19-27
+unsigned bin_sample(unsigned n, double p, Rng &rng);
+int round_binomially(double p, unsigned n, Rng &rng);
+// one sample of doub_multin / sing_multin (near_uniform.cpp:193-245, 277-313); false = null excitation
+bool nu_doub_sample(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &s, unsigned counts[][2], Rng &rng, uint8_t orbs[4], double *prob);
+void nu_sing_setup(const uint8_t *occ, unsigned n_elec, const Symm &s, unsigned counts[][2], unsigned *m_allow, unsigned *delta_s);
+void nu_sing_sample(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &s, const unsigned *m_allow, unsigned delta_s, Rng &rng, uint8_t orbs[2], double *prob);
+
+struct FciqmcParams {
+    double eps = 0.001;
+    uint32_t target_walkers = 0, init_thresh = 0;
+    size_t max_dets = 0;
+    uint32_t seed = 0;
+    bool counter_rng = false;
+};
+struct FciqmcLog { double numer, denom, shift, norm; int n_nonz; uint32_t n_ini; size_t curr_size, n_spawn; };
+// FRIES_bin/fciqmc_mol.cpp:35-480, --distribution NU, HF trial vector, HF start, one rank
+struct Fciqmc {
+    MolSys sys;
+    FciqmcParams par;
+    std::mt19937 mt;
+    Rng rng;
+    std::vector<uint32_t> proc_scr, vec_scr;
+    Vec sol;
+    std::vector<det_t> trial_det, htrial_det;
+    std::vector<double> trial_val, htrial_val;
+    double p_doub = 0, en_shift = 0, last_norm = 0;
+    det_t hf_det = 0;
+    unsigned iterat = 0;
+    std::vector<FciqmcLog> log;
+    void setup();
+    void iterate(unsigned n);
+};
+
 // runs fn(rank) on `size` in-process ranks that share one communicator (fn receives its Comm)
 void run_ranks(int size, const std::function<void(const Comm &)> &fn);
 

@@ -246,4 +246,43 @@ size_t fo_hh_vec(void *h, uint32_t rank, uint64_t *dets, double *vals, size_t ca
 int fo_hh_ref_proc(void *h) { return ((OracleHH *)h)->fr[0]->ref_proc; }
 uint64_t fo_hh_neel(void *h) { return ((OracleHH *)h)->fr[0]->neel; }
 
+
+// ---- fciqmc_mol (near-uniform); counter_rng = 0: the reference's mt19937 stream, 1: the counter-based stream the GPU can replay
+struct FqLog { double numer, denom, shift, norm; int32_t n_nonz; uint32_t n_ini, curr_size, n_spawn; };
+void *fo_fciqmc_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                       double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int counter_rng) {
+    Fciqmc *f = new Fciqmc();
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.target_walkers = target_walkers; f->par.init_thresh = init_thresh; f->par.max_dets = max_dets; f->par.seed = seed;
+    f->par.counter_rng = counter_rng != 0;
+    f->setup();
+    return f;
+}
+void fo_fciqmc_destroy(void *h) { delete (Fciqmc *)h; }
+int fo_fciqmc_iterate(void *h, uint32_t n, FqLog *logs) {
+    Fciqmc *f = (Fciqmc *)h;
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            f->iterate(1);
+            if (logs) {
+                const FciqmcLog &l = f->log.back();
+                logs[i].numer = l.numer; logs[i].denom = l.denom; logs[i].shift = l.shift; logs[i].norm = l.norm; logs[i].n_nonz = l.n_nonz;
+                logs[i].n_ini = l.n_ini; logs[i].curr_size = (uint32_t)l.curr_size; logs[i].n_spawn = (uint32_t)l.n_spawn;
+            }
+        }
+    } catch (std::exception &e) { fprintf(stderr, "fo_fciqmc_iterate: %s\n", e.what()); return 1; }
+    return 0;
+}
+size_t fo_fciqmc_vec(void *h, uint64_t *dets, double *vals, size_t cap) {
+    Fciqmc *f = (Fciqmc *)h;
+    size_t n = f->sol.curr_size;
+    if (dets && vals && cap >= n) for (size_t i = 0; i < n; i++) { dets[i] = f->sol.dets[i]; vals[i] = f->sol.vals[0][i]; }
+    return n;
+}
+double fo_fciqmc_p_doub(void *h) { return ((Fciqmc *)h)->p_doub; }
+
 }  // extern "C"

@@ -849,6 +849,186 @@ static int run_hh(int argc, char **argv) {
     return n_fail != 0;
 }
 
+
+// ------------------------------------------------------------------ fciqmc_mol (NU): reference loop vs the oracle in mt mode
+// ref_harness fciqmc <fcidump> <pg> <n_iter> <seed> <eps> <target_walkers> <max_dets> <initiator> <out>
+static int run_fciqmc(int argc, char **argv) {
+    if (argc < 11) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t target_walkers = strtoul(argv[7], 0, 10);
+    uint32_t max_n_dets = strtoul(argv[8], 0, 10); uint32_t init_thresh = strtoul(argv[9], 0, 10);
+    fcidump_input *in_data = parse_fcidump(path, pg);
+    unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
+    size_t det_size = CEILING(2 * n_orb, 8);
+    unsigned n_elec_unf = n_elec, tot_orb = n_orb;
+    uint8_t *symm = in_data->symm;
+    Matrix<double> *h_core = in_data->hcore; SymmERIs *eris = &in_data->eris;
+    uint8_t tmp_orbs[64], hf_det[8] = {0};
+    gen_hf_bitstring(n_orb, n_elec, hf_det);
+    find_bits(hf_det, tmp_orbs, det_size);
+    double hf_en = diag_matrel(tmp_orbs, tot_orb, *eris, *h_core, n_frz, n_elec);
+    std::mt19937 mt_obj(seed);
+    unsigned spawn_length = target_walkers * 2;
+    std::function<double(const uint8_t *)> diag_shortcut = [tot_orb, eris, h_core, n_frz, n_elec, hf_en](const uint8_t *occ) { return diag_matrel(occ, tot_orb, *eris, *h_core, n_frz, n_elec) - hf_en; };
+    SymmInfo symm_basis(symm, n_orb);
+    unsigned unocc_symm_cts[n_irreps][2];
+    std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
+    for (auto &x : proc_scrambler) x = mt_obj();
+    for (auto &x : vec_scrambler) x = mt_obj();
+    DistVec<int> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, 1, diag_shortcut, 1, proc_scrambler, vec_scrambler);
+    unsigned max_spawn = 500000;
+    std::vector<uint8_t> spawn_orbs_v(4 * (size_t)max_spawn); std::vector<double> spawn_probs(max_spawn);
+    uint8_t (*sing_orbs)[2] = (uint8_t (*)[2])spawn_orbs_v.data();
+    uint8_t (*doub_orbs)[4] = (uint8_t (*)[4])spawn_orbs_v.data();
+    size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
+    DistVec<double> trial_vec(1, 1, n_orb * 2, n_elec_unf, 1, proc_scrambler, vec_scrambler);
+    DistVec<double> htrial_vec(n_ex, n_ex, n_orb * 2, n_elec_unf, 1, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1);
+    trial_vec.perform_add(0); htrial_vec.perform_add(0);
+    trial_vec.collect_procs();
+    std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
+    for (size_t i = 0; i < trial_vec.curr_size(); i++) trial_hashes[i] = sol_vec.idx_to_hash(trial_vec.indices()[i], tmp_orbs);
+    h_op_offdiag(htrial_vec, symm, tot_orb, *eris, *h_core, spawn_orbs_v.data(), 4 * max_spawn, n_frz, n_elec_unf, 1, 1, 0);
+    htrial_vec.set_curr_vec_idx(0);
+    h_op_diag(htrial_vec, 0, 0, 1);
+    htrial_vec.add_vecs(0, 1);
+    htrial_vec.collect_procs();
+    std::vector<uintmax_t> htrial_hashes(htrial_vec.curr_size());
+    for (size_t i = 0; i < htrial_vec.curr_size(); i++) htrial_hashes[i] = sol_vec.idx_to_hash(htrial_vec.indices()[i], tmp_orbs);
+    sol_vec.gen_orb_list(hf_det, tmp_orbs);
+    size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, doub_orbs, symm);
+    size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
+    double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
+    sol_vec.add(hf_det, 100, 1);
+    sol_vec.perform_add(0);
+    double en_shift = 0, last_norm = 0, glob_norm = 0;
+
+    fo::Fciqmc fq;
+    fq.sys.n_orb = n_orb; fq.sys.n_elec = n_elec;
+    fill_oracle_ints(fq.sys.ints, *eris, *h_core, n_orb);
+    fq.sys.symm.init(symm, n_orb);
+    fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
+    fq.setup();
+    CHECK(same_bits(fq.p_doub, p_doub), "fciqmc p_doub");
+    // the sampling functions on their own, from identical mt19937 states
+    {
+        std::mt19937 ga(777 + seed), gb(777 + seed);
+        fo::Rng rb; rb.mt = &gb;
+        uint8_t occ[64];
+        for (int trial = 0; trial < 4000; trial++) {
+            fo::det_t d = 0;
+            std::mt19937 &rg = ga;
+            for (int sp = 0; sp < 2; sp++) { unsigned placed = 0; while (placed < n_elec / 2) { unsigned o = rg() % n_orb; if (!((d >> (o + sp * n_orb)) & 1)) { d |= (fo::det_t)1 << (o + sp * n_orb); placed++; } } }
+            for (int sp = 0; sp < 2; sp++) { unsigned placed = 0; fo::det_t dd = 0; while (placed < n_elec / 2) { unsigned o = gb() % n_orb; if (!((dd >> (o + sp * n_orb)) & 1)) { dd |= (fo::det_t)1 << (o + sp * n_orb); placed++; } } }
+            uint8_t db[8]; memcpy(db, &d, 8);
+            fo::occ_list(d, occ);
+            unsigned cr[n_irreps][2], co[fo::N_IRREPS][2];
+            count_symm_virt(cr, occ, n_elec, &symm_basis);
+            fo::count_symm_virt(co, occ, n_elec, fq.sys.symm);
+            unsigned ns = 1 + trial % 7;
+            uint8_t ro[64][4]; double rp[64];
+            unsigned nr = doub_multin(db, occ, n_elec, &symm_basis, cr, ns, ga, ro, rp);
+            unsigned no = 0; uint8_t oo[64][4]; double op[64];
+            for (unsigned i = 0; i < ns; i++) if (fo::nu_doub_sample(d, occ, n_elec, fq.sys.symm, co, rb, oo[no], &op[no])) no++;
+            CHECK(nr == no, "doub_multin count %u %u", nr, no);
+            for (unsigned i = 0; i < std::min(nr, no); i++) CHECK(!memcmp(ro[i], oo[i], 4) && same_bits(rp[i], op[i]), "doub_multin sample");
+            uint8_t rs[64][2]; double rsp[64];
+            unsigned nsr = sing_multin(db, occ, n_elec, &symm_basis, cr, ns, ga, rs, rsp);
+            unsigned m_allow[64], delta_s;
+            fo::nu_sing_setup(occ, n_elec, fq.sys.symm, co, m_allow, &delta_s);
+            unsigned nso = delta_s == n_elec ? 0 : ns;
+            CHECK(nsr == nso, "sing_multin count");
+            for (unsigned i = 0; i < nso; i++) { uint8_t so[2]; double sp2; fo::nu_sing_sample(d, occ, n_elec, fq.sys.symm, m_allow, delta_s, rb, so, &sp2); CHECK(!memcmp(rs[i], so, 2) && same_bits(rsp[i], sp2), "sing_multin sample"); }
+            unsigned nb = 1 + trial % 50; double pp = (trial % 97) / 97.0;
+            CHECK(bin_sample(nb, pp, ga) == fo::bin_sample(nb, pp, rb), "bin_sample");
+            double pr = -1.7 + (trial % 41) * 0.1;
+            CHECK(round_binomially(pr, nb, ga) == fo::round_binomially(pr, nb, rb), "round_binomially");
+        }
+    }
+    FILE *f = fopen(argv[10], "w");
+    fprintf(f, "# golden trajectory from the reference (fciqmc_mol.cpp loop, NU, 1 rank); cols: it numer denom norm shift n_nonz n_ini curr_size n_spawn digest\n");
+    for (unsigned iterat = 0; iterat < n_iter; iterat++) {
+        int n_nonz = 0; size_t n_ini = 0, n_spawn = 0;
+        for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
+            int *curr_el = sol_vec[det_idx];
+            uint8_t *curr_det = sol_vec.indices()[det_idx];
+            unsigned n_walk = abs(*curr_el);
+            if (n_walk == 0) continue;
+            n_nonz++;
+            int ini_flag = n_walk > init_thresh;
+            n_ini += ini_flag;
+            int walk_sign = 1 - ((*curr_el >> (sizeof(int) * 8 - 1)) & 2);
+            uint8_t *occ_orbs = sol_vec.orbs_at_pos(det_idx);
+            count_symm_virt(unocc_symm_cts, occ_orbs, n_elec_unf, &symm_basis);
+            unsigned n_doub = bin_sample(n_walk, p_doub, mt_obj);
+            unsigned n_sing = n_walk - n_doub;
+            if (n_doub > max_spawn || n_sing > max_spawn) { fprintf(stderr, "harness: max_spawn exceeded\n"); return 2; }
+            n_doub = doub_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_doub, mt_obj, doub_orbs, spawn_probs.data());
+            uint8_t new_det[8];
+            for (size_t w = 0; w < n_doub; w++) {
+                double matr_el = doub_matr_el_nosgn(doub_orbs[w], tot_orb, *eris, n_frz);
+                matr_el *= eps / spawn_probs[w] / p_doub;
+                int spawn_walker = round_binomially(matr_el, 1, mt_obj);
+                if (spawn_walker != 0) {
+                    memcpy(new_det, curr_det, det_size);
+                    spawn_walker *= -doub_det_parity(new_det, doub_orbs[w]) * walk_sign;
+                    if (!sol_vec.add(new_det, spawn_walker, ini_flag)) { fprintf(stderr, "adder full\n"); return 2; }
+                    n_spawn++;
+                }
+            }
+            n_sing = sing_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_sing, mt_obj, sing_orbs, spawn_probs.data());
+            for (size_t w = 0; w < n_sing; w++) {
+                double matr_el = sing_matr_el_nosgn(sing_orbs[w], occ_orbs, tot_orb, *eris, *h_core, n_frz, n_elec_unf);
+                matr_el *= eps / spawn_probs[w] / (1 - p_doub);
+                int spawn_walker = round_binomially(matr_el, 1, mt_obj);
+                if (spawn_walker != 0) {
+                    memcpy(new_det, curr_det, det_size);
+                    spawn_walker *= -sing_det_parity(new_det, sing_orbs[w]) * walk_sign;
+                    if (!sol_vec.add(new_det, spawn_walker, ini_flag)) { fprintf(stderr, "adder full\n"); return 2; }
+                    n_spawn++;
+                }
+            }
+            double diag_el = sol_vec.matr_el_at_pos(det_idx);
+            double matr_el = (1 - eps * (diag_el - en_shift)) * walk_sign;
+            int new_val = round_binomially(matr_el, n_walk, mt_obj);
+            if (new_val == 0 && sol_vec.indices()[det_idx] != hf_det) sol_vec.del_at_pos(det_idx);
+            *curr_el = new_val;
+        }
+        sol_vec.perform_add(0);
+        double norm_out = 0;
+        if ((iterat + 1) % 10 == 0) {
+            glob_norm = sol_vec.local_norm();
+            adjust_shift(&en_shift, glob_norm, &last_norm, target_walkers, 0.05 / eps / 10);
+            norm_out = glob_norm;
+        }
+        double numer = sol_vec.dot(htrial_vec.indices(), htrial_vec.values(), htrial_vec.curr_size(), htrial_hashes);
+        double denom = sol_vec.dot(trial_vec.indices(), trial_vec.values(), trial_vec.curr_size(), trial_hashes);
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < sol_vec.curr_size(); i++) {
+            double rv = sol_vec.values()[i];
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol_vec.indices()[i], det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        fprintf(f, "%u %a %a %a %a %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, norm_out, en_shift, n_nonz, n_ini, (size_t)sol_vec.curr_size(), n_spawn, hsh);
+        fq.iterate(1);
+        const fo::FciqmcLog &lg = fq.log.back();
+        CHECK(same_bits(lg.numer, numer) && same_bits(lg.denom, denom), "fciqmc it %u numer/denom %a %a | %a %a", iterat, lg.numer, numer, lg.denom, denom);
+        CHECK(same_bits(lg.norm, norm_out) && same_bits(lg.shift, en_shift), "fciqmc it %u norm/shift", iterat);
+        CHECK(lg.n_nonz == n_nonz && lg.n_ini == n_ini && lg.curr_size == sol_vec.curr_size() && lg.n_spawn == n_spawn, "fciqmc it %u counts nnz %d/%d ini %u/%zu size %zu/%zu spawn %zu/%zu",
+              iterat, lg.n_nonz, n_nonz, lg.n_ini, n_ini, lg.curr_size, (size_t)sol_vec.curr_size(), lg.n_spawn, n_spawn);
+        size_t bad = 0, nmin = std::min(lg.curr_size, (size_t)sol_vec.curr_size());
+        for (size_t i = 0; i < nmin; i++) {
+            int rv = sol_vec.values()[i];
+            if ((double)rv != fq.sol.vals[0][i]) bad++;
+            if (rv != 0 && to_u64(sol_vec.indices()[i], det_size) != fq.sol.dets[i]) bad++;
+        }
+        CHECK(bad == 0, "fciqmc it %u vector mismatch in %zu slots", iterat, bad);
+    }
+    fclose(f);
+    printf("FCIQMC iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, sol_vec.n_nonz());
+    return n_fail != 0;
+}
+
 int main(int argc, char **argv) {
     MPI_Init(NULL, NULL);
     int rc = 2;
@@ -859,6 +1039,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "hh")) rc = run_hh(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "fciqmc")) rc = run_fciqmc(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
     else fprintf(stderr, "unknown command\n");
     MPI_Finalize();

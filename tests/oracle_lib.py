@@ -71,6 +71,14 @@ def load():
         lib.fo_hh_ref_proc.argtypes = [C.c_void_p]
         lib.fo_hh_neel.restype = C.c_uint64
         lib.fo_hh_neel.argtypes = [C.c_void_p]
+        lib.fo_fciqmc_create.restype = C.c_void_p
+        lib.fo_fciqmc_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        lib.fo_fciqmc_destroy.argtypes = [C.c_void_p]
+        lib.fo_fciqmc_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_fciqmc_vec.restype = C.c_size_t
+        lib.fo_fciqmc_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_fciqmc_p_doub.restype = C.c_double
+        lib.fo_fciqmc_p_doub.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -271,3 +279,42 @@ class OracleHH:
     @property
     def neel(self):
         return int(self.lib.fo_hh_neel(self.h))
+
+
+FQLOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("norm", "f8"), ("n_nonz", "i4"), ("n_ini", "u4"), ("curr_size", "u4"),
+                        ("n_spawn", "u4")], align=True)
+
+
+class OracleFciqmc:
+    """fo::Fciqmc -- CPU restatement of fciqmc_mol (near-uniform generator, one rank).  counter_rng=False consumes the
+    reference's sequential mt19937 stream (pinned against the reference loop); counter_rng=True uses the counter-based
+    stream the GPU replays."""
+
+    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False):
+        self.lib = load()
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, int(counter_rng))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.fo_fciqmc_destroy(self.h)
+            self.h = None
+
+    def iterate(self, n):
+        logs = np.zeros(n, dtype=FQLOG_DTYPE)
+        if self.lib.fo_fciqmc_iterate(self.h, n, _p(logs)):
+            raise RuntimeError("oracle fciqmc failed")
+        return logs
+
+    def vector(self):
+        n = self.lib.fo_fciqmc_vec(self.h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_fciqmc_vec(self.h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
+
+    @property
+    def p_doub(self):
+        return self.lib.fo_fciqmc_p_doub(self.h)

@@ -89,6 +89,29 @@ def test_sharding_hash_matches_reference_ranks(oracle, mols):
         assert nz.size > 0 and all(orc.idx_to_proc(x) == k for x in nz[:200])
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_runs"]))
+def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
+    """fciqmc_mol (near-uniform generator) restated, consuming the reference's mt19937 stream: every logged scalar, the walker
+    counts and the digest of (position, determinant, walkers) against the reference's own loop."""
+    r = golden_io.manifest()["fciqmc_runs"][name]
+    rows = []
+    with open(os.path.join(golden_io.GOLD, name + ".traj")) as f:
+        for ln in f:
+            if ln.startswith("#"):
+                continue
+            t = ln.split()
+            rows.append((float.fromhex(t[1]), float.fromhex(t[2]), float.fromhex(t[3]), float.fromhex(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[8]), int(t[9], 16)))
+    orc = oracle.OracleFciqmc(mols(r["shape"]), epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"],
+                              seed=r["seed"], counter_rng=False)
+    logs = orc.iterate(r["n_iter"])
+    for i, row in enumerate(rows):
+        lg = logs[i]
+        assert (float(lg["numer"]), float(lg["denom"]), float(lg["norm"]), float(lg["shift"])) == row[:4], (name, i)
+        assert (int(lg["n_nonz"]), int(lg["n_ini"]), int(lg["curr_size"]), int(lg["n_spawn"])) == row[4:8], (name, i)
+    d, v = orc.vector()
+    assert golden_io.vec_hash(d, v) == rows[-1][8]
+
+
 def _hh_params(r):
     return dict(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
                 vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
