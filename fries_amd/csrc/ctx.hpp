@@ -86,6 +86,15 @@ struct FriesCtx;
 // gathers c->comm.small_send[0, bytes) of every rank; returns the device address of the rank-ordered blocks
 const void *fr_allgather(FriesCtx *c, size_t bytes);
 
+// FCIQMC work arrays (fciqmc.hip): per stored determinant and per spawning attempt
+struct FqWork {
+    uint32_t cap_d, cap_a;
+    uint32_t *n_doub, *n_att, *att_off; double *new_val;
+    uint32_t *blk_att, *blk_nz, *blk_ini, *blk_sp, *totals;
+    double *sp_val; det_t *sp_det; uint8_t *sp_ini;
+    double *norm;
+};
+
 struct FriesCtx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -95,6 +104,10 @@ struct FriesCtx {
     uint32_t *d_proc_scr = nullptr;          // proc_hash_ scrambler on the device
     void *own_small = nullptr;               // size == 1: engine-owned small_send
     double *d_norms_keep = nullptr, *d_seq_scratch = nullptr;
+    // FCIQMC driver (fciqmc.hip)
+    bool fq_mode = false;
+    fries_fciqmc_params fq{};
+    FqWork fqw{};
     // Hubbard-Holstein driver (hh.hip)
     bool hh_mode = false, hh_keep0 = false;
     fries_hh_params hh{};
@@ -167,6 +180,9 @@ void fr_death_clone(FriesCtx *c, uint32_t vec_size_before);
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm);
 void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
+// fciqmc.hip
+void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p);
+void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg);
 // hh.hip
 void fr_hh_setup(FriesCtx *c, const fries_hh_params *p);
 void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg);

@@ -1,0 +1,356 @@
+// fciqmc_mol on the device (FRIES_bin/fciqmc_mol.cpp:331-412, near-uniform excitation generator, near_uniform.cpp).
+//
+// The reference consumes one sequential mt19937 stream whose length per determinant depends on the values drawn (rejection
+// loops), which no parallel sampler can replay.  The device draws every uniform from a counter-based stream
+//     u = hash(seed, iteration, determinant, attempt, purpose, n-th draw of that attempt) / 2^32
+// -- the same i.i.d. uniforms, a different stream.  The tests' CPU restatement of the reference has that stream as a second mode,
+// so the device trajectory is checked bit for bit against it, while its sampling functions and loop are pinned against the
+// reference itself on the reference's own mt19937 stream.  Walker numbers are integers held exactly in the vector's doubles.
+#include "ctx.hpp"
+#include "hbpp_rows.hpp"
+
+struct FqRng {
+    unsigned long long key; uint32_t ctr;
+    __device__ __forceinline__ void begin(unsigned long long seed, unsigned long long iter, det_t det, uint32_t attempt, uint32_t purpose) {
+        unsigned long long h = fr_mix64(seed ^ 0x9e3779b97f4a7c15ull);
+        h = fr_mix64(h ^ (iter * 0xd1b54a32d192ed03ull));
+        h = fr_mix64(h ^ det);
+        h = fr_mix64(h ^ (((unsigned long long)attempt << 8) | purpose));
+        key = h; ctr = 0;
+    }
+    __device__ __forceinline__ double uni() {
+        unsigned long long h = fr_mix64(key + (unsigned long long)(++ctr) * 0x9e3779b97f4a7c15ull);
+        return (uint32_t)(h >> 32) / (1. + 4294967295.0);
+    }
+    __device__ __forceinline__ unsigned choose(unsigned nmax) { return (unsigned)(uni() * nmax); }     // near_uniform.cpp:41-44
+};
+enum { FQ_BIN = 0, FQ_DOUB = 1, FQ_SING = 2, FQ_ROUND_D = 3, FQ_ROUND_S = 4, FQ_DEATH = 5 };
+
+// per stored determinant: walkers split into double / single attempts (bin_sample, :352), death / cloning (:396-403)
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter, double p_doub,
+                                                       double eps, double shift, uint32_t init_thresh) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    fr_stage_tables(&T, S.hb);
+    const uint32_t n = V.st->curr_size;
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t att = 0, nz = 0, ini = 0;
+    if (d < n) {
+        const double cur = V.v0[d];
+        const int cur_i = (int)cur;
+        const unsigned n_walk = (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        uint32_t n_doub = 0, n_sing = 0;
+        double new_val = 0;
+        if (n_walk) {
+            nz = 1; ini = n_walk > init_thresh;
+            const int sign = cur_i < 0 ? -1 : 1;
+            const det_t det = V.dets[d];
+            FqRng rng;
+            rng.begin(seed, iter, det, 0, FQ_BIN);
+            for (unsigned i = 0; i < n_walk; i++) n_doub += rng.uni() < p_doub;
+            n_sing = n_walk - n_doub;
+            // sing_multin returns nothing when no electron has a symmetry-allowed excitation (near_uniform.cpp:293-295)
+            if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
+            double dg = V.diag[d];
+            if (dg != dg) { dg = fr_diag_matrel(det, S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[d] = dg; }
+            const double m = (1 - eps * (dg - shift)) * sign;
+            const int flr = (int)floor(m);
+            const double prob = m - flr;
+            int ret = flr * (int)n_walk;
+            rng.begin(seed, iter, det, 0, FQ_DEATH);
+            for (unsigned i = 0; i < n_walk; i++) ret += rng.uni() < prob;
+            new_val = (double)ret;
+        }
+        Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing; Q.new_val[d] = new_val;
+        att = n_doub + n_sing;
+    }
+    uint32_t b_att = fr_block_sum_u32(att, shu);
+    __syncthreads();
+    uint32_t b_nz = fr_block_sum_u32(nz, shu);
+    __syncthreads();
+    uint32_t b_ini = fr_block_sum_u32(ini, shu);
+    if (threadIdx.x == 0) { Q.blk_att[blockIdx.x] = b_att; Q.blk_nz[blockIdx.x] = b_nz; Q.blk_ini[blockIdx.x] = b_ini; }
+}
+
+// exclusive offsets of every determinant's attempts; totals (one workgroup per FR_BLOCK determinants, block prefix re-reduced)
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_offsets(VecDev V, FqWork Q) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const unsigned nblk = (n + FR_BLOCK - 1) / FR_BLOCK;
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += Q.blk_att[i]; off = fr_block_sum_u32(x, shu); }
+    __syncthreads();
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t a = d < n ? Q.n_att[d] : 0u, tot;
+    uint32_t incl = fr_block_scan_u32(a, shu, &tot);
+    if (d < n) Q.att_off[d] = off + incl - a;
+    if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) {
+        Q.totals[0] = off + incl;       // attempts
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        uint32_t x = 0, y = 0;
+        for (unsigned i = threadIdx.x; i < nblk; i += blockDim.x) { x += Q.blk_nz[i]; y += Q.blk_ini[i]; }
+        uint32_t sx = fr_block_sum_u32(x, shu);
+        __syncthreads();
+        uint32_t sy = fr_block_sum_u32(y, shu);
+        if (threadIdx.x == 0) { Q.totals[1] = sx; Q.totals[2] = sy; }
+    }
+}
+
+// one spawning attempt per lane: excitation (doub_multin / sing_multin for one sample), matrix element, stochastic rounding
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter, double p_doub,
+                                                         double eps, uint32_t init_thresh) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    fr_stage_tables(&T, S.hb);
+    const uint32_t n = V.st->curr_size, A = Q.totals[0];
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    double sp_val = 0; det_t sp_det = 0; uint32_t sp_ini = 0;
+    if (a < A) {
+        // owner determinant: last d with att_off[d] <= a (empty determinants share their successor's offset)
+        uint32_t lo = 0, hi = n - 1;
+        while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (Q.att_off[mid] <= a) lo = mid; else hi = mid - 1; }
+        while (Q.n_att[lo] == 0 && lo > 0) lo--;       // cannot happen (an empty determinant never owns an attempt), kept for safety
+        const uint32_t d = lo, i = a - Q.att_off[d], n_doub = Q.n_doub[d];
+        const det_t det = V.dets[d];
+        const int cur_i = (int)V.v0[d];
+        const unsigned n_walk = (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        const int sign = cur_i < 0 ? -1 : 1;
+        sp_ini = n_walk > init_thresh;
+        const unsigned n_orb = T.n_orb, n_elec = T.n_elec;
+        SymCounts sc; fr_count_symm_virt(sc, T, det);
+        FqRng rng;
+        if (i < n_doub) {       // ---- double (near_uniform.cpp:193-245)
+            rng.begin(seed, iter, det, i, FQ_DOUB);
+            unsigned tri = rng.choose(n_elec * (n_elec - 1) / 2);
+            unsigned i1 = (unsigned)((sqrt(tri * 8. + 1) - 1) / 2);
+            unsigned i2 = (unsigned)(tri - i1 * (i1 + 1.) / 2);
+            i1 += 1;
+            unsigned orb1 = fr_nth_bit(det, i1), orb2 = fr_nth_bit(det, i2);
+            unsigned spin1 = i1 / (n_elec / 2), spin2 = i2 / (n_elec / 2);
+            unsigned sym_prod = T.irrep[orb1 % n_orb] ^ T.irrep[orb2 % n_orb];
+            unsigned same_symm = (sym_prod == 0 && spin1 == spin2) ? 1u : 0u;
+            unsigned n_allow = spin1 == spin2 ? n_orb - n_elec / 2 : 2 * n_orb - n_elec;
+            for (unsigned k = 0; k < 8; k++) {
+                if (sc.c[k ^ sym_prod][spin2] == same_symm) n_allow -= sc.c[k][spin1];
+                if (spin1 != spin2 && sc.c[k ^ sym_prod][spin1] == same_symm) n_allow -= sc.c[k][spin2];
+            }
+            if (n_allow != 0) {
+                int virt_choice;
+                unsigned a_spin, b_spin, n_virt2, orbital;
+                if (n_allow <= 3) {
+                    virt_choice = (int)rng.choose(n_allow);
+                    if (spin1 == spin2) { a_spin = spin1; b_spin = a_spin; } else { a_spin = 0; b_spin = 1; }
+                    orbital = 0;
+                    while (virt_choice >= 0 && orbital < n_orb) {
+                        if (!fr_bit(det, orbital + a_spin * n_orb)) {
+                            n_virt2 = sc.c[sym_prod ^ T.irrep[orbital]][b_spin] - ((sym_prod == 0 && a_spin == b_spin) ? 1u : 0u);
+                            if (n_virt2 != 0) virt_choice -= 1;
+                        }
+                        orbital += 1;
+                    }
+                    if (virt_choice >= 0) {
+                        a_spin = 1; b_spin = 0;
+                        while (virt_choice >= 0 && orbital < 2 * n_orb) {
+                            if (!fr_bit(det, orbital)) {
+                                n_virt2 = sc.c[sym_prod ^ T.irrep[orbital - n_orb]][b_spin] - ((sym_prod == 0 && a_spin == b_spin) ? 1u : 0u);
+                                if (n_virt2 != 0) virt_choice -= 1;
+                            }
+                            orbital += 1;
+                        }
+                        orbital -= n_orb;
+                    }
+                    virt_choice = (int)(orbital - 1 + a_spin * n_orb);
+                }
+                else {
+                    n_virt2 = 0;
+                    while (n_virt2 == 0) {
+                        if (spin1 == spin2) { a_spin = spin1; b_spin = a_spin; virt_choice = (int)(rng.choose(n_orb) + a_spin * n_orb); }
+                        else { virt_choice = (int)rng.choose(2 * n_orb); a_spin = (unsigned)virt_choice / n_orb; b_spin = 1 - a_spin; }
+                        if (!fr_bit(det, (unsigned)virt_choice))
+                            n_virt2 = sc.c[sym_prod ^ T.irrep[(unsigned)virt_choice % n_orb]][b_spin] - ((sym_prod == 0 && a_spin == b_spin) ? 1u : 0u);
+                    }
+                }
+                const unsigned unocc1 = (unsigned)virt_choice;
+                a_spin = unocc1 / n_orb;
+                b_spin = spin1 ^ spin2 ^ a_spin;
+                const unsigned a_symm = T.irrep[unocc1 % n_orb], b_symm = sym_prod ^ a_symm;
+                const unsigned m_a_b = sc.c[b_symm][b_spin] - ((sym_prod == 0 && a_spin == b_spin) ? 1u : 0u);
+                int orb_idx = (int)rng.choose(m_a_b);
+                unsigned unocc2 = 0, symm_idx = 1;
+                while (orb_idx >= 0) {
+                    unocc2 = T.lookup[b_symm][symm_idx] + b_spin * n_orb;
+                    if (!fr_bit(det, unocc2) && unocc2 != unocc1) orb_idx -= 1;
+                    symm_idx += 1;
+                }
+                const unsigned m_b_a = sc.c[a_symm][a_spin] - ((sym_prod == 0 && a_spin == b_spin) ? 1u : 0u);
+                const double prob = 2. / n_elec / (n_elec - 1) / n_allow * (1. / m_a_b + 1. / m_b_a);
+                const unsigned o1 = orb2, o2 = orb1, u1 = unocc1 < unocc2 ? unocc1 : unocc2, u2 = unocc1 < unocc2 ? unocc2 : unocc1;
+                double m = fr_doub_matrel(o1, o2, u1, u2, S.eris, n_orb);
+                m *= eps / prob / p_doub;
+                rng.begin(seed, iter, det, i, FQ_ROUND_D);
+                const int flr = (int)floor(m);
+                int sp = flr + (rng.uni() < m - flr ? 1 : 0);
+                if (sp != 0) {
+                    sp *= -fr_doub_parity(det, o1, o2, u1, u2) * sign;
+                    sp_val = (double)sp;
+                    sp_det = (det & ~(1ull << o1) & ~(1ull << o2)) | (1ull << u1) | (1ull << u2);
+                }
+            }
+        }
+        else {                  // ---- single (near_uniform.cpp:277-313)
+            const uint32_t j = i - n_doub;
+            unsigned m_allow[64], delta_s = 0, e = 0;
+            for (det_t b = det; b; b &= b - 1, e++) {
+                unsigned o = __ffsll((long long)b) - 1;
+                unsigned na = sc.c[T.irrep[o % n_orb]][e / (n_elec / 2)];
+                m_allow[e] = na;
+                if (na == 0) delta_s++;
+            }
+            rng.begin(seed, iter, det, j, FQ_SING);
+            unsigned elec = 0, na = 0;
+            while (na == 0) { elec = rng.choose(n_elec); na = m_allow[elec]; }
+            const unsigned occ_orb = fr_nth_bit(det, elec), occ_symm = T.irrep[occ_orb % n_orb], spin = occ_orb / n_orb;
+            int symm_idx = -1;
+            unsigned orbital = 0;
+            while (symm_idx == -1) {
+                symm_idx = (int)rng.choose(T.lookup[occ_symm][0]);
+                orbital = spin * n_orb + T.lookup[occ_symm][symm_idx + 1];
+                if (fr_bit(det, orbital)) symm_idx = -1;
+            }
+            const double prob = 1. / m_allow[elec] / (n_elec - delta_s);
+            double m = fr_sing_matrel(det, occ_orb, orbital, S.h_core, S.eris, n_orb);
+            m *= eps / prob / (1 - p_doub);
+            rng.begin(seed, iter, det, j, FQ_ROUND_S);
+            const int flr = (int)floor(m);
+            int sp = flr + (rng.uni() < m - flr ? 1 : 0);
+            if (sp != 0) {
+                sp *= -fr_sing_parity(det, occ_orb, orbital) * sign;
+                sp_val = (double)sp;
+                sp_det = (det & ~(1ull << occ_orb)) | (1ull << orbital);
+            }
+        }
+        Q.sp_val[a] = sp_val; Q.sp_det[a] = sp_det; Q.sp_ini[a] = (uint8_t)sp_ini;
+    }
+    uint32_t bc = fr_block_sum_u32(sp_val != 0 ? 1u : 0u, shu);
+    if (threadIdx.x == 0) Q.blk_sp[blockIdx.x] = bc;
+}
+
+// ordered compaction of the non-zero spawns into the spawn list (the order of the reference's add() calls)
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_compact(FqWork Q, SpawnBuf S) {
+    __shared__ uint32_t shu[4];
+    const uint32_t A = Q.totals[0];
+    const unsigned nblk = (A + FR_BLOCK - 1) / FR_BLOCK;
+    if (nblk == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *S.n_spawn = 0; return; }
+    if (blockIdx.x >= nblk) return;
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += Q.blk_sp[i]; off = fr_block_sum_u32(x, shu); }
+    __syncthreads();
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = (a < A && Q.sp_val[a] != 0) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(f, shu, &tot);
+    if (f) { uint32_t o = off + incl - 1; if (o < S.cap) { S.det[o] = Q.sp_det[a]; S.val[o] = Q.sp_val[a]; S.ini[o] = Q.sp_ini[a]; } }
+    if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) *S.n_spawn = off + incl;
+}
+
+// the post-death walker numbers become the stored values (:403) and |walkers| is summed for the shift update (:416-417)
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_apply(VecDev V, FqWork Q) {
+    const uint32_t n = V.st->curr_size;
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n) V.v0[d] = Q.new_val[d];
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_norm(VecDev V, double *out) {
+    __shared__ double shd[4];
+    const uint32_t n = V.st->curr_size;
+    double acc = 0;      // integers: any summation order is exact
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += fabs(V.v0[i]);
+    double r = fr_block_sum(acc, shd);
+    if (threadIdx.x == 0) atomicAdd(out, r);
+}
+
+void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
+    if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
+    if (p->max_dets == 0 || p->target_walkers == 0) throw FriesError("max_dets and target_walkers must be positive");
+    if (c->n_ranks > 1) throw FriesError("fciqmc_mol is one rank for now");
+    c->fq = *p; c->fq_mode = true;
+    c->eps = p->epsilon; c->target_norm = p->target_walkers; c->en_shift = 0; c->last_one_norm = 0; c->iterat = 0;
+    c->mt.seed(p->seed);
+    c->proc_scr.resize(2 * c->n_orb); c->vec_scr.resize(2 * c->n_orb);
+    for (auto &x : c->proc_scr) x = c->mt();        // fciqmc_mol.cpp:126-128
+    for (auto &x : c->vec_scr) x = c->mt();         // :134-136
+    if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
+    uint32_t spawn_length = p->target_walkers * 2;      // :107 with one rank
+    c->adder_cap = spawn_length;
+    fr_vec_alloc(c, &c->vec, p->max_dets);
+    fr_spawn_alloc(c, spawn_length + 4096);
+    fr_vcomp_alloc(c, p->max_dets);                 // dots
+    FqWork &Q = c->fqw;
+    Q.cap_d = p->max_dets; Q.cap_a = spawn_length + 4096;
+    Q.n_doub = fr_alloc<uint32_t>(Q.cap_d); Q.n_att = fr_alloc<uint32_t>(Q.cap_d); Q.att_off = fr_alloc<uint32_t>(Q.cap_d); Q.new_val = fr_alloc<double>(Q.cap_d);
+    unsigned nb = fr_blocks(Q.cap_d, FR_BLOCK) + 1, nba = fr_blocks(Q.cap_a, FR_BLOCK) + 1;
+    Q.blk_att = fr_alloc<uint32_t>(nb); Q.blk_nz = fr_alloc<uint32_t>(nb); Q.blk_ini = fr_alloc<uint32_t>(nb); Q.blk_sp = fr_alloc<uint32_t>(nba);
+    Q.totals = fr_alloc<uint32_t>(4); Q.norm = fr_alloc<double>(1);
+    Q.sp_val = fr_alloc<double>(Q.cap_a); Q.sp_det = fr_alloc<det_t>(Q.cap_a); Q.sp_ini = fr_alloc<uint8_t>(Q.cap_a);
+    fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
+    double v = 100; uint8_t one = 1; uint32_t n1 = 1;       // :239-243
+    FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
+    fr_vec_merge(c, &c->vec, 1, true);
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+}
+
+void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
+    hipStream_t st = c->stream;
+    const fries_fciqmc_params &P = c->fq;
+    FqWork &Q = c->fqw;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_vec_maybe_rebuild(c, &c->vec);
+    const uint32_t n = c->h_vst.curr_size;
+    if (n > Q.cap_d) throw FriesError("vector larger than the FCIQMC work arrays");
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    const unsigned gd = fr_blocks(n ? n : 1, FR_BLOCK);
+    FR_LAUNCH(c, "k_fq_count", k_fq_count, dim3(gd), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift, P.initiator);
+    FR_LAUNCH(c, "k_fq_offsets", k_fq_offsets, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
+    uint32_t tot[3];
+    FR_HIP(hipMemcpyAsync(tot, Q.totals, 12, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    const uint32_t A = tot[0];
+    if (A > Q.cap_a) throw FriesError("Insufficient memory allocated in adder");       // more attempts than 2 x target walkers
+    const unsigned ga = fr_blocks(A ? A : 1, FR_BLOCK);
+    FR_LAUNCH(c, "k_fq_attempt", k_fq_attempt, dim3(ga), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, P.initiator);
+    FR_LAUNCH(c, "k_fq_compact", k_fq_compact, dim3(ga), dim3(FR_BLOCK), Q, c->sp);
+    FR_LAUNCH(c, "k_fq_apply", k_fq_apply, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
+    uint32_t n_spawn = 0;
+    FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder");
+    if (n_spawn) fr_vec_merge(c, &c->vec, n_spawn, true);           // one perform_add into the column itself (:413)
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (c->h_vst.err) throw FriesError("device error in the FCIQMC merge (capacity, hash table or electron count)");
+    double norm = 0;
+    if ((c->iterat + 1) % 10 == 0) {                                // :415-427
+        FR_HIP(hipMemsetAsync(Q.norm, 0, 8, st));
+        unsigned gn = fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK);
+        if (gn > 1024) gn = 1024;
+        FR_LAUNCH(c, "k_fq_norm", k_fq_norm, dim3(gn), dim3(FR_BLOCK), c->vec, Q.norm);
+        FR_HIP(hipMemcpyAsync(&norm, Q.norm, 8, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        double damp = 0.05 / c->eps / 10;
+        if (c->last_one_norm) { c->en_shift -= damp * log(norm / c->last_one_norm); c->last_one_norm = norm; }
+        if (c->last_one_norm == 0 && norm > c->target_norm) c->last_one_norm = norm;
+    }
+    fr_dots(c, &c->numer, &c->denom);
+    c->iterat++;
+    c->tot_iters++; c->tot_spawns += n_spawn;
+    if (lg) {
+        lg->numer = c->numer; lg->denom = c->denom; lg->shift = c->en_shift; lg->norm = norm;
+        lg->n_nonz = (int32_t)tot[1]; lg->n_ini = tot[2]; lg->curr_size = c->h_vst.curr_size; lg->n_spawn = n_spawn;
+        uint32_t e = 0;
+        FR_HIP(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+        lg->err = e | c->h_vst.err; lg->n_attempts = A;
+    }
+}

@@ -22,7 +22,7 @@ EXPORTS = [
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
-    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers",
+    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
 ]
 
 
@@ -37,6 +37,15 @@ class HHParams(C.Structure):
     _fields_ = [("n_elec", C.c_uint32), ("n_sites", C.c_uint32), ("eps", C.c_double), ("U", C.c_double), ("omega", C.c_double), ("g", C.c_double),
                 ("gs_energy", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double), ("vec_nonz", C.c_uint32), ("max_dets", C.c_uint32),
                 ("seed", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class FciqmcParams(C.Structure):
+    """struct fries_fciqmc_params"""
+    _fields_ = [("epsilon", C.c_double), ("target_walkers", C.c_uint32), ("initiator", C.c_uint32), ("max_dets", C.c_uint32), ("seed", C.c_uint32)]
+
+
+FCIQMC_LOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("norm", "f8"), ("n_nonz", "i4"), ("n_ini", "u4"), ("curr_size", "u4"),
+                             ("n_spawn", "u4"), ("n_attempts", "u4"), ("err", "u4")], align=True)
 
 
 class IterLog(C.Structure):
@@ -91,6 +100,8 @@ def load_library() -> C.CDLL:
     lib.fries_prof_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fries_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
     lib.fries_get_scramblers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_fciqmc_setup.argtypes = [C.c_void_p, C.POINTER(FciqmcParams)]
+    lib.fries_fciqmc_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_hh_setup.argtypes = [C.c_void_p, C.POINTER(HHParams)]
     lib.fries_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]
@@ -184,6 +195,19 @@ class FriEngine:
         p = FrisysParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
         self._ck(self.lib.fries_frisys_setup(self.h, C.byref(p)))
         self.max_dets = max_dets
+
+    # ---- fciqmc_mol
+    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0):
+        """fciqmc_mol with the near-uniform excitation generator (FRIES_bin/fciqmc_mol.cpp, --distribution NU): HF trial vector,
+        100 walkers on HF to start; uniforms from a counter-based stream (see csrc/fciqmc.hip)."""
+        p = FciqmcParams(epsilon, target_walkers, initiator, max_dets, seed)
+        self._ck(self.lib.fries_fciqmc_setup(self.h, C.byref(p)))
+        self.max_dets = max_dets
+
+    def iterate_fciqmc(self, n_iter: int):
+        logs = np.zeros(n_iter, dtype=FCIQMC_LOG_DTYPE)
+        self._ck(self.lib.fries_fciqmc_iterate(self.h, n_iter, _ptr(logs)))
+        return logs
 
     # ---- frisys_hh
     def setup_hh(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0):

@@ -127,6 +127,25 @@ typedef struct {
 int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
 int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
 
+/* ---- fciqmc_mol: FCIQMC with the near-uniform excitation generator (FRIES_bin/fciqmc_mol.cpp, --distribution NU), HF trial
+ * vector, start from 100 walkers on HF, one rank.  The reference's sequential mt19937 stream cannot be replayed in parallel;
+ * the engine draws from a counter-based stream keyed by (seed, iteration, determinant, attempt, purpose) -- the same uniforms
+ * in distribution -- which the CPU oracle shares, and the oracle's functions and loop are pinned against the reference on the
+ * reference's own stream (oracle/ref_harness.cpp: fciqmc).  Walker numbers are exact integers in the vector's doubles. */
+typedef struct {
+    double epsilon;
+    uint32_t target_walkers, initiator, max_dets, seed;
+} fries_fciqmc_params;
+typedef struct {
+    double numer, denom;        /* projnum.txt / projden.txt */
+    double shift, norm;         /* S.txt; walkers at the last shift update (N.txt), 0 on other iterations */
+    int32_t n_nonz;             /* nnonz.txt */
+    uint32_t n_ini;             /* nini.txt */
+    uint32_t curr_size, n_spawn, n_attempts, err;
+} fries_fciqmc_log;
+int fries_fciqmc_setup(fries_ctx *ctx, const fries_fciqmc_params *p);
+int fries_fciqmc_iterate(fries_ctx *ctx, uint32_t n_iter, fries_fciqmc_log *logs);
+
 /* DistVec accessors (FRIES/vec_utils.hpp:506-535): positions [0, curr_size) incl. holes (value 0) */
 int fries_vec_info(fries_ctx *ctx, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free);
 int fries_vec_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);

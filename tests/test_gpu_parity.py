@@ -353,3 +353,31 @@ def test_cli_driver_reproduces_reference_outputs(tmp_path):
     assert np.loadtxt(out2 + "projnum.txt").size == 5
     keep = vals[:n_saved] != 0
     assert np.fromfile(out2 + "dets0.dat", dtype=np.uint8).size // nb > 0 and int(keep.sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,eps,target,ini,seed,n_it", [("Ne", 0.004, 20000, 3, 5, 300), ("N2", 0.006, 50000, 2, 9, 350), ("H2O", 0.004, 30000, 0, 11, 250)])
+def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, ini, seed, n_it):
+    """fciqmc_mol (near-uniform generator) on the device against the CPU oracle, both on the counter-based uniform stream: walker
+    numbers, positions, spawn counts and shifts identical at every iteration.  (The oracle on the reference's own mt19937 stream
+    is pinned against the reference loop in the CPU suite.)"""
+    from fries_amd.engine import FriEngine
+    mol = mols(shape)
+    orc = oracle.OracleFciqmc(mol, epsilon=eps, target_walkers=target, max_dets=200000, initiator=ini, seed=seed, counter_rng=True)
+    eng = FriEngine(mol)
+    eng.setup_fciqmc(epsilon=eps, target_walkers=target, max_dets=200000, initiator=ini, seed=seed)
+    assert eng.p_doub == orc.p_doub
+    lo = orc.iterate(n_it)
+    lg = eng.iterate_fciqmc(n_it)
+    assert int(lg["err"].max()) == 0
+    for f in ("n_nonz", "n_ini", "curr_size", "n_spawn"):
+        assert np.array_equal(lg[f].astype(np.int64), lo[f].astype(np.int64)), (shape, f, np.nonzero(lg[f].astype(np.int64) != lo[f].astype(np.int64))[0][:5])
+    assert np.array_equal(lg["shift"], lo["shift"]) and np.array_equal(lg["norm"], lo["norm"]) and np.array_equal(lg["denom"], lo["denom"])
+    assert np.all(np.abs(lg["numer"] - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    gd, gv = eng.vector()
+    od, ov = orc.vector()
+    assert gd.size == od.size and np.array_equal(gv, ov)
+    nz = ov != 0
+    assert np.array_equal(gd[nz], od[nz])
+    assert int(lo["n_nonz"][-1]) > 30 and int(lo["n_spawn"].sum()) > 200         # walkers did spread and spawn
+    eng.close()
