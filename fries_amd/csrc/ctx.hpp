@@ -90,7 +90,7 @@ const void *fr_allgather(FriesCtx *c, size_t bytes);
 struct FqWork {
     uint32_t cap_d, cap_a;
     uint32_t *n_doub, *n_att, *att_off; double *new_val;
-    uint32_t *blk_att, *blk_nz, *blk_ini, *blk_sp, *totals;
+    uint32_t *blk_att, *blk_nz, *blk_ini, *blk_sp, *totals, *heavy;      // totals: attempts, non-zero, initiators, heavy determinants
     double *sp_val; det_t *sp_det; uint8_t *sp_ini;
     double *norm;
 };

@@ -24,6 +24,7 @@ struct FqRng {
     }
     __device__ __forceinline__ unsigned choose(unsigned nmax) { return (unsigned)(uni() * nmax); }     // near_uniform.cpp:41-44
 };
+#define FQ_HEAVY 128u
 enum { FQ_BIN = 0, FQ_DOUB = 1, FQ_SING = 2, FQ_ROUND_D = 3, FQ_ROUND_S = 4, FQ_DEATH = 5 };
 
 // per stored determinant: walkers split into double / single attempts (bin_sample, :352), death / cloning (:396-403)
@@ -45,31 +46,86 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
             nz = 1; ini = n_walk > init_thresh;
             const int sign = cur_i < 0 ? -1 : 1;
             const det_t det = V.dets[d];
-            FqRng rng;
-            rng.begin(seed, iter, det, 0, FQ_BIN);
-            for (unsigned i = 0; i < n_walk; i++) n_doub += rng.uni() < p_doub;
-            n_sing = n_walk - n_doub;
-            // sing_multin returns nothing when no electron has a symmetry-allowed excitation (near_uniform.cpp:293-295)
-            if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
             double dg = V.diag[d];
             if (dg != dg) { dg = fr_diag_matrel(det, S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[d] = dg; }
-            const double m = (1 - eps * (dg - shift)) * sign;
-            const int flr = (int)floor(m);
-            const double prob = m - flr;
-            int ret = flr * (int)n_walk;
-            rng.begin(seed, iter, det, 0, FQ_DEATH);
-            for (unsigned i = 0; i < n_walk; i++) ret += rng.uni() < prob;
-            new_val = (double)ret;
+            if (n_walk > FQ_HEAVY) {
+                // a determinant with many walkers draws one uniform per walker, twice: handed to a whole workgroup (k_fq_heavy);
+                // the counter-based stream is addressable by draw index, so the draws can be split over lanes
+                uint32_t slot = atomicAdd(&Q.totals[3], 1u);
+                Q.heavy[slot] = d;
+                n_doub = 0; n_sing = 0; new_val = cur;
+            }
+            else {
+                FqRng rng;
+                rng.begin(seed, iter, det, 0, FQ_BIN);
+                for (unsigned i = 0; i < n_walk; i++) n_doub += rng.uni() < p_doub;
+                n_sing = n_walk - n_doub;
+                // sing_multin returns nothing when no electron has a symmetry-allowed excitation (near_uniform.cpp:293-295)
+                if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
+                const double m = (1 - eps * (dg - shift)) * sign;
+                const int flr = (int)floor(m);
+                const double prob = m - flr;
+                int ret = flr * (int)n_walk;
+                rng.begin(seed, iter, det, 0, FQ_DEATH);
+                for (unsigned i = 0; i < n_walk; i++) ret += rng.uni() < prob;
+                new_val = (double)ret;
+            }
         }
         Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing; Q.new_val[d] = new_val;
-        att = n_doub + n_sing;
     }
-    uint32_t b_att = fr_block_sum_u32(att, shu);
-    __syncthreads();
     uint32_t b_nz = fr_block_sum_u32(nz, shu);
     __syncthreads();
     uint32_t b_ini = fr_block_sum_u32(ini, shu);
-    if (threadIdx.x == 0) { Q.blk_att[blockIdx.x] = b_att; Q.blk_nz[blockIdx.x] = b_nz; Q.blk_ini[blockIdx.x] = b_ini; }
+    if (threadIdx.x == 0) { Q.blk_nz[blockIdx.x] = b_nz; Q.blk_ini[blockIdx.x] = b_ini; }
+}
+
+// determinants with more than FQ_HEAVY walkers, one workgroup each: the same draws as the lane loop above (draw i of a stream is
+// hash(key + (i + 1) * golden), whoever evaluates it), counted with a workgroup reduction
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter, double p_doub,
+                                                       double eps, double shift) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    fr_stage_tables(&T, S.hb);
+    const uint32_t nh = Q.totals[3];
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t d = Q.heavy[h];
+        const int cur_i = (int)V.v0[d];
+        const unsigned n_walk = (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        const int sign = cur_i < 0 ? -1 : 1;
+        const det_t det = V.dets[d];
+        FqRng rb, rd;
+        rb.begin(seed, iter, det, 0, FQ_BIN);
+        rd.begin(seed, iter, det, 0, FQ_DEATH);
+        const double m = (1 - eps * (V.diag[d] - shift)) * sign;
+        const int flr = (int)floor(m);
+        const double prob = m - flr;
+        uint32_t c_doub = 0, c_live = 0;
+        for (unsigned i = threadIdx.x; i < n_walk; i += blockDim.x) {
+            rb.ctr = i; rd.ctr = i;         // uni() pre-increments: draw number i + 1 of each stream
+            c_doub += rb.uni() < p_doub;
+            c_live += rd.uni() < prob;
+        }
+        __syncthreads();
+        const uint32_t n_doub = fr_block_sum_u32(c_doub, shu);
+        __syncthreads();
+        const uint32_t n_live = fr_block_sum_u32(c_live, shu);
+        if (threadIdx.x == 0) {
+            uint32_t n_sing = n_walk - n_doub;
+            if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
+            Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing;
+            Q.new_val[d] = (double)(flr * (int)n_walk + (int)n_live);
+        }
+        __syncthreads();
+    }
+}
+
+// attempts per workgroup of determinants (after the heavy ones are known)
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_blocksum(VecDev V, FqWork Q) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = fr_block_sum_u32(d < n ? Q.n_att[d] : 0u, shu);
+    if (threadIdx.x == 0) Q.blk_att[blockIdx.x] = b;
 }
 
 // exclusive offsets of every determinant's attempts; totals (one workgroup per FR_BLOCK determinants, block prefix re-reduced)
@@ -291,7 +347,8 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     Q.n_doub = fr_alloc<uint32_t>(Q.cap_d); Q.n_att = fr_alloc<uint32_t>(Q.cap_d); Q.att_off = fr_alloc<uint32_t>(Q.cap_d); Q.new_val = fr_alloc<double>(Q.cap_d);
     unsigned nb = fr_blocks(Q.cap_d, FR_BLOCK) + 1, nba = fr_blocks(Q.cap_a, FR_BLOCK) + 1;
     Q.blk_att = fr_alloc<uint32_t>(nb); Q.blk_nz = fr_alloc<uint32_t>(nb); Q.blk_ini = fr_alloc<uint32_t>(nb); Q.blk_sp = fr_alloc<uint32_t>(nba);
-    Q.totals = fr_alloc<uint32_t>(4); Q.norm = fr_alloc<double>(1);
+    Q.totals = fr_alloc<uint32_t>(4); Q.norm = fr_alloc<double>(1); Q.heavy = fr_alloc<uint32_t>(Q.cap_d);
+    FR_HIP(hipMemsetAsync(Q.totals, 0, 16, c->stream));
     Q.sp_val = fr_alloc<double>(Q.cap_a); Q.sp_det = fr_alloc<det_t>(Q.cap_a); Q.sp_ini = fr_alloc<uint8_t>(Q.cap_a);
     fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
     double v = 100; uint8_t one = 1; uint32_t n1 = 1;       // :239-243
@@ -313,7 +370,10 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     if (n > Q.cap_d) throw FriesError("vector larger than the FCIQMC work arrays");
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     const unsigned gd = fr_blocks(n ? n : 1, FR_BLOCK);
+    FR_HIP(hipMemsetAsync(&Q.totals[3], 0, 4, st));
     FR_LAUNCH(c, "k_fq_count", k_fq_count, dim3(gd), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift, P.initiator);
+    FR_LAUNCH(c, "k_fq_heavy", k_fq_heavy, dim3(512), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift);
+    FR_LAUNCH(c, "k_fq_blocksum", k_fq_blocksum, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
     FR_LAUNCH(c, "k_fq_offsets", k_fq_offsets, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
     uint32_t tot[3];
     FR_HIP(hipMemcpyAsync(tot, Q.totals, 12, hipMemcpyDeviceToHost, st));
