@@ -58,18 +58,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 DRIVER = os.path.join(HERE, "frisys_mol_hip")
+DRIVERS = {name: os.path.join(HERE, name) for name in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip")}
 
 
 def build_drivers(force: bool = False) -> str:
-    """The C++ command-line driver (host side in the reference's language) linked against libfries_hip.so."""
-    src = os.path.join(HERE, "drivers", "frisys_mol_hip.cpp")
-    hdr = os.path.join(HERE, "..", "include", "fries_hip.h")
-    if force or _stale(DRIVER, [src, hdr, LIB]):
-        cmd = ["g++", "-std=c++17", "-O2", "-o", DRIVER, src, "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
-               "-Wl,-rpath-link,/opt/rocm/lib"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"g++ failed on frisys_mol_hip.cpp:\n{r.stdout}\n{r.stderr}")
+    """The C++ command-line drivers (host side in the reference's language) linked against libfries_hip.so."""
+    hdrs = [os.path.join(HERE, "..", "include", "fries_hip.h"), os.path.join(HERE, "drivers", "driver_common.hpp")]
+    for name, exe in DRIVERS.items():
+        src = os.path.join(HERE, "drivers", name + ".cpp")
+        if force or _stale(exe, [src, LIB] + hdrs):
+            cmd = ["g++", "-std=c++17", "-O2", "-o", exe, src, "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
+                   "-Wl,-rpath-link,/opt/rocm/lib"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"g++ failed on {name}.cpp:\n{r.stdout}\n{r.stderr}")
     return DRIVER
 
 

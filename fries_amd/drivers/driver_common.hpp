@@ -1,0 +1,92 @@
+// Host-side pieces shared by the command-line drivers: status check, the FCIDUMP reader (parse_fcidump / convert_symm,
+// FRIES/io_utils.cpp:189-318) and "--option value" parsing (argparse in the reference).
+#pragma once
+#include "../../include/fries_hip.h"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+static void ck(int rc) { if (rc) throw std::runtime_error(fries_last_error()); }
+
+struct Fcidump { uint32_t n_orb = 0, n_elec = 0; double core_en = 0; std::vector<uint8_t> symm; std::vector<double> hcore, eris; };
+
+// io_utils.cpp:189-239
+static void convert_symm(std::vector<uint8_t> &irreps, const std::string &pg_in) {
+    std::string pg = pg_in;
+    for (auto &ch : pg) ch = (char)tolower(ch);
+    std::vector<uint8_t> map;
+    unsigned max_label;
+    if (pg == "d2h") { map = {0, 7, 6, 1, 5, 2, 3, 4}; max_label = 8; }
+    else if (pg == "c2v" || pg == "c2h") { map = {0, 2, 3, 1}; max_label = 4; }
+    else if (pg == "d2") { map = {0, 3, 2, 1}; max_label = 4; }
+    else if (pg == "cs" || pg == "c2" || pg == "ci" || pg == "c1") { map = {0, 1}; max_label = 2; }
+    else throw std::runtime_error("Point group " + pg_in + " not recognized");
+    for (auto &ir : irreps) {
+        if (ir > max_label || ir == 0) {
+            std::stringstream msg;
+            msg << "irrep index " << (unsigned)ir << " read from the FCIDUMP file exceeds the maximum allowed irrep index (" << max_label << ") for point group " << pg_in;
+            throw std::runtime_error(msg.str());
+        }
+        ir = map[ir - 1];
+    }
+}
+
+static size_t tri(size_t i, size_t j) { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
+
+// io_utils.cpp:241-318: line 1 NORB / NELEC / MS2, line 2 ORBSYM, two more header lines, then "value i j k l" records
+static Fcidump parse_fcidump(const std::string &path, const std::string &point_group) {
+    std::ifstream in(path);
+    if (!in.is_open()) throw std::runtime_error("Could not open FCIDUMP file " + path);
+    std::string line;
+    std::getline(in, line);
+    auto field = [&](const char *key) {
+        size_t p = line.find(key);
+        if (p == std::string::npos) throw std::runtime_error(std::string("FCIDUMP header lacks ") + key);
+        size_t e = line.find(",", p);
+        return std::stoi(line.substr(p + strlen(key), e - (p + strlen(key))));
+    };
+    Fcidump f;
+    f.n_orb = (uint32_t)field("NORB="); f.n_elec = (uint32_t)field("NELEC=");
+    if (field("MS2=") != 0) throw std::runtime_error("MS2 is not zero in FCIDUMP file.");
+    std::getline(in, line);
+    size_t op = line.find("ORBSYM=");
+    if (op == std::string::npos) throw std::runtime_error("ORBSYM missing on line 2 of the FCIDUMP file");
+    std::stringstream ss(line.substr(op + 7));
+    std::string tok;
+    while (std::getline(ss, tok, ',')) { try { if (!tok.empty()) f.symm.push_back((uint8_t)std::stoi(tok)); } catch (std::invalid_argument &) {} }
+    if (f.symm.size() != f.n_orb) throw std::runtime_error("Number of irrep labels read in after ORBSYM in FCIDUMP file does not equal number of orbitals");
+    convert_symm(f.symm, point_group);
+    std::getline(in, line);     // ISYM
+    std::getline(in, line);     // &END
+    const size_t n = f.n_orb, np = n * (n + 1) / 2;
+    f.hcore.assign(n * n, 0.0); f.eris.assign(np * (np + 1) / 2, 0.0);
+    double v; unsigned o[4];
+    while (in >> v >> o[0] >> o[1] >> o[2] >> o[3]) {
+        if (!o[0] && !o[1] && !o[2] && !o[3]) f.core_en = v;
+        else if (!o[1] && !o[2] && !o[3]) continue;                  // orbital energy
+        else if (!o[2] && !o[3]) f.hcore[(o[0] - 1) * n + (o[1] - 1)] = f.hcore[(o[1] - 1) * n + (o[0] - 1)] = v;
+        else { size_t p1 = tri(o[0] - 1, o[1] - 1), p2 = tri(o[2] - 1, o[3] - 1); f.eris[tri(p1, p2)] = v; }     // 8-fold packed, ndarr.hpp:206-244
+    }
+    return f;
+}
+
+
+static std::map<std::string, std::string> parse_kv(int argc, char **argv) {
+    std::map<std::string, std::string> kv;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) != 0 || i + 1 >= argc) throw std::runtime_error("expected --option value pairs, got " + a);
+        kv[a.substr(2)] = argv[++i];
+    }
+    return kv;
+}
+static uint32_t wall_clock_seed() { return (uint32_t)std::chrono::high_resolution_clock::now().time_since_epoch().count(); }

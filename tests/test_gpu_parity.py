@@ -381,3 +381,47 @@ def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, 
     assert np.array_equal(gd[nz], od[nz])
     assert int(lo["n_nonz"][-1]) > 30 and int(lo["n_spawn"].sum()) > 200         # walkers did spread and spawn
     eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_drivers_hh_and_fciqmc(oracle, mols, tmp_path):
+    """frisys_hh_hip against the reference's golden trajectory (its parameter-file format included) and fciqmc_mol_hip against the
+    CPU restatement on the counter stream: the files the drivers write."""
+    import subprocess
+    from fries_amd import build
+    # ---- frisys_hh_hip
+    name = "hh_l6_m2000"
+    r = golden_io.manifest()["hh_runs"][name]
+    g = golden_io.read_traj(name)
+    pf = tmp_path / "hh_params.txt"
+    pf.write_text("n_elec\n%d\nlat_len\n%d\nn_dim\n1\neps\n%r\nU\n%r\nomega\n%r\ng\n%r\ngs_energy\n%r\n" % (r["n_elec"], r["n_sites"], r["eps"], r["U"], r["omega"], r["g"], r["gs_energy"]))
+    out = str(tmp_path / "hh") + "/"
+    os.makedirs(out)
+    n_it = 30
+    res = subprocess.run([build.DRIVERS["frisys_hh_hip"], "--params_path", str(pf), "--vec_nonz", str(r["vec_nonz"]), "--max_dets", str(r["max_dets"]), "--target",
+                          repr(r["target_norm"]), "--initiator", repr(r["initiator"]), "--max_iter", str(n_it), "--result_dir", out, "--seed", str(r["seed"])],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); sh = np.loadtxt(out + "S.txt"); nm = np.loadtxt(out + "norm.txt")
+    for i in range(n_it):
+        row = g["rows"][i]
+        assert den[i] == row["denom"] and abs(num[i] - row["numer"]) <= 1e-10 * max(1.0, abs(row["numer"]))
+    for k in range(n_it // 10):
+        assert sh[k] == g["rows"][10 * k + 9]["shift"] and nm[k] == g["rows"][10 * k + 9]["norm"]
+    # ---- fciqmc_mol_hip
+    mol = mols("Ne")
+    fc = str(tmp_path / "ne.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out2 = str(tmp_path / "fq") + "/"
+    os.makedirs(out2)
+    n_it = 60
+    res = subprocess.run([build.DRIVERS["fciqmc_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", "NU", "--target", "20000",
+                          "--max_dets", "100000", "--epsilon", "0.004", "--initiator", "3", "--max_iter", str(n_it), "--result_dir", out2, "--seed", "5"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    orc = oracle.OracleFciqmc(mol, epsilon=0.004, target_walkers=20000, max_dets=100000, initiator=3, seed=5, counter_rng=True)
+    lo = orc.iterate(n_it)
+    num = np.loadtxt(out2 + "projnum.txt"); den = np.loadtxt(out2 + "projden.txt"); nini = np.loadtxt(out2 + "nini.txt"); nnz = np.loadtxt(out2 + "nnonz.txt")
+    assert np.array_equal(den, lo["denom"]) and np.array_equal(nini.astype(np.int64), lo["n_ini"].astype(np.int64))
+    assert np.all(np.abs(num - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    assert np.array_equal(nnz.astype(np.int64), lo["n_nonz"][9::10].astype(np.int64))
