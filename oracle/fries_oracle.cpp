@@ -1748,6 +1748,78 @@ void nu_sing_sample(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &
     orbs[0] = (uint8_t)occ_orb; orbs[1] = (uint8_t)orbital;
 }
 
+
+void setup_alias(const double *probs, unsigned *aliases, double *alias_probs, size_t n) {
+    size_t n_s = 0, n_b = 0;
+    unsigned smaller[256], bigger[256];
+    for (unsigned i = 0; i < n; i++) {
+        aliases[i] = i;
+        alias_probs[i] = n * probs[i];
+        if (alias_probs[i] < 1) smaller[n_s++] = i; else bigger[n_b++] = i;
+    }
+    while (n_s > 0 && n_b > 0) {
+        unsigned sm = smaller[n_s - 1], b = bigger[n_b - 1];
+        aliases[sm] = b;
+        alias_probs[b] += alias_probs[sm] - 1;
+        if (alias_probs[b] < 1) { smaller[n_s - 1] = b; n_b--; }
+        else n_s--;
+    }
+}
+unsigned sample_alias_one(const unsigned *aliases, const double *alias_probs, size_t n, Rng &rng) {
+    uint8_t chosen = (uint8_t)(rng.uni() * n);
+    if (rng.uni() < alias_probs[chosen]) return chosen;
+    return aliases[chosen];
+}
+
+unsigned hb_doub_multi(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &sy, const HBInfo &hb, unsigned num_sampl, Rng &rng, uint64_t iter,
+                       uint8_t *orbs, double *prob, uint32_t *att) {
+    const unsigned n_orb = hb.n_orb, n_virt = n_orb - n_elec / 2;
+    unsigned alias_idx[64]; double alias_probs[64], probs[64];
+    // first occupied orbital of every sample (:614-617), then how many samples chose each electron (:619-625)
+    calc_o1_probs(hb, probs, n_elec, occ, 0);
+    setup_alias(probs, alias_idx, alias_probs, n_elec);
+    std::vector<unsigned> o1_samples(n_elec, 0);
+    for (unsigned i = 0; i < num_sampl; i++) {
+        rng.begin(iter, det, i, RNG_HB_O1);
+        o1_samples[sample_alias_one(alias_idx, alias_probs, n_elec, rng)]++;
+    }
+    unsigned tot = 0;
+    std::vector<uint8_t> o2s, u1s;
+    for (unsigned e = 0; e < n_elec; e++) {
+        unsigned loc = o1_samples[e];
+        if (loc == 0) continue;
+        o2s.resize(loc); u1s.resize(loc);
+        calc_o2_probs(hb, probs, n_elec, occ, e);           // second occupied orbital for the whole group (:636-639)
+        unsigned o1 = occ[e];
+        setup_alias(probs, alias_idx, alias_probs, n_elec);
+        for (unsigned k = 0; k < loc; k++) { rng.begin(iter, det, (e << 20) | k, RNG_HB_O2); o2s[k] = (uint8_t)sample_alias_one(alias_idx, alias_probs, n_elec, rng); }
+        calc_u1_probs(hb, probs, o1, occ, n_elec, 0);       // first virtual for the whole group (:641-644)
+        setup_alias(probs, alias_idx, alias_probs, n_virt);
+        for (unsigned k = 0; k < loc; k++) { rng.begin(iter, det, (e << 20) | k, RNG_HB_U1); u1s[k] = (uint8_t)sample_alias_one(alias_idx, alias_probs, n_virt, rng); }
+        for (unsigned k = 0; k < loc; k++) {                // second virtual, one sample at a time (:646-679)
+            unsigned o2 = occ[o2s[k]];
+            unsigned u1 = find_nth_virt(occ, o1 / n_orb, n_elec, n_orb, u1s[k]);
+            unsigned u2_symm = sy.irrep[o1 % n_orb] ^ sy.irrep[o2 % n_orb] ^ sy.irrep[u1 % n_orb];
+            uint16_t num_u2 = 0;
+            double u2_norm = calc_u2_probs(hb, probs, o1, o2, u1, sy, &num_u2);
+            if (u2_norm != 0) {
+                setup_alias(probs, alias_idx, alias_probs, num_u2);
+                rng.begin(iter, det, (e << 20) | k, RNG_HB_U2);
+                unsigned u2 = sample_alias_one(alias_idx, alias_probs, num_u2, rng);
+                u2 = sy.lk(u2_symm, u2 + 1) + n_orb * (o2 / n_orb);
+                if ((det >> u2) & 1) continue;
+                uint8_t *o = &orbs[4 * tot];
+                if (o1 > o2) { o[0] = (uint8_t)o2; o[1] = (uint8_t)o1; } else { o[0] = (uint8_t)o1; o[1] = (uint8_t)o2; }
+                if (u1 > u2) { o[2] = (uint8_t)u2; o[3] = (uint8_t)u1; } else { o[2] = (uint8_t)u1; o[3] = (uint8_t)u2; }
+                prob[tot] = calc_norm_wt(hb, o, occ, n_elec, det, sy);
+                att[tot] = (e << 20) | k;
+                tot++;
+            }
+        }
+    }
+    return tot;
+}
+
 void Fciqmc::setup() {
     const unsigned n_orb = sys.n_orb, n_elec = sys.n_elec;
     uint8_t tmp[64];
@@ -1797,6 +1869,7 @@ void Fciqmc::setup() {
     }
     sol.add(hf_det, 100, 1);      // :239-243
     sol.perform_add(0);
+    if (par.heat_bath) sys.hb.set_up(sys.ints);       // :310-313
     en_shift = 0; last_norm = 0; iterat = 0;
 }
 
@@ -1829,7 +1902,8 @@ void Fciqmc::iterate(unsigned n_iter) {
             if (orbs.size() < 4 * (size_t)n_walk) { orbs.resize(4 * (size_t)n_walk); probs.resize(n_walk); }
             unsigned nn = 0;
             std::vector<uint32_t> att(n_doub);       // which attempt produced sample w: counter mode keys the rounding draw by it
-            for (unsigned i = 0; i < n_doub; i++) {
+            if (par.heat_bath) nn = hb_doub_multi(det, occ, n_elec, sys.symm, sys.hb, n_doub, rng, iterat, orbs.data(), probs.data(), att.data());      // :366-368
+            else for (unsigned i = 0; i < n_doub; i++) {
                 rng.begin(iterat, det, i, RNG_DOUB);
                 if (nu_doub_sample(det, occ, n_elec, sys.symm, counts, rng, &orbs[4 * nn], &probs[nn])) { att[nn] = i; nn++; }
             }

@@ -322,7 +322,15 @@ struct Rng {
     double uni();
     static uint64_t mix(uint64_t x);
 };
-enum { RNG_BIN = 0, RNG_DOUB = 1, RNG_SING = 2, RNG_ROUND_D = 3, RNG_ROUND_S = 4, RNG_DEATH = 5 };
+enum { RNG_BIN = 0, RNG_DOUB = 1, RNG_SING = 2, RNG_ROUND_D = 3, RNG_ROUND_S = 4, RNG_DEATH = 5, RNG_HB_O1 = 6, RNG_HB_O2 = 7, RNG_HB_U1 = 8, RNG_HB_U2 = 9 };
+// FRIES/compress_utils.cpp:823-856 / 858-877 (one sample)
+void setup_alias(const double *probs, unsigned *aliases, double *alias_probs, size_t n_states);
+unsigned sample_alias_one(const unsigned *aliases, const double *alias_probs, size_t n_states, Rng &rng);
+// FRIES/Hamiltonians/heat_bathPP.cpp:601-683: num_sampl heat-bath double excitations of one determinant.  Samples come out grouped
+// by their first occupied orbital.  att[k] = (electron index of o1) << 20 | index inside that group: what counter mode keys the
+// later draws of sample k by.  iter: iteration number for the counter keys.
+unsigned hb_doub_multi(det_t det, const uint8_t *occ, unsigned n_elec, const Symm &s, const HBInfo &hb, unsigned num_sampl, Rng &rng, uint64_t iter,
+                       uint8_t *orbs /* 4 per sample */, double *prob, uint32_t *att);
 // FRIES/Hamiltonians/near_uniform.cpp:31-39, compress_utils.cpp:19-27
 unsigned bin_sample(unsigned n, double p, Rng &rng);
 int round_binomially(double p, unsigned n, Rng &rng);
@@ -337,6 +345,7 @@ struct FciqmcParams {
     size_t max_dets = 0;
     uint32_t seed = 0;
     bool counter_rng = false;
+    bool heat_bath = false;         // --distribution HB (hb_doub_multi for the doubles) instead of NU
 };
 struct FciqmcLog { double numer, denom, shift, norm; int n_nonz; uint32_t n_ini; size_t curr_size, n_spawn; };
 // FRIES_bin/fciqmc_mol.cpp:35-480, --distribution NU, HF trial vector, HF start, one rank

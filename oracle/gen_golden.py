@@ -34,9 +34,11 @@ MPIEXEC = "/opt/conda/bin/mpiexec"
 
 # fciqmc_mol, near-uniform excitation generator, one rank: name -> (shape, n_iter, seed, eps, target_walkers, max_dets, initiator)
 FCIQMC_RUNS = {
-    "fciqmc_ne": ("Ne", 200, 5, 0.002, 5000, 20000, 3),
-    "fciqmc_n2": ("N2", 300, 9, 0.004, 20000, 100000, 2),
-    "fciqmc_h2o_ini0": ("H2O", 150, 11, 0.002, 10000, 100000, 0),
+    "fciqmc_ne": ("Ne", 200, 5, 0.002, 5000, 20000, 3, "NU"),
+    "fciqmc_n2": ("N2", 300, 9, 0.004, 20000, 100000, 2, "NU"),
+    "fciqmc_h2o_ini0": ("H2O", 150, 11, 0.002, 10000, 100000, 0, "NU"),
+    "fciqmc_n2_hb": ("N2", 200, 9, 0.004, 20000, 100000, 2, "HB"),
+    "fciqmc_h2o_hb_ini0": ("H2O", 150, 11, 0.002, 10000, 100000, 0, "HB"),
 }
 
 # frisys_hh (1-D Hubbard-Holstein): name -> (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, initiator, target)
@@ -82,12 +84,12 @@ def main():
             manifest["mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz,
                                               max_dets=maxd, initiator=ini, target_norm=tgt, distribution=dist)
         manifest["fciqmc_runs"] = {}
-        for name, (shape, n_iter, seed, eps, tw, maxd, ini) in FCIQMC_RUNS.items():
+        for name, (shape, n_iter, seed, eps, tw, maxd, ini, dist) in FCIQMC_RUNS.items():
             mol = fcidump.synthetic(shape)
             path = os.path.join(tmp, shape + ".FCIDUMP")
             out = os.path.join(GOLD, name + ".traj")
-            subprocess.run([HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out], check=True)
-            manifest["fciqmc_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini)
+            subprocess.run([HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
+            manifest["fciqmc_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist)
         manifest["hh_runs"] = {}
         for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HH_RUNS.items():
             out = os.path.join(GOLD, name + ".traj")

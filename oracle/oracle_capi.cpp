@@ -252,6 +252,7 @@ struct FqLog { double numer, denom, shift, norm; int32_t n_nonz; uint32_t n_ini,
 void *fo_fciqmc_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                        double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int counter_rng) {
     Fciqmc *f = new Fciqmc();
+    f->par.heat_bath = (counter_rng & 2) != 0; counter_rng &= 1;        // bit 1 of the flag selects --distribution HB
     f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
     f->sys.ints.n_orb = n_orb;
     f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);

@@ -851,13 +851,14 @@ static int run_hh(int argc, char **argv) {
 
 
 // ------------------------------------------------------------------ fciqmc_mol (NU): reference loop vs the oracle in mt mode
-// ref_harness fciqmc <fcidump> <pg> <n_iter> <seed> <eps> <target_walkers> <max_dets> <initiator> <out>
+// ref_harness fciqmc <fcidump> <pg> <n_iter> <seed> <eps> <target_walkers> <max_dets> <initiator> <out> [NU|HB]
 static int run_fciqmc(int argc, char **argv) {
     if (argc < 11) { fprintf(stderr, "usage: see header\n"); return 2; }
     const char *path = argv[2], *pg = argv[3];
     unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
     double eps = atof(argv[6]); uint32_t target_walkers = strtoul(argv[7], 0, 10);
     uint32_t max_n_dets = strtoul(argv[8], 0, 10); uint32_t init_thresh = strtoul(argv[9], 0, 10);
+    const bool heat_bath = argc > 11 && !strcmp(argv[11], "HB");
     fcidump_input *in_data = parse_fcidump(path, pg);
     unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
     size_t det_size = CEILING(2 * n_orb, 8);
@@ -909,7 +910,9 @@ static int run_fciqmc(int argc, char **argv) {
     fill_oracle_ints(fq.sys.ints, *eris, *h_core, n_orb);
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
+    fq.par.heat_bath = heat_bath;
     fq.setup();
+    hb_info *hb_probs = heat_bath ? set_up(tot_orb, n_orb, *eris) : NULL;
     CHECK(same_bits(fq.p_doub, p_doub), "fciqmc p_doub");
     // the sampling functions on their own, from identical mt19937 states
     {
@@ -940,6 +943,15 @@ static int run_fciqmc(int argc, char **argv) {
             unsigned nso = delta_s == n_elec ? 0 : ns;
             CHECK(nsr == nso, "sing_multin count");
             for (unsigned i = 0; i < nso; i++) { uint8_t so[2]; double sp2; fo::nu_sing_sample(d, occ, n_elec, fq.sys.symm, m_allow, delta_s, rb, so, &sp2); CHECK(!memcmp(rs[i], so, 2) && same_bits(rsp[i], sp2), "sing_multin sample"); }
+            if (heat_bath && trial < 1500) {
+                unsigned nh = 1 + trial % 23;
+                uint8_t hr[64][4]; double hp[64];
+                unsigned cr2 = hb_doub_multi(db, occ, n_elec, &symm_basis, hb_probs, nh, ga, hr, hp);
+                uint8_t ho[64 * 4]; double hq[64]; uint32_t hatt[64];
+                unsigned co2 = fo::hb_doub_multi(d, occ, n_elec, fq.sys.symm, fq.sys.hb, nh, rb, 0, ho, hq, hatt);
+                CHECK(cr2 == co2, "hb_doub_multi count %u %u", cr2, co2);
+                for (unsigned i = 0; i < std::min(cr2, co2); i++) CHECK(!memcmp(hr[i], &ho[4 * i], 4) && same_bits(hp[i], hq[i]), "hb_doub_multi sample %u", i);
+            }
             unsigned nb = 1 + trial % 50; double pp = (trial % 97) / 97.0;
             CHECK(bin_sample(nb, pp, ga) == fo::bin_sample(nb, pp, rb), "bin_sample");
             double pr = -1.7 + (trial % 41) * 0.1;
@@ -964,7 +976,8 @@ static int run_fciqmc(int argc, char **argv) {
             unsigned n_doub = bin_sample(n_walk, p_doub, mt_obj);
             unsigned n_sing = n_walk - n_doub;
             if (n_doub > max_spawn || n_sing > max_spawn) { fprintf(stderr, "harness: max_spawn exceeded\n"); return 2; }
-            n_doub = doub_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_doub, mt_obj, doub_orbs, spawn_probs.data());
+            if (heat_bath) n_doub = hb_doub_multi(curr_det, occ_orbs, n_elec_unf, &symm_basis, hb_probs, n_doub, mt_obj, doub_orbs, spawn_probs.data());
+            else n_doub = doub_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_doub, mt_obj, doub_orbs, spawn_probs.data());
             uint8_t new_det[8];
             for (size_t w = 0; w < n_doub; w++) {
                 double matr_el = doub_matr_el_nosgn(doub_orbs[w], tot_orb, *eris, n_frz);

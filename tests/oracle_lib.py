@@ -290,12 +290,14 @@ class OracleFciqmc:
     reference's sequential mt19937 stream (pinned against the reference loop); counter_rng=True uses the counter-based
     stream the GPU replays."""
 
-    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False):
+    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU"):
         self.lib = load()
+        if distribution not in ("NU", "HB"):
+            raise RuntimeError('"dist_str" argument must be either "NU" or "HB"')
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
-        self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, int(counter_rng))
+        self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, int(counter_rng) | (2 if distribution == "HB" else 0))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -91,7 +91,7 @@ def test_sharding_hash_matches_reference_ranks(oracle, mols):
 
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_runs"]))
 def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
-    """fciqmc_mol (near-uniform generator) restated, consuming the reference's mt19937 stream: every logged scalar, the walker
+    """fciqmc_mol (near-uniform and heat-bath generators) restated, consuming the reference's mt19937 stream: every logged scalar, the walker
     counts and the digest of (position, determinant, walkers) against the reference's own loop."""
     r = golden_io.manifest()["fciqmc_runs"][name]
     rows = []
@@ -102,7 +102,7 @@ def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
             t = ln.split()
             rows.append((float.fromhex(t[1]), float.fromhex(t[2]), float.fromhex(t[3]), float.fromhex(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[8]), int(t[9], 16)))
     orc = oracle.OracleFciqmc(mols(r["shape"]), epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"],
-                              seed=r["seed"], counter_rng=False)
+                              seed=r["seed"], counter_rng=False, distribution=r["distribution"])
     logs = orc.iterate(r["n_iter"])
     for i, row in enumerate(rows):
         lg = logs[i]
