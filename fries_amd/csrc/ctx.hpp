@@ -93,6 +93,7 @@ struct FqWork {
     uint32_t *blk_att, *blk_nz, *blk_ini, *blk_sp, *totals, *heavy;      // totals: attempts, non-zero, initiators, heavy determinants
     double *sp_val; det_t *sp_det; uint8_t *sp_ini;
     double *norm;
+    uint32_t *o1cnt;            // heat-bath generator: samples per first occupied electron, [determinant][electron]
 };
 
 struct FriesCtx {

@@ -25,7 +25,35 @@ struct FqRng {
     __device__ __forceinline__ unsigned choose(unsigned nmax) { return (unsigned)(uni() * nmax); }     // near_uniform.cpp:41-44
 };
 #define FQ_HEAVY 128u
-enum { FQ_BIN = 0, FQ_DOUB = 1, FQ_SING = 2, FQ_ROUND_D = 3, FQ_ROUND_S = 4, FQ_DEATH = 5 };
+enum { FQ_BIN = 0, FQ_DOUB = 1, FQ_SING = 2, FQ_ROUND_D = 3, FQ_ROUND_S = 4, FQ_DEATH = 5, FQ_HB_O1 = 6, FQ_HB_O2 = 7, FQ_HB_U1 = 8, FQ_HB_U2 = 9 };
+
+// alias method (compress_utils.cpp:823-877) on a probability row of at most 32 states
+struct FqAlias { uint8_t alias[32]; double prob[32]; };
+__device__ inline void fq_setup_alias(FqAlias &A, const double *probs, unsigned n) {
+    unsigned n_s = 0, n_b = 0;
+    uint8_t smaller[32], bigger[32];
+    for (unsigned i = 0; i < n; i++) {
+        A.alias[i] = (uint8_t)i;
+        A.prob[i] = n * probs[i];
+        if (A.prob[i] < 1) smaller[n_s++] = (uint8_t)i; else bigger[n_b++] = (uint8_t)i;
+    }
+    while (n_s > 0 && n_b > 0) {
+        unsigned sm = smaller[n_s - 1], b = bigger[n_b - 1];
+        A.alias[sm] = (uint8_t)b;
+        A.prob[b] += A.prob[sm] - 1;
+        if (A.prob[b] < 1) { smaller[n_s - 1] = (uint8_t)b; n_b--; }
+        else n_s--;
+    }
+}
+__device__ __forceinline__ unsigned fq_sample_alias(const FqAlias &A, unsigned n, FqRng &rng) {
+    unsigned chosen = (unsigned)(uint8_t)(rng.uni() * n);
+    return rng.uni() < A.prob[chosen] ? chosen : A.alias[chosen];
+}
+// calc_o1_probs (heat_bathPP.cpp:182-200): normalised s_tens of the occupied orbitals
+__device__ inline void fq_o1_probs(const HbTables &T, det_t det, double *p) {
+    RowInfo ri = fr_row2_setup<false>(T, det);
+    fr_row2_visit<false>(T, det, [&](unsigned s, double w) { p[s] = w * ri.inv_norm; });
+}
 
 // per stored determinant: walkers split into double / single attempts (bin_sample, :352), death / cloning (:396-403)
 __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter, double p_doub,
@@ -69,6 +97,15 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
                 rng.begin(seed, iter, det, 0, FQ_DEATH);
                 for (unsigned i = 0; i < n_walk; i++) ret += rng.uni() < prob;
                 new_val = (double)ret;
+                if (Q.o1cnt) {          // heat-bath doubles: how many samples chose each electron as o1 (heat_bathPP.cpp:614-625)
+                    const unsigned ne = T.n_elec;
+                    double p1[32]; FqAlias A;
+                    uint32_t cnt[32];
+                    for (unsigned e = 0; e < ne; e++) cnt[e] = 0;
+                    if (n_doub) { fq_o1_probs(T, det, p1); fq_setup_alias(A, p1, ne); }
+                    for (unsigned i = 0; i < n_doub; i++) { rng.begin(seed, iter, det, i, FQ_HB_O1); cnt[fq_sample_alias(A, ne, rng)]++; }
+                    for (unsigned e = 0; e < ne; e++) Q.o1cnt[(size_t)d * ne + e] = cnt[e];
+                }
             }
         }
         Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing; Q.new_val[d] = new_val;
@@ -114,6 +151,18 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy(VecDev V, SysDev S, FqWor
             if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
             Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing;
             Q.new_val[d] = (double)(flr * (int)n_walk + (int)n_live);
+        }
+        if (Q.o1cnt) {
+            __shared__ FqAlias As;
+            __shared__ uint32_t hist[32];
+            const unsigned ne = T.n_elec;
+            if (threadIdx.x == 0) { double p1[32]; fq_o1_probs(T, det, p1); fq_setup_alias(As, p1, ne); }
+            if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+            __syncthreads();
+            FqRng r1;
+            for (unsigned i = threadIdx.x; i < n_doub; i += blockDim.x) { r1.begin(seed, iter, det, i, FQ_HB_O1); atomicAdd(&hist[fq_sample_alias(As, ne, r1)], 1u); }
+            __syncthreads();
+            if (threadIdx.x < ne) Q.o1cnt[(size_t)d * ne + threadIdx.x] = hist[threadIdx.x];
         }
         __syncthreads();
     }
@@ -177,7 +226,59 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
         const unsigned n_orb = T.n_orb, n_elec = T.n_elec;
         SymCounts sc; fr_count_symm_virt(sc, T, det);
         FqRng rng;
-        if (i < n_doub) {       // ---- double (near_uniform.cpp:193-245)
+        if (i < n_doub && Q.o1cnt) {       // ---- heat-bath double (heat_bathPP.cpp:601-683): group = electron chosen as o1, k-th sample of the group
+            const uint32_t *oc = Q.o1cnt + (size_t)d * n_elec;
+            unsigned e = 0, off = 0;
+            while (e + 1 < n_elec && off + oc[e] <= i) { off += oc[e]; e++; }
+            const unsigned k = i - off;
+            const uint32_t att = (e << 20) | k;
+            const unsigned n_virt = n_orb - n_elec / 2;
+            const unsigned o1 = fr_nth_bit(det, e);
+            double pr[32]; FqAlias A;
+            {   // second occupied orbital: calc_o2_probs (:203-233)
+                RowInfo ri = fr_row3_setup(T, det, e);
+                fr_row3_visit(T, det, e, ri.aux, [&](unsigned s2, double w) { pr[s2] = w * ri.inv_norm; });
+                fq_setup_alias(A, pr, n_elec);
+            }
+            rng.begin(seed, iter, det, att, FQ_HB_O2);
+            const unsigned o2 = fr_nth_bit(det, fq_sample_alias(A, n_elec, rng));
+            {   // first virtual: calc_u1_probs (:273-319)
+                RowInfo ri = fr_row4_setup(T, det, o1, false);
+                for (unsigned q = 0; q < n_virt; q++) pr[q] = 0;
+                fr_row4_visit(T, det, o1, false, [&](unsigned s2, double w) { pr[s2] = w * ri.inv_norm; });
+                fq_setup_alias(A, pr, n_virt);
+            }
+            rng.begin(seed, iter, det, att, FQ_HB_U1);
+            const unsigned u1 = fr_find_nth_virt(det, (int)(o1 / n_orb), n_orb, fq_sample_alias(A, n_virt, rng));
+            {   // second virtual: calc_u2_probs (:322-365)
+                const unsigned u2_symm = T.irrep[o1 % n_orb] ^ T.irrep[o2 % n_orb] ^ T.irrep[u1 % n_orb];
+                double norm = 0;
+                const unsigned num_u2 = fr_row5_visit<false>(T, det, o1, o2, u1, [&](unsigned s2, double w) { pr[s2] = w; norm += w; });
+                if (norm != 0) {
+                    const double inv = 1 / norm;
+                    for (unsigned q = 0; q < num_u2; q++) pr[q] *= inv;
+                    fq_setup_alias(A, pr, num_u2);
+                    rng.begin(seed, iter, det, att, FQ_HB_U2);
+                    unsigned u2 = fq_sample_alias(A, num_u2, rng);
+                    u2 = T.lookup[u2_symm][u2 + 1] + n_orb * (o2 / n_orb);
+                    if (!fr_bit(det, u2)) {
+                        const unsigned a1 = o1 < o2 ? o1 : o2, a2 = o1 < o2 ? o2 : o1, b1 = u1 < u2 ? u1 : u2, b2 = u1 < u2 ? u2 : u1;
+                        const double prob = fr_norm_wt(T, det, a1, a2, b1, b2);
+                        double m = fr_doub_matrel(a1, a2, b1, b2, S.eris, n_orb);
+                        m *= eps / prob / p_doub;
+                        rng.begin(seed, iter, det, att, FQ_ROUND_D);
+                        const int flr = (int)floor(m);
+                        int sp = flr + (rng.uni() < m - flr ? 1 : 0);
+                        if (sp != 0) {
+                            sp *= -fr_doub_parity(det, a1, a2, b1, b2) * sign;
+                            sp_val = (double)sp;
+                            sp_det = (det & ~(1ull << a1) & ~(1ull << a2)) | (1ull << b1) | (1ull << b2);
+                        }
+                    }
+                }
+            }
+        }
+        else if (i < n_doub) {       // ---- near-uniform double (near_uniform.cpp:193-245)
             rng.begin(seed, iter, det, i, FQ_DOUB);
             unsigned tri = rng.choose(n_elec * (n_elec - 1) / 2);
             unsigned i1 = (unsigned)((sqrt(tri * 8. + 1) - 1) / 2);
@@ -350,6 +451,8 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     Q.totals = fr_alloc<uint32_t>(4); Q.norm = fr_alloc<double>(1); Q.heavy = fr_alloc<uint32_t>(Q.cap_d);
     FR_HIP(hipMemsetAsync(Q.totals, 0, 16, c->stream));
     Q.sp_val = fr_alloc<double>(Q.cap_a); Q.sp_det = fr_alloc<det_t>(Q.cap_a); Q.sp_ini = fr_alloc<uint8_t>(Q.cap_a);
+    Q.o1cnt = p->heat_bath ? fr_alloc<uint32_t>((size_t)Q.cap_d * c->n_elec) : nullptr;
+    if (p->heat_bath && (c->n_elec > 32 || c->n_orb - c->n_elec / 2 > 32)) throw FriesError("heat-bath sampling supports at most 32 electrons / 32 virtual orbitals per spin");
     fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
     double v = 100; uint8_t one = 1; uint32_t n1 = 1;       // :239-243
     FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));

@@ -1,6 +1,6 @@
-// fciqmc_mol on the MI355X engine (FRIES_bin/fciqmc_mol.cpp, --distribution NU) over the C ABI.
+// fciqmc_mol on the MI355X engine (FRIES_bin/fciqmc_mol.cpp, --distribution NU or HB) over the C ABI.
 //
-//   fciqmc_mol_hip --fcidump_path F --point_group D2h --distribution NU --target W --max_dets N --epsilon E
+//   fciqmc_mol_hip --fcidump_path F --point_group D2h --distribution NU|HB --target W --max_dets N --epsilon E
 //                  [--initiator I] [--max_iter K] [--result_dir DIR/] [--seed S] [--device D]
 //
 // Output files as the reference's (fciqmc_mol.cpp:262-300, 415-445): projnum.txt, projden.txt, nini.txt every iteration; S.txt,
@@ -12,7 +12,7 @@ int main(int argc, char **argv) {
     try {
         kv = parse_kv(argc, argv);
         for (const char *k : {"fcidump_path", "max_dets", "epsilon"}) if (!kv.count(k)) throw std::runtime_error(std::string("missing required option --") + k);
-        if (kv.count("distribution") && kv["distribution"] != "NU") throw std::runtime_error("only the near-uniform generator (--distribution NU) is built");
+        if (!kv.count("distribution") || (kv["distribution"] != "NU" && kv["distribution"] != "HB")) throw std::runtime_error("\"dist_str\" argument must be either \"NU\" or \"HB\"");
     } catch (std::exception &ex) { std::cerr << "\nError parsing command line: " << ex.what() << "\n\n"; return 1; }
     try {
         const std::string pg = kv.count("point_group") ? kv["point_group"] : "C1";
@@ -24,7 +24,8 @@ int main(int argc, char **argv) {
         uint32_t seed = kv.count("seed") ? (uint32_t)std::stoul(kv["seed"]) : wall_clock_seed();
         std::cout << "seed on process 0 is " << seed << std::endl;
         fries_fciqmc_params p{std::stod(kv["epsilon"]), kv.count("target") ? (uint32_t)std::stoul(kv["target"]) : 0u,
-                              kv.count("initiator") ? (uint32_t)std::stoul(kv["initiator"]) : 0u, (uint32_t)std::stoul(kv["max_dets"]), seed};
+                              kv.count("initiator") ? (uint32_t)std::stoul(kv["initiator"]) : 0u, (uint32_t)std::stoul(kv["max_dets"]), seed,
+                              kv["distribution"] == "HB" ? 1 : 0, 0};
         ck(fries_fciqmc_setup(ctx, &p));
         const uint32_t max_iter = kv.count("max_iter") ? (uint32_t)std::stoul(kv["max_iter"]) : 1000000u;
         std::ofstream num_file(rd + "projnum.txt", std::ofstream::app), den_file(rd + "projden.txt", std::ofstream::app), shift_file(rd + "S.txt", std::ofstream::app),

@@ -41,7 +41,8 @@ class HHParams(C.Structure):
 
 class FciqmcParams(C.Structure):
     """struct fries_fciqmc_params"""
-    _fields_ = [("epsilon", C.c_double), ("target_walkers", C.c_uint32), ("initiator", C.c_uint32), ("max_dets", C.c_uint32), ("seed", C.c_uint32)]
+    _fields_ = [("epsilon", C.c_double), ("target_walkers", C.c_uint32), ("initiator", C.c_uint32), ("max_dets", C.c_uint32), ("seed", C.c_uint32),
+                ("heat_bath", C.c_int32), ("pad", C.c_int32)]
 
 
 FCIQMC_LOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("norm", "f8"), ("n_nonz", "i4"), ("n_ini", "u4"), ("curr_size", "u4"),
@@ -197,10 +198,12 @@ class FriEngine:
         self.max_dets = max_dets
 
     # ---- fciqmc_mol
-    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0):
+    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, distribution="NU"):
         """fciqmc_mol with the near-uniform excitation generator (FRIES_bin/fciqmc_mol.cpp, --distribution NU): HF trial vector,
         100 walkers on HF to start; uniforms from a counter-based stream (see csrc/fciqmc.hip)."""
-        p = FciqmcParams(epsilon, target_walkers, initiator, max_dets, seed)
+        if distribution not in ("NU", "HB"):
+            raise RuntimeError('"dist_str" argument must be either "NU" or "HB"')
+        p = FciqmcParams(epsilon, target_walkers, initiator, max_dets, seed, 1 if distribution == "HB" else 0, 0)
         self._ck(self.lib.fries_fciqmc_setup(self.h, C.byref(p)))
         self.max_dets = max_dets
 

@@ -127,7 +127,7 @@ typedef struct {
 int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
 int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
 
-/* ---- fciqmc_mol: FCIQMC with the near-uniform excitation generator (FRIES_bin/fciqmc_mol.cpp, --distribution NU), HF trial
+/* ---- fciqmc_mol: FCIQMC with the near-uniform or the heat-bath excitation generator (FRIES_bin/fciqmc_mol.cpp), HF trial
  * vector, start from 100 walkers on HF, one rank.  The reference's sequential mt19937 stream cannot be replayed in parallel;
  * the engine draws from a counter-based stream keyed by (seed, iteration, determinant, attempt, purpose) -- the same uniforms
  * in distribution -- which the CPU oracle shares, and the oracle's functions and loop are pinned against the reference on the
@@ -135,6 +135,8 @@ int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
 typedef struct {
     double epsilon;
     uint32_t target_walkers, initiator, max_dets, seed;
+    int32_t heat_bath;          /* 0: --distribution NU (near_uniform.cpp), 1: --distribution HB (hb_doub_multi, heat_bathPP.cpp:601-683) */
+    int32_t pad;
 } fries_fciqmc_params;
 typedef struct {
     double numer, denom;        /* projnum.txt / projden.txt */

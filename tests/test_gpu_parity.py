@@ -356,16 +356,17 @@ def test_cli_driver_reproduces_reference_outputs(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,eps,target,ini,seed,n_it", [("Ne", 0.004, 20000, 3, 5, 300), ("N2", 0.006, 50000, 2, 9, 350), ("H2O", 0.004, 30000, 0, 11, 250)])
-def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, ini, seed, n_it):
-    """fciqmc_mol (near-uniform generator) on the device against the CPU oracle, both on the counter-based uniform stream: walker
+@pytest.mark.parametrize("shape,eps,target,ini,seed,n_it,dist", [("Ne", 0.004, 20000, 3, 5, 300, "NU"), ("N2", 0.006, 50000, 2, 9, 350, "NU"), ("H2O", 0.004, 30000, 0, 11, 250, "NU"),
+                                                                 ("N2", 0.006, 50000, 2, 9, 300, "HB"), ("H2O", 0.004, 30000, 0, 11, 250, "HB")])
+def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, ini, seed, n_it, dist):
+    """fciqmc_mol (near-uniform and heat-bath generators) on the device against the CPU oracle, both on the counter-based uniform stream: walker
     numbers, positions, spawn counts and shifts identical at every iteration.  (The oracle on the reference's own mt19937 stream
     is pinned against the reference loop in the CPU suite.)"""
     from fries_amd.engine import FriEngine
     mol = mols(shape)
-    orc = oracle.OracleFciqmc(mol, epsilon=eps, target_walkers=target, max_dets=200000, initiator=ini, seed=seed, counter_rng=True)
+    orc = oracle.OracleFciqmc(mol, epsilon=eps, target_walkers=target, max_dets=200000, initiator=ini, seed=seed, counter_rng=True, distribution=dist)
     eng = FriEngine(mol)
-    eng.setup_fciqmc(epsilon=eps, target_walkers=target, max_dets=200000, initiator=ini, seed=seed)
+    eng.setup_fciqmc(epsilon=eps, target_walkers=target, max_dets=200000, initiator=ini, seed=seed, distribution=dist)
     assert eng.p_doub == orc.p_doub
     lo = orc.iterate(n_it)
     lg = eng.iterate_fciqmc(n_it)
