@@ -59,6 +59,9 @@ struct CompWork {
     uint32_t *keep;               // bit s = sub-element s preserved exactly
     double *S;                    // inclusive lbound after each element
     uint32_t *kin, *cnt;
+    uint32_t *kend;               // tooth index after each element (propagation repair, see k_sys_prop)
+    uint32_t *act[2], *act_n;     // active lists of the propagation repair, and their lengths [2]
+    uint32_t prop;                // 1: repair by parallel propagation (many repairs expected), 0: short sequential fix-up
     uint32_t *e_wi, *e_sub;       // emissions: source element, sub index
     double *e_val;
     double *psum[2];              // per-block partial sums (FR_MAX_PART each)
@@ -282,9 +285,11 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
         uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x[it], e, Se, &k, unit, p_doub, 0);
         W.S[e] = Se; W.kin[e] = kin; W.cnt[e] = c;
         cnt_t += c;
-        if (k != fr_teeth_below(th, Se)) {      // tooth backlog: repaired by k_sys_fixup
+        if (W.prop) W.kend[e] = k;
+        if (k != fr_teeth_below(th, Se)) {      // the comb is not where the next lane assumes: repaired by k_sys_fixup / k_sys_prop
             uint32_t slot = atomicAdd(&fin->n_fix, 1u);
-            if (slot < FR_MAX_PART) W.fix_list[slot] = (uint32_t)e;
+            if (W.prop) { if (e + 1 < n_in) W.act[0][atomicAdd(&W.act_n[0], 1u)] = (uint32_t)(e + 1); }
+            else if (slot < FR_MAX_PART) W.fix_list[slot] = (uint32_t)e;
         }
         Sprev = Se;
     }
@@ -322,6 +327,39 @@ __global__ void k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, d
             W.pcnt[1][e2 / FR_TILE] += c - old;
             done_upto = e2 + 1;
             if (k == fr_teeth_below(th, W.S[e2])) break;
+        }
+    }
+}
+
+// Parallel form of the repair, for inputs that need thousands of them (frisys_hh: its stage-1 rows {t, g} do not sum to one, so an
+// element that was never examined keeps wt_remain = value while its sub-weights span 1.7 x value, and the row walk may take a tooth
+// that lies beyond the element's own range, compress_utils.cpp:766-790).  Every lane of k_sys_count assumed the comb pointer
+// T(lbound of its predecessor); an element whose predecessor left the comb elsewhere is re-evaluated from the pointer the
+// predecessor really left, and if its own exit pointer changes its successor is re-evaluated in the next round.  The dependency
+// only runs forward, so the rounds end with every element started from its predecessor's exit pointer: the sequential result.
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_sys_prop(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, int in) {
+    __shared__ HbTables T;
+    __shared__ Teeth Tsh;
+    if (STAGE != 1) fr_stage_tables(&T, Tg);
+    fr_stage_teeth(&Tsh, W.teeth);
+    CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
+    const unsigned n_in = fin->n_in;
+    const uint32_t n_act = W.act_n[in];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) {
+        const uint32_t e = W.act[in][i];
+        const uint32_t kin_new = W.kend[e - 1];
+        if (kin_new == W.kin[e]) continue;
+        ElemIn x1[1];
+        fr_load_elems<STAGE, 1>(W, V, cur, e, n_in, x1);
+        uint32_t k = kin_new;
+        const uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, &Tsh, x1[0], e, W.S[e], &k, fin->unit, p_doub, 0);
+        const uint32_t old = W.cnt[e];
+        W.kin[e] = kin_new; W.cnt[e] = c;
+        if (c != old) atomicAdd(&W.pcnt[1][e / FR_TILE], c - old);
+        if (k != W.kend[e]) {
+            W.kend[e] = k;
+            if (e + 1 < n_in) W.act[in ^ 1][atomicAdd(&W.act_n[in ^ 1], 1u)] = e + 1;
         }
     }
 }

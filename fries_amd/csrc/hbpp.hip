@@ -271,6 +271,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     }
     W.wt_remain = fr_alloc<double>(cap); W.keep = fr_alloc<uint32_t>(cap); W.S = fr_alloc<double>(cap);
     W.kin = fr_alloc<uint32_t>(cap); W.cnt = fr_alloc<uint32_t>(cap);
+    W.kend = nullptr; W.act[0] = W.act[1] = nullptr; W.act_n = nullptr; W.prop = 0;
     W.e_wi = fr_alloc<uint32_t>(cap); W.e_sub = fr_alloc<uint32_t>(cap); W.e_val = fr_alloc<double>(cap);
     W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
     W.teeth = fr_alloc<Teeth>(1);
@@ -429,11 +430,36 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc);
         FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), Q2, acc, from);
     }
+    if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
-    FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
+    if (W.prop) {
+        // rounds of parallel propagation until no element's entry pointer changes (a host round trip per round: this is the
+        // frisys_hh path, where one stage needs ~1e4 repairs; the molecular path keeps the short sequential fix-up below)
+        int in = 0;
+        for (int round = 0; ; round++) {
+            uint32_t na = 0;
+            FR_HIP(hipMemcpyAsync(&na, &W.act_n[in], 4, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+            if (na == 0) break;
+            if (na > W.cap) throw FriesError("comb repair list overflow");
+            if (round > 100000) throw FriesError("comb repair did not settle");
+            FR_HIP(hipMemsetAsync(&W.act_n[in ^ 1], 0, 4, st));
+            unsigned gp = fr_blocks(na, FR_BLOCK);
+            if (gp > 1024) gp = 1024;
+            FR_LAUNCH(c, "k_sys_prop", (k_sys_prop<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in);
+            in ^= 1;
+        }
+    }
+    else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     if (n_out_host) {
         FR_HIP(hipMemcpyAsync(n_out_host, &W.state[FR_MAX_ROUNDS + 1].n_out, 4, hipMemcpyDeviceToHost, st));
+    }
+    if (c->dbg == 5) {
+        CompState fs; FksScal hs;
+        FR_HIP(hipMemcpy(&fs, &W.state[FR_MAX_ROUNDS + 1], sizeof(fs), hipMemcpyDeviceToHost));
+        FR_HIP(hipMemcpy(&hs, F.scal, sizeof(hs), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[stage %d] n_in %u n_rem %u unit %.6g loc_norm %.6g G %.6g n_fix %u n_out %u n_pass %d replays %d\n", STAGE, fs.n_in, fs.n_rem, fs.unit, fs.loc_norm, fs.G, fs.n_fix, fs.n_out, hs.n_pass, it);
     }
 }
 

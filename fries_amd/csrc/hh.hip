@@ -197,6 +197,8 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     fr_vec_alloc(c, &c->vec, p->max_dets);
     c->vec.hh_sites = L; c->vec.hh_nelec = p->n_elec; c->vec.hh_buckets = p->max_dets; c->vec.hh_scr = c->d_vec_scr;
     fr_hbpp_alloc(c, wcap);
+    // un-normalised stage-1 rows make comb repairs the rule rather than the exception (comp_kernels.hpp: k_sys_prop)
+    c->W.prop = 1; c->W.kend = fr_alloc<uint32_t>(wcap); c->W.act[0] = fr_alloc<uint32_t>(wcap + 1); c->W.act[1] = fr_alloc<uint32_t>(wcap + 1); c->W.act_n = fr_alloc<uint32_t>(2);
     fr_spawn_alloc(c, p->vec_nonz + 4096);
     fr_xch_alloc(c, p->vec_nonz + 4096);
     fr_vcomp_alloc(c, p->max_dets);
