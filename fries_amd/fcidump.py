@@ -31,6 +31,10 @@ _SHAPES = {
     "N2": (10, "D2h", [0, 5, 0, 6, 7, 2, 3, 5, 0, 6, 7, 0, 2, 3, 5, 5, 0, 1, 6, 7, 4, 5, 0, 2, 3, 5]),
     "H2O": (10, "C2v", [0, 0, 3, 0, 2, 0, 3, 3, 0, 0, 2, 3, 1, 0, 2, 3, 0, 3, 0, 2, 1, 0, 0, 3]),
     "Ne": (8, "D2h", [0, 5, 6, 7, 0, 5, 6, 7, 0, 0, 1, 2, 3, 5, 6, 7, 0, 0, 0, 1, 2, 3]),
+    # edge cases for the tests (not reference systems): the largest index one 64-bit word holds (32 spatial orbitals, every bit
+    # of the determinant used), in two irreps; and the smallest closed shell with a choice to make (2 electrons in 4 orbitals)
+    "MAX32": (6, "Cs", [0, 1] * 16),
+    "MIN4": (2, "C1", [0, 0, 0, 0]),
 }
 
 

@@ -22,6 +22,10 @@ RUNS = {
     "n2_m10000_unnorm_ini0": ("N2", 40, 7, 0.01, 10000, 10000, 80000, 0.0, 5000.0, "HB_unnorm", 0),
     "h2o_m5000_hb": ("H2O", 60, 99, 0.005, 5000, 8000, 80000, 3.0, 2000.0, "HB", 0),
     "n2_m30000_unnorm": ("N2", 30, 31, 0.01, 30000, 30000, 200000, 0.5, 10000.0, "HB_unnorm", 0),
+    # edge shapes: 32 spatial orbitals (the whole 64-bit index), 2 electrons in 4 orbitals
+    "max32_m3000_unnorm": ("MAX32", 25, 3, 0.01, 3000, 3000, 60000, 1.0, 1500.0, "HB_unnorm", 0),
+    "max32_m3000_hb": ("MAX32", 25, 3, 0.01, 3000, 3000, 60000, 1.0, 1500.0, "HB", 0),
+    "min4_m50_unnorm": ("MIN4", 25, 3, 0.01, 50, 50, 1000, 1.0, 25.0, "HB_unnorm", 0),
 }
 
 # multi-rank runs under mpiexec -n P: name -> (n_ranks, same tuple as RUNS without the snapshot field)
@@ -56,7 +60,7 @@ def main():
     subprocess.run([HARNESS, "unit"], check=True)
     subprocess.run([HARNESS, "hbpp_all", os.path.join(GOLD, "hbpp_all.txt")], check=True)
     with tempfile.TemporaryDirectory() as tmp:
-        for shape in ("Ne", "N2", "H2O"):
+        for shape in ("Ne", "N2", "H2O", "MAX32", "MIN4"):
             mol = fcidump.synthetic(shape)
             path = os.path.join(tmp, shape + ".FCIDUMP")
             fcidump.write_fcidump(path, mol)

@@ -140,6 +140,11 @@ RUNS = [
     ("H2O", dict(epsilon=0.005, vec_nonz=5000, mat_nonz=8000, max_dets=80000, target_norm=2000.0, initiator=3.0, seed=99, distribution="HB"), 50),
     ("N2", dict(epsilon=0.01, vec_nonz=100000, mat_nonz=100000, max_dets=600000, target_norm=30000.0, initiator=0.0, seed=5, distribution="HB_unnorm"), 25),
     ("N2", dict(epsilon=0.01, vec_nonz=50000, mat_nonz=120000, max_dets=600000, target_norm=30000.0, initiator=0.5, seed=6, distribution="HB"), 25),
+    # edge cases: 32 spatial orbitals (every bit of the 64-bit index in use), and 2 electrons in 4 orbitals (one electron per spin)
+    ("MAX32", dict(epsilon=0.01, vec_nonz=3000, mat_nonz=3000, max_dets=60000, target_norm=1500.0, initiator=1.0, seed=3, distribution="HB_unnorm"), 20),
+    ("MAX32", dict(epsilon=0.01, vec_nonz=3000, mat_nonz=3000, max_dets=60000, target_norm=1500.0, initiator=1.0, seed=3, distribution="HB"), 20),
+    ("MIN4", dict(epsilon=0.01, vec_nonz=50, mat_nonz=50, max_dets=1000, target_norm=25.0, initiator=1.0, seed=3, distribution="HB_unnorm"), 20),
+    ("MIN4", dict(epsilon=0.01, vec_nonz=50, mat_nonz=50, max_dets=1000, target_norm=25.0, initiator=1.0, seed=3, distribution="HB"), 20),
 ]
 
 
