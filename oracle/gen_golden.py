@@ -28,6 +28,9 @@ RUNS = {
     "min4_m50_unnorm": ("MIN4", 25, 3, 0.01, 50, 50, 1000, 1.0, 25.0, "HB_unnorm", 0),
 }
 
+# binary checkpoints written by the reference itself (DistVec::save): run name -> after how many iterations
+CHECKPOINTS = {"ne_m2000_unnorm": 40}
+
 # multi-rank runs under mpiexec -n P: name -> (n_ranks, same tuple as RUNS without the snapshot field)
 MPI_RUNS = {
     "n2_m10000_unnorm_p2": (2, ("N2", 40, 7, 0.01, 10000, 10000, 80000, 0.0, 5000.0, "HB_unnorm")),
@@ -74,7 +77,17 @@ def main():
             cmd = [HARNESS, "frisys", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist, out]
             if snap:
                 cmd.append(str(snap))
-            subprocess.run(cmd, check=True)
+            env = dict(os.environ)
+            if name in CHECKPOINTS:     # DistVec::save of the reference after that many iterations
+                ckdir = os.path.join(tmp, name + "_ck") + "/"
+                os.makedirs(ckdir)
+                env.update(FRIES_SAVE_DIR=ckdir, FRIES_SAVE_AT=str(CHECKPOINTS[name]))
+            subprocess.run(cmd, check=True, env=env)
+            if name in CHECKPOINTS:
+                manifest.setdefault("checkpoints", {})[name] = dict(
+                    after_iterations=CHECKPOINTS[name], dense_txt=open(ckdir + "dense.txt").read(),
+                    **{fn.replace(".", "_") + "_sha256": hashlib.sha256(open(ckdir + fn, "rb").read()).hexdigest() for fn in ("dets0.dat", "vals0.dat")},
+                    **{fn.replace(".", "_") + "_bytes": os.path.getsize(ckdir + fn) for fn in ("dets0.dat", "vals0.dat")})
             manifest["runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd,
                                           initiator=ini, target_norm=tgt, distribution=dist)
         manifest["mpi_runs"] = {}

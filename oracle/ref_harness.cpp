@@ -441,6 +441,8 @@ static int run_frisys(int argc, char **argv, bool time_only) {
         }
         CHECK(bad == 0, "it %u vector mismatch in %zu slots", it, bad);
         fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success, hsh);
+        if (getenv("FRIES_SAVE_DIR") && getenv("FRIES_SAVE_AT") && it + 1 == (unsigned)atoi(getenv("FRIES_SAVE_AT")))
+            rr.sol->save(std::string(getenv("FRIES_SAVE_DIR")));       // the reference's own checkpoint writer (vec_utils.hpp:713-746)
         if (snap_every && ((it + 1) % snap_every == 0 || it + 1 == n_iter)) {
             fprintf(f, "SNAP %u %zu\n", it, (size_t)rr.sol->curr_size());
             for (size_t i = 0; i < rr.sol->curr_size(); i++) {

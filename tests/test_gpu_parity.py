@@ -346,6 +346,15 @@ def test_cli_driver_reproduces_reference_outputs(tmp_path):
         dets |= raw.reshape(n_saved, nb)[:, b].astype(np.uint64) << np.uint64(8 * b)
     assert golden_io.vec_hash(dets, vals[:n_saved]) == g["rows"][n_it - 1]["hash"]
     assert np.fromfile(out1 + "hash.dat", dtype=np.uint32).size == 2 * mol.n_orb
+    # the same files as the reference's own DistVec::save wrote after the same 40 iterations, byte for byte
+    import hashlib
+    ck = golden_io.manifest()["checkpoints"][name]
+    assert ck["after_iterations"] == n_it
+    for fn in ("dets0.dat", "vals0.dat"):
+        blob = open(out1 + fn, "rb").read()
+        assert len(blob) == ck[fn.replace(".", "_") + "_bytes"], fn
+        assert hashlib.sha256(blob).hexdigest() == ck[fn.replace(".", "_") + "_sha256"], fn
+    assert open(out1 + "dense.txt").read() == ck["dense_txt"]
     # --load_dir: the stored non-zeros come back in file order (DistVec::load) and the run continues
     out2 = str(tmp_path / "run2") + "/"
     os.makedirs(out2)
