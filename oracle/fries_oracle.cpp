@@ -666,6 +666,169 @@ void sys_comp(double *vals, size_t len, double *loc_norms, unsigned n_samp, std:
     for (int p = 0; p < cm.size; p++) loc_norms[p] = all[p];
 }
 
+// ---------------------------------------------------------------- pivotal compression
+// compress_utils.cpp:389-518.  The vector is cut into consecutive sampling units of weight seg_norm / n_samp; from the
+// elements wholly inside a unit (plus the residual piece handed over by the previous unit) one candidate H is drawn, then
+// either H or the element straddling the unit's upper border is sampled and the other is handed to the next unit.
+void piv_samp_serial(double *vals, size_t len, double seg_norm, uint32_t n_samp, std::vector<uint8_t> &flag, std::mt19937 &mt) {
+    if (n_samp == 0) {                                   // :391-403
+        for (size_t i = 0; i < len; i++) {
+            if (flag[i]) flag[i] = 0;
+            else vals[i] = 0;
+            if (vals[i] == 0) flag[i] = 1;
+        }
+        return;
+    }
+    const double unit = seg_norm / n_samp;
+    std::vector<double> wt(16);          // wt[0]: residual piece; wt[1..]: the unit's unpreserved elements in order
+    wt[0] = 0;
+    size_t pos = 0, resid = 0;
+    uint32_t n_done = 0;
+    auto sgn_unit = [unit](double v) { return unit * ((v > 0) - (v < 0)); };
+    while (pos < len && n_done < n_samp) {
+        size_t n_wt = 1, used = 0;
+        double cum = wt[0];
+        for (; cum < unit && pos + used < len; used++) {               // :414-424
+            if (!flag[pos + used]) {
+                if (n_wt == wt.size()) wt.resize(2 * wt.size());
+                wt[n_wt] = fabs(vals[pos + used]);
+                cum += wt[n_wt];
+                n_wt++;
+            }
+        }
+        const bool at_end = pos + used == len;
+        size_t n_inner = used > 0 ? used - 1 : 0;        // elements before the border element (:425-428)
+        if (at_end) n_inner++;
+        const double over = cum - unit;                   // b_n: the part of the border element beyond this unit
+        if (!at_end) { n_wt--; cum -= wt[n_wt]; }        // :430-433
+        const double under = unit - cum;                  // a_n: the part of the border element inside this unit
+        double r = mt() / (1. + UINT32_MAX) * cum;      // :437-446
+        double run = 0;
+        size_t H = 0;
+        while (run < r && H < n_wt) { run += wt[H]; H++; }
+        if (r > 0) H--;
+        if (H != 0 && pos != 0) { vals[resid] = 0; flag[resid] = 1; }       // the residual piece can no longer be drawn (:447-450)
+        double p_pass = under / (unit - over);           // :453-456
+        if (at_end) p_pass = 0;
+        r = mt() / (1. + UINT32_MAX);
+        if (r < p_pass) {                                 // border element sampled, H handed on (:458-476)
+            size_t k = 1;
+            for (size_t o = 0; o < n_inner; o++) {
+                if (!flag[pos + o]) {
+                    if (k == H) resid = pos + o;
+                    else { vals[pos + o] = 0; flag[pos + o] = 1; }
+                    k++;
+                }
+                else flag[pos + o] = 0;
+            }
+            vals[pos + n_inner] = sgn_unit(vals[pos + n_inner]);
+        }
+        else {                                            // H sampled, border element handed on (:477-501)
+            if (H == 0) vals[resid] = sgn_unit(vals[resid]);
+            size_t k = 1;
+            for (size_t o = 0; o < n_inner; o++) {
+                if (!flag[pos + o]) {
+                    if (k != H) { vals[pos + o] = 0; flag[pos + o] = 1; }
+                    else vals[pos + o] = sgn_unit(vals[pos + o]);
+                    k++;
+                }
+                else flag[pos + o] = 0;
+            }
+            resid = pos + n_inner;
+        }
+        pos += n_inner + 1;
+        wt[0] = over;
+        n_done++;
+    }
+    for (; pos < len; pos++) {                            // :506-513
+        if (!flag[pos]) { vals[pos] = 0; flag[pos] = 1; }
+        else flag[pos] = 0;
+    }
+    if (resid < len) { vals[resid] = 0; flag[resid] = 1; }     // :515-518
+}
+
+// compress_utils.cpp:552-604
+uint32_t piv_budget(const double *loc_norms, uint32_t n_samp, std::mt19937 &mt, const Comm &cm) {
+    std::vector<uint32_t> budgets(cm.size, 0);
+    if (cm.rank == 0) {
+        double glob = 0;
+        for (int p = 0; p < cm.size; p++) glob += loc_norms[p];
+        uint32_t tot = 0, n_frac = 0;
+        std::vector<double> frac(cm.size);
+        for (int p = 0; p < cm.size; p++) {
+            budgets[p] = loc_norms[p] / glob * n_samp;
+            tot += budgets[p];
+            frac[p] = loc_norms[p] - budgets[p] * glob / n_samp;
+            if (frac[p] < 1e-12) frac[p] = 0;
+            if (frac[p] > 0) n_frac++;
+        }
+        if (n_frac == n_samp - tot) {
+            for (int p = 0; p < cm.size; p++) if (frac[p] > 0) budgets[p]++;
+            tot = n_samp;
+        }
+        if (tot < n_samp) {
+            std::vector<uint8_t> none(cm.size, 0);
+            piv_samp_serial(frac.data(), cm.size, glob * (n_samp - tot) / n_samp, n_samp - tot, none, mt);
+            for (int p = 0; p < cm.size; p++) if (frac[p] > 0) budgets[p]++;
+        }
+    }
+    std::vector<uint32_t> all((size_t)cm.size * cm.size);      // MPI_Scatter from rank 0
+    cm.allgather(budgets.data(), all.data(), sizeof(uint32_t) * cm.size);
+    return all[cm.rank];
+}
+
+// compress_utils.cpp:606-681
+double adjust_probs(double *vals, size_t len, uint32_t *n_samp_loc, double exp_nsamp_loc, uint32_t n_samp_tot, double tot_norm, std::vector<uint8_t> &flag) {
+    const double top = ceill(exp_nsamp_loc);
+    const double resid = exp_nsamp_loc - (unsigned int)exp_nsamp_loc;
+    const double unit = tot_norm / n_samp_tot;
+    const double loc_norm = exp_nsamp_loc * unit;
+    bool too_big = false;
+    for (size_t i = 0; i < len && !too_big; i++) if (!flag[i] && fabs(vals[i]) >= loc_norm / top) too_big = true;
+    if (!too_big) return loc_norm;
+    double counter = exp_nsamp_loc;
+    if (*n_samp_loc > exp_nsamp_loc) {                   // the budget was rounded up: inflate small elements, pin large ones
+        for (size_t i = 0; i < len; i++) {
+            if (flag[i]) continue;
+            int8_t sg = 2 * (vals[i] > 0) - 1;
+            double pi = fabs(vals[i]) / unit;
+            if (pi < resid) { counter += pi / resid - pi; vals[i] /= resid; }
+            else { counter -= pi; vals[i] = sg * unit; flag[i] = 1; (*n_samp_loc)--; }
+            if (counter >= *n_samp_loc) { vals[i] += sg * unit * (*n_samp_loc - counter); break; }
+        }
+    }
+    else {                                                // rounded down: shrink
+        for (size_t i = 0; i < len; i++) {
+            if (flag[i]) continue;
+            int8_t sg = 2 * (vals[i] > 0) - 1;
+            double pi = fabs(vals[i]) / unit;
+            if (pi > resid) { double q = (pi - resid) / (1 - resid); counter += q - pi; vals[i] = sg * q * unit; }
+            else { counter -= pi; vals[i] = 0; }
+            if (counter <= *n_samp_loc) { vals[i] += sg * unit * (*n_samp_loc - counter); break; }
+        }
+    }
+    return *n_samp_loc * loc_norm / exp_nsamp_loc;
+}
+
+// compress_utils.cpp:354-386
+void piv_comp_parallel(double *vals, size_t len, uint32_t compress_size, std::vector<size_t> &srt, std::vector<uint8_t> &flag, std::mt19937 &mt, const Comm &cm) {
+    std::vector<double> norms(cm.size);
+    unsigned n_samp = compress_size;
+    double glob;
+    double mine = find_preserve(vals, srt, flag, len, &n_samp, &glob, cm);
+    cm.allgather(&mine, norms.data(), sizeof(double));
+    glob = 0;
+    for (int p = 0; p < cm.size; p++) glob += norms[p];
+    uint32_t loc_samp = 0;
+    double new_norm = 0;
+    if (n_samp != 0) {
+        loc_samp = piv_budget(norms.data(), n_samp, mt, cm);
+        cm.sum((int)loc_samp);                            // the reference's consistency check (a collective)
+        new_norm = adjust_probs(vals, len, &loc_samp, n_samp * norms[cm.rank] / glob, n_samp, glob, flag);
+    }
+    piv_samp_serial(vals, len, new_norm, loc_samp, flag, mt);
+}
+
 double find_keep_sub(const double *values, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
                      size_t count, unsigned *n_samp, double *wt_remain, const Comm &cm) {
     double loc = 0, glob = 0;

@@ -154,6 +154,16 @@ size_t sys_sub(const double *values, const uint32_t *n_div, SubWts &sw, const ui
 // FRIES/compress_utils.cpp:797-820
 size_t comp_sub(const double *values, size_t count, const uint32_t *n_div, SubWts &sw, const uint16_t *sub_sizes,
                 unsigned n_samp, double *wt_remain, double rn, double *new_vals, size_t (*new_idx)[2], const Comm &cm = Comm::self());
+// ---- pivotal compression (FRIES/compress_utils.cpp:354-681)
+// :389-518.  flag[] in: elements preserved exactly; out: elements that ended up zero (to be deleted).
+void piv_samp_serial(double *vals, size_t len, double seg_norm, uint32_t n_samp, std::vector<uint8_t> &flag, std::mt19937 &mt);
+// :552-604.  Rank 0 apportions the samples among the ranks (it alone draws from its generator).
+uint32_t piv_budget(const double *loc_norms, uint32_t n_samp, std::mt19937 &mt, const Comm &cm = Comm::self());
+// :606-681
+double adjust_probs(double *vals, size_t len, uint32_t *n_samp_loc, double exp_nsamp_loc, uint32_t n_samp_tot, double tot_norm, std::vector<uint8_t> &flag);
+// :354-386
+void piv_comp_parallel(double *vals, size_t len, uint32_t compress_size, std::vector<size_t> &srt, std::vector<uint8_t> &flag, std::mt19937 &mt,
+                       const Comm &cm = Comm::self());
 // FRIES/compress_utils.cpp:684-693
 void adjust_shift(double *shift, double one_norm, double *last_norm, double target_norm, double damp);
 

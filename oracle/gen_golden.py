@@ -62,6 +62,7 @@ def main():
     manifest = {"runs": {}, "ints": {}}
     subprocess.run([HARNESS, "unit"], check=True)
     subprocess.run([HARNESS, "hbpp_all", os.path.join(GOLD, "hbpp_all.txt")], check=True)
+    subprocess.run([HARNESS, "piv", os.path.join(GOLD, "piv_comp.txt")], check=True)
     with tempfile.TemporaryDirectory() as tmp:
         for shape in ("Ne", "N2", "H2O", "MAX32", "MIN4"):
             mol = fcidump.synthetic(shape)

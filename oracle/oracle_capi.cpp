@@ -129,6 +129,24 @@ void fo_compress_vec(void *h, uint32_t n_samp, double rn, uint32_t *n_kept, doub
     if (n_kept) *n_kept = n_samp - ns;
     if (glob_norm) *glob_norm = gn;
 }
+// compress_vecs with one vector (vec_utils.cpp:9-32): piv_comp_parallel on column 0 with the handle's generator, then the deletes
+void fo_compress_vec_piv(void *h, uint32_t n_samp) {
+    Frisys *f = (Frisys *)h;
+    Vec &v = f->sol;
+    if (f->srt.size() < v.max_size) { f->srt.resize(v.max_size); f->keep.resize(v.max_size, 0); }
+    piv_comp_parallel(v.vals[0].data(), v.curr_size, n_samp, f->srt, f->keep, f->mt);
+    for (size_t i = 0; i < v.curr_size; i++) if (f->keep[i]) { v.del_at_pos(i); f->keep[i] = 0; }
+}
+uint32_t fo_next_draw(void *h) { return (uint32_t)((Frisys *)h)->mt(); }
+// piv_comp_parallel on a bare array with a generator seeded here; flags_out: elements to delete; returns the generator's next draw
+uint32_t fo_piv_comp(double *vals, size_t len, uint32_t compress_size, uint32_t seed, uint8_t *flags_out) {
+    std::mt19937 g(seed);
+    std::vector<size_t> srt(len);
+    std::vector<uint8_t> flag(len, 0);
+    piv_comp_parallel(vals, len, compress_size, srt, flag, g);
+    memcpy(flags_out, flag.data(), len);
+    return (uint32_t)g();
+}
 // DistVec::add x n + perform_add(0) on the handle's stored vector (column 0)
 void fo_vec_add(void *h, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n) {
     Frisys *f = (Frisys *)h;

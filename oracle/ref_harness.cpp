@@ -236,6 +236,99 @@ static int run_unit() {
     return n_fail != 0;
 }
 
+// ------------------------------------------------------------------ pivotal compression (compress_utils.cpp:354-681)
+static void piv_random_vec(std::mt19937 &mt, std::vector<double> &v, int style) {
+    for (auto &x : v) {
+        double u = mt() / (1. + UINT32_MAX);
+        double a = style == 0 ? exp(6 * u) : (style == 1 ? u : exp(14 * u));
+        x = (mt() & 1 ? 1 : -1) * a * ((mt() % 7) ? 1 : 0);
+    }
+}
+static int run_piv(const char *out) {
+    std::mt19937 mt(4321);
+    // piv_comp_parallel on random vectors, the two generators starting from the same state
+    for (int trial = 0; trial < 400; trial++) {
+        size_t n = 30 + mt() % 4000;
+        std::vector<double> v(n), v2;
+        piv_random_vec(mt, v, trial % 3);
+        v2 = v;
+        uint32_t cs = 1 + mt() % (trial % 5 == 0 ? 2 * n : n);
+        uint32_t seed = mt();
+        std::mt19937 g_r(seed), g_o(seed);
+        std::vector<size_t> srt_r(n), srt_o(n);
+        std::vector<bool> k_r(n, false); std::vector<uint8_t> k_o(n, 0);
+        piv_comp_parallel(v.data(), n, cs, srt_r, k_r, g_r);
+        fo::piv_comp_parallel(v2.data(), n, cs, srt_o, k_o, g_o);
+        size_t bad = 0, nz = 0;
+        for (size_t i = 0; i < n; i++) { if (!same_bits(v[i], v2[i]) || (bool)k_r[i] != (bool)k_o[i]) bad++; if (v[i] != 0) nz++; }
+        CHECK(bad == 0, "piv_comp_parallel trial %d: %zu mismatches", trial, bad);
+        CHECK(nz <= cs, "piv_comp_parallel trial %d: %zu non-zeros for a budget of %u", trial, nz, cs);
+        CHECK(g_r() == g_o(), "piv_comp_parallel generator state, trial %d", trial);
+    }
+    // piv_samp_serial alone: arbitrary preserved flags, budgets and segment norms (elements may exceed the sampling unit)
+    for (int trial = 0; trial < 400; trial++) {
+        size_t n = 10 + mt() % 3000;
+        std::vector<double> v(n), v2;
+        piv_random_vec(mt, v, trial % 3);
+        std::vector<bool> k_r(n); std::vector<uint8_t> k_o(n);
+        double norm = 0;
+        for (size_t i = 0; i < n; i++) { bool k = mt() % 5 == 0; k_r[i] = k; k_o[i] = k; if (!k) norm += fabs(v[i]); }
+        v2 = v;
+        uint32_t ns = trial % 11 == 0 ? 0 : 1 + mt() % (n / 2);
+        if (trial % 4 == 1) norm *= 0.5 + mt() / (1. + UINT32_MAX);
+        uint32_t seed = mt();
+        std::mt19937 g_r(seed), g_o(seed);
+        piv_samp_serial(v.data(), n, norm, ns, k_r, g_r);
+        fo::piv_samp_serial(v2.data(), n, norm, ns, k_o, g_o);
+        size_t bad = 0;
+        for (size_t i = 0; i < n; i++) if (!same_bits(v[i], v2[i]) || (bool)k_r[i] != (bool)k_o[i]) bad++;
+        CHECK(bad == 0, "piv_samp_serial trial %d: %zu mismatches", trial, bad);
+        CHECK(g_r() == g_o(), "piv_samp_serial generator state, trial %d", trial);
+    }
+    // adjust_probs with fractional local budgets, rounded up and down
+    for (int trial = 0; trial < 400; trial++) {
+        size_t n = 10 + mt() % 2000;
+        std::vector<double> v(n), v2;
+        piv_random_vec(mt, v, 1);
+        std::vector<bool> k_r(n); std::vector<uint8_t> k_o(n);
+        double norm = 0;
+        for (size_t i = 0; i < n; i++) { bool k = mt() % 9 == 0; k_r[i] = k; k_o[i] = k; if (!k) norm += fabs(v[i]); }
+        v2 = v;
+        uint32_t tot = 2 + mt() % n;
+        double share = 0.2 + 0.6 * (mt() / (1. + UINT32_MAX));
+        double tot_norm = norm / share;
+        double exp_loc = tot * norm / tot_norm;
+        uint32_t nl_r = (uint32_t)exp_loc + (mt() & 1), nl_o = nl_r;
+        double a = adjust_probs(v.data(), n, &nl_r, exp_loc, tot, tot_norm, k_r);
+        double b = fo::adjust_probs(v2.data(), n, &nl_o, exp_loc, tot, tot_norm, k_o);
+        size_t bad = 0;
+        for (size_t i = 0; i < n; i++) if (!same_bits(v[i], v2[i]) || (bool)k_r[i] != (bool)k_o[i]) bad++;
+        CHECK(bad == 0 && same_bits(a, b) && nl_r == nl_o, "adjust_probs trial %d: %zu mismatches, %a %a, %u %u", trial, bad, a, b, nl_r, nl_o);
+    }
+    // known answers for tests/golden
+    FILE *f = fopen(out, "w");
+    fprintf(f, "# piv_comp_parallel of the reference (compress_utils.cpp:354-386), one rank.  case <len> <compress_size> <mt19937 seed>, then per element:\n"
+               "# <input> <output> <flag after>, then the generator's next draw.  Doubles are C99 hex floats.\n");
+    const size_t lens[4] = {12, 300, 900, 1500};
+    const uint32_t css[4] = {5, 40, 700, 333};
+    for (int k = 0; k < 4; k++) {
+        size_t n = lens[k];
+        std::vector<double> v(n), in;
+        piv_random_vec(mt, v, k % 2);
+        in = v;
+        uint32_t seed = 100 + k;
+        std::mt19937 g(seed);
+        std::vector<size_t> srt(n); std::vector<bool> kp(n, false);
+        piv_comp_parallel(v.data(), n, css[k], srt, kp, g);
+        fprintf(f, "case %zu %u %u\n", n, css[k], seed);
+        for (size_t i = 0; i < n; i++) fprintf(f, "%a %a %d\n", in[i], v[i], (int)kp[i]);
+        fprintf(f, "next %u\n", (unsigned)g());
+    }
+    fclose(f);
+    printf("PIV checks=%d fails=%d\n", n_chk, n_fail);
+    return n_fail != 0;
+}
+
 // ------------------------------------------------------------------ reference frisys loop (1 rank)
 struct RefRun {
     fcidump_input *in;
@@ -1049,6 +1142,7 @@ int main(int argc, char **argv) {
     int rc = 2;
     if (argc >= 2 && !strcmp(argv[1], "unit")) rc = run_unit();
     else if (argc >= 3 && !strcmp(argv[1], "hbpp_all")) rc = run_hbpp_all(argv[2]);
+    else if (argc >= 3 && !strcmp(argv[1], "piv")) rc = run_piv(argv[2]);
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);

@@ -83,3 +83,22 @@ def read_hbpp_all():
 # [new_hb_all] configuration (tests/test_hamiltonian.cpp:454-487 of the reference): Ne-like, 22 orbitals, 8 unfrozen electrons
 HBPP_ALL_SYMM = [0, 5, 6, 7, 0, 5, 6, 7, 0, 0, 1, 2, 3, 5, 6, 7, 0, 0, 0, 1, 2, 3]
 TENSOR_ID = {"s_tens": 0, "d_same": 1, "d_diff": 2, "exch_sqrt": 3, "diag_sqrt": 4, "exch_norms": 5, "s_norm": 6}
+
+
+def read_piv_cases():
+    """tests/golden/piv_comp.txt: what the reference's piv_comp_parallel returned (one rank)."""
+    cases = []
+    with open(os.path.join(GOLD, "piv_comp.txt")) as f:
+        cur = None
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "case":
+                cur = dict(len=int(t[1]), compress_size=int(t[2]), seed=int(t[3]), inp=[], out=[], flag=[])
+                cases.append(cur)
+            elif t[0] == "next":
+                cur["next"] = int(t[1])
+            else:
+                cur["inp"].append(float.fromhex(t[0])); cur["out"].append(float.fromhex(t[1])); cur["flag"].append(int(t[2]))
+    return cases

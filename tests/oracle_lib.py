@@ -50,6 +50,11 @@ def load():
         lib.fo_set_p_doub.argtypes = [C.c_void_p, C.c_double]
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_next_draw.restype = C.c_uint32
+        lib.fo_next_draw.argtypes = [C.c_void_p]
+        lib.fo_piv_comp.restype = C.c_uint32
+        lib.fo_piv_comp.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.fo_vec_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
         lib.fo_frisys_restart.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_uint32]
         lib.fo_hash.restype = C.c_uint64
@@ -186,6 +191,12 @@ class OracleFrisys:
     def restart(self, seed, en_shift=0.0, last_one_norm=0.0, iterat=0):
         self.lib.fo_frisys_restart(self.h, seed, en_shift, last_one_norm, iterat)
 
+    def compress_vec_piv(self, n_samp):
+        self.lib.fo_compress_vec_piv(self.h, n_samp)
+
+    def next_draw(self):
+        return self.lib.fo_next_draw(self.h)
+
 
 class OracleRanks:
     """P in-process ranks of fo::Frisys sharing one communicator -- the reference under `mpiexec -n P`
@@ -320,3 +331,12 @@ class OracleFciqmc:
     @property
     def p_doub(self):
         return self.lib.fo_fciqmc_p_doub(self.h)
+
+
+def piv_comp(vals, compress_size, seed):
+    """fo::piv_comp_parallel (one rank) on a copy of vals: (new values, delete flags, the generator's next draw)."""
+    lib = load()
+    v = np.ascontiguousarray(vals, dtype=np.float64).copy()
+    fl = np.zeros(v.size, dtype=np.uint8)
+    nxt = lib.fo_piv_comp(v.ctypes.data, v.size, compress_size, seed, fl.ctypes.data)
+    return v, fl, nxt

@@ -213,6 +213,21 @@ def test_oracle_compression_is_identity_when_budget_exceeds_nnz(oracle, mols):
     assert np.array_equal(v2, vals) and np.isclose(gn, np.abs(vals).sum())
 
 
+def test_oracle_pivotal_compression_known_answers(oracle):
+    """fo::piv_comp_parallel against what the reference's own piv_comp_parallel produced (compress_utils.cpp:354-386):
+    values, delete flags and generator position, bit for bit; plus the budget invariants."""
+    import numpy as np
+    cases = golden_io.read_piv_cases()
+    assert len(cases) == 4
+    for cs in cases:
+        v, fl, nxt = oracle.piv_comp(np.array(cs["inp"]), cs["compress_size"], cs["seed"])
+        assert v.tobytes() == np.array(cs["out"]).tobytes()
+        assert fl.tolist() == cs["flag"]
+        assert nxt == cs["next"]
+        assert np.count_nonzero(v) <= cs["compress_size"]
+        assert np.all((v != 0) | (fl == 1) | (np.array(cs["inp"]) == 0))
+
+
 def test_library_exports_every_declared_symbol():
     """libfries_hip.so loads on a GPU-less host and exports exactly what include/fries_hip.h declares."""
     from fries_amd import engine
