@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfries_hip.so")
-SOURCES = ["hbpp.hip", "vec.hip", "compress.hip", "system.hip", "hh.hip", "fciqmc.hip", "driver.hip"]
+SOURCES = ["hbpp.hip", "vec.hip", "compress.hip", "pivotal.hip", "system.hip", "hh.hip", "fciqmc.hip", "driver.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 
 

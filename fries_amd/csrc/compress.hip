@@ -134,6 +134,12 @@ static void run_seq_from(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound, SeqS
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, from);
 }
 
+// exact in-order sum of the unpreserved |v| into vc.seq.total (what find_preserve returns, compress_utils.cpp:98-101)
+void fr_unkept_norm(FriesCtx *c, uint32_t bound) {
+    AccUnkept au{c->vec.v0, c->vc.keep, c->vec.st};
+    run_seq(c, c->vc.seq, au, bound);
+}
+
 static __global__ void k_put_double(const double *src, double *dst) { *dst = *src; }
 // sum_mpi of one double: 0 + x_0 + x_1 + ... in rank order (compress_utils.hpp:177-187)
 static __global__ void k_sum_ranks(const double *all, int n_ranks, double *out) {

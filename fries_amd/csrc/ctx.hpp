@@ -75,6 +75,22 @@ struct AccUnkept {          // compress_utils.cpp:98-101 and the lbound of sys_c
     __device__ double get(size_t i) const { return keep[i] ? 0.0 : fabs(v[i]); }
 };
 
+// pivotal compression scratch (pivotal.hip)
+struct PivUnit {
+    uint32_t H;             // 0: the residual piece was drawn; k >= 1: the k-th unpreserved element of the unit
+    uint32_t new_resid;     // the element this unit hands on (unless it hands on the one it received)
+    uint8_t pass;           // 1: border element sampled, the drawn candidate handed on
+    uint8_t pad[3];
+};
+struct PivScal { uint32_t n_units, end_pos, too_big, n_loc; double new_norm_unused; };
+
+struct PivBuf {
+    uint32_t cap = 0;
+    uint32_t *start = nullptr; double *carry = nullptr;      // per unit: first element, overshoot carried in
+    double *U = nullptr;                                     // two uniforms per unit
+    PivUnit *unit = nullptr;
+    PivScal *scal = nullptr;
+};
 // ranks (include/fries_hip.h: fries_comm).  size == 1: no callbacks, the "gathered" block is the send block.
 struct fries_comm_ops {
     void *user; int32_t rank, size;
@@ -136,6 +152,7 @@ struct FriesCtx {
     uint32_t *d_nsucc = nullptr;
     SpawnBuf sp{};
     VcompBuf vc{};
+    PivBuf piv{};
     uint32_t *d_err = nullptr;
     // trial vectors (replicated, small)
     uint32_t n_trial = 0, n_htrial = 0;
@@ -181,6 +198,10 @@ void fr_death_clone(FriesCtx *c, uint32_t vec_size_before);
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm);
 void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
+void fr_unkept_norm(FriesCtx *c, uint32_t bound);
+// pivotal.hip
+void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *glob_norm);
+void fr_test_piv_adjust(FriesCtx *c, uint32_t *n_loc_io, double exp_loc, uint32_t n_tot, double tot_norm, double *new_norm, uint8_t *flags_out);
 // fciqmc.hip
 void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p);
 void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg);

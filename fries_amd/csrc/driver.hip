@@ -78,6 +78,7 @@ static void check_dev_err(FriesCtx *c) {
     if (e & FR_ERR_HASH_FULL) m += " determinant hash table full;";
     if (e & FR_ERR_ROUNDS) m += " exact-preservation rounds did not converge;";
     if (e & FR_ERR_BACKLOG) m += " too many comb repairs;";
+    if (e & FR_ERR_PIV) m += " pivotal compression met an unpreserved element of two sampling units or more;";
     throw FriesError(m);
 }
 
@@ -253,6 +254,8 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     hipFree(b.keep); hipFree(b.del); hipFree(b.S);
     for (int k = 0; k < 2; k++) { hipFree(b.psum[k]); hipFree(b.pcnt[k]); }
     hipFree(b.state); hipFree(b.teeth); hipFree(b.dots); hipFree(b.fix_list);
+    PivBuf &pv = h->c.piv;
+    if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); }
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
     if (h->c.stream) hipStreamDestroy(h->c.stream);
@@ -533,6 +536,24 @@ extern "C" int fries_compress_vec(fries_ctx *h, uint32_t n_samp_in, double rn, u
     FR_API_END
 }
 
+extern "C" int fries_compress_vec_piv(fries_ctx *h, uint32_t n_samp_in, uint32_t *n_kept, double *glob_norm) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_piv_comp(c, n_samp_in, n_kept, glob_norm);
+    check_dev_err(c);
+    FR_API_END
+}
+extern "C" int fries_test_piv_adjust(fries_ctx *h, uint32_t *n_samp_loc, double exp_nsamp_loc, uint32_t n_samp_tot, double tot_norm, double *new_norm, uint8_t *flags_out) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_test_piv_adjust(c, n_samp_loc, exp_nsamp_loc, n_samp_tot, tot_norm, new_norm, flags_out);
+    check_dev_err(c);
+    FR_API_END
+}
+extern "C" uint32_t fries_next_draw(fries_ctx *h) { return (uint32_t)h->c.mt(); }
+
 __global__ void k_test_teeth(Teeth *t, double r0, double unit, uint32_t n, double *pos, const double *q, uint32_t nq, uint32_t *below) {
     if (blockIdx.x == 0 && threadIdx.x == 0) fr_build_teeth(t, r0, unit, n, 0.0);
 }
@@ -618,7 +639,10 @@ extern "C" int fries_prof_enable(fries_ctx *h, int on) {
     if (on) c->prof_agg.clear();
     FR_API_END
 }
-extern "C" int fries_prof_count(fries_ctx *h) { return (int)h->c.prof_agg.size(); }
+extern "C" int fries_prof_count(fries_ctx *h) {
+    try { hipSetDevice(h->c.device); prof_collect(&h->c); } catch (...) { return -1; }     // spans recorded by the single-operator entry points
+    return (int)h->c.prof_agg.size();
+}
 extern "C" int fries_prof_get(fries_ctx *h, int i, char *name, size_t name_cap, double *total_ms, uint64_t *calls) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;

@@ -69,7 +69,7 @@ struct VecDev {
 };
 #define FR_HH_PH_BITS 3
 
-enum { FR_ERR_CAP = 1, FR_ERR_SPAWN_CAP = 2, FR_ERR_NELEC = 4, FR_ERR_HASH_FULL = 8, FR_ERR_ROUNDS = 16, FR_ERR_BACKLOG = 32 };
+enum { FR_ERR_CAP = 1, FR_ERR_SPAWN_CAP = 2, FR_ERR_NELEC = 4, FR_ERR_HASH_FULL = 8, FR_ERR_ROUNDS = 16, FR_ERR_BACKLOG = 32, FR_ERR_PIV = 64 };
 
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ int fr_lane() { return threadIdx.x & 63; }

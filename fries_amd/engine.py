@@ -23,6 +23,7 @@ EXPORTS = [
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
+    "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust",
 ]
 
 
@@ -92,6 +93,10 @@ def load_library() -> C.CDLL:
     lib.fries_apply_hbpp_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_size_t), C.c_void_p]
     lib.fries_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.fries_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.fries_test_piv_adjust.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_double), C.c_void_p]
+    lib.fries_next_draw.restype = C.c_uint32
+    lib.fries_next_draw.argtypes = [C.c_void_p]
     lib.fries_test_teeth.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_test_seqsum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -286,6 +291,24 @@ class FriEngine:
         gn = C.c_double()
         self._ck(self.lib.fries_compress_vec(self.h, n_samp, rn, C.byref(nk), C.byref(gn)))
         return nk.value, gn.value
+
+    def compress_vec_piv(self, n_samp: int):
+        """compress_vecs with one vector (vec_utils.cpp:9-32): pivotal compression of column 0 to at most n_samp
+        non-zeros, drawing from the engine's mt19937; returns (elements preserved exactly, one-norm before)."""
+        nk = C.c_uint32()
+        gn = C.c_double()
+        self._ck(self.lib.fries_compress_vec_piv(self.h, n_samp, C.byref(nk), C.byref(gn)))
+        return nk.value, gn.value
+
+    def test_piv_adjust(self, n_loc: int, exp_loc: float, n_tot: int, tot_norm: float):
+        nl = C.c_uint32(n_loc)
+        nn = C.c_double()
+        fl = np.zeros(max(self.vec_info()[0], 1), dtype=np.uint8)
+        self._ck(self.lib.fries_test_piv_adjust(self.h, C.byref(nl), exp_loc, n_tot, tot_norm, C.byref(nn), _ptr(fl)))
+        return nl.value, nn.value, fl
+
+    def next_draw(self) -> int:
+        return int(self.lib.fries_next_draw(self.h))
 
     def test_teeth(self, r0: float, unit: float, n: int, queries):
         q = np.ascontiguousarray(queries, dtype=np.float64)

@@ -167,6 +167,14 @@ int fries_apply_hbpp_sys(fries_ctx *ctx, uint32_t n_samp, const double rn[5], in
  * of frisys_mol.cpp:534-539 */
 int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_kept, double *glob_norm);
 
+/* compress_vecs with one vector (FRIES/vec_utils.cpp:9-32): piv_comp_parallel on column 0 -- find_preserve,
+ * piv_budget, adjust_probs, piv_samp_serial (compress_utils.cpp:354-681) -- then the deletes.  The uniforms are the
+ * context's mt19937 stream (the generator the reference's caller passes in), two per sampling unit.  One rank. */
+int fries_compress_vec_piv(fries_ctx *ctx, uint32_t n_samp, uint32_t *n_kept, double *glob_norm);
+/* the next raw draw of the context's mt19937 (advances it): lets a caller interleave its own draws as the reference's
+ * drivers do, and tests check the generator's position */
+uint32_t fries_next_draw(fries_ctx *ctx);
+
 /* Restart: re-seed the driver RNG, restore the energy shift / last norm / iteration count -- the part of
  * --load_dir that is not the vector (frisys_mol.cpp:257-263, 284-286); pair with fries_vec_load. */
 int fries_frisys_restart(fries_ctx *ctx, uint32_t seed, double en_shift, double last_one_norm, uint32_t iterat);
@@ -179,6 +187,11 @@ int fries_counters(fries_ctx *ctx, uint64_t *iters, uint64_t *spawns, uint64_t *
 int fries_prof_enable(fries_ctx *ctx, int on);
 int fries_prof_count(fries_ctx *ctx);
 int fries_prof_get(fries_ctx *ctx, int i, char *name, size_t name_cap, double *total_ms, uint64_t *calls);
+
+/* test hook: adjust_probs (compress_utils.cpp:606-681) on column 0 with nothing preserved; flags_out[curr_size] = the
+ * elements it pinned to one sampling unit */
+int fries_test_piv_adjust(fries_ctx *ctx, uint32_t *n_samp_loc, double exp_nsamp_loc, uint32_t n_samp_tot, double tot_norm,
+                          double *new_norm, uint8_t *flags_out);
 
 /* test hook: positions of the first n comb teeth built from (r0, unit) -- see csrc/teeth.hpp */
 int fries_test_teeth(fries_ctx *ctx, double r0, double unit, uint32_t n, double *out_pos, const double *query, uint32_t nq, uint32_t *out_below);

@@ -147,6 +147,13 @@ uint32_t fo_piv_comp(double *vals, size_t len, uint32_t compress_size, uint32_t 
     memcpy(flags_out, flag.data(), len);
     return (uint32_t)g();
 }
+// adjust_probs on a bare array with nothing preserved; flags_out: the elements it pinned
+double fo_adjust_probs(double *vals, size_t len, uint32_t *n_samp_loc, double exp_nsamp_loc, uint32_t n_samp_tot, double tot_norm, uint8_t *flags_out) {
+    std::vector<uint8_t> flag(len, 0);
+    double r = adjust_probs(vals, len, n_samp_loc, exp_nsamp_loc, n_samp_tot, tot_norm, flag);
+    memcpy(flags_out, flag.data(), len);
+    return r;
+}
 // DistVec::add x n + perform_add(0) on the handle's stored vector (column 0)
 void fo_vec_add(void *h, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n) {
     Frisys *f = (Frisys *)h;

@@ -51,6 +51,8 @@ def load():
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_adjust_probs.restype = C.c_double
+        lib.fo_adjust_probs.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_double, C.c_uint32, C.c_double, C.c_void_p]
         lib.fo_next_draw.restype = C.c_uint32
         lib.fo_next_draw.argtypes = [C.c_void_p]
         lib.fo_piv_comp.restype = C.c_uint32
@@ -340,3 +342,13 @@ def piv_comp(vals, compress_size, seed):
     fl = np.zeros(v.size, dtype=np.uint8)
     nxt = lib.fo_piv_comp(v.ctypes.data, v.size, compress_size, seed, fl.ctypes.data)
     return v, fl, nxt
+
+
+def adjust_probs(vals, n_loc, exp_loc, n_tot, tot_norm):
+    """fo::adjust_probs on a copy of vals with nothing preserved: (new values, n_loc, new norm, pinned flags)."""
+    lib = load()
+    v = np.ascontiguousarray(vals, dtype=np.float64).copy()
+    fl = np.zeros(v.size, dtype=np.uint8)
+    nl = C.c_uint32(n_loc)
+    nn = lib.fo_adjust_probs(v.ctypes.data, v.size, C.byref(nl), exp_loc, n_tot, tot_norm, fl.ctypes.data)
+    return v, nl.value, nn, fl

@@ -230,6 +230,81 @@ def test_compression_is_identity_when_budget_exceeds_nnz(Engine, mols):
     eng.close()
 
 
+def _distinct_dets(n):
+    """n distinct determinant labels for vector-level operator tests (no Hamiltonian involved)."""
+    return (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(2654435761)) | np.uint64(1 << 40)
+
+
+def test_pivotal_compression_known_answers(Engine, mols):
+    """fries_compress_vec_piv against what the reference's piv_comp_parallel returned (tests/golden/piv_comp.txt):
+    values, deleted positions and the generator's position, bit for bit."""
+    mol = mols("N2")
+    for cs in golden_io.read_piv_cases():
+        eng = Engine(mol)
+        eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=4000, seed=3)
+        inp = np.array(cs["inp"])
+        eng.vec_load(_distinct_dets(inp.size), inp)
+        eng.restart(cs["seed"])
+        eng.compress_vec_piv(cs["compress_size"])
+        _, v = eng.vector()
+        assert v.tobytes() == np.array(cs["out"]).tobytes(), cs["len"]
+        assert eng.vec_info()[1] == inp.size - int(np.sum(cs["flag"]))
+        assert eng.next_draw() == cs["next"]
+        eng.close()
+
+
+@pytest.mark.parametrize("n,budget,style,seed", [(5000, 1200, 0, 1), (200000, 50000, 1, 2), (200000, 150000, 0, 3), (1000000, 400000, 2, 4),
+                                                 (1000000, 3000, 0, 5), (300000, 400000, 1, 6), (64, 10, 0, 7), (65, 64, 1, 8)])
+def test_pivotal_compression_matches_oracle(Engine, oracle, mols, n, budget, style, seed):
+    """the device operator against the CPU restatement (pinned to the reference) at sizes up to 1e6 elements; also the
+    operator's invariants: at most `budget` non-zeros, sampled magnitudes all equal, preserved elements untouched."""
+    mol = mols("N2")
+    rng = np.random.RandomState(seed)
+    u = rng.random_sample(n)
+    mag = np.exp(6 * u) if style == 0 else (u if style == 1 else np.exp(14 * u))
+    vals = np.where(rng.random_sample(n) < 0.85, mag * np.where(rng.random_sample(n) < 0.5, 1.0, -1.0), 0.0)
+    eng = Engine(mol)
+    eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=n + 1000, seed=3)
+    eng.vec_load(_distinct_dets(n), vals)
+    eng.restart(1000 + seed)
+    nk, gn = eng.compress_vec_piv(budget)
+    _, v = eng.vector()
+    ov, ofl, onext = oracle.piv_comp(vals, budget, 1000 + seed)
+    assert np.array_equal(v, ov), int(np.sum(v != ov))
+    assert eng.next_draw() == onext
+    assert eng.vec_info()[1] == n - int(ofl.sum())
+    nz = v != 0
+    assert int(nz.sum()) <= budget
+    changed = nz & (v != vals)
+    if changed.any():
+        assert np.unique(np.abs(v[changed])).size == 1
+    eng.close()
+
+
+@pytest.mark.parametrize("n,seed,up", [(3000, 2, 0), (3000, 2, 1), (3000, 18, 1), (100000, 5, 0), (100000, 5, 1), (100000, 23, 1), (70, 5, 1)])
+def test_pivotal_adjust_probs_matches_oracle(Engine, oracle, mols, n, seed, up):
+    """adjust_probs (the re-weighting a rank applies when its integer sample budget was rounded up or down from its
+    expected share) on the device against the restatement: values, pinned elements, budget and returned norm."""
+    mol = mols("N2")
+    rng = np.random.RandomState(seed)
+    vals = rng.random_sample(n) * np.where(rng.random_sample(n) < 0.5, 1.0, -1.0) * (rng.random_sample(n) < 0.9)
+    norm = float(np.abs(vals).sum())
+    share = 0.2 + 0.6 * rng.random_sample()
+    n_tot = int(rng.randint(n, 2 * n))
+    tot_norm = norm / share
+    exp_loc = n_tot * norm / tot_norm
+    n_loc = int(exp_loc) + up
+    eng = Engine(mol)
+    eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=n + 1000, seed=3)
+    eng.vec_load(_distinct_dets(n), vals)
+    nl, nn, fl = eng.test_piv_adjust(n_loc, exp_loc, n_tot, tot_norm)
+    _, v = eng.vector()
+    ov, onl, onn, ofl = oracle.adjust_probs(vals, n_loc, exp_loc, n_tot, tot_norm)
+    assert not np.array_equal(ov, vals)            # the case does exercise the re-weighting
+    assert np.array_equal(v, ov) and nl == onl and nn == onn and np.array_equal(fl[:n], ofl)
+    eng.close()
+
+
 def test_full_size_invariants_m1e6(Engine, mols):
     """BASELINE.json's full size (m = 1e6) through size-independent properties: the compression conserves the
     one-norm, keeps at most vec_nonz elements, every stored determinant has n_elec electrons and is unique, and a
