@@ -22,7 +22,8 @@ void fr_vcomp_alloc(FriesCtx *c, uint32_t cap) {
 
 // v0 <- v0 * (1 - eps (H_ii - S)) for the elements that existed before the spawns were merged,
 // then v0 += v1, v1 <- 0; publishes per-block sums of |v0| (round 0 of find_preserve).
-__global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, SysDev S, uint32_t vec_size_before, double eps, double shift, uint32_t n_samp) {
+// add_col1 == 0: column 1 is left alone and only the block sums of |v0| are published (frifull_mol keeps the previous vector there)
+__global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, SysDev S, uint32_t vec_size_before, double eps, double shift, uint32_t n_samp, int add_col1) {
     __shared__ double shd[12];
     const uint32_t n = V.st->curr_size;
     const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
@@ -43,8 +44,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
             if (d != d) { d = fr_diag_matrel(V.dets[i], S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[i] = d; }
             v *= 1 - eps * (d - shift);
         }
-        v += V.v1[i] * 1.0;
-        V.v0[i] = v; V.v1[i] = 0;
+        if (add_col1) { v += V.v1[i] * 1.0; V.v0[i] = v; V.v1[i] = 0; }
         sum += fabs(v);
     }
     double bs;
@@ -55,7 +55,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
 void fr_death_clone(FriesCtx *c, uint32_t vec_size_before) {
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     uint32_t bound = c->h_vst.curr_size;
-    FR_LAUNCH(c, "k_death_clone", k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), c->vec, c->vc, S, vec_size_before, c->eps, c->en_shift, c->vec_nonz);
+    FR_LAUNCH(c, "k_death_clone", k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), c->vec, c->vc, S, vec_size_before, c->eps, c->en_shift, c->vec_nonz, 1);
+}
+// round 0 of find_preserve on column 0 as it stands
+void fr_abs_sums(FriesCtx *c) {
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    uint32_t bound = c->h_vst.curr_size;
+    FR_LAUNCH(c, "k_abs_sums", k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), c->vec, c->vc, S, 0u, c->eps, c->en_shift, c->vec_nonz, 0);
 }
 
 // One round of the exact-preservation fixed point: keep every element with

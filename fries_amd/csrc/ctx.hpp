@@ -153,6 +153,9 @@ struct FriesCtx {
     SpawnBuf sp{};
     VcompBuf vc{};
     PivBuf piv{};
+    // frifull_mol: per-determinant excitation counts / offsets of the deterministic H application (system.hip)
+    bool full_mode = false;
+    uint32_t full_cap = 0, *full_cnt = nullptr, *full_nz = nullptr, *full_off = nullptr;
     uint32_t *d_err = nullptr;
     // trial vectors (replicated, small)
     uint32_t n_trial = 0, n_htrial = 0;
@@ -195,6 +198,7 @@ void fr_spawn_from_comp(FriesCtx *c);
 // compress.hip
 void fr_vcomp_alloc(FriesCtx *c, uint32_t cap);
 void fr_death_clone(FriesCtx *c, uint32_t vec_size_before);
+void fr_abs_sums(FriesCtx *c);
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm);
 void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
@@ -214,3 +218,5 @@ int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 // system.hip
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);
+void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac);
+uint64_t fr_h_offdiag_vec(FriesCtx *c, double h_fac);

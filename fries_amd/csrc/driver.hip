@@ -204,7 +204,110 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     }
 }
 
+// ------------------------------------------------------------------ frifull_mol (FRIES_bin/frifull_mol.cpp)
+static void frifull_setup(FriesCtx *c, const fries_frifull_params *p) {
+    if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
+    if (c->n_ranks > 1) throw FriesError("frifull_mol runs on one rank in this version");
+    if (p->max_dets == 0 || p->vec_nonz == 0) throw FriesError("max_dets and vec_nonz must be positive");
+    c->eps = p->epsilon; c->target_norm = p->target_norm; c->init_thresh = 0;
+    c->vec_nonz = p->vec_nonz; c->mat_nonz = 0; c->full_mode = true;
+    c->en_shift = 0; c->last_one_norm = 0; c->iterat = 0;
+    c->mt.seed(p->seed);
+    c->proc_scr.resize(2 * c->n_orb); c->vec_scr.resize(2 * c->n_orb);
+    for (auto &x : c->proc_scr) x = c->mt();        // frifull_mol.cpp:96-98
+    for (auto &x : c->vec_scr) x = c->mt();         // :104-107
+    if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
+    uint32_t scap = p->spawn_cap ? p->spawn_cap : 8000000u;
+    if (scap > 8000000u) scap = 8000000u;           // one merge handles FR_MAX_PART tiles of spawns
+    fr_vec_alloc(c, &c->vec, p->max_dets);
+    fr_spawn_alloc(c, scap);
+    fr_vcomp_alloc(c, p->max_dets);
+    c->W.kin = fr_alloc<uint32_t>(p->max_dets);     // sys_comp's tooth-index scratch (the HB-PP arrays are not allocated here)
+    // trial vector = HF (:121-147); there is no H * trial in this driver
+    c->n_trial = 1; c->n_htrial = 0;
+    c->tr_det = fr_alloc<det_t>(1); c->tr_val = fr_alloc<double>(1);
+    c->htr_det = fr_alloc<det_t>(1); c->htr_val = fr_alloc<double>(1);
+    double one = 1.0;
+    FR_HIP(hipMemcpyAsync(c->tr_det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemcpyAsync(c->tr_val, &one, 8, hipMemcpyHostToDevice, c->stream));
+    {   // start from 100 * |HF> (:186-190)
+        double v = 100; uint8_t ini = 1; uint32_t n1 = 1;
+        FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.ini, &ini, 1, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
+        fr_vec_merge(c, &c->vec, 1, true);
+    }
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    check_dev_err(c);
+}
+
+// one iteration of frifull_mol.cpp:258-304.  The reference alternates between its two value columns; here the current
+// vector is always "column 0" and the two device arrays trade places at the end of the iteration.
+static void frifull_iterate(FriesCtx *c, fries_iter_log *lg) {
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_vec_maybe_rebuild(c, &c->vec);
+    double unused = 0, denom = 0, numer = 0;
+    fr_dots(c, &unused, &denom);                      // :259-260
+    fr_abs_sums(c);
+    uint32_t n_samp = c->vec_nonz;
+    double glob_norm = 0;
+    fr_find_preserve(c, &n_samp, &glob_norm);         // :263-264
+    c->glob_norm = glob_norm;
+    c->nkept = c->vec_nonz - n_samp;
+    const unsigned shift_interval = 10;
+    const double shift_damping = 0.05;
+    if ((c->iterat + 1) % shift_interval == 0) {     // :272-278
+        double damp = shift_damping / shift_interval / c->eps;
+        if (c->last_one_norm) { c->en_shift -= damp * log(glob_norm / c->last_one_norm); c->last_one_norm = glob_norm; }
+        if (c->last_one_norm == 0 && glob_norm > c->target_norm) c->last_one_norm = glob_norm;
+    }
+    double rn_sys = uni(c->mt);
+    fr_sys_comp(c, n_samp, rn_sys);                   // :283-289 (an element leaves the table only when it is zero in both columns)
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_h_diag_vec(c, 1 + c->eps * c->en_shift, -c->eps);            // :291
+    uint64_t n_add = fr_h_offdiag_vec(c, -c->eps);                  // :293
+    std::swap(c->vec.v0, c->vec.v1);                                // :294
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (c->h_vst.err) check_dev_err(c);
+    fr_dots(c, &unused, &numer);
+    numer = ((1 + c->eps * c->en_shift) * denom - numer) / c->eps;  // :296-298
+    c->numer = numer; c->denom = denom;
+    c->num_success = (uint32_t)(n_add > 0xffffffffull ? 0xffffffffull : n_add);
+    c->iterat++; c->tot_iters++; c->tot_spawns += n_add;
+    if (c->prof_on) prof_collect(c);
+    if (lg) {
+        lg->numer = c->numer; lg->denom = c->denom; lg->shift = c->en_shift; lg->norm = c->glob_norm;
+        lg->nkept = c->nkept; lg->n_nonz = c->h_vst.n_nonz; lg->curr_size = c->h_vst.curr_size;
+        lg->num_success = c->num_success;
+        for (int k = 0; k < 5; k++) lg->comp_len[k] = 0;
+        uint32_t e = 0;
+        FR_HIP(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+        lg->err = e | c->h_vst.err;
+    }
+}
+
 // ------------------------------------------------------------------ C ABI
+extern "C" int fries_frifull_setup(fries_ctx *h, const fries_frifull_params *p) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (c->vec.dets) throw FriesError("this context already holds a driver; create a new one");
+    frifull_setup(c, p);
+    FR_API_END
+}
+extern "C" int fries_frifull_iterate(fries_ctx *h, uint32_t n_iter, fries_iter_log *logs) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->full_mode) throw FriesError("fries_frifull_setup must be called first");
+    for (uint32_t k = 0; k < n_iter; k++) {
+        frifull_iterate(c, logs ? &logs[k] : nullptr);
+        check_dev_err(c);
+    }
+    FR_API_END
+}
+
 extern "C" int fries_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -257,6 +360,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     PivBuf &pv = h->c.piv;
     if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); }
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
+    if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); }
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
     if (h->c.stream) hipStreamDestroy(h->c.stream);
     delete h;

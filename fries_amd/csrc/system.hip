@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_enum(const det_t *src, const doubl
         uint32_t incl = fr_block_scan_u32(f, shu, &tot);
         if (pass && f) {
             uint32_t o = obase + n_written + incl - 1;
-            out.det[o] = nd; out.val[o] = m; out.orbs[o] = fr_code(o1, o2, u1, u2);
+            out.det[o] = nd; out.val[o] = m; if (out.orbs) out.orbs[o] = fr_code(o1, o2, u1, u2);
         }
         n_allowed += tot_ok; n_written += tot;
     }
@@ -263,4 +263,73 @@ void fr_h_trial_setup(FriesCtx *c) {
     FR_HIP(hipMemcpy(c->tr_val, &one, 8, hipMemcpyHostToDevice));
     FR_HIP(hipMemcpy(c->htr_det, od.data(), 8 * od.size(), hipMemcpyHostToDevice));
     FR_HIP(hipMemcpy(c->htr_val, ov.data(), 8 * ov.size(), hipMemcpyHostToDevice));
+}
+
+// ------------------------------------------------------------------ deterministic H on the stored vector (frifull_mol)
+// h_op_diag (molecule.cpp:205-219): column 1 <- column 0 * (id_fac + h_fac * H_ii), zero where column 0 is zero
+__global__ void __launch_bounds__(FR_BLOCK) k_hop_diag(VecDev V, SysDev S, double id_fac, double h_fac) {
+    const uint32_t n = V.st->curr_size;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = V.v0[i], o = 0;
+    if (v != 0) {
+        double d = V.diag[i];
+        if (d != d) { d = fr_diag_matrel(V.dets[i], S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[i] = d; }
+        o = v * (id_fac + h_fac * d);
+    }
+    V.v1[i] = o;
+}
+void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac) {
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
+    FR_LAUNCH(c, "k_hop_diag", k_hop_diag, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, S, id_fac, h_fac);
+}
+
+// h_op_offdiag (molecule.cpp:448-665, spin_parity 0) from column 0 into column 1: every symmetry-allowed single excitation of
+// every stored determinant in storage order, then every double, each worth value * h_fac * <j|H|i>; the annihilating
+// merge takes them in that order.  The spawn buffer holds sp.cap entries, so the list is produced and merged in chunks of
+// whole determinants (the reference's Adder does the same every 1e6 adds).  Returns the number of non-zero adds.
+uint64_t fr_h_offdiag_vec(FriesCtx *c, double h_fac) {
+    hipStream_t st = c->stream;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    const uint32_t ns = c->h_vst.curr_size;
+    if (ns == 0) return 0;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    if (c->full_cap < ns) {
+        if (c->full_cnt) { FR_HIP(hipFree(c->full_cnt)); FR_HIP(hipFree(c->full_nz)); FR_HIP(hipFree(c->full_off)); }
+        c->full_cap = c->vec.cap;
+        c->full_cnt = fr_alloc<uint32_t>(2 * (size_t)c->full_cap); c->full_nz = fr_alloc<uint32_t>(2 * (size_t)c->full_cap); c->full_off = fr_alloc<uint32_t>(2 * (size_t)c->full_cap);
+    }
+    // the source column must not move while its excitations are merged into the other one: both live in the same arrays
+    EnumOut eo{nullptr, nullptr, nullptr};
+    for (int mode = 0; mode < 2; mode++)
+        FR_LAUNCH(c, "k_enum", k_enum, dim3(ns), dim3(FR_BLOCK), c->vec.dets, c->vec.v0, ns, S, mode, 0, c->full_cnt, c->full_nz, c->full_off, eo, h_fac);
+    std::vector<uint32_t> nz(2 * (size_t)ns), off(2 * (size_t)ns);
+    FR_HIP(hipMemcpyAsync(nz.data(), c->full_nz, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    FR_HIP(hipMemsetAsync(c->sp.ini, 1, c->sp.cap, st));
+    eo.det = c->sp.det; eo.val = c->sp.val;
+    uint64_t n_add = 0;
+    for (int mode = 0; mode < 2; mode++) {
+        uint32_t d0 = 0;
+        while (d0 < ns) {
+            uint32_t d1 = d0, tot = 0;
+            while (d1 < ns && (uint64_t)tot + nz[2 * (size_t)d1 + mode] <= c->sp.cap) { off[2 * (size_t)d1 + mode] = tot; tot += nz[2 * (size_t)d1 + mode]; d1++; }
+            if (d1 == d0) throw FriesError("spawn buffer smaller than one determinant's excitation list");
+            if (tot) {
+                FR_HIP(hipMemcpyAsync(c->full_off + 2 * (size_t)d0, off.data() + 2 * (size_t)d0, 8 * (size_t)(d1 - d0), hipMemcpyHostToDevice, st));
+                FR_LAUNCH(c, "k_enum", k_enum, dim3(d1 - d0), dim3(FR_BLOCK), c->vec.dets + d0, c->vec.v0 + d0, d1 - d0, S, mode, 1, c->full_cnt + 2 * (size_t)d0,
+                          c->full_nz + 2 * (size_t)d0, c->full_off + 2 * (size_t)d0, eo, h_fac);
+                FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &tot, 4, hipMemcpyHostToDevice, st));
+                FR_HIP(hipStreamSynchronize(st));       // tot and off are host temporaries
+                fr_vec_merge(c, &c->vec, tot, false);
+                fr_vec_sync_state(c, &c->vec, &c->h_vst);
+                if (c->h_vst.err) return n_add;
+                fr_vec_maybe_rebuild(c, &c->vec);
+                n_add += tot;
+            }
+            d0 = d1;
+        }
+    }
+    return n_add;
 }

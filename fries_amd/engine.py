@@ -23,7 +23,7 @@ EXPORTS = [
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
-    "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust",
+    "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
 ]
 
 
@@ -31,6 +31,11 @@ class FrisysParams(C.Structure):
     _fields_ = [("epsilon", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double),
                 ("vec_nonz", C.c_uint32), ("mat_nonz", C.c_uint32), ("max_dets", C.c_uint32),
                 ("seed", C.c_uint32), ("hb_unnorm", C.c_int32)]
+
+
+class FrifullParams(C.Structure):
+    _fields_ = [("epsilon", C.c_double), ("target_norm", C.c_double), ("vec_nonz", C.c_uint32), ("max_dets", C.c_uint32),
+                ("seed", C.c_uint32), ("spawn_cap", C.c_uint32)]
 
 
 class HHParams(C.Structure):
@@ -108,6 +113,8 @@ def load_library() -> C.CDLL:
     lib.fries_get_scramblers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.fries_fciqmc_setup.argtypes = [C.c_void_p, C.POINTER(FciqmcParams)]
     lib.fries_fciqmc_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.fries_frifull_setup.argtypes = [C.c_void_p, C.POINTER(FrifullParams)]
+    lib.fries_frifull_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_hh_setup.argtypes = [C.c_void_p, C.POINTER(HHParams)]
     lib.fries_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]
@@ -215,6 +222,18 @@ class FriEngine:
     def iterate_fciqmc(self, n_iter: int):
         logs = np.zeros(n_iter, dtype=FCIQMC_LOG_DTYPE)
         self._ck(self.lib.fries_fciqmc_iterate(self.h, n_iter, _ptr(logs)))
+        return logs
+
+    # ---- frifull_mol
+    def setup_full(self, *, epsilon, vec_nonz, max_dets, target_norm=0.0, seed=0, spawn_cap=0):
+        """frifull_mol (FRIES_bin/frifull_mol.cpp): vector compression + the Hamiltonian applied in full, start from 100 x HF."""
+        p = FrifullParams(epsilon, target_norm, vec_nonz, max_dets, seed, spawn_cap)
+        self._ck(self.lib.fries_frifull_setup(self.h, C.byref(p)))
+        self.max_dets = max_dets
+
+    def iterate_full(self, n_iter: int, want_logs: bool = True):
+        logs = np.zeros(n_iter, dtype=ITERLOG_DTYPE) if want_logs else None
+        self._ck(self.lib.fries_frifull_iterate(self.h, n_iter, _ptr(logs) if want_logs else None))
         return logs
 
     # ---- frisys_hh

@@ -112,6 +112,20 @@ double fries_p_doub(fries_ctx *ctx);
 int fries_get_scramblers(fries_ctx *ctx, uint32_t *proc_scrambler, uint32_t *vec_scrambler, size_t n);
 uint64_t fries_kernel_launches(fries_ctx *ctx);
 
+/* ---- frifull_mol: FRI with the Hamiltonian applied in full (FRIES_bin/frifull_mol.cpp:258-304): systematic compression of
+ * the vector to vec_nonz non-zeros, then every symmetry-allowed single and double excitation of every remaining determinant
+ * (h_op_diag / h_op_offdiag, FRIES/Hamiltonians/molecule.cpp:205-219, 448-665) merged into the other value column.  HF trial
+ * vector, start from 100 x HF, one rank.  Logs: numer / denom as written to projnum.txt / projden.txt (:296-300), norm = the
+ * one-norm before compression, num_success = non-zero excitations added; n_nonz / curr_size count stored determinants (an entry
+ * is released only when it is zero in both value columns, vec_utils.hpp:458-476, so the table keeps growing as in the
+ * reference).  spawn_cap: excitations merged per batch (0 = 8e6). */
+typedef struct {
+    double epsilon, target_norm;
+    uint32_t vec_nonz, max_dets, seed, spawn_cap;
+} fries_frifull_params;
+int fries_frifull_setup(fries_ctx *ctx, const fries_frifull_params *p);
+int fries_frifull_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
+
 /* ---- frisys_hh: FRI with systematic matrix compression for the 1-D Hubbard-Holstein model (FRIES_bin/frisys_hh.cpp),
  * open boundaries, hopping t = 1, 3 bits per phonon (:96).  Parameters are those of the reference's params file
  * (parse_hh_input, FRIES/io_utils.cpp:320-405: n_elec, lat_len, eps, U, omega, g, gs_energy) and command line (:15-23),

@@ -1149,6 +1149,113 @@ double Vec::dot(const std::vector<det_t> &d2, const std::vector<double> &v2) con
     return numer;
 }
 
+// ------------------------------------------------------------------ deterministic H application, frifull_mol
+size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, double h_fac) {
+    const unsigned n_elec = sys.n_elec, n_orb = sys.n_orb;
+    const unsigned origin = v.cur;
+    std::vector<uint8_t> ex;
+    size_t n_calls = 0;
+    for (int kind = 0; kind < 2; kind++) {            // all singles (:562-608), then all doubles (:610-664)
+        int keep_going = 1;
+        size_t ex_idx = 0, n_ex = 0, det_idx = 0;
+        double cur_el = 0;
+        det_t cur_det = 0;
+        const uint8_t *occ = nullptr;
+        while (keep_going) {
+            keep_going = 0;
+            const double *before = v.vals[origin].data();
+            v.cur = dest;
+            while (true) {
+                if (ex_idx >= n_ex) {
+                    if (det_idx >= vec_size) break;
+                    cur_el = before[det_idx];
+                    if (cur_el == 0) { det_idx++; continue; }
+                    cur_det = v.dets[det_idx];
+                    occ = v.orbs_at(det_idx);
+                    n_ex = kind == 0 ? sing_ex_symm(cur_det, occ, n_elec, n_orb, ex, sys.symm.irrep.data())
+                                     : doub_ex_symm(cur_det, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
+                    if (n_ex == 0) { det_idx++; continue; }     // (the reference has this guard for singles only; a molecule always has doubles)
+                    ex_idx = 0;
+                    det_idx++;
+                }
+                det_t nd = cur_det;
+                double m;
+                if (kind == 0) { m = sing_matrel_nosgn(&ex[2 * ex_idx], occ, sys.ints, n_elec); m *= sing_det_parity(&nd, &ex[2 * ex_idx]); }
+                else { m = doub_matrel_nosgn(&ex[4 * ex_idx], sys.ints); m *= doub_det_parity(&nd, &ex[4 * ex_idx]); }
+                ex_idx++;
+                keep_going = 1;
+                m *= cur_el * h_fac;
+                n_calls++;
+                if (!v.add(nd, m, 1)) break;
+            }
+            keep_going = v.cm.sum(keep_going);
+            v.perform_add(0);
+        }
+    }
+    return n_calls;
+}
+
+void h_op_diag(Vec &v, unsigned dest, double id_fac, double h_fac, const MolSys &sys) {
+    const std::vector<double> &src = v.vals[v.cur];
+    for (size_t i = 0; i < v.curr_size; i++) {
+        double cv = src[i];
+        if (cv != 0) {
+            if (v.diag[i] != v.diag[i]) v.diag[i] = diag_matrel(v.orbs_at(i), sys.ints, sys.n_elec) - sys.hf_en;      // matr_el_at_pos, vec_utils.hpp:548-556
+            v.vals[dest][i] = cv * (id_fac + h_fac * v.diag[i]);
+        }
+        else v.vals[dest][i] = 0;
+    }
+    v.cur = dest;
+}
+
+void Frifull::setup() {
+    const unsigned n_orb = sys.n_orb, n_elec = sys.n_elec;
+    uint8_t tmp[64];
+    hf_det = gen_hf_det(n_orb, n_elec);
+    occ_list(hf_det, tmp);
+    sys.hf_en = diag_matrel(tmp, sys.ints, n_elec);
+    mt.seed(par.seed);
+    proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
+    for (auto &x : proc_scr) x = mt();     // frifull_mol.cpp:96-98
+    for (auto &x : vec_scr) x = mt();      // :104-107
+    sol.init(par.max_dets, 1000000, n_elec, 2, Comm::self(), proc_scr.data());     // the Adder's size only sets how often perform_add runs
+    trial_det = {hf_det}; trial_val = {1.0};
+    sol.add(hf_det, 100, 1);               // :186-190
+    sol.perform_add(0);
+    srt.resize(sol.max_size); keep.assign(sol.max_size, 0);
+    en_shift = 0; last_one_norm = 0; iterat = 0; vec_idx = 0;
+}
+
+void Frifull::iterate(unsigned n) {
+    const double eps = par.eps;
+    const double shift_damping = 0.05;
+    const unsigned shift_interval = 10;
+    for (unsigned k = 0; k < n; k++, iterat++) {
+        IterLog lg{};
+        sol.cur = vec_idx;
+        double denom = sol.dot(trial_det, trial_val);           // :259-260
+        if (srt.size() < sol.max_size) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
+        unsigned n_samp = par.vec_nonz;
+        double glob_norm;
+        double mine = find_preserve(sol.vals[vec_idx].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm);
+        lg.nkept = par.vec_nonz - n_samp;
+        if ((iterat + 1) % shift_interval == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, par.target_norm, shift_damping / shift_interval / eps);
+        double rn_sys = mt() / (1. + UINT32_MAX);
+        sys_comp(sol.vals[vec_idx].data(), sol.curr_size, &mine, n_samp, keep, rn_sys);
+        for (size_t i = 0; i < sol.curr_size; i++) if (keep[i]) { sol.del_at_pos(i); keep[i] = 0; }
+        h_op_diag(sol, !vec_idx, 1 + eps * en_shift, -eps, sys);      // :288
+        sol.cur = vec_idx;
+        lg.num_success = h_op_offdiag(sol, sol.curr_size, sys, !vec_idx, -eps);
+        vec_idx = !vec_idx;
+        sol.cur = vec_idx;
+        double numer = sol.dot(trial_det, trial_val);
+        numer = ((1 + eps * en_shift) * denom - numer) / eps;       // :295
+        lg.numer = numer; lg.denom = denom; lg.shift = en_shift; lg.norm = glob_norm;
+        lg.n_nonz = sol.n_nonz; lg.curr_size = sol.curr_size;
+        log.push_back(lg);
+    }
+}
+
 // ------------------------------------------------------------------ apply_HBPP_sys
 void HBScratch::init(size_t length, size_t n_subwt) {
     len = length; vec_len = 0;

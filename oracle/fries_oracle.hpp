@@ -275,6 +275,32 @@ struct Frisys {
     void setup();
     void iterate(unsigned n);
 };
+// ---------------------------------------------------------------- deterministic H application + frifull_mol
+// FRIES/Hamiltonians/molecule.cpp:448-665 without time-reversal symmetry (spin_parity 0): every symmetry-allowed single
+// excitation of every stored determinant, then every double, each added to column dest as value * h_fac * <j|H|i>.
+// Returns the number of add() calls.
+size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, double h_fac);
+// molecule.cpp:205-219
+void h_op_diag(Vec &v, unsigned dest, double id_fac, double h_fac, const MolSys &sys);
+struct FrifullParams { double eps = 0.01, target_norm = 0; uint32_t vec_nonz = 0; size_t max_dets = 0; uint32_t seed = 0; };
+// FRIES_bin/frifull_mol.cpp:27-336 with one rank, HF trial vector, HF start, seed injected instead of the wall clock (:63-65)
+struct Frifull {
+    MolSys sys;
+    FrifullParams par;
+    std::mt19937 mt;
+    std::vector<uint32_t> proc_scr, vec_scr;
+    Vec sol;
+    std::vector<det_t> trial_det;
+    std::vector<double> trial_val;
+    double en_shift = 0, last_one_norm = 0;
+    det_t hf_det = 0;
+    unsigned iterat = 0, vec_idx = 0;
+    std::vector<size_t> srt; std::vector<uint8_t> keep;
+    std::vector<IterLog> log;       // num_success = add() calls of the off-diagonal application
+    void setup();
+    void iterate(unsigned n);
+};
+
 // ---------------------------------------------------------------- Hubbard-Holstein (frisys_hh)
 // bit string = [alpha sites | beta sites | ph_bits per site] (hh_vec.hpp:22, hub_holstein.cpp:139-171)
 struct HHParams {

@@ -48,6 +48,13 @@ FCIQMC_RUNS = {
     "fciqmc_h2o_hb_ini0": ("H2O", 150, 11, 0.002, 10000, 100000, 0, "HB"),
 }
 
+# frifull_mol (Hamiltonian applied in full), one rank: name -> (shape, n_iter, seed, eps, vec_nonz, max_dets, target)
+FULL_RUNS = {
+    "full_ne_m300": ("Ne", 40, 5, 0.01, 300, 400000, 120.0),
+    "full_n2_m400": ("N2", 25, 7, 0.01, 400, 2000000, 150.0),
+    "full_h2o_m200": ("H2O", 30, 11, 0.005, 200, 1000000, 110.0),
+}
+
 # frisys_hh (1-D Hubbard-Holstein): name -> (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, initiator, target)
 HH_RUNS = {
     "hh_l6_m2000": (1, 60, 5, 6, 6, 0.01, 2.0, 0.5, 0.3, -3.0, 2000, 20000, 1.0, 1000.0),
@@ -108,6 +115,13 @@ def main():
             out = os.path.join(GOLD, name + ".traj")
             subprocess.run([HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
             manifest["fciqmc_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist)
+        manifest["full_runs"] = {}
+        for name, (shape, n_iter, seed, eps, vnz, maxd, tgt) in FULL_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([HARNESS, "frifull", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(maxd), repr(tgt), out], check=True)
+            manifest["full_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, max_dets=maxd, target_norm=tgt)
         manifest["hh_runs"] = {}
         for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HH_RUNS.items():
             out = os.path.join(GOLD, name + ".traj")

@@ -129,6 +129,41 @@ void fo_compress_vec(void *h, uint32_t n_samp, double rn, uint32_t *n_kept, doub
     if (n_kept) *n_kept = n_samp - ns;
     if (glob_norm) *glob_norm = gn;
 }
+// frifull_mol (fo::Frifull)
+void *fo_frifull_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                        double eps, double target, uint32_t vec_nonz, uint32_t max_dets, uint32_t seed) {
+    Frifull *f = new Frifull();
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.target_norm = target; f->par.vec_nonz = vec_nonz; f->par.max_dets = max_dets; f->par.seed = seed;
+    f->setup();
+    return f;
+}
+void fo_frifull_destroy(void *h) { delete (Frifull *)h; }
+void fo_frifull_iterate(void *h, uint32_t n, OracleLog *logs) {
+    Frifull *f = (Frifull *)h;
+    for (uint32_t i = 0; i < n; i++) {
+        f->iterate(1);
+        if (logs) {
+            const IterLog &l = f->log.back();
+            OracleLog &o = logs[i];
+            o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.nkept = l.nkept;
+            o.n_nonz = l.n_nonz; o.curr_size = (uint32_t)l.curr_size; o.num_success = (uint32_t)l.num_success;
+            for (int k = 0; k < 5; k++) o.comp_len[k] = 0;
+            o.err = 0;
+        }
+    }
+}
+// the current value column over positions [0, curr_size)
+size_t fo_frifull_vec(void *h, uint64_t *dets, double *vals, size_t cap) {
+    Frifull *f = (Frifull *)h;
+    size_t n = f->sol.curr_size;
+    if (cap >= n) for (size_t i = 0; i < n; i++) { dets[i] = f->sol.dets[i]; vals[i] = f->sol.vals[f->vec_idx][i]; }
+    return n;
+}
 // compress_vecs with one vector (vec_utils.cpp:9-32): piv_comp_parallel on column 0 with the handle's generator, then the deletes
 void fo_compress_vec_piv(void *h, uint32_t n_samp) {
     Frisys *f = (Frisys *)h;

@@ -472,6 +472,85 @@ struct RefRun {
     }
 };
 
+// ------------------------------------------------------------------ reference frifull_mol loop (FRIES_bin/frifull_mol.cpp:258-304)
+struct RefFull {
+    RefRun rr;
+    int vec_idx = 0;
+    std::vector<uint8_t> scratch;
+    double numer = 0, denom = 0, glob_norm = 0; unsigned nkept = 0;
+    void setup(const char *path, const char *pg, uint32_t seed, double eps, uint32_t vnz, size_t max_dets, double tgt) {
+        rr.setup(path, pg, seed, eps, vnz, vnz, max_dets, 0.0, tgt, 1);
+        scratch.resize(4 * (size_t)rr.n_orb * rr.n_orb * rr.n_elec * rr.n_elec);
+    }
+    void iterate() {
+        DistVec<double> &sol_vec = *rr.sol;
+        const double eps = rr.eps;
+        denom = sol_vec.dot(rr.trial->indices(), rr.trial->values(), rr.trial->curr_size(), rr.trial_hashes);
+        unsigned n_samp = rr.vec_nonz;
+        double loc_norms[1];
+        if (sol_vec.max_size() > rr.srt.size()) { rr.srt.resize(sol_vec.max_size()); rr.keep.resize(sol_vec.max_size(), false); }
+        loc_norms[0] = find_preserve(sol_vec.values(), rr.srt, rr.keep, sol_vec.curr_size(), &n_samp, &glob_norm);
+        nkept = rr.vec_nonz - n_samp;
+        if ((rr.iterat + 1) % 10 == 0) adjust_shift(&rr.en_shift, glob_norm, &rr.last_one_norm, rr.target, 0.05 / 10 / eps);
+        double rn_sys = rr.mt() / (1. + UINT32_MAX);
+        sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, rr.keep, rn_sys);
+        for (size_t i = 0; i < sol_vec.curr_size(); i++) if (rr.keep[i]) { sol_vec.del_at_pos(i); rr.keep[i] = 0; }
+        h_op_diag(sol_vec, !vec_idx, 1 + eps * rr.en_shift, -eps);
+        sol_vec.set_curr_vec_idx(vec_idx);
+        h_op_offdiag(sol_vec, rr.in->symm, rr.n_orb, rr.in->eris, *rr.in->hcore, scratch.data(), scratch.size(), 0, rr.n_elec, !vec_idx, -eps, 0);
+        vec_idx = !vec_idx;
+        numer = sol_vec.dot(rr.trial->indices(), rr.trial->values(), rr.trial->curr_size(), rr.trial_hashes);
+        numer = ((1 + eps * rr.en_shift) * denom - numer) / eps;
+        rr.iterat++;
+    }
+};
+
+static int run_frifull(int argc, char **argv) {
+    if (argc < 11) { fprintf(stderr, "usage: frifull <fcidump> <pg> <n_iter> <seed> <eps> <vec_nonz> <max_dets> <target> <out>\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10);
+    size_t max_dets = strtoull(argv[8], 0, 10); double tgt = atof(argv[9]);
+    const char *out = argv[10];
+    RefFull rf;
+    rf.setup(path, pg, seed, eps, vnz, max_dets, tgt);
+    RefRun &rr = rf.rr;
+    fo::Frifull fr;
+    fr.sys.n_orb = rr.n_orb; fr.sys.n_elec = rr.n_elec;
+    fill_oracle_ints(fr.sys.ints, rr.in->eris, *rr.in->hcore, rr.n_orb);
+    fr.sys.symm.init(rr.in->symm, rr.n_orb);
+    fr.par.eps = eps; fr.par.target_norm = tgt; fr.par.vec_nonz = vnz; fr.par.max_dets = max_dets; fr.par.seed = seed;
+    fr.setup();
+    FILE *f = fopen(out, "w");
+    fprintf(f, "# golden trajectory from the reference (frifull_mol.cpp loop, 1 rank, symmetry-packed integrals); cols: it numer denom norm shift nkept n_nonz curr_size n_add hash (doubles as C99 hex floats)\n");
+    fprintf(f, "# args:");
+    for (int i = 2; i < 10; i++) fprintf(f, " %s", i == 2 ? "<fcidump>" : argv[i]);
+    fprintf(f, "\n# p_doub %a hf_en %a n_htrial %zu\n", 0.0, rr.hf_en, (size_t)0);
+    for (unsigned it = 0; it < n_iter; it++) {
+        rf.iterate();
+        fr.iterate(1);
+        const fo::IterLog &lg = fr.log.back();
+        CHECK(same_bits(lg.numer, rf.numer) && same_bits(lg.denom, rf.denom), "it %u numer/denom %a %a | %a %a", it, lg.numer, rf.numer, lg.denom, rf.denom);
+        CHECK(same_bits(lg.norm, rf.glob_norm) && same_bits(lg.shift, rr.en_shift), "it %u norm/shift", it);
+        CHECK(lg.nkept == rf.nkept && lg.n_nonz == rr.sol->n_nonz() && lg.curr_size == rr.sol->curr_size(), "it %u counts nkept %u/%u nnz %d/%d size %zu/%zu", it, lg.nkept, rf.nkept, lg.n_nonz, rr.sol->n_nonz(), lg.curr_size, (size_t)rr.sol->curr_size());
+        size_t n = std::min(lg.curr_size, (size_t)rr.sol->curr_size());
+        size_t bad = 0;
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < n; i++) {
+            double rv = rr.sol->values()[i];          // the column the next iteration starts from
+            fo::det_t rd = to_u64(rr.sol->indices()[i], rr.det_size);
+            if (!same_bits(rv, fr.sol.vals[fr.vec_idx][i])) bad++;
+            if (rv != 0 && rd != fr.sol.dets[i]) bad++;
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        CHECK(bad == 0, "it %u vector mismatch in %zu slots", it, bad);
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rf.numer, rf.denom, rf.glob_norm, rr.en_shift, rf.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), lg.num_success, hsh);
+    }
+    fclose(f);
+    printf("FRIFULL iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, rr.sol->n_nonz());
+    return n_fail != 0;
+}
+
 static void setup_oracle_from_ref(fo::Frisys &fr, RefRun &rr, uint32_t seed, size_t max_dets) {
     fr.sys.n_orb = rr.n_orb; fr.sys.n_elec = rr.n_elec;
     fill_oracle_ints(fr.sys.ints, rr.in->eris, *rr.in->hcore, rr.n_orb);
@@ -1143,6 +1222,7 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "unit")) rc = run_unit();
     else if (argc >= 3 && !strcmp(argv[1], "hbpp_all")) rc = run_hbpp_all(argv[2]);
     else if (argc >= 3 && !strcmp(argv[1], "piv")) rc = run_piv(argv[2]);
+    else if (argc >= 2 && !strcmp(argv[1], "frifull")) rc = run_frifull(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);

@@ -51,6 +51,12 @@ def load():
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_frifull_create.restype = C.c_void_p
+        lib.fo_frifull_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.fo_frifull_destroy.argtypes = [C.c_void_p]
+        lib.fo_frifull_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_frifull_vec.restype = C.c_size_t
+        lib.fo_frifull_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_adjust_probs.restype = C.c_double
         lib.fo_adjust_probs.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_double, C.c_uint32, C.c_double, C.c_void_p]
         lib.fo_next_draw.restype = C.c_uint32
@@ -198,6 +204,34 @@ class OracleFrisys:
 
     def next_draw(self):
         return self.lib.fo_next_draw(self.h)
+
+
+class OracleFull:
+    """fo::Frifull -- the sequential CPU restatement of frifull_mol (one rank)."""
+
+    def __init__(self, mol, *, epsilon, vec_nonz, max_dets, target_norm=0.0, seed=0):
+        self.lib = load()
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.h = self.lib.fo_frifull_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, vec_nonz, max_dets, seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.fo_frifull_destroy(self.h)
+            self.h = None
+
+    def iterate(self, n):
+        logs = np.zeros(n, dtype=LOG_DTYPE)
+        self.lib.fo_frifull_iterate(self.h, n, _p(logs))
+        return logs
+
+    def vector(self):
+        n = self.lib.fo_frifull_vec(self.h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_frifull_vec(self.h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]
 
 
 class OracleRanks:

@@ -39,6 +39,23 @@ def test_oracle_reproduces_reference_trajectory(oracle, mols, name):
             assert golden_io.vec_hash(d, v) == row["hash"], (name, row["it"])
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["full_runs"]))
+def test_oracle_frifull_reproduces_reference(oracle, mols, name):
+    """fo::Frifull against what the reference's frifull_mol loop logged (deterministic H application + vector compression)."""
+    r = golden_io.manifest()["full_runs"][name]
+    g = golden_io.read_traj(name)
+    orc = oracle.OracleFull(mols(r["shape"]), epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], seed=r["seed"])
+    for row in g["rows"][:15]:
+        lg = orc.iterate(1)[0]
+        for f in ("numer", "denom", "norm", "shift"):
+            assert float(lg[f]) == row[f], (name, row["it"], f)
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (name, row["it"], f)
+        if row["it"] % 5 == 4:
+            d, v = orc.vector()
+            assert golden_io.vec_hash(d, v) == row["hash"], (name, row["it"])
+
+
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["mpi_runs"]))
 def test_oracle_ranks_reproduce_reference_under_mpiexec(oracle, mols, name):
     """The multi-rank oracle (P in-process ranks) against what every rank of the real reference logged under

@@ -186,6 +186,26 @@ def test_frisys_trajectory_matches_reference_golden(Engine, mols, name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["full_runs"]))
+def test_frifull_trajectory_matches_reference_golden(Engine, mols, name):
+    """frifull_mol on the device (vector compression, then every single and double excitation of every determinant merged in
+    the reference's order) against what the real reference logged: counts, norms, shifts and stored values bit for bit."""
+    r = golden_io.manifest()["full_runs"][name]
+    g = golden_io.read_traj(name)
+    eng = Engine(mols(r["shape"]))
+    eng.setup_full(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], seed=r["seed"], spawn_cap=300000)
+    for row in g["rows"]:
+        lg = eng.iterate_full(1)[0]
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (row["it"], f, int(lg[f]), row[f])
+        assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"] and float(lg["denom"]) == row["denom"], row["it"]
+        assert abs(lg["numer"] / lg["denom"] - row["numer"] / row["denom"]) < ENERGY_TOL
+        if row["it"] % 5 == 4:
+            d, v = eng.vector()
+            assert golden_io.vec_hash(d, v) == row["hash"], row["it"]
+    eng.close()
+
+
 def test_vector_add_and_annihilation_semantics(Engine, oracle, mols):
     """DistVec add / perform_add rules (reference tests/test_vector.cpp:192-224, vec_utils.hpp:606-641):
     initiator spawns create determinants, non-initiator spawns only reach occupied ones, opposite signs cancel,
