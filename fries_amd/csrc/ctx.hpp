@@ -155,7 +155,7 @@ struct FriesCtx {
     PivBuf piv{};
     // frifull_mol: per-determinant excitation counts / offsets of the deterministic H application (system.hip)
     bool full_mode = false;
-    uint32_t full_cap = 0, *full_cnt = nullptr, *full_nz = nullptr, *full_off = nullptr;
+    uint32_t full_cap = 0, *full_cnt = nullptr, *full_nz = nullptr, *full_off = nullptr, *full_list = nullptr;
     uint32_t *d_err = nullptr;
     // trial vectors (replicated, small)
     uint32_t n_trial = 0, n_htrial = 0;

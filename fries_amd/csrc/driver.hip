@@ -360,7 +360,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     PivBuf &pv = h->c.piv;
     if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); }
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
-    if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); }
+    if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); hipFree(h->c.full_list); }
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
     if (h->c.stream) hipStreamDestroy(h->c.stream);
     delete h;

@@ -128,15 +128,16 @@ __device__ __forceinline__ bool fr_enum_candidate(const HbTables &T, det_t det, 
 
 // counts[2*d + mode] = symmetry-allowed excitations; nz[2*d+mode] = those with a non-zero element
 __global__ void __launch_bounds__(FR_BLOCK) k_enum(const det_t *src, const double *src_val, uint32_t n_src, SysDev S, int mode, int pass,
-                                                   uint32_t *counts, uint32_t *nz, const uint32_t *offsets, EnumOut out, double h_fac) {
+                                                   uint32_t *counts, uint32_t *nz, const uint32_t *offsets, EnumOut out, double h_fac, const uint32_t *src_idx = nullptr) {
     __shared__ HbTables T;
     __shared__ uint32_t shu[4];
     fr_stage_tables(&T, S.hb);
     const unsigned n = T.n_orb, ne = T.n_elec, h = ne / 2;
-    const uint32_t d = blockIdx.x;
+    const uint32_t d = blockIdx.x;              // counts / nz / offsets are indexed by list entry
     if (d >= n_src) return;
-    const det_t det = src[d];
-    const double cur = src_val[d];
+    const uint32_t at = src_idx ? src_idx[d] : d;
+    const det_t det = src[at];
+    const double cur = src_val[at];
     uint32_t n_cand = mode == 0 ? ne * n : h * h * n * n + 2 * (h * (h - 1) / 2) * n * n;
     uint32_t n_allowed = 0, n_written = 0;
     uint32_t obase = pass ? offsets[2 * d + mode] : 0;
@@ -285,6 +286,33 @@ void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac) {
     FR_LAUNCH(c, "k_hop_diag", k_hop_diag, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, S, id_fac, h_fac);
 }
 
+// positions with a non-zero value in column 0, ascending (the determinants h_op_offdiag visits, molecule.cpp:569-574)
+__global__ void __launch_bounds__(FR_BLOCK) k_src_count(VecDev V, uint32_t *pcnt) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) { size_t i = base + it; if (i < n && V.v0[i] != 0) cnt++; }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) pcnt[blockIdx.x] = bc;
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_src_write(VecDev V, const uint32_t *pcnt, uint32_t *list, uint32_t *n_out) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t f[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { size_t i = base + it; f[it] = (i < n && V.v0[i] != 0) ? 1u : 0u; tsum += f[it]; }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t r = off + incl - tsum;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) if (f[it]) list[r++] = (uint32_t)(base + it);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = off + tot;
+}
+
 // h_op_offdiag (molecule.cpp:448-665, spin_parity 0) from column 0 into column 1: every symmetry-allowed single excitation of
 // every stored determinant in storage order, then every double, each worth value * h_fac * <j|H|i>; the annihilating
 // merge takes them in that order.  The spawn buffer holds sp.cap entries, so the list is produced and merged in chunks of
@@ -296,30 +324,39 @@ uint64_t fr_h_offdiag_vec(FriesCtx *c, double h_fac) {
     if (ns == 0) return 0;
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     if (c->full_cap < ns) {
-        if (c->full_cnt) { FR_HIP(hipFree(c->full_cnt)); FR_HIP(hipFree(c->full_nz)); FR_HIP(hipFree(c->full_off)); }
+        if (c->full_cnt) { FR_HIP(hipFree(c->full_cnt)); FR_HIP(hipFree(c->full_nz)); FR_HIP(hipFree(c->full_off)); FR_HIP(hipFree(c->full_list)); }
         c->full_cap = c->vec.cap;
         c->full_cnt = fr_alloc<uint32_t>(2 * (size_t)c->full_cap); c->full_nz = fr_alloc<uint32_t>(2 * (size_t)c->full_cap); c->full_off = fr_alloc<uint32_t>(2 * (size_t)c->full_cap);
+        c->full_list = fr_alloc<uint32_t>(c->full_cap);
     }
-    // the source column must not move while its excitations are merged into the other one: both live in the same arrays
+    // the determinants with a non-zero value, in storage order
+    const unsigned gt = fr_blocks(ns, FR_TILE);
+    FR_LAUNCH(c, "k_src_count", k_src_count, dim3(gt), dim3(FR_BLOCK), c->vec, c->sp.pcnt);
+    FR_LAUNCH(c, "k_src_write", k_src_write, dim3(gt), dim3(FR_BLOCK), c->vec, c->sp.pcnt, c->full_list, c->full_off);
+    uint32_t nl = 0;
+    FR_HIP(hipMemcpyAsync(&nl, c->full_off, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    if (nl == 0) return 0;
     EnumOut eo{nullptr, nullptr, nullptr};
     for (int mode = 0; mode < 2; mode++)
-        FR_LAUNCH(c, "k_enum", k_enum, dim3(ns), dim3(FR_BLOCK), c->vec.dets, c->vec.v0, ns, S, mode, 0, c->full_cnt, c->full_nz, c->full_off, eo, h_fac);
-    std::vector<uint32_t> nz(2 * (size_t)ns), off(2 * (size_t)ns);
-    FR_HIP(hipMemcpyAsync(nz.data(), c->full_nz, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
+        FR_LAUNCH(c, "k_enum", k_enum, dim3(nl), dim3(FR_BLOCK), c->vec.dets, c->vec.v0, nl, S, mode, 0, c->full_cnt, c->full_nz, c->full_off, eo, h_fac, c->full_list);
+    std::vector<uint32_t> nz(2 * (size_t)nl), off(2 * (size_t)nl);
+    FR_HIP(hipMemcpyAsync(nz.data(), c->full_nz, 8 * (size_t)nl, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));
     FR_HIP(hipMemsetAsync(c->sp.ini, 1, c->sp.cap, st));
     eo.det = c->sp.det; eo.val = c->sp.val;
     uint64_t n_add = 0;
+    // (the source column does not move while its excitations are merged into the other one: positions are stable)
     for (int mode = 0; mode < 2; mode++) {
         uint32_t d0 = 0;
-        while (d0 < ns) {
+        while (d0 < nl) {
             uint32_t d1 = d0, tot = 0;
-            while (d1 < ns && (uint64_t)tot + nz[2 * (size_t)d1 + mode] <= c->sp.cap) { off[2 * (size_t)d1 + mode] = tot; tot += nz[2 * (size_t)d1 + mode]; d1++; }
+            while (d1 < nl && (uint64_t)tot + nz[2 * (size_t)d1 + mode] <= c->sp.cap) { off[2 * (size_t)d1 + mode] = tot; tot += nz[2 * (size_t)d1 + mode]; d1++; }
             if (d1 == d0) throw FriesError("spawn buffer smaller than one determinant's excitation list");
             if (tot) {
                 FR_HIP(hipMemcpyAsync(c->full_off + 2 * (size_t)d0, off.data() + 2 * (size_t)d0, 8 * (size_t)(d1 - d0), hipMemcpyHostToDevice, st));
-                FR_LAUNCH(c, "k_enum", k_enum, dim3(d1 - d0), dim3(FR_BLOCK), c->vec.dets + d0, c->vec.v0 + d0, d1 - d0, S, mode, 1, c->full_cnt + 2 * (size_t)d0,
-                          c->full_nz + 2 * (size_t)d0, c->full_off + 2 * (size_t)d0, eo, h_fac);
+                FR_LAUNCH(c, "k_enum", k_enum, dim3(d1 - d0), dim3(FR_BLOCK), c->vec.dets, c->vec.v0, d1 - d0, S, mode, 1, c->full_cnt + 2 * (size_t)d0,
+                          c->full_nz + 2 * (size_t)d0, c->full_off + 2 * (size_t)d0, eo, h_fac, c->full_list + d0);
                 FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &tot, 4, hipMemcpyHostToDevice, st));
                 FR_HIP(hipStreamSynchronize(st));       // tot and off are host temporaries
                 fr_vec_merge(c, &c->vec, tot, false);

@@ -535,3 +535,30 @@ def test_cli_drivers_hh_and_fciqmc(oracle, mols, tmp_path):
     assert np.array_equal(den, lo["denom"]) and np.array_equal(nini.astype(np.int64), lo["n_ini"].astype(np.int64))
     assert np.all(np.abs(num - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
     assert np.array_equal(nnz.astype(np.int64), lo["n_nonz"][9::10].astype(np.int64))
+
+
+def test_cli_driver_frifull(mols, tmp_path):
+    """frifull_mol_hip: the files it writes against the reference's golden trajectory."""
+    import subprocess
+    from fries_amd import build
+    name = "full_ne_m300"
+    r = golden_io.manifest()["full_runs"][name]
+    g = golden_io.read_traj(name)
+    mol = mols(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "full") + "/"
+    os.makedirs(out)
+    n_it = 30
+    res = subprocess.run([build.DRIVERS["frifull_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--epsilon", repr(r["epsilon"]), "--vec_nonz",
+                          str(r["vec_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--max_iter", str(n_it), "--result_dir", out,
+                          "--seed", str(r["seed"])], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); sh = np.loadtxt(out + "S.txt"); nm = np.loadtxt(out + "norm.txt"); nk = np.loadtxt(out + "nkept.txt")
+    for i in range(n_it):
+        row = g["rows"][i]
+        assert den[i] == row["denom"] and abs(num[i] - row["numer"]) <= 1e-10 * max(1.0, abs(row["numer"])) and int(nk[i]) == row["nkept"]
+    for k in range(n_it // 10):
+        assert sh[k] == g["rows"][10 * k + 9]["shift"] and nm[k] == g["rows"][10 * k + 9]["norm"]
+    bad = subprocess.run([build.DRIVERS["frifull_mol_hip"], "--hf_path", "x/"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "fcidump_path" in bad.stderr
