@@ -58,6 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 DRIVER = os.path.join(HERE, "frisys_mol_hip")
+FACADE_TEST = os.path.join(HERE, "..", "tests", "cpp", "test_facade")
 DRIVERS = {name: os.path.join(HERE, name) for name in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip", "frifull_mol_hip")}
 
 
@@ -72,6 +73,14 @@ def build_drivers(force: bool = False) -> str:
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"g++ failed on {name}.cpp:\n{r.stdout}\n{r.stderr}")
+    # host-side facade test (include/fries_facade.hpp), run by tests/test_gpu_parity.py on the GPU box
+    src = os.path.join(HERE, "..", "tests", "cpp", "test_facade.cpp")
+    if force or _stale(FACADE_TEST, [src, LIB, os.path.join(HERE, "..", "include", "fries_facade.hpp")] + hdrs):
+        cmd = ["g++", "-std=c++17", "-O2", "-o", FACADE_TEST, src, "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN/../../fries_amd", "-Wl,-rpath,/opt/rocm/lib",
+               "-Wl,-rpath-link,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed on test_facade.cpp:\n{r.stdout}\n{r.stderr}")
     return DRIVER
 
 

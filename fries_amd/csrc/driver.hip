@@ -579,6 +579,86 @@ extern "C" int fries_vec_add(fries_ctx *h, const uint64_t *dets, const double *v
     FR_API_END
 }
 
+// DistVec::add x n + perform_add(0) with curr_vec_idx = column: column 1 is where the drivers collect the spawns, judged by the
+// initiator rule against column 0 (frisys_mol.cpp:424-471, vec_utils.hpp:606-641)
+extern "C" int fries_vec_add_to(fries_ctx *h, int column, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (column != 0 && column != 1) throw FriesError("column must be 0 or 1");
+    if (n > c->sp.cap) throw FriesError("Too many elements added to Adder - must call perform_add() more frequently.");
+    if (c->use_comm) throw FriesError("fries_vec_add_to is a one-rank entry point; with ranks, adds travel inside fries_frisys_iterate");
+    std::vector<det_t> d; std::vector<double> v; std::vector<uint8_t> f;
+    for (size_t i = 0; i < n; i++) if (vals[i] != 0) { d.push_back(dets[i]); v.push_back(vals[i]); f.push_back(ini[i]); }
+    uint32_t m = (uint32_t)d.size();
+    if (m) {
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+        fr_vec_maybe_rebuild(c, &c->vec);           // tombstones of earlier deletes (the fused loop does this once per iteration)
+        FR_HIP(hipMemcpyAsync(c->sp.det, d.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
+        fr_vec_merge(c, &c->vec, m, column == 0);
+    }
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    check_dev_err(c);
+    FR_API_END
+}
+
+// frisys_mol.cpp:487-499: v0[i] *= 1 - eps (H_ii - shift) for the first vec_size positions, add_vecs(0, 1), zero_vec on column 1
+extern "C" int fries_death_clone(fries_ctx *h, double eps, double shift, uint32_t vec_size) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    const double se = c->eps, ss = c->en_shift;
+    c->eps = eps; c->en_shift = shift;
+    fr_death_clone(c, vec_size);
+    c->eps = se; c->en_shift = ss;
+    check_dev_err(c);
+    FR_API_END
+}
+
+// DistVec::dot with H * trial and with the trial vector (frisys_mol.cpp:511-517, vec_utils.hpp:228-238)
+extern "C" int fries_dots(fries_ctx *h, double *numer, double *denom) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    double nu = 0, de = 0;
+    fr_dots(c, &nu, &de);
+    if (numer) *numer = nu;
+    if (denom) *denom = de;
+    FR_API_END
+}
+
+// find_preserve on column 0 (compress_utils.cpp:29-105): *n_samp in = budget, out = samples left; the preserved set stays on
+// the device for fries_sys_comp.  Returns through glob_norm the one-norm before compression.
+extern "C" int fries_find_preserve(fries_ctx *h, uint32_t *n_samp, double *glob_norm) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    const uint32_t save = c->vec_nonz;
+    c->vec_nonz = *n_samp;
+    fr_abs_sums(c);
+    c->vec_nonz = save;
+    double gn = 0;
+    fr_find_preserve(c, n_samp, &gn);
+    if (glob_norm) *glob_norm = gn;
+    check_dev_err(c);
+    FR_API_END
+}
+// sys_comp (compress_utils.cpp:283-327) after fries_find_preserve, followed by the driver's deletes (frisys_mol.cpp:534-539)
+extern "C" int fries_sys_comp(fries_ctx *h, uint32_t n_samp, double rn) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_sys_comp(c, n_samp, rn);
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    check_dev_err(c);
+    FR_API_END
+}
+
 extern "C" int fries_vec_load(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;

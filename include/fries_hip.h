@@ -167,6 +167,16 @@ int fries_vec_info(fries_ctx *ctx, uint32_t *curr_size, int32_t *n_nonz, uint32_
 int fries_vec_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
 /* DistVec::add + perform_add(0) into column 0 with one rank (vec_utils.hpp:418-440, 606-641) */
 int fries_vec_add(fries_ctx *ctx, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n);
+/* the same with curr_vec_idx = column (0 or 1): column 1 collects the spawns under the initiator rule (frisys_mol.cpp:424-471) */
+int fries_vec_add_to(fries_ctx *ctx, int column, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n);
+/* frisys_mol.cpp:487-499: death / cloning of the first vec_size positions, add_vecs(0, 1), zero_vec on column 1 */
+int fries_death_clone(fries_ctx *ctx, double eps, double shift, uint32_t vec_size);
+/* DistVec::dot with H * trial (numer) and the trial vector (denom) (frisys_mol.cpp:511-517) */
+int fries_dots(fries_ctx *ctx, double *numer, double *denom);
+/* find_preserve (compress_utils.cpp:29-105) and sys_comp (:283-327) as two calls, as in the drivers' loops; the preserved
+ * set lives on the device in between; fries_sys_comp ends with the deletes of frisys_mol.cpp:534-539 */
+int fries_find_preserve(fries_ctx *ctx, uint32_t *n_samp, double *glob_norm);
+int fries_sys_comp(fries_ctx *ctx, uint32_t n_samp, double rn);
 /* replaces the stored vector: determinants land in positions 0..n-1 (DistVec::load, vec_utils.hpp:761-844) */
 int fries_vec_load(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n);
 int fries_htrial_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
