@@ -251,6 +251,17 @@ def main():
                               "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                               "avg_launch_us": avg_s * 1e6, "calls_per_iter": calls / args.profile_steps,
                               "share_of_kernel_time": ms / tot_ms, "n_nonz": info[1]}
+        # the measured device copy bandwidth of this box beside the nominal peak (read + write of 1 GiB on the
+        # engine's stream, HIP events), and the whole iteration / the spawn term against it
+        try:
+            copy_gbs = eng.copy_bandwidth(1 << 30, 5)
+            result["roofline"]["measured_copy_GBs"] = copy_gbs
+            result["roofline"]["frac_of_measured_copy"] = (ach / copy_gbs) if ach else None
+            result["iteration_frac_of_measured_copy"] = 312.0 * m * iters_per_s / world / 1e9 / copy_gbs
+            result["spawn_term_GBs"] = 64.0 * result["spawns_per_s"] / world / 1e9       # 64 B per spawn (assembly + merge)
+        except Exception as ex:      # the measurement is informative only
+            result["roofline"]["measured_copy_GBs"] = None
+            print("copy-bandwidth measurement skipped: %r" % (ex,), file=sys.stderr)
         result["kernel_time_ms_per_iter"] = tot_ms / args.profile_steps
         result["top_kernels"] = {k: {"ms_per_iter": v[0] / args.profile_steps, "calls_per_iter": v[1] / args.profile_steps}
                                  for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("FRIES_BENCH_TOPK", "8"))]}

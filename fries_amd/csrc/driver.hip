@@ -823,6 +823,29 @@ extern "C" int fries_prof_enable(fries_ctx *h, int on) {
     if (on) c->prof_agg.clear();
     FR_API_END
 }
+// device-to-device copy bandwidth of this GPU (bytes read + bytes written per second), the measured denominator beside the
+// nominal HBM peak
+extern "C" int fries_measure_copy_bandwidth(fries_ctx *h, size_t bytes, int reps, double *gb_per_s) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    void *a = nullptr, *b = nullptr;
+    FR_HIP(hipMalloc(&a, bytes)); FR_HIP(hipMalloc(&b, bytes));
+    FR_HIP(hipMemsetAsync(a, 1, bytes, c->stream));
+    FR_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream));
+    hipEvent_t e0, e1;
+    FR_HIP(hipEventCreate(&e0)); FR_HIP(hipEventCreate(&e1));
+    FR_HIP(hipEventRecord(e0, c->stream));
+    for (int k = 0; k < reps; k++) FR_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream));
+    FR_HIP(hipEventRecord(e1, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    FR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gb_per_s = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(a); hipFree(b);
+    FR_API_END
+}
+
 extern "C" int fries_prof_count(fries_ctx *h) {
     try { hipSetDevice(h->c.device); prof_collect(&h->c); } catch (...) { return -1; }     // spans recorded by the single-operator entry points
     return (int)h->c.prof_agg.size();

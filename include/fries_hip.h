@@ -207,6 +207,8 @@ int fries_frisys_restart(fries_ctx *ctx, uint32_t seed, double en_shift, double 
  * find_keep_sub replays, elements emitted by the five HB-PP stages */
 int fries_counters(fries_ctx *ctx, uint64_t *iters, uint64_t *spawns, uint64_t *launches, uint64_t *fks_replays, uint64_t *stage_elems);
 
+/* device-to-device copy bandwidth of the context's GPU in GB/s (read + write), `reps` copies of `bytes` on the engine's stream */
+int fries_measure_copy_bandwidth(fries_ctx *ctx, size_t bytes, int reps, double *gb_per_s);
 /* Per-kernel timing with HIP events recorded on the engine's own stream (off by default). */
 int fries_prof_enable(fries_ctx *ctx, int on);
 int fries_prof_count(fries_ctx *ctx);
