@@ -81,8 +81,9 @@ struct PivUnit {
     uint32_t new_resid;     // the element this unit hands on (unless it hands on the one it received)
     uint8_t pass;           // 1: border element sampled, the drawn candidate handed on
     uint8_t pad[3];
+    uint32_t n_inner;       // elements of the unit before its border element
 };
-struct PivScal { uint32_t n_units, end_pos, too_big, n_loc; double new_norm_unused; };
+struct PivScal { uint32_t n_units, end_pos, too_big, n_loc, uncertain, pad; };
 
 struct PivBuf {
     uint32_t cap = 0;
@@ -90,6 +91,8 @@ struct PivBuf {
     double *U = nullptr;                                     // two uniforms per unit
     PivUnit *unit = nullptr;
     PivScal *scal = nullptr;
+    void *tile_dd = nullptr;                                 // double-double tile sums / offsets of the parallel cut-point search
+    uint64_t n_certified = 0, n_fallback = 0; uint32_t last_reason = 0;                // calls settled by the parallel search / by the sequential chain
 };
 // ranks (include/fries_hip.h: fries_comm).  size == 1: no callbacks, the "gathered" block is the send block.
 struct fries_comm_ops {

@@ -358,7 +358,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     for (int k = 0; k < 2; k++) { hipFree(b.psum[k]); hipFree(b.pcnt[k]); }
     hipFree(b.state); hipFree(b.teeth); hipFree(b.dots); hipFree(b.fix_list);
     PivBuf &pv = h->c.piv;
-    if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); }
+    if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); hipFree(pv.tile_dd); }
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
     if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); hipFree(h->c.full_list); }
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
@@ -735,6 +735,11 @@ extern "C" int fries_test_piv_adjust(fries_ctx *h, uint32_t *n_samp_loc, double 
     fr_test_piv_adjust(c, n_samp_loc, exp_nsamp_loc, n_samp_tot, tot_norm, new_norm, flags_out);
     check_dev_err(c);
     FR_API_END
+}
+extern "C" int fries_piv_stats(fries_ctx *h, uint64_t *n_certified, uint64_t *n_fallback) {
+    if (n_certified) *n_certified = h->c.piv.n_certified;
+    if (n_fallback) *n_fallback = h->c.piv.n_fallback;
+    return (int)h->c.piv.last_reason;      // why the last fallback happened: 1 cut point near a border, 2 divmod, 4 walk, 8 candidate draw, 16 pass draw
 }
 extern "C" uint32_t fries_next_draw(fries_ctx *h) { return (uint32_t)h->c.mt(); }
 

@@ -11,11 +11,13 @@
 // Results are the reference's bit for bit; the uniforms are the engine's mt19937 stream, two per unit, in unit order.
 #include "ctx.hpp"
 
+struct DD_host { double hi, lo; };
 static void piv_alloc(FriesCtx *c, PivBuf &P, uint32_t cap) {
     if (P.cap >= cap) return;
     if (P.start) { FR_HIP(hipFree(P.start)); FR_HIP(hipFree(P.carry)); FR_HIP(hipFree(P.U)); FR_HIP(hipFree(P.unit)); FR_HIP(hipFree(P.scal)); }
     P.start = fr_alloc<uint32_t>(cap); P.carry = fr_alloc<double>(cap); P.U = fr_alloc<double>(2 * (size_t)cap); P.unit = fr_alloc<PivUnit>(cap);
     P.scal = fr_alloc<PivScal>(1);
+    if (!P.tile_dd) P.tile_dd = fr_alloc<DD_host>(FR_MAX_PART);
     P.cap = cap;
 }
 
@@ -142,16 +144,133 @@ __global__ void __launch_bounds__(64) k_piv_chain(VecDev V, VcompBuf B, PivBuf P
     if (lane == 0) { P.scal->n_units = n_units; P.scal->end_pos = end_pos; }
 }
 
+// ------------------------------------------------------------------ the cut points in parallel
+// In exact arithmetic element i closes a unit iff floor(P_i / unit) > floor(P_{i-1} / unit), P = inclusive prefix sums of the
+// unpreserved magnitudes, and the overshoot carried on is P_i mod unit.  The reference's running sum differs from that ideal
+// by its accumulated rounding: every add rounds by at most 2^-53 * 2 unit, the subtraction of unit at a border is exact
+// (Sterbenz), so after i adds |drift| <= i * 2.3e-16 * unit.  The prefix sums are formed in double-double (error ~1e-32
+// relative, negligible), every element checks that its distance to the nearest unit border exceeds that drift bound, and
+// k_piv_decide checks its own comparisons the same way.  If all clear, the decisions -- the only thing the outputs depend
+// on -- are provably the reference's; otherwise the caller falls back to the sequential k_piv_chain.
+struct DD { double hi, lo; };
+__device__ __forceinline__ DD dd_make(double a) { return DD{a, 0.0}; }
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+    double s = a.hi + b.hi, bb = s - a.hi;
+    double e = (a.hi - (s - bb)) + (b.hi - bb);       // two_sum
+    e += a.lo + b.lo;
+    double hi = s + e, lo = e - (hi - s);             // quick_two_sum
+    return DD{hi, lo};
+}
+__device__ __forceinline__ DD dd_shfl_up(DD v, int off) { return DD{__shfl_up(v.hi, off), __shfl_up(v.lo, off)}; }
+// inclusive scan over the workgroup; sh: 4 DD
+__device__ __forceinline__ DD dd_block_scan(DD x, DD *sh, DD *total) {
+    const int lane = fr_lane(), w = threadIdx.x >> 6;
+    DD v = x;
+    for (int off = 1; off < 64; off <<= 1) { DD t = dd_shfl_up(v, off); if (lane >= off) v = dd_add(t, v); }
+    __syncthreads();
+    if (lane == 63) sh[w] = v;
+    __syncthreads();
+    DD base = dd_make(0.0), tot = dd_make(0.0);
+    for (int k = 0; k < 4; k++) { if (k < w) base = dd_add(base, sh[k]); tot = dd_add(tot, sh[k]); }
+    if (w > 0) v = dd_add(base, v);
+    *total = tot;
+    return v;
+}
+__device__ __forceinline__ double piv_weight(const VecDev &V, const VcompBuf &B, uint32_t i, uint32_t n) { return (i < n && !B.keep[i]) ? fabs(V.v0[i]) : 0.0; }
+
+__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_tiles(VecDev V, VcompBuf B, DD *tile_sum) {
+    __shared__ DD sh[4];
+    const uint32_t n = V.st->curr_size;
+    const uint32_t base = blockIdx.x * FR_TILE + threadIdx.x * FR_ITEMS;
+    DD s = dd_make(0.0);
+    for (int it = 0; it < FR_ITEMS; it++) s = dd_add(s, dd_make(piv_weight(V, B, base + it, n)));
+    DD tot;
+    dd_block_scan(s, sh, &tot);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+// exclusive prefix over the tiles (one workgroup; <= FR_MAX_PART tiles)
+__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_scan(DD *tile_sum, uint32_t n_tiles) {
+    __shared__ DD sh[4];
+    const uint32_t per = (n_tiles + FR_BLOCK - 1) / FR_BLOCK;
+    const uint32_t t0 = threadIdx.x * per;
+    DD s = dd_make(0.0);
+    for (uint32_t t = t0; t < t0 + per && t < n_tiles; t++) s = dd_add(s, tile_sum[t]);
+    DD tot;
+    DD incl = dd_block_scan(s, sh, &tot);
+    DD run = dd_add(incl, DD{-s.hi, -s.lo});
+    for (uint32_t t = t0; t < t0 + per && t < n_tiles; t++) { DD x = tile_sum[t]; tile_sum[t] = run; run = dd_add(run, x); }
+}
+__global__ void k_pivdd_init(PivBuf P, VecDev V) {
+    P.scal->n_units = V.st->curr_size ? 1u : 0u; P.scal->end_pos = V.st->curr_size; P.scal->uncertain = 0;
+    P.start[0] = 0; P.carry[0] = 0;
+}
+// floor(P / unit) and the remainder, P >= 0
+__device__ __forceinline__ void dd_divmod(DD Pv, double unit, double *q_out, double *r_out) {
+    double q = floor(Pv.hi / unit);
+    for (int guard = 0; guard < 4; guard++) {
+        double p = q * unit, e = __fma_rn(q, unit, -p);        // q * unit exactly as p + e
+        DD r = dd_add(Pv, DD{-p, -e});
+        double rr = r.hi + r.lo;
+        if (rr < 0) { q -= 1; continue; }
+        if (rr >= unit) { q += 1; continue; }
+        *q_out = q; *r_out = rr;
+        return;
+    }
+    *q_out = q; *r_out = -1;      // not settled: the caller treats a negative remainder as uncertain
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_cuts(VecDev V, VcompBuf B, PivBuf P, const DD *tile_off, double unit, uint32_t n_samp, double tol_per_add, uint32_t *err, int dbg) {
+    __shared__ DD sh[4];
+    const uint32_t n = V.st->curr_size;
+    const uint32_t base = blockIdx.x * FR_TILE + threadIdx.x * FR_ITEMS;
+    double w[FR_ITEMS];
+    DD s = dd_make(0.0);
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { w[it] = piv_weight(V, B, base + it, n); s = dd_add(s, dd_make(w[it])); }
+    DD tot;
+    DD incl = dd_block_scan(s, sh, &tot);
+    DD run = dd_add(dd_add(tile_off[blockIdx.x], incl), DD{-s.hi, -s.lo});      // exclusive prefix at my first element
+    uint32_t unsure_bits = 0; bool toobig = false;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        const uint32_t i = base + it;
+        if (i >= n || w[it] == 0.0) continue;
+        if (w[it] >= unit) toobig = true;
+        double q0, r0, q1, r1;
+        dd_divmod(run, unit, &q0, &r0);
+        run = dd_add(run, dd_make(w[it]));
+        dd_divmod(run, unit, &q1, &r1);
+        // whether the very last element closes its unit changes nothing: either way the unit ends with the vector (:425-428)
+        const double tol = (i + 1 == n) ? -1.0 : tol_per_add * ((double)i + 64.0);
+        if (r0 < 0 || r1 < 0) { unsure_bits |= 2u; continue; }
+        if (q1 > q0) {           // closes unit q1 - 1; the running sum lands r1 above the border
+            if (q1 != q0 + 1) toobig = true;
+            if (r1 <= tol || (unit - r0 <= tol_per_add * ((double)i + 64.0))) { unsure_bits |= 1u; if (dbg) printf("[piv] crossing i=%u of %u q0=%.0f q1=%.0f r0/unit=%.3e r1/unit=%.3e tol/unit=%.3e w/unit=%.3e\n", i, n, q0, q1, r0 / unit, r1 / unit, tol / unit, w[it] / unit); }
+            const double m = q1;
+            const uint32_t nxt = i + 1;
+            if (m < (double)n_samp && nxt < n) { const uint32_t mi = (uint32_t)m; P.start[mi] = nxt; P.carry[mi] = r1; atomicAdd(&P.scal->n_units, 1u); }
+            if (m == (double)n_samp) P.scal->end_pos = nxt < n ? nxt : n;
+        }
+        else if (unit - r1 <= tol) { unsure_bits |= 1u; if (dbg) printf("[piv] inside i=%u of %u q=%.0f (unit-r1)/unit=%.3e tol/unit=%.3e\n", i, n, q1, (unit - r1) / unit, tol / unit); }
+    }
+    if (toobig) atomicOr(err, FR_ERR_PIV);
+    if (unsure_bits) atomicOr(&P.scal->uncertain, unsure_bits);
+}
+
 __device__ __forceinline__ double fr_sgn_unit(double unit, double v) { return unit * ((v > 0) - (v < 0)); }
 
-// One sampling unit (compress_utils.cpp:409-502 without the residual bookkeeping, which k_piv_resid does)
-__global__ void __launch_bounds__(FR_BLOCK) k_piv_unit(VecDev V, VcompBuf B, PivBuf P, double unit, uint32_t *err) {
+// One sampling unit, decision only (compress_utils.cpp:409-457 without side effects): which candidate H is drawn and
+// whether the border element is sampled.  carry is exact after k_piv_chain; after the parallel cut-point search
+// (k_pivdd_*) it is the ideal value, off from the reference's running sum by at most `tol` (the worst-case rounding
+// drift of that sum), and then every comparison made here must clear that margin or the unit is reported uncertified.
+__global__ void __launch_bounds__(FR_BLOCK) k_piv_decide(VecDev V, VcompBuf B, PivBuf P, double unit, double tol_per_add, uint32_t *err) {
     const uint32_t n = V.st->curr_size;
     const uint32_t n_units = P.scal->n_units;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_units) return;
+    const bool certify = tol_per_add > 0;
     const uint32_t pos = P.start[k];
     const double carry = P.carry[k];
+    uint32_t unsure_bits = 0;
     // the unit's elements: cum in the reference's order
     double cum = carry, last = 0;
     uint32_t used = 0, n_wt = 1;
@@ -161,42 +280,67 @@ __global__ void __launch_bounds__(FR_BLOCK) k_piv_unit(VecDev V, VcompBuf B, Piv
     }
     const bool at_end = pos + used == n;
     if (used == 0) { atomicOr(err, FR_ERR_PIV); return; }
+    const double tol = certify ? tol_per_add * ((double)pos + (double)used + 64.0) * 2.0 : -1.0;      // carried drift + this unit's own adds; < 0: nothing to certify
     uint32_t n_inner = used - 1;
     if (at_end) n_inner++;
+    if (certify) {      // the walk must end where the cut-point search put the border
+        const uint32_t next_start = (k + 1 < n_units) ? P.start[k + 1] : (at_end ? n + 1 : P.scal->end_pos);
+        if (!at_end && pos + used != next_start) unsure_bits |= 4u;
+        if (at_end && k + 1 < n_units) unsure_bits |= 4u;
+    }
     const double over = cum - unit;
     if (!at_end) { n_wt--; cum -= last; }
     const double under = unit - cum;
     // candidate among the residual piece and the inner elements (:437-446)
-    double r = P.U[2 * (size_t)k] * cum;
+    const double r = P.U[2 * (size_t)k] * cum;
     double run = 0;
     uint32_t H = 0, h_idx = FR_NOPOS, e = pos;
-    if (run < r && H < n_wt) { run += carry; H++; }
+    if (r != 0 && fabs(r) <= tol) unsure_bits |= 8u;
+    if (run < r && H < n_wt) { run += carry; H++; if (fabs(run - r) <= tol) unsure_bits |= 8u; }
     while (run < r && H < n_wt) {
         while (B.keep[e]) e++;
         run += fabs(V.v0[e]); h_idx = e; e++; H++;
+        if (fabs(run - r) <= tol) unsure_bits |= 8u;
     }
     if (r > 0) H--;
     if (H == 0) h_idx = FR_NOPOS;
     double p_pass = under / (unit - over);
     if (at_end) p_pass = 0;
-    const bool pass = P.U[2 * (size_t)k + 1] < p_pass;
+    const double u2 = P.U[2 * (size_t)k + 1];
+    const bool pass = u2 < p_pass;
+    if (certify && !at_end) {
+        const double den = unit - over;
+        if (!(den > 4 * tol) || fabs(u2 - p_pass) <= 2 * tol * (1 + fabs(p_pass)) / (den - 2 * tol) + 1e-15) unsure_bits |= 16u;
+    }
+    if (certify && unsure_bits) atomicOr(&P.scal->uncertain, unsure_bits);
+    PivUnit u;
+    u.H = H; u.pass = pass ? 1 : 0; u.pad[0] = u.pad[1] = u.pad[2] = 0;
+    u.new_resid = pass ? h_idx : pos + n_inner;      // pass with H == 0 hands on the residual it received (FR_NOPOS here)
+    u.n_inner = n_inner;
+    P.unit[k] = u;
+}
+
+// ... and what it does to its own elements (:458-501)
+__global__ void __launch_bounds__(FR_BLOCK) k_piv_apply(VecDev V, VcompBuf B, PivBuf P, double unit) {
+    const uint32_t n_units = P.scal->n_units;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_units) return;
+    const uint32_t pos = P.start[k];
+    const PivUnit u = P.unit[k];
+    const bool pass = u.pass != 0;
     // the first unit's residual is element 0 itself, and the reference touches it before the unit's own elements (:478-480)
-    if (k == 0 && !pass && H == 0) V.v0[0] = fr_sgn_unit(unit, V.v0[0]);
+    if (k == 0 && !pass && u.H == 0) V.v0[0] = fr_sgn_unit(unit, V.v0[0]);
     uint32_t cnt = 1;
-    for (uint32_t o = 0; o < n_inner; o++) {
+    for (uint32_t o = 0; o < u.n_inner; o++) {
         const uint32_t i = pos + o;
         if (!B.keep[i]) {
-            if (cnt == H) { if (!pass) V.v0[i] = fr_sgn_unit(unit, V.v0[i]); }
+            if (cnt == u.H) { if (!pass) V.v0[i] = fr_sgn_unit(unit, V.v0[i]); }
             else { V.v0[i] = 0; B.del[i] = 1; }
             cnt++;
         }
         else B.keep[i] = 0;
     }
-    if (pass) V.v0[pos + n_inner] = fr_sgn_unit(unit, V.v0[pos + n_inner]);
-    PivUnit u;
-    u.H = H; u.pass = pass ? 1 : 0; u.pad[0] = u.pad[1] = u.pad[2] = 0;
-    u.new_resid = pass ? h_idx : pos + n_inner;      // pass with H == 0 hands on the residual it received (FR_NOPOS here)
-    P.unit[k] = u;
+    if (pass) V.v0[pos + u.n_inner] = fr_sgn_unit(unit, V.v0[pos + u.n_inner]);
 }
 
 // The residual element of unit k is whatever the nearest earlier unit handed on (:447-450, :478-480), and the last
@@ -296,17 +440,46 @@ void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *
     if (loc_samp == 0) FR_LAUNCH(c, "k_piv_none", k_piv_none, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B);
     else {
         const double unit = new_norm / loc_samp;
-        FR_LAUNCH(c, "k_piv_chain", k_piv_chain, dim3(1), dim3(64), c->vec, B, P, unit, loc_samp, c->d_err);
-        PivScal hs;
-        FR_HIP(hipMemcpyAsync(&hs, P.scal, sizeof(hs), hipMemcpyDeviceToHost, st));
-        FR_HIP(hipStreamSynchronize(st));
-        if (hs.n_units > P.cap) throw FriesError("pivotal compression: more sampling units than the work arrays hold");
-        if (hs.n_units) {
+        const double tol_per_add = 2.5e-16 * unit;          // rounding drift of the reference's running sum per add (see k_pivdd_*)
+        bool chain = getenv("FRIES_PIV_CHAIN") != nullptr;  // force the sequential search (tests)
+        const std::mt19937 mt_saved = c->mt;
+        const unsigned n_tiles = fr_blocks(bound, FR_TILE);
+        PivScal hs{};
+        auto read_scal = [&]() { FR_HIP(hipMemcpyAsync(&hs, P.scal, sizeof(hs), hipMemcpyDeviceToHost, st)); FR_HIP(hipStreamSynchronize(st)); };
+        auto draw = [&]() {
+            if (hs.n_units > P.cap) throw FriesError("pivotal compression: more sampling units than the work arrays hold");
             std::vector<double> u(2 * (size_t)hs.n_units);
-            for (auto &x : u) x = c->mt() / (1. + UINT32_MAX);          // two per unit, in unit order (:437, :457)
-            FR_HIP(hipMemcpyAsync(P.U, u.data(), u.size() * 8, hipMemcpyHostToDevice, st));
+            for (size_t q = 0; q < 2 * (size_t)hs.n_units; q++) u[q] = c->mt() / (1. + UINT32_MAX);       // two per unit, in unit order (:437, :457)
+            FR_HIP(hipMemcpyAsync(P.U, u.data(), 16 * (size_t)hs.n_units, hipMemcpyHostToDevice, st));
             FR_HIP(hipStreamSynchronize(st));
-            FR_LAUNCH(c, "k_piv_unit", k_piv_unit, dim3(fr_blocks(hs.n_units, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P, unit, c->d_err);
+        };
+        if (!chain) {
+            DD *td = (DD *)P.tile_dd;
+            FR_LAUNCH(c, "k_pivdd_init", k_pivdd_init, dim3(1), dim3(1), P, c->vec);
+            FR_LAUNCH(c, "k_pivdd_tiles", k_pivdd_tiles, dim3(n_tiles), dim3(FR_BLOCK), c->vec, B, td);
+            FR_LAUNCH(c, "k_pivdd_scan", k_pivdd_scan, dim3(1), dim3(FR_BLOCK), td, n_tiles);
+            FR_LAUNCH(c, "k_pivdd_cuts", k_pivdd_cuts, dim3(n_tiles), dim3(FR_BLOCK), c->vec, B, P, td, unit, loc_samp, tol_per_add, c->d_err, c->dbg == 7 ? 1 : 0);
+            read_scal();
+            if (hs.uncertain) { chain = true; P.last_reason = hs.uncertain; }
+            else if (hs.n_units) {
+                draw();
+                FR_LAUNCH(c, "k_piv_decide", k_piv_decide, dim3(fr_blocks(hs.n_units, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P, unit, tol_per_add, c->d_err);
+                read_scal();
+                if (hs.uncertain) { chain = true; c->mt = mt_saved; P.last_reason = hs.uncertain; }
+            }
+            if (!chain) P.n_certified++;
+        }
+        if (chain) {            // the reference's own order of operations, one wave
+            P.n_fallback++;
+            FR_LAUNCH(c, "k_piv_chain", k_piv_chain, dim3(1), dim3(64), c->vec, B, P, unit, loc_samp, c->d_err);
+            read_scal();
+            if (hs.n_units) {
+                draw();
+                FR_LAUNCH(c, "k_piv_decide", k_piv_decide, dim3(fr_blocks(hs.n_units, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P, unit, 0.0, c->d_err);
+            }
+        }
+        if (hs.n_units) {
+            FR_LAUNCH(c, "k_piv_apply", k_piv_apply, dim3(fr_blocks(hs.n_units, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P, unit);
             FR_LAUNCH(c, "k_piv_resid", k_piv_resid, dim3(fr_blocks((size_t)hs.n_units + 1, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P, unit);
         }
         if (hs.end_pos < bound) FR_LAUNCH(c, "k_piv_tail", k_piv_tail, dim3(fr_blocks(bound - hs.end_pos, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P);

@@ -24,7 +24,7 @@ EXPORTS = [
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
-    "fries_measure_copy_bandwidth", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
+    "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
 ]
 
 
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.fries_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.fries_test_piv_adjust.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_double), C.c_void_p]
     lib.fries_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    lib.fries_piv_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fries_next_draw.restype = C.c_uint32
     lib.fries_next_draw.argtypes = [C.c_void_p]
     lib.fries_test_teeth.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -332,6 +333,11 @@ class FriEngine:
         out = C.c_double()
         self._ck(self.lib.fries_measure_copy_bandwidth(self.h, nbytes, reps, C.byref(out)))
         return out.value
+
+    def piv_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.last_piv_reason = self.lib.fries_piv_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def next_draw(self) -> int:
         return int(self.lib.fries_next_draw(self.h))

@@ -195,6 +195,9 @@ int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_k
  * piv_budget, adjust_probs, piv_samp_serial (compress_utils.cpp:354-681) -- then the deletes.  The uniforms are the
  * context's mt19937 stream (the generator the reference's caller passes in), two per sampling unit.  One rank. */
 int fries_compress_vec_piv(fries_ctx *ctx, uint32_t n_samp, uint32_t *n_kept, double *glob_norm);
+/* how many fries_compress_vec_piv calls were settled by the parallel, certified cut-point search and how many fell back to the
+ * sequential one (csrc/pivotal.hip); FRIES_PIV_CHAIN=1 in the environment forces the sequential search */
+int fries_piv_stats(fries_ctx *ctx, uint64_t *n_certified, uint64_t *n_fallback);
 /* the next raw draw of the context's mt19937 (advances it): lets a caller interleave its own draws as the reference's
  * drivers do, and tests check the generator's position */
 uint32_t fries_next_draw(fries_ctx *ctx);

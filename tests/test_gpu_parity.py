@@ -273,11 +273,13 @@ def test_pivotal_compression_known_answers(Engine, mols):
         eng.close()
 
 
+@pytest.mark.parametrize("chain", [False, True])
 @pytest.mark.parametrize("n,budget,style,seed", [(5000, 1200, 0, 1), (200000, 50000, 1, 2), (200000, 150000, 0, 3), (1000000, 400000, 2, 4),
                                                  (1000000, 3000, 0, 5), (300000, 400000, 1, 6), (64, 10, 0, 7), (65, 64, 1, 8)])
-def test_pivotal_compression_matches_oracle(Engine, oracle, mols, n, budget, style, seed):
-    """the device operator against the CPU restatement (pinned to the reference) at sizes up to 1e6 elements; also the
-    operator's invariants: at most `budget` non-zeros, sampled magnitudes all equal, preserved elements untouched."""
+def test_pivotal_compression_matches_oracle(Engine, oracle, mols, n, budget, style, seed, chain):
+    """the device operator against the CPU restatement (pinned to the reference) at sizes up to 1e6 elements, through the
+    parallel certified cut-point search and through the sequential one; also the operator's invariants: at most `budget`
+    non-zeros, sampled magnitudes all equal, preserved elements untouched."""
     mol = mols("N2")
     rng = np.random.RandomState(seed)
     u = rng.random_sample(n)
@@ -287,7 +289,16 @@ def test_pivotal_compression_matches_oracle(Engine, oracle, mols, n, budget, sty
     eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=n + 1000, seed=3)
     eng.vec_load(_distinct_dets(n), vals)
     eng.restart(1000 + seed)
-    nk, gn = eng.compress_vec_piv(budget)
+    if chain:
+        os.environ["FRIES_PIV_CHAIN"] = "1"
+    try:
+        nk, gn = eng.compress_vec_piv(budget)
+    finally:
+        os.environ.pop("FRIES_PIV_CHAIN", None)
+    cert, fall = eng.piv_stats()
+    assert (cert == 0 and fall <= 1) if chain else (cert + fall <= 1)
+    if not chain and n >= 1000 and cert + fall == 1:      # (no sampling at all when the budget covers every non-zero)
+        assert cert == 1, ("the parallel cut-point search should settle a generic vector", eng.last_piv_reason)
     _, v = eng.vector()
     ov, ofl, onext = oracle.piv_comp(vals, budget, 1000 + seed)
     assert np.array_equal(v, ov), int(np.sum(v != ov))
@@ -298,6 +309,26 @@ def test_pivotal_compression_matches_oracle(Engine, oracle, mols, n, budget, sty
     changed = nz & (v != vals)
     if changed.any():
         assert np.unique(np.abs(v[changed])).size == 1
+    eng.close()
+
+
+def test_pivotal_compression_falls_back_when_a_cut_point_sits_on_a_border(Engine, oracle, mols):
+    """equal magnitudes make every fourth running sum land exactly on a sampling-unit border: the parallel search cannot
+    certify that against the rounding of the reference's running sum, reports it, and the sequential search settles it."""
+    mol = mols("N2")
+    n = 6000
+    rng = np.random.RandomState(11)
+    vals = np.where(np.arange(n) < 4096, np.where(rng.random_sample(n) < 0.5, 1.0, -1.0), 0.0)
+    eng = Engine(mol)
+    eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=n + 1000, seed=3)
+    eng.vec_load(_distinct_dets(n), vals)
+    eng.restart(42)
+    eng.compress_vec_piv(1024)
+    cert, fall = eng.piv_stats()
+    assert (cert, fall) == (0, 1) and eng.last_piv_reason & 1
+    _, v = eng.vector()
+    ov, ofl, onext = oracle.piv_comp(vals, 1024, 42)
+    assert np.array_equal(v, ov) and eng.next_draw() == onext and int(np.count_nonzero(v)) == 1024
     eng.close()
 
 
