@@ -341,11 +341,12 @@ template <int STAGE, bool NEW_HB>
 __global__ void __launch_bounds__(FR_BLOCK) k_sys_prop(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, int in) {
     __shared__ HbTables T;
     __shared__ Teeth Tsh;
+    const uint32_t n_act = W.act_n[in];
+    if (blockIdx.x * blockDim.x >= n_act) return;        // rounds are enqueued in batches: most of a late batch finds nothing to do
     if (STAGE != 1) fr_stage_tables(&T, Tg);
     fr_stage_teeth(&Tsh, W.teeth);
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
     const unsigned n_in = fin->n_in;
-    const uint32_t n_act = W.act_n[in];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) {
         const uint32_t e = W.act[in][i];
         const uint32_t kin_new = W.kend[e - 1];

@@ -433,21 +433,25 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
     if (W.prop) {
-        // rounds of parallel propagation until no element's entry pointer changes (a host round trip per round: this is the
-        // frisys_hh path, where one stage needs ~1e4 repairs; the molecular path keeps the short sequential fix-up below)
+        // rounds of parallel propagation until no element's entry pointer changes: enqueued in batches of 8 (a round that finds
+        // an empty list returns at once), one host look at the list length per batch.  This is the frisys_hh path, where one
+        // stage needs ~1e4 repairs; the molecular path keeps the short sequential fix-up below.
         int in = 0;
-        for (int round = 0; ; round++) {
-            uint32_t na = 0;
-            FR_HIP(hipMemcpyAsync(&na, &W.act_n[in], 4, hipMemcpyDeviceToHost, st));
-            FR_HIP(hipStreamSynchronize(st));
-            if (na == 0) break;
-            if (na > W.cap) throw FriesError("comb repair list overflow");
+        uint32_t na = 0;
+        FR_HIP(hipMemcpyAsync(&na, &W.act_n[0], 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        if (na > W.cap) throw FriesError("comb repair list overflow");
+        for (int round = 0; na != 0; ) {
             if (round > 100000) throw FriesError("comb repair did not settle");
-            FR_HIP(hipMemsetAsync(&W.act_n[in ^ 1], 0, 4, st));
             unsigned gp = fr_blocks(na, FR_BLOCK);
             if (gp > 1024) gp = 1024;
-            FR_LAUNCH(c, "k_sys_prop", (k_sys_prop<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in);
-            in ^= 1;
+            for (int k = 0; k < 8; k++, round++) {      // the list can only grow by the elements it names: later rounds are never longer
+                FR_HIP(hipMemsetAsync(&W.act_n[in ^ 1], 0, 4, st));
+                FR_LAUNCH(c, "k_sys_prop", (k_sys_prop<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in);
+                in ^= 1;
+            }
+            FR_HIP(hipMemcpyAsync(&na, &W.act_n[in], 4, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
         }
     }
     else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
