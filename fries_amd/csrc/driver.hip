@@ -136,9 +136,27 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     fr_spawn_alloc(c, p->mat_nonz + 4096);
     fr_xch_alloc(c, p->mat_nonz + 4096);
     fr_vcomp_alloc(c, p->max_dets);
-    fr_h_trial_setup(c);        // replicated: every rank enumerates H|HF> (the reference gathers the shards, vec_utils.hpp:920-952)
+    if (c->ham_shift_set) c->hf_en = c->ham_shift_hf_en;        // --ham_shift (:95-98)
+    fr_h_trial_setup(c);        // replicated: every rank enumerates H * trial (the reference gathers the shards, vec_utils.hpp:920-952)
+    if (!c->in_ini_det.empty()) {
+        // --ini_vec (:264-274): rank 0 add()s every entry in file order; each rank receives the ones it owns in that order
+        std::vector<det_t> d; std::vector<double> v;
+        for (size_t i = 0; i < c->in_ini_det.size(); i++)
+            if (c->in_ini_val[i] != 0 && fr_host_idx_to_proc(c, c->in_ini_det[i]) == c->rank) { d.push_back(c->in_ini_det[i]); v.push_back(c->in_ini_val[i]); }
+        uint32_t m = (uint32_t)d.size();
+        if (m > c->sp.cap) throw FriesError("initial vector larger than the spawn buffer");
+        if (m) {
+            std::vector<uint8_t> f(m, 1);
+            FR_HIP(hipMemcpyAsync(c->sp.det, d.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
+            fr_vec_merge(c, &c->vec, m, true);
+            FR_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
     // start from 100 * |HF> on the rank that owns it (:277-281)
-    if (c->rank == c->hf_proc) {
+    else if (c->rank == c->hf_proc) {
         double v = 100; uint8_t one = 1; uint32_t n1 = 1;
         FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
         FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
@@ -288,6 +306,26 @@ static void frifull_iterate(FriesCtx *c, fries_iter_log *lg) {
 }
 
 // ------------------------------------------------------------------ C ABI
+// the driver's optional inputs; all three must precede fries_frisys_setup
+extern "C" int fries_set_trial_vector(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n) {
+    FR_API_BEGIN
+    if (h->c.vec.dets) throw FriesError("fries_set_trial_vector must be called before fries_frisys_setup");
+    h->c.in_trial_det.assign(dets, dets + n); h->c.in_trial_val.assign(vals, vals + n);
+    FR_API_END
+}
+extern "C" int fries_set_initial_vector(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n) {
+    FR_API_BEGIN
+    if (h->c.vec.dets) throw FriesError("fries_set_initial_vector must be called before fries_frisys_setup");
+    h->c.in_ini_det.assign(dets, dets + n); h->c.in_ini_val.assign(vals, vals + n);
+    FR_API_END
+}
+extern "C" int fries_set_ham_shift(fries_ctx *h, double hf_en) {
+    FR_API_BEGIN
+    if (h->c.vec.dets) throw FriesError("fries_set_ham_shift must be called before fries_frisys_setup");
+    h->c.ham_shift_set = true; h->c.ham_shift_hf_en = hf_en;
+    FR_API_END
+}
+
 extern "C" int fries_frifull_setup(fries_ctx *h, const fries_frifull_params *p) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;

@@ -254,14 +254,27 @@ void fr_h_trial_setup(FriesCtx *c) {
     std::vector<double> val{1.0}, ov;
     uint32_t n_sing = 0, n_doub = 0;
     fr_h_apply_list(c, src, val, od, ov, &n_sing, &n_doub);
-    c->p_doub = (double)n_doub / (n_sing + n_doub);        // frisys_mol.cpp:216-220
+    c->p_doub = (double)n_doub / (n_sing + n_doub);        // frisys_mol.cpp:216-220 (always from the HF determinant)
     c->W.row1[0] = c->p_doub; c->W.row1[1] = 1 - c->p_doub;    // heat_bathPP.cpp:714-727
-    c->n_trial = 1; c->n_htrial = (uint32_t)od.size();
-    c->tr_det = fr_alloc<det_t>(1); c->tr_val = fr_alloc<double>(1);
+    if (!c->in_trial_det.empty()) {
+        // --trial_vec (frisys_mol.cpp:157-181): the entries are add()ed in file order, so zero values never arrive and a repeated
+        // determinant sums into its first position; then H * trial by h_op_offdiag / h_op_diag / add_vecs (:205-210)
+        src.clear(); val.clear();
+        for (size_t i = 0; i < c->in_trial_det.size(); i++) {
+            if (c->in_trial_val[i] == 0) continue;
+            size_t j = 0;
+            while (j < src.size() && src[j] != c->in_trial_det[i]) j++;
+            if (j == src.size()) { src.push_back(c->in_trial_det[i]); val.push_back(c->in_trial_val[i]); }
+            else val[j] += c->in_trial_val[i];
+        }
+        if (src.empty()) throw FriesError("the trial vector holds no non-zero element");
+        fr_h_apply_list(c, src, val, od, ov, nullptr, nullptr);
+    }
+    c->n_trial = (uint32_t)src.size(); c->n_htrial = (uint32_t)od.size();
+    c->tr_det = fr_alloc<det_t>(src.size()); c->tr_val = fr_alloc<double>(src.size());
     c->htr_det = fr_alloc<det_t>(od.size()); c->htr_val = fr_alloc<double>(od.size());
-    double one = 1.0;
-    FR_HIP(hipMemcpy(c->tr_det, &c->hf_det, 8, hipMemcpyHostToDevice));
-    FR_HIP(hipMemcpy(c->tr_val, &one, 8, hipMemcpyHostToDevice));
+    FR_HIP(hipMemcpy(c->tr_det, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
+    FR_HIP(hipMemcpy(c->tr_val, val.data(), 8 * val.size(), hipMemcpyHostToDevice));
     FR_HIP(hipMemcpy(c->htr_det, od.data(), 8 * od.size(), hipMemcpyHostToDevice));
     FR_HIP(hipMemcpy(c->htr_val, ov.data(), 8 * ov.size(), hipMemcpyHostToDevice));
 }

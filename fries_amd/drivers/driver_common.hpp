@@ -90,3 +90,20 @@ static std::map<std::string, std::string> parse_kv(int argc, char **argv) {
     return kv;
 }
 static uint32_t wall_clock_seed() { return (uint32_t)std::chrono::high_resolution_clock::now().time_since_epoch().count(); }
+
+// read_dets + load_vec_txt (FRIES/io_utils.cpp:447-482, 565-586): <prefix>dets holds one determinant per token as a signed 64-bit
+// integer (byte k of the bit string = bits 8k..8k+7), <prefix>vals one value per token; the shorter file decides the length
+static size_t load_vec_txt(const std::string &prefix, std::vector<uint64_t> &dets, std::vector<double> &vals) {
+    std::ifstream file_d(prefix + "dets");
+    if (!file_d.is_open()) throw std::runtime_error("Could not open file: " + prefix + "dets");
+    dets.clear(); vals.clear();
+    long long in_det;
+    while (file_d >> in_det) dets.push_back((uint64_t)in_det);
+    std::ifstream file_v(prefix + "vals");
+    if (!file_v.is_open()) throw std::runtime_error("Could not open file: " + prefix + "vals");
+    double v;
+    while (file_v >> v) vals.push_back(v);
+    if (vals.size() > dets.size()) { std::cerr << "Warning: fewer determinants (" << dets.size() << ") than values (" << vals.size() << ") read in\n"; vals.resize(dets.size()); }
+    else if (vals.size() < dets.size()) { std::cerr << "Warning: fewer values (" << vals.size() << ") than determinants (" << dets.size() << ") read in\n"; dets.resize(vals.size()); }
+    return vals.size();
+}

@@ -2,17 +2,20 @@
 // (FRIES_bin/frisys_mol.cpp) over the C ABI of libfries_hip.so (include/fries_hip.h).
 //
 //   frisys_mol_hip --fcidump_path F --point_group D2h --distribution HB_unnorm --vec_nonz N --mat_nonz N --max_dets N
-//                  [--target T] [--initiator I] [--epsilon E] [--max_iter K] [--result_dir DIR/] [--load_dir DIR/] [--seed S] [--device D]
+//                  [--target T] [--initiator I] [--epsilon E] [--max_iter K] [--result_dir DIR/] [--load_dir DIR/]
+//                  [--ini_vec PREFIX] [--trial_vec PREFIX] [--ham_shift E] [--seed S] [--device D]
 //
 // Host side only: option parsing (argparse there, a loop here), the FCIDUMP reader (parse_fcidump / convert_symm,
 // FRIES/io_utils.cpp:189-318), the text outputs projnum.txt / projden.txt / S.txt / norm.txt / nkept.txt / params.txt
 // (frisys_mol.cpp:288-345, 505-531) and the binary checkpoint dets0.dat / vals0.dat / dense.txt / hash.dat
 // (DistVec::save / load, FRIES/vec_utils.hpp:703-844; save_proc_hash, io_utils.cpp:589-606).  Everything numeric runs on
-// the GPU.  One rank; ranks are driven through fries_set_comm.
+// the GPU.  --ini_vec / --trial_vec read the reference's text vectors (<prefix>dets, <prefix>vals; load_vec_txt, io_utils.cpp:447-482).
+// --det_space (the semi-stochastic space) is not implemented.  One rank; ranks are driven through fries_set_comm.
 #include "driver_common.hpp"
 
 struct Args {
-    std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir;
+    std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir, ini_vec, trial_vec;
+    bool have_ham_shift = false; double ham_shift = 0;
     double target = 0, initiator = 0, epsilon = 0.01;
     uint32_t max_iter = 1000000, vec_nonz = 0, mat_nonz = 0, max_dets = 0, seed = 0, device = 0;
     bool have_seed = false;
@@ -28,6 +31,10 @@ static Args parse_args(int argc, char **argv) {
     if (kv.count("distribution")) r.dist = kv["distribution"];
     if (kv.count("result_dir")) r.result_dir = kv["result_dir"];
     if (kv.count("load_dir")) r.load_dir = kv["load_dir"];
+    if (kv.count("ini_vec")) r.ini_vec = kv["ini_vec"];
+    if (kv.count("trial_vec")) r.trial_vec = kv["trial_vec"];
+    if (kv.count("ham_shift")) { r.ham_shift = std::stod(kv["ham_shift"]); r.have_ham_shift = true; }
+    if (kv.count("det_space")) throw std::runtime_error("--det_space (semi-stochastic space) is not implemented in frisys_mol_hip");
     if (kv.count("target")) r.target = std::stod(kv["target"]);
     if (kv.count("initiator")) r.initiator = std::stod(kv["initiator"]);
     if (kv.count("epsilon")) r.epsilon = std::stod(kv["epsilon"]);
@@ -93,6 +100,10 @@ int main(int argc, char **argv) {
         if (!args.have_seed) seed = wall_clock_seed();      // frisys_mol.cpp:104-106
         std::cout << "seed on process 0 is " << seed << std::endl;
         fries_frisys_params p{args.epsilon, args.target, args.initiator, args.vec_nonz, args.mat_nonz, args.max_dets, seed, args.dist == "HB_unnorm" ? 1 : 0};
+        std::vector<uint64_t> tdets; std::vector<double> tvals;
+        if (!args.trial_vec.empty()) { load_vec_txt(args.trial_vec, tdets, tvals); ck(fries_set_trial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }      // :157-181
+        if (args.load_dir.empty() && !args.ini_vec.empty()) { load_vec_txt(args.ini_vec, tdets, tvals); ck(fries_set_initial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }   // :264-274
+        if (args.have_ham_shift) ck(fries_set_ham_shift(ctx, args.ham_shift - in.core_en));      // :95-98
         ck(fries_frisys_setup(ctx, &p));
         double en_shift = 0, last_norm = 0;
         if (!args.load_dir.empty()) {                       // :257-263, :284-286
@@ -115,6 +126,7 @@ int main(int argc, char **argv) {
             param_f << "FRI calculation\nFCIDUMP path: " << args.fcidump_path << "\nepsilon (imaginary time step): " << args.epsilon << "\nTarget norm " << args.target
                     << "\nInitiator threshold: " << args.initiator << "\nMatrix nonzero: " << args.mat_nonz << "\nVector nonzero: " << args.vec_nonz << "\n";
             if (!args.load_dir.empty()) param_f << "Restarting calculation from " << args.load_dir << "\n";
+            else if (!args.ini_vec.empty()) param_f << "Initializing calculation from vector files with prefix " << args.ini_vec << '\n';
             else param_f << "Initializing calculation from HF unit vector\n";
         }
         {   // hash.dat: the proc scrambler (io_utils.cpp:589-606); one rank never uses it, but a restart on several ranks would

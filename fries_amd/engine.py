@@ -24,7 +24,7 @@ EXPORTS = [
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
-    "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
+    "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
 ]
 
 
@@ -103,6 +103,9 @@ def load_library() -> C.CDLL:
     lib.fries_test_piv_adjust.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_double), C.c_void_p]
     lib.fries_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     lib.fries_piv_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fries_set_trial_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_set_initial_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_set_ham_shift.argtypes = [C.c_void_p, C.c_double]
     lib.fries_next_draw.restype = C.c_uint32
     lib.fries_next_draw.argtypes = [C.c_void_p]
     lib.fries_test_teeth.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -203,9 +206,19 @@ class FriEngine:
         return out, sg
 
     # ---- frisys_mol
-    def setup(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm"):
+    def setup(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm",
+              trial=None, ini=None, ham_shift=None):
+        """frisys_mol setup.  trial / ini: (dets, vals) of --trial_vec / --ini_vec; ham_shift: the diagonal offset that replaces
+        the HF energy (--ham_shift minus the core energy)."""
         if distribution not in ("HB", "HB_unnorm"):
             raise RuntimeError('"dist_str" argument must be either "HB" or "HB_unnorm"')
+        for pair, fn in ((trial, self.lib.fries_set_trial_vector), (ini, self.lib.fries_set_initial_vector)):
+            if pair is not None:
+                d = np.ascontiguousarray(pair[0], dtype=np.uint64)
+                v = np.ascontiguousarray(pair[1], dtype=np.float64)
+                self._ck(fn(self.h, _ptr(d), _ptr(v), min(d.size, v.size)))
+        if ham_shift is not None:
+            self._ck(self.lib.fries_set_ham_shift(self.h, float(ham_shift)))
         if self.comm is not None and self.comm.big_bytes < 16 * (mat_nonz + 4096):
             raise RuntimeError("TorchComm was sized for a smaller mat_nonz")
         p = FrisysParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)

@@ -100,6 +100,13 @@ typedef struct {
     uint32_t err;
 } fries_iter_log;
 
+/* Optional inputs of the frisys_mol driver, each before fries_frisys_setup:
+ *   --trial_vec (frisys_mol.cpp:157-181): the vector the energy is projected on, entries add()ed in the given order;
+ *   --ini_vec   (:264-274): the starting vector instead of 100 x HF, entries add()ed in the given order (from rank 0);
+ *   --ham_shift (:95-98): the offset subtracted from every diagonal element instead of the HF energy (pass ham_shift - core_en). */
+int fries_set_trial_vector(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n);
+int fries_set_initial_vector(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n);
+int fries_set_ham_shift(fries_ctx *ctx, double hf_en);
 /* frisys_mol.cpp:76-346: scramblers, solution vector, HF trial vector and H*trial, p_doub, HF start.
  * With ranks: vec_nonz / mat_nonz / target_norm are the GLOBAL budgets, max_dets is per rank, and every rank
  * must pass the same seed (the reference broadcasts rank 0's scramblers and uniforms). */

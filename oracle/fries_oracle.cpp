@@ -1493,6 +1493,45 @@ void Frisys::setup() {
     size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
     sc.init(spawn_length, n_states);
 
+    if (has_ham_shift) sys.hf_en = ham_shift;            // :95-98
+    if (!trial_in_det.empty()) {
+        // trial vector from file (:157-181): rank 0 adds every entry to trial_vec and htrial_vec, then H * trial by the general
+        // h_op_offdiag / h_op_diag / add_vecs (:205-210) and both are replicated (collect_procs)
+        size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
+        size_t tot = 2 * trial_in_det.size();
+        Vec tv, ht;
+        tv.init(tot, tot, n_elec, 1, cm, proc_scr.data());
+        ht.init(tot * n_ex / cm.size, tot * n_ex / cm.size, n_elec, 2, cm, proc_scr.data());
+        if (cm.rank == 0) for (size_t i = 0; i < trial_in_det.size(); i++) { tv.add(trial_in_det[i], trial_in_val[i], 1); ht.add(trial_in_det[i], trial_in_val[i], 1); }
+        tv.perform_add(0); ht.perform_add(0);
+        h_op_offdiag(ht, ht.curr_size, sys, 1, 1.0);
+        ht.cur = 0;
+        h_op_diag(ht, 0, 0, 1, sys);
+        ht.add_vecs(0, 1);
+        auto gather = [&](Vec &v, std::vector<det_t> &od, std::vector<double> &ov) {
+            std::vector<std::vector<uint8_t>> snd(cm.size), rcv;
+            size_t n = v.curr_size;
+            std::vector<uint8_t> mine(n * 16);
+            if (n) { memcpy(mine.data(), v.dets.data(), n * 8); memcpy(mine.data() + n * 8, v.vals[0].data(), n * 8); }
+            for (int d = 0; d < cm.size; d++) snd[d] = mine;
+            if (cm.size == 1) rcv = snd; else cm.alltoallv(snd, rcv);
+            od.clear(); ov.clear();
+            for (int sr = 0; sr < cm.size; sr++) {
+                size_t k = rcv[sr].size() / 16, o = od.size();
+                od.resize(o + k); ov.resize(o + k);
+                if (k) { memcpy(&od[o], rcv[sr].data(), k * 8); memcpy(&ov[o], rcv[sr].data() + k * 8, k * 8); }
+            }
+        };
+        gather(tv, trial_det, trial_val);
+        gather(ht, htrial_det, htrial_val);
+        uint8_t hf_occ[64];
+        occ_list(hf_det, hf_occ);
+        std::vector<uint8_t> ex;
+        size_t n_doub = doub_ex_symm(hf_det, hf_occ, n_elec, n_orb, ex, sys.symm.irrep.data());      // :216-220
+        size_t n_sing2 = count_singex(hf_det, hf_occ, n_elec, sys.symm);
+        p_doub = (double)n_doub / (n_sing2 + n_doub);
+    }
+    else {
     // trial = HF; H*trial by full enumeration (:163-214, molecule.cpp:448-665)
     trial_det = {hf_det}; trial_val = {1.0};
     {
@@ -1555,7 +1594,9 @@ void Frisys::setup() {
         size_t n_sing2 = count_singex(hf_det, occ, n_elec, sys.symm);
         p_doub = (double)n_doub / (n_sing2 + n_doub);
     }
-    if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);       // :277-279
+    }
+    if (!ini_det.empty()) { if (cm.rank == 0) for (size_t i = 0; i < ini_det.size(); i++) sol.add(ini_det[i], ini_val[i], 1); }      // :264-274
+    else if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);       // :277-279
     sol.perform_add(0);
     sys.hb.set_up(sys.ints);
     srt.assign(sol.max_size, 0); keep.assign(sol.max_size, 0);

@@ -265,6 +265,11 @@ struct Frisys {
     HBScratch sc;
     std::vector<det_t> trial_det, htrial_det;
     std::vector<double> trial_val, htrial_val;
+    // optional inputs of the driver: --trial_vec, --ini_vec (text vectors, rank 0 reads and adds them: frisys_mol.cpp:157-181,
+    // 264-274) and --ham_shift (:95-98: the diagonal offset replaces the HF energy; core energy already subtracted by the caller)
+    std::vector<det_t> trial_in_det, ini_det;
+    std::vector<double> trial_in_val, ini_val;
+    bool has_ham_shift = false; double ham_shift = 0;
     double p_doub = 0, en_shift = 0, last_one_norm = 0;
     det_t hf_det = 0;
     unsigned iterat = 0;

@@ -28,6 +28,12 @@ RUNS = {
     "min4_m50_unnorm": ("MIN4", 25, 3, 0.01, 50, 50, 1000, 1.0, 25.0, "HB_unnorm", 0),
 }
 
+# driver options beyond the defaults: --trial_vec / --ini_vec text vectors (written below from H|HF>) and --ham_shift
+EXTRA_RUNS = {
+    "n2_m5000_trial_ini": (("N2", 30, 13, 0.01, 5000, 5000, 60000, 0.5, 3000.0, "HB_unnorm"), dict(trial="n2_trial_", ini="n2_ini_")),
+    "ne_m2000_ham_shift": (("Ne", 30, 21, 0.01, 2000, 2000, 20000, 1.0, 1000.0, "HB_unnorm"), dict(ham_shift=-44.3)),
+}
+
 # binary checkpoints written by the reference itself (DistVec::save): run name -> after how many iterations
 CHECKPOINTS = {"ne_m2000_unnorm": 40}
 
@@ -98,6 +104,37 @@ def main():
                     **{fn.replace(".", "_") + "_bytes": os.path.getsize(ckdir + fn) for fn in ("dets0.dat", "vals0.dat")})
             manifest["runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd,
                                           initiator=ini, target_norm=tgt, distribution=dist)
+        # text vectors for --trial_vec / --ini_vec: the first 25 entries of H|HF> of the N2 shape (HF first), committed as fixtures
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        import numpy as np
+        mol = fcidump.synthetic("N2")
+        orc = oracle_lib.OracleFrisys(mol, epsilon=0.01, vec_nonz=10, mat_nonz=10, max_dets=100, seed=1)
+        hd, hv = orc.htrial()
+        with open(os.path.join(GOLD, "n2_trial_dets"), "w") as f:
+            f.write("".join("%d\n" % int(d) for d in hd[:25]))
+        with open(os.path.join(GOLD, "n2_trial_vals"), "w") as f:
+            f.write("".join("%r\n" % (1.0 if i == 0 else float(-0.05 * np.sign(hv[i]) * (1 + 0.01 * i))) for i in range(25)))
+        with open(os.path.join(GOLD, "n2_ini_dets"), "w") as f:
+            f.write("".join("%d\n" % int(d) for d in hd[:25][::-1]))
+        with open(os.path.join(GOLD, "n2_ini_vals"), "w") as f:
+            f.write("".join("%r\n" % (float(60.0 if i == 24 else -3.0 * np.sign(hv[24 - i]))) for i in range(25)))
+        manifest["extra_runs"] = {}
+        for name, ((shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt, dist), extra) in EXTRA_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            out = os.path.join(GOLD, name + ".traj")
+            env = dict(os.environ)
+            if "trial" in extra:
+                env["FRIES_TRIAL"] = os.path.join(GOLD, extra["trial"])
+            if "ini" in extra:
+                env["FRIES_INI"] = os.path.join(GOLD, extra["ini"])
+            if "ham_shift" in extra:
+                env["FRIES_HAM_SHIFT"] = repr(extra["ham_shift"])
+            subprocess.run([HARNESS, "frisys", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist, out],
+                           check=True, env=env)
+            manifest["extra_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd,
+                                                initiator=ini, target_norm=tgt, distribution=dist, **extra)
         manifest["mpi_runs"] = {}
         for name, (n_ranks, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt, dist)) in MPI_RUNS.items():
             mol = fcidump.synthetic(shape)

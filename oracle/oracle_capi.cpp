@@ -27,6 +27,26 @@ void *fo_frisys_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, c
     f->setup();
     return f;
 }
+// the same with the driver's optional inputs (--trial_vec, --ini_vec, --ham_shift); n == 0 / has_shift == 0 leave the defaults
+void *fo_frisys_create_ex(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                          double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm,
+                          const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const double *in_val, size_t n_in,
+                          int has_shift, double ham_shift_hf_en) {
+    Frisys *f = new Frisys();
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.target_norm = target; f->par.init_thresh = init;
+    f->par.vec_nonz = vec_nonz; f->par.mat_nonz = mat_nonz; f->par.max_dets = max_dets;
+    f->par.new_hb = hb_unnorm != 0; f->par.seed = seed;
+    if (n_tr) { f->trial_in_det.assign(tr_det, tr_det + n_tr); f->trial_in_val.assign(tr_val, tr_val + n_tr); }
+    if (n_in) { f->ini_det.assign(in_det, in_det + n_in); f->ini_val.assign(in_val, in_val + n_in); }
+    if (has_shift) { f->has_ham_shift = true; f->ham_shift = ham_shift_hf_en; }
+    f->setup();
+    return f;
+}
 void fo_frisys_destroy(void *h) { delete (Frisys *)h; }
 void fo_frisys_iterate(void *h, uint32_t n, OracleLog *logs) {
     Frisys *f = (Frisys *)h;

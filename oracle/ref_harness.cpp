@@ -350,6 +350,7 @@ struct RefRun {
     std::function<double(uint8_t *, uint8_t *)> sing_sc;
     std::function<double(uint8_t *)> doub_sc;
     std::vector<uint32_t> proc_scr, vec_scr;
+    std::vector<fo::det_t> trial_in_det, ini_in_det; std::vector<double> trial_in_val, ini_in_val;      // what the text files held
     // per-iteration record
     double numer, denom, glob_norm; unsigned nkept; size_t num_success;
 
@@ -362,6 +363,7 @@ struct RefRun {
         gen_hf_bitstring(n_orb, n_elec, hf_det);
         find_bits(hf_det, tmp_orbs, det_size);
         hf_en = diag_matrel(tmp_orbs, n_orb, *eris, *h_core, 0, n_elec);
+        if (getenv("FRIES_HAM_SHIFT")) hf_en = atof(getenv("FRIES_HAM_SHIFT")) - in->core_en;      // --ham_shift (frisys_mol.cpp:95-98)
         mt.seed(seed);
         MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
         MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
@@ -380,10 +382,23 @@ struct RefRun {
         size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
         comp = new HBCompressSys(spawn_length, n_states);
         size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
-        unsigned tot_trial = CEILING(1 * 2, n_procs);
+        // --trial_vec (frisys_mol.cpp:157-181): the reference's own text reader, through the solution vector's arrays as there
+        size_t n_trial = 1;
+        const char *trial_prefix = getenv("FRIES_TRIAL");
+        Matrix<uint8_t> &load_dets = sol->indices();
+        double *load_vals = (double *)sol->values();
+        if (trial_prefix) n_trial = load_vec_txt(std::string(trial_prefix), load_dets, load_vals);
+        unsigned tot_trial = sum_mpi((int)n_trial, proc_rank, n_procs);
+        tot_trial = CEILING(tot_trial * 2, n_procs);
         trial = new DistVec<double>(tot_trial + 2, tot_trial + 2, n_orb * 2, n_elec, n_procs, proc_scr, vec_scr);
-        htrial = new DistVec<double>(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec, n_procs, diag_sc, 2, proc_scr, vec_scr);
-        if ((int)hf_proc == proc_rank) { trial->add(hf_det, 1, 1); htrial->add(hf_det, 1, 1); }
+        htrial = new DistVec<double>((size_t)tot_trial * n_ex / n_procs + 2 * n_ex, (size_t)tot_trial * n_ex / n_procs + 2 * n_ex, n_orb * 2, n_elec, n_procs, diag_sc, 2, proc_scr, vec_scr);
+        if (trial_prefix) {
+            for (size_t i = 0; i < n_trial; i++) { trial->add(load_dets[i], load_vals[i], 1); htrial->add(load_dets[i], load_vals[i], 1); }
+            trial_in_det.clear(); trial_in_val.clear();
+            for (size_t i = 0; i < n_trial; i++) { trial_in_det.push_back(to_u64(load_dets[i], det_size)); trial_in_val.push_back(load_vals[i]); }
+            bzero(load_vals, (n_trial + 1) * sizeof(double));
+        }
+        else if ((int)hf_proc == proc_rank) { trial->add(hf_det, 1, 1); htrial->add(hf_det, 1, 1); }
         trial->perform_add(0); htrial->perform_add(0);
         trial->collect_procs();
         trial_hashes.resize(trial->curr_size());
@@ -400,7 +415,17 @@ struct RefRun {
         size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec, n_orb, (uint8_t (*)[4])scratch.data(), in->symm);
         size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec, basis_symm);
         p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-        if ((int)hf_proc == proc_rank) sol->add(hf_det, 100, 1);
+        if (getenv("FRIES_INI")) {       // --ini_vec (:264-274)
+            Matrix<uint8_t> ini_dets(sol->max_size(), det_size);
+            double *lv = sol->values();
+            size_t n_dets = load_vec_txt(std::string(getenv("FRIES_INI")), ini_dets, lv);
+            ini_in_det.clear(); ini_in_val.clear();
+            for (size_t i = 0; i < n_dets; i++) { ini_in_det.push_back(to_u64(ini_dets[i], det_size)); ini_in_val.push_back(lv[i]); }
+            for (size_t i = 0; i < n_dets; i++) sol->add(ini_dets[i], lv[i], 1);
+            n_dets++;
+            bzero(lv, n_dets * sizeof(double));
+        }
+        else if ((int)hf_proc == proc_rank) sol->add(hf_det, 100, 1);
         sol->perform_add(0);
         hb = set_up(n_orb, n_orb, *eris);
         srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
@@ -558,6 +583,9 @@ static void setup_oracle_from_ref(fo::Frisys &fr, RefRun &rr, uint32_t seed, siz
     fr.par.eps = rr.eps; fr.par.target_norm = rr.target; fr.par.init_thresh = rr.init_thresh;
     fr.par.vec_nonz = rr.vec_nonz; fr.par.mat_nonz = rr.mat_nonz; fr.par.max_dets = max_dets;
     fr.par.new_hb = rr.new_hb; fr.par.seed = seed;
+    fr.trial_in_det = rr.trial_in_det; fr.trial_in_val = rr.trial_in_val;
+    fr.ini_det = rr.ini_in_det; fr.ini_val = rr.ini_in_val;
+    if (getenv("FRIES_HAM_SHIFT")) { fr.has_ham_shift = true; fr.ham_shift = rr.hf_en; }
     fr.setup();
 }
 

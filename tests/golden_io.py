@@ -102,3 +102,13 @@ def read_piv_cases():
             else:
                 cur["inp"].append(float.fromhex(t[0])); cur["out"].append(float.fromhex(t[1])); cur["flag"].append(int(t[2]))
     return cases
+
+
+def read_text_vector(prefix):
+    """<prefix>dets / <prefix>vals under tests/golden: the reference's text vector format (io_utils.cpp:447-482, 565-586)."""
+    with open(os.path.join(GOLD, prefix + "dets")) as f:
+        dets = np.array([int(t) for t in f.read().split()], dtype=np.int64).astype(np.uint64)
+    with open(os.path.join(GOLD, prefix + "vals")) as f:
+        vals = np.array([float(t) for t in f.read().split()])
+    n = min(dets.size, vals.size)
+    return dets[:n], vals[:n]

@@ -39,6 +39,35 @@ def test_oracle_reproduces_reference_trajectory(oracle, mols, name):
             assert golden_io.vec_hash(d, v) == row["hash"], (name, row["it"])
 
 
+def _extras(r):
+    kw = {}
+    if "trial" in r:
+        kw["trial"] = golden_io.read_text_vector(r["trial"])
+    if "ini" in r:
+        kw["ini"] = golden_io.read_text_vector(r["ini"])
+    if "ham_shift" in r:
+        kw["ham_shift"] = r["ham_shift"]            # the synthetic FCIDUMPs carry no core energy
+    return kw
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["extra_runs"]))
+def test_oracle_driver_options_reproduce_reference(oracle, mols, name):
+    """--trial_vec / --ini_vec (text vectors through the reference's own reader) and --ham_shift: the restatement against the
+    reference's trajectory, bit for bit."""
+    r = golden_io.manifest()["extra_runs"][name]
+    g = golden_io.read_traj(name)
+    orc = oracle.OracleFrisys(mols(r["shape"]), **_run_params(r), **_extras(r))
+    assert orc.p_doub == g["p_doub"] and orc.hf_energy == g["hf_en"]
+    for row in g["rows"]:
+        lg = orc.iterate(1)[0]
+        for f in ("numer", "denom", "norm", "shift"):
+            assert float(lg[f]) == row[f], (name, row["it"], f)
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (name, row["it"], f)
+    d, v = orc.vector()
+    assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"]
+
+
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["full_runs"]))
 def test_oracle_frifull_reproduces_reference(oracle, mols, name):
     """fo::Frifull against what the reference's frifull_mol loop logged (deterministic H application + vector compression)."""

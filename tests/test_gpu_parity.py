@@ -186,6 +186,35 @@ def test_frisys_trajectory_matches_reference_golden(Engine, mols, name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["extra_runs"]))
+def test_frisys_driver_options_match_reference_golden(Engine, mols, name):
+    """--trial_vec (a 25-determinant trial vector: H * trial by full enumeration of every entry), --ini_vec and --ham_shift on
+    the device against the reference's trajectory."""
+    r = golden_io.manifest()["extra_runs"][name]
+    g = golden_io.read_traj(name)
+    kw = {}
+    if "trial" in r:
+        kw["trial"] = golden_io.read_text_vector(r["trial"])
+    if "ini" in r:
+        kw["ini"] = golden_io.read_text_vector(r["ini"])
+    if "ham_shift" in r:
+        kw["ham_shift"] = r["ham_shift"]
+    eng = Engine(mols(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"], **kw)
+    assert eng.p_doub == g["p_doub"]
+    for row in g["rows"]:
+        lg = eng.iterate(1)[0]
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (row["it"], f)
+        assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"]
+        assert abs(lg["numer"] / lg["denom"] - row["numer"] / row["denom"]) < ENERGY_TOL
+        assert abs(lg["denom"] - row["denom"]) <= 1e-12 * abs(row["denom"])
+    d, v = eng.vector()
+    assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"]
+    eng.close()
+
+
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["full_runs"]))
 def test_frifull_trajectory_matches_reference_golden(Engine, mols, name):
     """frifull_mol on the device (vector compression, then every single and double excitation of every determinant merged in
@@ -607,3 +636,34 @@ def test_cpp_facade_operator_level_loop(mols, tmp_path):
     fcidump.write_fcidump(fc, mol)
     res = subprocess.run([build.FACADE_TEST, fc, mol.point_group, "30"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "fails=0" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
+
+
+def test_cli_driver_text_vectors_and_ham_shift(mols, tmp_path):
+    """frisys_mol_hip --trial_vec / --ini_vec read the reference's text vector files; --ham_shift: the written files against the
+    reference's trajectories."""
+    import subprocess
+    from fries_amd import build
+    for name in sorted(golden_io.manifest()["extra_runs"]):
+        r = golden_io.manifest()["extra_runs"][name]
+        g = golden_io.read_traj(name)
+        mol = mols(r["shape"])
+        fc = str(tmp_path / (name + ".FCIDUMP"))
+        fcidump.write_fcidump(fc, mol)
+        out = str(tmp_path / name) + "/"
+        os.makedirs(out)
+        n_it = 20
+        cmd = [build.DRIVER, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--vec_nonz", str(r["vec_nonz"]),
+               "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--initiator", repr(r["initiator"]),
+               "--epsilon", repr(r["epsilon"]), "--max_iter", str(n_it), "--result_dir", out, "--seed", str(r["seed"])]
+        if "trial" in r:
+            cmd += ["--trial_vec", os.path.join(golden_io.GOLD, r["trial"])]
+        if "ini" in r:
+            cmd += ["--ini_vec", os.path.join(golden_io.GOLD, r["ini"])]
+        if "ham_shift" in r:
+            cmd += ["--ham_shift", repr(r["ham_shift"])]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+        num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nk = np.loadtxt(out + "nkept.txt")
+        for i in range(n_it):
+            row = g["rows"][i]
+            assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10 and int(nk[i]) == row["nkept"]
