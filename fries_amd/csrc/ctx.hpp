@@ -148,6 +148,7 @@ struct FriesCtx {
     // HB-PP work arrays
     CompWork W{};
     Fks2Work F2{};
+    uint32_t *fks_sxk8 = nullptr; double *fks_sxg8 = nullptr;
     FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
     unsigned fks_grid = 1280;
     bool warm_start = true;

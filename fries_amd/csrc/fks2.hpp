@@ -42,7 +42,7 @@ struct FksScal {
 // positions persist, so this is a close first guess; any guess converges to the same (unique) consistent assignment.
 struct FksSaved {
     int valid, n_pass;
-    uint32_t n0, nchunk;
+    uint32_t n0, nchunk, nb8;
     double G0;
     double psG[FR_FKS_PMAX];
     uint32_t psN[FR_FKS_PMAX];
@@ -58,6 +58,7 @@ struct Fks2Work {
     uint32_t *hist;                         // [FR_MAX_ROUNDS] changed flag per replay, for the host
     uint32_t *dbg_cnt;                      // [FR_MAX_ROUNDS][4] FRIES_DBG=3 statistics
     FksSaved *saved; uint32_t *wk, *wkx; double *wg, *wgx;     // this stage's warm-start record: saved ck / cg / ckx / cgx
+    uint32_t *sxk8; double *sxg8;           // stage 1 only: the settled per-group prefixes inside the chunks (vector positions persist between iterations)
 };
 #define FR_FKS_CHUNK 2048                   // groups per scan workgroup
 #define FR_FKS_MAXCHUNK 1024
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     const bool warm0 = !final && zp && S.warm;               // replay 0 of a warm start: prefixes from the saved chunk totals
     const int vup = S.valid_upto;
     const unsigned n_chunk_saved = warm0 ? F.saved->nchunk : 0u;
+    const unsigned saved_nb8 = warm0 ? F.saved->nb8 : 0u;
     const double wsc = S.warm_scale;
     uint32_t *const dk8 = F.dk8[it & 1];
     double *const dg8 = F.dg8[it & 1], *const ws8 = F.ws8[it & 1];
@@ -232,7 +234,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         auto prefix = [&](int p, double *xg, uint32_t *xk) {
             *xg = 0.0; *xk = 0u;
             if (warm0) {        // previous iteration's chunk profile, linear inside the chunk
-                if (my_chunk < n_chunk_saved) {
+                if (F.sxk8 && b < saved_nb8 && my_chunk < n_chunk_saved) {       // stage 1: the same elements sat in this group last time
+                    const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
+                    *xg = (F.wgx[cx] + F.sxg8[(size_t)p * stride + b]) * wsc;
+                    *xk = F.wkx[cx] + F.sxk8[(size_t)p * stride + b];
+                }
+                else if (my_chunk < n_chunk_saved) {
                     const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
                     *xg = (F.wgx[cx] + F.wg[cx] * chunk_frac) * wsc;
                     *xk = F.wkx[cx] + (uint32_t)((double)F.wk[cx] * chunk_frac);
@@ -485,8 +492,21 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
         }
     if (threadIdx.x == 0) {
         FksSaved *V = F.saved;
-        V->n_pass = n_pass; V->n0 = S->n0; V->nchunk = nchunk; V->G0 = S->psG[0];
+        V->n_pass = n_pass; V->n0 = S->n0; V->nchunk = nchunk; V->nb8 = nb8; V->G0 = S->psG[0];
         for (int p = 0; p < n_pass; p++) { V->psG[p] = S->psG[p]; V->psN[p] = S->psN[p]; }
         V->valid = (S->overflow || !(S->psG[0] > 0)) ? 0 : 1;
     }
+}
+
+// stage 1: keeps the settled replay's per-group prefixes for the next iteration's first replay
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save_groups(Fks2Work F) {
+    const FksScal *S = F.scal;
+    const unsigned nb8 = S->n_in / 8 + 1;
+    const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
+    const size_t stride = F.nb8_cap;
+    for (int p = blockIdx.y; p < n_pass; p += gridDim.y)
+        for (unsigned b = blockIdx.x * blockDim.x + threadIdx.x; b < nb8; b += gridDim.x * blockDim.x) {
+            F.sxk8[(size_t)p * stride + b] = F.xk8[(size_t)p * stride + b];
+            F.sxg8[(size_t)p * stride + b] = F.xg8[(size_t)p * stride + b];
+        }
 }

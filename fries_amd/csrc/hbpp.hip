@@ -290,6 +290,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         FR_HIP(hipMemset(F.hist, 0, 4 * (FR_MAX_ROUNDS + 2)));
         F.dbg_cnt = fr_alloc<uint32_t>((size_t)FR_MAX_ROUNDS * 4);
         FR_HIP(hipMemset(F.dbg_cnt, 0, (size_t)FR_MAX_ROUNDS * 16));
+        c->fks_sxk8 = fr_alloc<uint32_t>(n8); c->fks_sxg8 = fr_alloc<double>(n8);
         c->fks_saved = fr_alloc<FksSaved>(8);
         FR_HIP(hipMemset(c->fks_saved, 0, 8 * sizeof(FksSaved)));
         c->fks_wk = fr_alloc<uint32_t>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK); c->fks_wg = fr_alloc<double>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK);
@@ -354,6 +355,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     Fks2Work F = c->F2;
     F.saved = c->fks_saved + STAGE; F.wk = c->fks_wk + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wg = c->fks_wg + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
     F.wkx = c->fks_wkx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wgx = c->fks_wgx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
+    F.sxk8 = (STAGE == 1 && !getenv("FRIES_NO_GROUP_WARM")) ? c->fks_sxk8 : nullptr; F.sxg8 = F.sxk8 ? c->fks_sxg8 : nullptr;
     const int warm = c->warm_start ? 1 : 0;
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
     if (gridE > c->fks_grid) gridE = c->fks_grid;          // persistent workgroups (5 per CU), each strides over the tiles
@@ -407,6 +409,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
     FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
+    if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_PMAX), dim3(FR_BLOCK), F);
     // settled: recompute every wt_remain with the budget of its last flagged sweep
     FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
     AccWt acc{W.wt_remain, &W.state[0]};
