@@ -158,6 +158,26 @@ def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
     assert golden_io.vec_hash(d, v) == rows[-1][8]
 
 
+@pytest.mark.parametrize("dist", ["NU", "HB"])
+def test_fciqmc_counter_stream_is_statistically_the_reference_stream(oracle, mols, dist):
+    """the counter-based uniform stream the GPU replays cannot reproduce the reference's mt19937
+    trajectory, so besides the function-level and lockstep pins the two streams must agree in distribution: projected energies
+    (ratio of time-averaged numerator and denominator after equilibration) over independent seeds, within four standard errors."""
+    import numpy as np
+    mol = mols("Ne")
+
+    def energy(seed, counter):
+        o = oracle.OracleFciqmc(mol, epsilon=0.02, target_walkers=4000, max_dets=60000, initiator=0, seed=seed, counter_rng=counter, distribution=dist)
+        lg = o.iterate(2000)
+        return float(np.sum(lg["numer"][1000:]) / np.sum(lg["denom"][1000:]))
+
+    a = np.array([energy(s, False) for s in range(1, 8)])
+    b = np.array([energy(s, True) for s in range(1, 8)])
+    se = np.sqrt(a.var(ddof=1) / a.size + b.var(ddof=1) / b.size)
+    assert abs(a.mean() - b.mean()) < 4 * se, (a.mean(), b.mean(), se)
+    assert se < 5e-4 and abs(a.mean() - b.mean()) < 1e-3
+
+
 def _hh_params(r):
     return dict(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
                 vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
