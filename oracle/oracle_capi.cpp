@@ -149,6 +149,52 @@ void fo_compress_vec(void *h, uint32_t n_samp, double rn, uint32_t *n_kept, doub
     if (n_kept) *n_kept = n_samp - ns;
     if (glob_norm) *glob_norm = gn;
 }
+// sum over every symmetry-allowed double excitation of `det` of calc_norm_wt (heat_bathPP.cpp:413-481): the probability
+// hb_doub_multi assigns to it.  What is missing from 1 is the mass of draws it rejects (an occupied second virtual).
+double fo_norm_wt_sum(void *h, uint64_t det, uint32_t *n_doub) {
+    Frisys *f = (Frisys *)h;
+    uint8_t occ[64];
+    occ_list(det, occ);
+    std::vector<uint8_t> ex;
+    size_t nd = doub_ex_symm(det, occ, f->sys.n_elec, f->sys.n_orb, ex, f->sys.symm.irrep.data());
+    double tot = 0;
+    for (size_t e = 0; e < nd; e++) tot += calc_norm_wt(f->sys.hb, &ex[4 * e], occ, f->sys.n_elec, det, f->sys.symm);
+    if (n_doub) *n_doub = (uint32_t)nd;
+    return tot;
+}
+// n_draws heat-bath double excitations of `det` (hb_doub_multi on the reference's mt19937 stream, 32 per call): how often each
+// symmetry-allowed double came out, the probability calc_norm_wt reported for it, and the probability listed for excitation k
+// of the enumeration.  Returns the number of accepted draws.
+uint64_t fo_hb_sample_hist(void *h, uint64_t det, uint64_t n_draws, uint32_t seed, uint64_t *counts, double *reported, double *listed, size_t cap) {
+    Frisys *f = (Frisys *)h;
+    uint8_t occ[64];
+    occ_list(det, occ);
+    std::vector<uint8_t> ex;
+    size_t nd = doub_ex_symm(det, occ, f->sys.n_elec, f->sys.n_orb, ex, f->sys.symm.irrep.data());
+    if (cap < nd) return 0;
+    std::unordered_map<uint32_t, size_t> where;
+    for (size_t e = 0; e < nd; e++) {
+        uint32_t key; memcpy(&key, &ex[4 * e], 4);
+        where[key] = e;
+        counts[e] = 0; reported[e] = 0;
+        listed[e] = calc_norm_wt(f->sys.hb, &ex[4 * e], occ, f->sys.n_elec, det, f->sys.symm);
+    }
+    std::mt19937 g(seed);
+    Rng rng; rng.mt = &g;
+    uint64_t accepted = 0;
+    uint8_t orbs[32 * 4]; double prob[32]; uint32_t att[32];
+    for (uint64_t done = 0; done < n_draws; done += 32) {
+        unsigned got = hb_doub_multi(det, occ, f->sys.n_elec, f->sys.symm, f->sys.hb, 32, rng, 0, orbs, prob, att);
+        for (unsigned k = 0; k < got; k++) {
+            uint32_t key; memcpy(&key, &orbs[4 * k], 4);
+            auto it = where.find(key);
+            if (it == where.end()) return ~(uint64_t)0;        // a draw outside the enumeration
+            counts[it->second]++; reported[it->second] = prob[k];
+        }
+        accepted += got;
+    }
+    return accepted;
+}
 // frifull_mol (fo::Frifull)
 void *fo_frifull_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                         double eps, double target, uint32_t vec_nonz, uint32_t max_dets, uint32_t seed) {

@@ -178,6 +178,31 @@ def test_fciqmc_counter_stream_is_statistically_the_reference_stream(oracle, mol
     assert se < 5e-4 and abs(a.mean() - b.mean()) < 1e-3
 
 
+def test_heat_bath_probabilities_are_the_sampling_frequencies(oracle, mols):
+    """the probability calc_norm_wt reports for a heat-bath double excitation (heat_bathPP.cpp:413-481) is the
+    frequency with which hb_doub_multi draws it; the accepted fraction is the listed total (the rest is draws it rejects)."""
+    import ctypes as C
+    import numpy as np
+    lib = oracle.load()
+    lib.fo_hb_sample_hist.restype = C.c_uint64
+    lib.fo_hb_sample_hist.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    mol = mols("Ne")
+    orc = oracle.OracleFrisys(mol, epsilon=0.01, vec_nonz=10, mat_nonz=10, max_dets=100, seed=1, distribution="HB")
+    hd, _ = orc.htrial()
+    n = 400000
+    for det in (int(hd[0]), int(hd[7])):
+        cnt = np.zeros(4096, dtype=np.uint64); rep = np.zeros(4096); lst = np.zeros(4096)
+        acc = lib.fo_hb_sample_hist(orc.h, det, n, 17, cnt.ctypes.data, rep.ctypes.data, lst.ctypes.data, cnt.size)
+        assert 0 < acc <= n
+        k = int(np.flatnonzero(lst > 0)[-1]) + 1
+        p, c = lst[:k], cnt[:k].astype(float)
+        assert np.all((rep[:k] == 0) | (rep[:k] == p))                      # what a draw reports is the listed probability, bit for bit
+        assert abs(acc / n - p.sum()) < 5 * np.sqrt(p.sum() * (1 - p.sum()) / n)
+        z = (c / n - p) / np.sqrt(np.maximum(p * (1 - p), 1e-300) / n)
+        assert np.max(np.abs(z)) < 5.5, float(np.max(np.abs(z)))
+        assert abs(np.mean(z ** 2) - 1) < 0.25                              # chi-square per bin ~ 1
+
+
 def _hh_params(r):
     return dict(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
                 vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
