@@ -379,22 +379,99 @@ __global__ void __launch_bounds__(FR_BLOCK) k_piv_tail(VecDev V, VcompBuf B, Piv
 
 void fr_unkept_norm(FriesCtx *c, uint32_t bound);      // compress.hip
 
-// compress_utils.cpp:552-604 with one rank (the scatter is the identity); draws from mt only if samples are left over
-static uint32_t piv_budget_one_rank(double loc_norm, uint32_t n_samp) {
-    double glob = 0;
-    glob += loc_norm;
-    uint32_t budget = loc_norm / glob * n_samp;
-    uint32_t tot = budget;
-    double frac = loc_norm - budget * glob / n_samp;
-    if (frac < 1e-12) frac = 0;
-    uint32_t n_frac = frac > 0 ? 1 : 0;
-    if (n_frac == n_samp - tot) { if (frac > 0) budget++; tot = n_samp; }
-    if (tot < n_samp) throw FriesError("pivotal budgeting left samples unassigned on a single rank");
-    return budget;
+// piv_samp_serial (compress_utils.cpp:389-518) on the host, for the handful of fractional rank weights piv_budget samples
+// from (one per rank): the same sequence of operations on plain arrays.
+static void piv_samp_host(std::vector<double> &vals, double seg_norm, uint32_t n_samp, std::vector<uint8_t> &flag, std::mt19937 &mt) {
+    const size_t len = vals.size();
+    if (n_samp == 0) {
+        for (size_t i = 0; i < len; i++) { if (flag[i]) flag[i] = 0; else vals[i] = 0; if (vals[i] == 0) flag[i] = 1; }
+        return;
+    }
+    const double unit = seg_norm / n_samp;
+    std::vector<double> wt(len + 2);
+    wt[0] = 0;
+    size_t pos = 0, resid = 0;
+    uint32_t n_done = 0;
+    auto sgn_unit = [unit](double v) { return unit * ((v > 0) - (v < 0)); };
+    while (pos < len && n_done < n_samp) {
+        size_t n_wt = 1, used = 0;
+        double cum = wt[0];
+        for (; cum < unit && pos + used < len; used++)
+            if (!flag[pos + used]) { wt[n_wt] = fabs(vals[pos + used]); cum += wt[n_wt]; n_wt++; }
+        const bool at_end = pos + used == len;
+        size_t n_inner = used > 0 ? used - 1 : 0;
+        if (at_end) n_inner++;
+        const double over = cum - unit;
+        if (!at_end) { n_wt--; cum -= wt[n_wt]; }
+        const double under = unit - cum;
+        double r = mt() / (1. + UINT32_MAX) * cum;
+        double run = 0;
+        size_t H = 0;
+        while (run < r && H < n_wt) { run += wt[H]; H++; }
+        if (r > 0) H--;
+        if (H != 0 && pos != 0) { vals[resid] = 0; flag[resid] = 1; }
+        double p_pass = under / (unit - over);
+        if (at_end) p_pass = 0;
+        r = mt() / (1. + UINT32_MAX);
+        size_t k = 1;
+        if (r < p_pass) {
+            for (size_t o = 0; o < n_inner; o++) {
+                if (!flag[pos + o]) { if (k == H) resid = pos + o; else { vals[pos + o] = 0; flag[pos + o] = 1; } k++; }
+                else flag[pos + o] = 0;
+            }
+            vals[pos + n_inner] = sgn_unit(vals[pos + n_inner]);
+        }
+        else {
+            if (H == 0) vals[resid] = sgn_unit(vals[resid]);
+            for (size_t o = 0; o < n_inner; o++) {
+                if (!flag[pos + o]) { if (k != H) { vals[pos + o] = 0; flag[pos + o] = 1; } else vals[pos + o] = sgn_unit(vals[pos + o]); k++; }
+                else flag[pos + o] = 0;
+            }
+            resid = pos + n_inner;
+        }
+        pos += n_inner + 1;
+        wt[0] = over;
+        n_done++;
+    }
+    for (; pos < len; pos++) { if (!flag[pos]) { vals[pos] = 0; flag[pos] = 1; } else flag[pos] = 0; }
+    if (resid < len) { vals[resid] = 0; flag[resid] = 1; }
+}
+
+// piv_budget (compress_utils.cpp:552-604): rank 0 apportions the n_samp samples among the ranks from their remaining norms --
+// the integer parts of the shares, then one more for the ranks a pivotal draw over the fractional parts selects (its generator
+// alone advances) -- and scatters them; here the scatter is an all-gather of rank 0's table.
+static uint32_t piv_budget(FriesCtx *c, const std::vector<double> &norms, uint32_t n_samp) {
+    const int P = c->n_ranks;
+    std::vector<uint32_t> budgets(P, 0);
+    if (c->rank == 0) {
+        double glob = 0;
+        for (int p = 0; p < P; p++) glob += norms[p];
+        uint32_t tot = 0, n_frac = 0;
+        std::vector<double> frac(P);
+        for (int p = 0; p < P; p++) {
+            budgets[p] = norms[p] / glob * n_samp;
+            tot += budgets[p];
+            frac[p] = norms[p] - budgets[p] * glob / n_samp;
+            if (frac[p] < 1e-12) frac[p] = 0;
+            if (frac[p] > 0) n_frac++;
+        }
+        if (n_frac == n_samp - tot) { for (int p = 0; p < P; p++) if (frac[p] > 0) budgets[p]++; tot = n_samp; }
+        if (tot < n_samp) {
+            std::vector<uint8_t> none(P, 0);
+            piv_samp_host(frac, glob * (n_samp - tot) / n_samp, n_samp - tot, none, c->mt);
+            for (int p = 0; p < P; p++) if (frac[p] > 0) budgets[p]++;
+        }
+    }
+    if (!c->use_comm) return budgets[0];
+    FR_HIP(hipMemcpyAsync(c->comm.small_send, budgets.data(), 4 * (size_t)P, hipMemcpyHostToDevice, c->stream));
+    const void *all = fr_allgather(c, 4 * (size_t)P);
+    std::vector<uint32_t> got(P);
+    FR_HIP(hipMemcpyAsync(got.data(), all, 4 * (size_t)P, hipMemcpyDeviceToHost, c->stream));      // rank 0's block
+    FR_HIP(hipStreamSynchronize(c->stream));
+    return got[c->rank];
 }
 
 void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *glob_norm_out) {
-    if (c->n_ranks > 1) throw FriesError("pivotal compression is built for one rank in this version");
     VcompBuf &B = c->vc;
     hipStream_t st = c->stream;
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
@@ -417,12 +494,20 @@ void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *
         FR_HIP(hipMemcpyAsync(&mine, B.seq.total, 8, hipMemcpyDeviceToHost, st));
         FR_HIP(hipStreamSynchronize(st));
     }
+    // every rank's remaining norm, then their sum in rank order (compress_utils.cpp:366-371)
+    std::vector<double> norms(c->n_ranks, mine);
+    if (c->use_comm) {
+        FR_HIP(hipMemcpyAsync(c->comm.small_send, &mine, 8, hipMemcpyHostToDevice, st));
+        const void *all = fr_allgather(c, 8);
+        FR_HIP(hipMemcpyAsync(norms.data(), all, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+    }
     double glob = 0;
-    glob += mine;                                       // compress_utils.cpp:368-371
+    for (int p = 0; p < c->n_ranks; p++) glob += norms[p];
     uint32_t loc_samp = 0;
     double new_norm = 0;
     if (n_samp != 0) {
-        loc_samp = piv_budget_one_rank(mine, n_samp);
+        loc_samp = piv_budget(c, norms, n_samp);
         // adjust_probs (:606-681)
         const double exp_loc = n_samp * mine / glob;
         const double top = ceill(exp_loc);

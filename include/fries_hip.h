@@ -200,7 +200,8 @@ int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_k
 
 /* compress_vecs with one vector (FRIES/vec_utils.cpp:9-32): piv_comp_parallel on column 0 -- find_preserve,
  * piv_budget, adjust_probs, piv_samp_serial (compress_utils.cpp:354-681) -- then the deletes.  The uniforms are the
- * context's mt19937 stream (the generator the reference's caller passes in), two per sampling unit.  One rank. */
+ * context's mt19937 stream (the generator the reference's caller passes in), two per sampling unit.  With ranks: a collective
+ * call (two all-gathers); rank 0's generator also serves piv_budget. */
 int fries_compress_vec_piv(fries_ctx *ctx, uint32_t n_samp, uint32_t *n_kept, double *glob_norm);
 /* how many fries_compress_vec_piv calls were settled by the parallel, certified cut-point search and how many fell back to the
  * sequential one (csrc/pivotal.hip); FRIES_PIV_CHAIN=1 in the environment forces the sequential search */

@@ -319,6 +319,22 @@ int fo_ranks_iterate(void *h, uint32_t n, OracleLog *logs) {
     } catch (std::exception &e) { fprintf(stderr, "fo_ranks_iterate: %s\n", e.what()); return 1; }
     return 0;
 }
+// compress_vecs with one vector on every rank (piv_comp_parallel over the communicator, then the deletes); each rank draws from its own generator
+int fo_ranks_compress_piv(void *h, uint32_t n_samp) {
+    OracleRanks *R = (OracleRanks *)h;
+    int P = (int)R->fr.size();
+    try {
+        run_ranks(P, [&](const Comm &c) {
+            Frisys &f = *R->fr[c.rank];
+            f.cm = c; f.sol.cm = c;
+            Vec &v = f.sol;
+            if (f.srt.size() < v.max_size) { f.srt.resize(v.max_size); f.keep.resize(v.max_size, 0); }
+            piv_comp_parallel(v.vals[0].data(), v.curr_size, n_samp, f.srt, f.keep, f.mt, c);
+            for (size_t i = 0; i < v.curr_size; i++) if (f.keep[i]) { v.del_at_pos(i); f.keep[i] = 0; }
+        });
+    } catch (std::exception &e) { fprintf(stderr, "fo_ranks_compress_piv: %s\n", e.what()); return 1; }
+    return 0;
+}
 void *fo_ranks_get(void *h, uint32_t rank) { return ((OracleRanks *)h)->fr[rank].get(); }   // a Frisys* for fo_frisys_vec etc.
 int fo_ranks_hf_proc(void *h) { return ((OracleRanks *)h)->fr[0]->hf_proc; }
 int fo_idx_to_proc(void *h, uint64_t det) { return ((Frisys *)h)->sol.idx_to_proc(det); }

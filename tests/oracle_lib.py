@@ -73,6 +73,7 @@ def load():
         lib.fo_ranks_create.argtypes = [C.c_uint32] + lib.fo_frisys_create.argtypes
         lib.fo_ranks_destroy.argtypes = [C.c_void_p]
         lib.fo_ranks_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_ranks_compress_piv.argtypes = [C.c_void_p, C.c_uint32]
         lib.fo_ranks_get.restype = C.c_void_p
         lib.fo_ranks_get.argtypes = [C.c_void_p, C.c_uint32]
         lib.fo_ranks_hf_proc.argtypes = [C.c_void_p]
@@ -271,6 +272,15 @@ class OracleRanks:
         if self.lib.fo_ranks_iterate(self.h, n, _p(logs)):
             raise RuntimeError("oracle ranks failed")
         return logs
+
+    def restart(self, seed):
+        """every rank's generator re-seeded (and shift / iteration counters reset), like FriEngine.restart on every rank"""
+        for r in range(self.n_ranks):
+            self.lib.fo_frisys_restart(self._rank(r), seed, 0.0, 0.0, 0)
+
+    def compress_piv(self, n_samp):
+        if self.lib.fo_ranks_compress_piv(self.h, n_samp):
+            raise RuntimeError("oracle ranks: pivotal compression failed")
 
     @property
     def hf_proc(self):

@@ -81,6 +81,26 @@ def main():
     d, v = eng.vector()
     if not res["fails"] and golden_io.vec_hash(d, v) != rows[-1]["hash"]:
         res["fails"].append(("digest",))
+    # optionally: pivotal compression of the sharded vector (piv_comp_parallel over the ranks) against the in-process rank oracle
+    piv_budget = int(os.environ.get("FRIES_RANKS_PIV", "0"))
+    if piv_budget and not hh and not res["fails"]:
+        import oracle_lib
+        orc = oracle_lib.OracleRanks(world, mol, epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"],
+                                     target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+        orc.iterate(len(rows))
+        od0, ov0 = orc.vector(rank)
+        if not (np.array_equal(ov0, v) and np.array_equal(od0[ov0 != 0], d[v != 0])):
+            res["fails"].append(("oracle ranks differ before the compression",))
+        eng.restart(4242)
+        orc.restart(4242)
+        eng.compress_vec_piv(piv_budget)
+        orc.compress_piv(piv_budget)
+        d2, v2 = eng.vector()
+        od, ov = orc.vector(rank)
+        if not np.array_equal(ov, v2):
+            res["fails"].append(("pivotal compression", int(np.sum(ov != v2)), int(np.count_nonzero(v2)), int(np.count_nonzero(ov))))
+        res["piv_nonzero"] = int(np.count_nonzero(v2))
+        res["piv_stats"] = list(eng.piv_stats())
     res["ok"] = not res["fails"]
     res["n_allgather"] = comm.n_allgather; res["n_alltoallv"] = comm.n_alltoallv; res["iters"] = len(rows)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:

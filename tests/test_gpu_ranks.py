@@ -72,3 +72,25 @@ def test_one_rank_communicator_over_rccl(tmp_path):
     rep = json.loads(fn.read_text())
     assert rep["ok"], rep["fails"]
     assert rep["n_alltoallv"] == rep["iters"] and rep["n_allgather"] > 10 * rep["iters"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,budget", [("n2_m10000_unnorm_p2", 3000), ("h2o_m5000_hb_p3", 1500)])
+def test_pivotal_compression_over_ranks(name, budget, tmp_path):
+    """compress_vecs over a sharded vector (piv_comp_parallel with piv_budget apportioning the samples among the ranks,
+    adjust_probs re-weighting each shard, per-rank pivotal sampling) against the in-process rank oracle, shard by shard."""
+    r = golden_io.manifest()["mpi_runs"][name]
+    P = r["n_ranks"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", FRIES_RANKS_PIV=str(budget))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "gloo", str(tmp_path), "12"]
+    res = _run_ranks(cmd, env, 300)
+    total = 0
+    for k in range(P):
+        fn = tmp_path / f"rank{k}.json"
+        assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+        rep = json.loads(fn.read_text())
+        assert rep["ok"], rep["fails"]
+        total += rep["piv_nonzero"]
+    assert 0 < total <= budget
+    assert res.returncode == 0, res.stderr[-4000:]
