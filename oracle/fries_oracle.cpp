@@ -2137,35 +2137,43 @@ void Fciqmc::setup() {
     hf_det = gen_hf_det(n_orb, n_elec);
     occ_list(hf_det, tmp);
     sys.hf_en = diag_matrel(tmp, sys.ints, n_elec);
-    mt.seed(par.seed);
-    proc_scr.resize(2 * n_orb); vec_scr.resize(2 * n_orb);
-    for (auto &x : proc_scr) x = mt();     // fciqmc_mol.cpp:126-128
+    mt.seed(par.seed + (uint32_t)cm.rank);          // fciqmc_mol.cpp:102-104: one generator per process
+    proc_scr.assign(2 * n_orb, 0); vec_scr.resize(2 * n_orb);
+    if (cm.rank == 0) for (auto &x : proc_scr) x = mt();     // :123-131, then MPI_Bcast
+    if (cm.size > 1) {
+        std::vector<uint32_t> all((size_t)cm.size * 2 * n_orb);
+        cm.allgather(proc_scr.data(), all.data(), sizeof(uint32_t) * 2 * n_orb);
+        std::copy(all.begin(), all.begin() + 2 * n_orb, proc_scr.begin());
+    }
     for (auto &x : vec_scr) x = mt();      // :134-136
     if (par.counter_rng) { rng.mt = nullptr; rng.seed = par.seed; } else rng.mt = &mt;
-    unsigned spawn_length = par.target_walkers * 2;      // / n_procs^2, one rank (:107)
-    sol.init(par.max_dets, spawn_length, n_elec, 1);
-    // trial = HF, H trial by enumeration (:148-191), as in frisys_mol
+    unsigned spawn_length = par.target_walkers / cm.size / cm.size * 2;      // :107
+    sol.init(par.max_dets, spawn_length, n_elec, 1, cm, proc_scr.data());
+    hf_proc = sol.idx_to_proc(hf_det);
+    // trial = HF, H trial by enumeration on the rank that owns HF, then replicated (:148-191), as in frisys_mol
     trial_det = {hf_det}; trial_val = {1.0};
     {
         size_t n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
-        Vec ht; ht.init(2 * n_ex, 2 * n_ex, n_elec, 2);
-        ht.add(hf_det, 1, 1); ht.perform_add(0);
+        Vec ht; ht.init(2 * n_ex, 2 * n_ex, n_elec, 2, cm, proc_scr.data());
+        if (cm.rank == hf_proc) ht.add(hf_det, 1, 1);
+        ht.perform_add(0);
         std::vector<uint8_t> ex;
         ht.cur = 1;
+        double cur_el = cm.rank == hf_proc ? ht.vals[0][0] : 0;
         size_t n_sing = sing_ex_symm(hf_det, tmp, n_elec, n_orb, ex, sys.symm.irrep.data());
-        for (size_t e = 0; e < n_sing; e++) {
+        for (size_t e = 0; e < n_sing && cm.rank == hf_proc; e++) {
             double m = sing_matrel_nosgn(&ex[2 * e], tmp, sys.ints, n_elec);
             det_t nd = hf_det;
             m *= sing_det_parity(&nd, &ex[2 * e]);
-            ht.add(nd, m * 1.0, 1);
+            ht.add(nd, m * cur_el * 1.0, 1);
         }
         ht.perform_add(0);
         size_t n_doub = doub_ex_symm(hf_det, tmp, n_elec, n_orb, ex, sys.symm.irrep.data());
-        for (size_t e = 0; e < n_doub; e++) {
+        for (size_t e = 0; e < n_doub && cm.rank == hf_proc; e++) {
             double m = doub_matrel_nosgn(&ex[4 * e], sys.ints);
             det_t nd = hf_det;
             m *= doub_det_parity(&nd, &ex[4 * e]);
-            ht.add(nd, m * 1.0, 1);
+            ht.add(nd, m * cur_el * 1.0, 1);
         }
         ht.perform_add(0);
         for (size_t i = 0; i < ht.curr_size; i++) {
@@ -2173,17 +2181,27 @@ void Fciqmc::setup() {
             if (cv != 0) ht.vals[0][i] = cv * (diag_matrel(ht.orbs_at(i), sys.ints, n_elec) - sys.hf_en);
         }
         ht.add_vecs(0, 1);
-        htrial_det.assign(ht.dets.begin(), ht.dets.begin() + ht.curr_size);
-        htrial_val.assign(ht.vals[0].begin(), ht.vals[0].begin() + ht.curr_size);
+        // collect_procs (vec_utils.hpp:920-952): every rank ends with all shards, concatenated in rank order
+        std::vector<std::vector<uint8_t>> snd(cm.size), rcv;
+        size_t n = ht.curr_size;
+        std::vector<uint8_t> mine(n * 16);
+        if (n) { memcpy(mine.data(), ht.dets.data(), n * 8); memcpy(mine.data() + n * 8, ht.vals[0].data(), n * 8); }
+        for (int d = 0; d < cm.size; d++) snd[d] = mine;
+        if (cm.size == 1) rcv = snd; else cm.alltoallv(snd, rcv);
+        htrial_det.clear(); htrial_val.clear();
+        for (int sr = 0; sr < cm.size; sr++) {
+            size_t k = rcv[sr].size() / 16, o = htrial_det.size();
+            htrial_det.resize(o + k); htrial_val.resize(o + k);
+            if (k) { memcpy(&htrial_det[o], rcv[sr].data(), k * 8); memcpy(&htrial_val[o], rcv[sr].data() + k * 8, k * 8); }
+        }
         size_t n_sing2 = count_singex(hf_det, tmp, n_elec, sys.symm);
         p_doub = (double)n_doub / (n_sing2 + n_doub);
     }
-    sol.add(hf_det, 100, 1);      // :239-243
+    if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);      // :239-243
     sol.perform_add(0);
     if (par.heat_bath) sys.hb.set_up(sys.ints);       // :310-313
     en_shift = 0; last_norm = 0; iterat = 0;
 }
-
 void Fciqmc::iterate(unsigned n_iter) {
     const unsigned n_elec = sys.n_elec;
     const double eps = par.eps;
@@ -2263,11 +2281,19 @@ void Fciqmc::iterate(unsigned n_iter) {
         sol.perform_add(0);
         double glob_norm = 0;
         if ((iterat + 1) % shift_interval == 0) {          // :415-427
-            glob_norm = sol.local_norm();
+            glob_norm = cm.sum(sol.local_norm());
             adjust_shift(&en_shift, glob_norm, &last_norm, par.target_walkers, shift_damping / eps / shift_interval);
+            (void)cm.sum(n_nonz);                          // glob_nnonz (:422)
         }
         lg.numer = sol.dot(htrial_det, htrial_val);
         lg.denom = sol.dot(trial_det, trial_val);
+        if (cm.size > 1) {                                  // MPI_Gather to the rank that owns HF, added up in rank order (:433-441)
+            std::vector<double> all(2 * (size_t)cm.size);
+            double mine2[2] = {lg.numer, lg.denom};
+            cm.allgather(mine2, all.data(), 16);
+            lg.numer = 0; lg.denom = 0;
+            for (int q = 0; q < cm.size; q++) { lg.numer += all[2 * q]; lg.denom += all[2 * q + 1]; }
+        }
         lg.shift = en_shift; lg.norm = glob_norm; lg.n_nonz = n_nonz; lg.n_ini = n_ini; lg.curr_size = sol.curr_size; lg.n_spawn = n_spawn;
         log.push_back(lg);
     }

@@ -389,7 +389,8 @@ struct FciqmcParams {
     bool heat_bath = false;         // --distribution HB (hb_doub_multi for the doubles) instead of NU
 };
 struct FciqmcLog { double numer, denom, shift, norm; int n_nonz; uint32_t n_ini; size_t curr_size, n_spawn; };
-// FRIES_bin/fciqmc_mol.cpp:35-480, --distribution NU, HF trial vector, HF start, one rank
+// FRIES_bin/fciqmc_mol.cpp:35-480, HF trial vector, HF start; numer / denom are the rank-ordered sums every rank would see on
+// the rank that owns HF (:433-441), n_nonz / n_ini are this rank's (:329-340), norm the global walker number (:417)
 struct Fciqmc {
     MolSys sys;
     FciqmcParams par;
@@ -403,6 +404,8 @@ struct Fciqmc {
     det_t hf_det = 0;
     unsigned iterat = 0;
     std::vector<FciqmcLog> log;
+    Comm cm;                    // ranks: every process seeds its own generator (par.seed + rank), rank 0's scrambler is broadcast
+    int hf_proc = 0;
     void setup();
     void iterate(unsigned n);
 };

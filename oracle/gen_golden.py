@@ -54,6 +54,12 @@ FCIQMC_RUNS = {
     "fciqmc_h2o_hb_ini0": ("H2O", 150, 11, 0.002, 10000, 100000, 0, "HB"),
 }
 
+# fciqmc_mol under mpiexec -n P (one generator per rank, seeded seed + rank): name -> (n_ranks, same tuple as FCIQMC_RUNS)
+FCIQMC_MPI_RUNS = {
+    "fciqmc_n2_p2": (2, ("N2", 150, 9, 0.004, 20000, 100000, 2, "NU")),
+    "fciqmc_h2o_hb_p3": (3, ("H2O", 120, 11, 0.002, 10000, 100000, 0, "HB")),
+}
+
 # frifull_mol (Hamiltonian applied in full), one rank: name -> (shape, n_iter, seed, eps, vec_nonz, max_dets, target)
 FULL_RUNS = {
     "full_ne_m300": ("Ne", 40, 5, 0.01, 300, 400000, 120.0),
@@ -152,6 +158,13 @@ def main():
             out = os.path.join(GOLD, name + ".traj")
             subprocess.run([HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
             manifest["fciqmc_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist)
+        manifest["fciqmc_mpi_runs"] = {}
+        for name, (n_ranks, (shape, n_iter, seed, eps, tw, maxd, ini, dist)) in FCIQMC_MPI_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([MPIEXEC, "-n", str(n_ranks), HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
+            manifest["fciqmc_mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist)
         manifest["full_runs"] = {}
         for name, (shape, n_iter, seed, eps, vnz, maxd, tgt) in FULL_RUNS.items():
             mol = fcidump.synthetic(shape)

@@ -428,4 +428,50 @@ size_t fo_fciqmc_vec(void *h, uint64_t *dets, double *vals, size_t cap) {
 }
 double fo_fciqmc_p_doub(void *h) { return ((Fciqmc *)h)->p_doub; }
 
+// ---- fciqmc_mol on P in-process ranks (the reference under mpiexec -n P: own generator per rank, one all-to-all per iteration)
+struct OracleFqRanks { std::vector<std::unique_ptr<Fciqmc>> fr; };
+void *fo_fqranks_create(uint32_t n_ranks, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                        double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int flags) {
+    OracleFqRanks *R = new OracleFqRanks();
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        Fciqmc *f = new Fciqmc();
+        f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0;
+        f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+        f->sys.ints.n_orb = n_orb;
+        f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+        f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+        f->sys.symm.init(irreps, n_orb);
+        f->par.eps = eps; f->par.target_walkers = target_walkers; f->par.init_thresh = init_thresh; f->par.max_dets = max_dets; f->par.seed = seed;
+        R->fr.emplace_back(f);
+    }
+    try {
+        run_ranks((int)n_ranks, [&](const Comm &c) { Fciqmc &f = *R->fr[c.rank]; f.cm = c; f.setup(); });
+    } catch (std::exception &e) { fprintf(stderr, "fo_fqranks_create: %s\n", e.what()); delete R; return nullptr; }
+    return R;
+}
+void fo_fqranks_destroy(void *h) { delete (OracleFqRanks *)h; }
+// logs: [n_ranks][n] row-major
+int fo_fqranks_iterate(void *h, uint32_t n, FqLog *logs) {
+    OracleFqRanks *R = (OracleFqRanks *)h;
+    int P = (int)R->fr.size();
+    try {
+        run_ranks(P, [&](const Comm &c) {
+            Fciqmc &f = *R->fr[c.rank];
+            f.cm = c; f.sol.cm = c;
+            for (uint32_t i = 0; i < n; i++) {
+                f.iterate(1);
+                if (logs) {
+                    const FciqmcLog &l = f.log.back();
+                    FqLog &o = logs[(size_t)c.rank * n + i];
+                    o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.n_nonz = l.n_nonz;
+                    o.n_ini = l.n_ini; o.curr_size = (uint32_t)l.curr_size; o.n_spawn = (uint32_t)l.n_spawn;
+                }
+            }
+        });
+    } catch (std::exception &e) { fprintf(stderr, "fo_fqranks_iterate: %s\n", e.what()); return 1; }
+    return 0;
+}
+void *fo_fqranks_get(void *h, uint32_t rank) { return ((OracleFqRanks *)h)->fr[rank].get(); }      // a Fciqmc* for fo_fciqmc_vec
+int fo_fqranks_hf_proc(void *h) { return ((OracleFqRanks *)h)->fr[0]->hf_proc; }
+
 }  // extern "C"

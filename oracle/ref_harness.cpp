@@ -1061,6 +1061,9 @@ static int run_fciqmc(int argc, char **argv) {
     double eps = atof(argv[6]); uint32_t target_walkers = strtoul(argv[7], 0, 10);
     uint32_t max_n_dets = strtoul(argv[8], 0, 10); uint32_t init_thresh = strtoul(argv[9], 0, 10);
     const bool heat_bath = argc > 11 && !strcmp(argv[11], "HB");
+    int n_procs = 1, proc_rank = 0;
+    MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
+    MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
     fcidump_input *in_data = parse_fcidump(path, pg);
     unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
     size_t det_size = CEILING(2 * n_orb, 8);
@@ -1071,23 +1074,25 @@ static int run_fciqmc(int argc, char **argv) {
     gen_hf_bitstring(n_orb, n_elec, hf_det);
     find_bits(hf_det, tmp_orbs, det_size);
     double hf_en = diag_matrel(tmp_orbs, tot_orb, *eris, *h_core, n_frz, n_elec);
-    std::mt19937 mt_obj(seed);
-    unsigned spawn_length = target_walkers * 2;
+    std::mt19937 mt_obj(seed + (uint32_t)proc_rank);      // the reference seeds every process from its own clock (fciqmc_mol.cpp:102-104)
+    unsigned spawn_length = target_walkers / n_procs / n_procs * 2;      // :107
     std::function<double(const uint8_t *)> diag_shortcut = [tot_orb, eris, h_core, n_frz, n_elec, hf_en](const uint8_t *occ) { return diag_matrel(occ, tot_orb, *eris, *h_core, n_frz, n_elec) - hf_en; };
     SymmInfo symm_basis(symm, n_orb);
     unsigned unocc_symm_cts[n_irreps][2];
     std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
-    for (auto &x : proc_scrambler) x = mt_obj();
+    if (proc_rank == 0) for (auto &x : proc_scrambler) x = mt_obj();      // :123-131
+    MPI_Bcast(proc_scrambler.data(), 2 * n_orb, MPI_UNSIGNED, 0, MPI_COMM_WORLD);
     for (auto &x : vec_scrambler) x = mt_obj();
-    DistVec<int> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, 1, diag_shortcut, 1, proc_scrambler, vec_scrambler);
+    DistVec<int> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 1, proc_scrambler, vec_scrambler);
+    unsigned hf_proc = sol_vec.idx_to_proc(hf_det);
     unsigned max_spawn = 500000;
     std::vector<uint8_t> spawn_orbs_v(4 * (size_t)max_spawn); std::vector<double> spawn_probs(max_spawn);
     uint8_t (*sing_orbs)[2] = (uint8_t (*)[2])spawn_orbs_v.data();
     uint8_t (*doub_orbs)[4] = (uint8_t (*)[4])spawn_orbs_v.data();
     size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
-    DistVec<double> trial_vec(1, 1, n_orb * 2, n_elec_unf, 1, proc_scrambler, vec_scrambler);
-    DistVec<double> htrial_vec(n_ex, n_ex, n_orb * 2, n_elec_unf, 1, diag_shortcut, 2, proc_scrambler, vec_scrambler);
-    trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1);
+    DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
+    DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
     trial_vec.perform_add(0); htrial_vec.perform_add(0);
     trial_vec.collect_procs();
     std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
@@ -1103,9 +1108,10 @@ static int run_fciqmc(int argc, char **argv) {
     size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, doub_orbs, symm);
     size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
     double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-    sol_vec.add(hf_det, 100, 1);
+    if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
     sol_vec.perform_add(0);
     double en_shift = 0, last_norm = 0, glob_norm = 0;
+    const bool lockstep = n_procs == 1;
 
     fo::Fciqmc fq;
     fq.sys.n_orb = n_orb; fq.sys.n_elec = n_elec;
@@ -1113,11 +1119,11 @@ static int run_fciqmc(int argc, char **argv) {
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
     fq.par.heat_bath = heat_bath;
-    fq.setup();
+    if (lockstep) fq.setup();
     hb_info *hb_probs = heat_bath ? set_up(tot_orb, n_orb, *eris) : NULL;
-    CHECK(same_bits(fq.p_doub, p_doub), "fciqmc p_doub");
+    if (lockstep) CHECK(same_bits(fq.p_doub, p_doub), "fciqmc p_doub");
     // the sampling functions on their own, from identical mt19937 states
-    {
+    if (lockstep) {
         std::mt19937 ga(777 + seed), gb(777 + seed);
         fo::Rng rb; rb.mt = &gb;
         uint8_t occ[64];
@@ -1160,8 +1166,10 @@ static int run_fciqmc(int argc, char **argv) {
             CHECK(round_binomially(pr, nb, ga) == fo::round_binomially(pr, nb, rb), "round_binomially");
         }
     }
-    FILE *f = fopen(argv[10], "w");
-    fprintf(f, "# golden trajectory from the reference (fciqmc_mol.cpp loop, NU, 1 rank); cols: it numer denom norm shift n_nonz n_ini curr_size n_spawn digest\n");
+    std::string out_name(argv[10]);
+    if (n_procs > 1) out_name += ".r" + std::to_string(proc_rank);
+    FILE *f = fopen(out_name.c_str(), "w");
+    fprintf(f, "# golden trajectory from the reference (fciqmc_mol.cpp loop, %d rank(s), hf_proc %u); cols: it numer denom norm shift n_nonz n_ini curr_size n_spawn digest\n", n_procs, hf_proc);
     for (unsigned iterat = 0; iterat < n_iter; iterat++) {
         int n_nonz = 0; size_t n_ini = 0, n_spawn = 0;
         for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
@@ -1213,18 +1221,26 @@ static int run_fciqmc(int argc, char **argv) {
         sol_vec.perform_add(0);
         double norm_out = 0;
         if ((iterat + 1) % 10 == 0) {
-            glob_norm = sol_vec.local_norm();
+            glob_norm = sum_mpi(sol_vec.local_norm(), proc_rank, n_procs);
+            (void)sum_mpi((int)n_nonz, proc_rank, n_procs);      // glob_nnonz for nnonz.txt (:422)
             adjust_shift(&en_shift, glob_norm, &last_norm, target_walkers, 0.05 / eps / 10);
             norm_out = glob_norm;
         }
         double numer = sol_vec.dot(htrial_vec.indices(), htrial_vec.values(), htrial_vec.curr_size(), htrial_hashes);
         double denom = sol_vec.dot(trial_vec.indices(), trial_vec.values(), trial_vec.curr_size(), trial_hashes);
+        if (n_procs > 1) {      // gathered and added up in rank order on the rank that owns HF (:433-441); the others keep their own terms
+            double rn[64], rd[64];
+            MPI_Gather(&numer, 1, MPI_DOUBLE, rn, 1, MPI_DOUBLE, hf_proc, MPI_COMM_WORLD);
+            MPI_Gather(&denom, 1, MPI_DOUBLE, rd, 1, MPI_DOUBLE, hf_proc, MPI_COMM_WORLD);
+            if ((int)hf_proc == proc_rank) { numer = 0; denom = 0; for (int q = 0; q < n_procs; q++) { numer += rn[q]; denom += rd[q]; } }
+        }
         uint64_t hsh = 1469598103934665603ull;
         for (size_t i = 0; i < sol_vec.curr_size(); i++) {
             double rv = sol_vec.values()[i];
             if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol_vec.indices()[i], det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
         }
         fprintf(f, "%u %a %a %a %a %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, norm_out, en_shift, n_nonz, n_ini, (size_t)sol_vec.curr_size(), n_spawn, hsh);
+        if (!lockstep) continue;
         fq.iterate(1);
         const fo::FciqmcLog &lg = fq.log.back();
         CHECK(same_bits(lg.numer, numer) && same_bits(lg.denom, denom), "fciqmc it %u numer/denom %a %a | %a %a", iterat, lg.numer, numer, lg.denom, denom);
@@ -1240,6 +1256,7 @@ static int run_fciqmc(int argc, char **argv) {
         CHECK(bad == 0, "fciqmc it %u vector mismatch in %zu slots", iterat, bad);
     }
     fclose(f);
+    if (n_procs > 1) { if (proc_rank == 0) printf("FCIQMC_MPI ranks=%d iters=%u hf_proc=%u\n", n_procs, n_iter, hf_proc); return 0; }
     printf("FCIQMC iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, sol_vec.n_nonz());
     return n_fail != 0;
 }

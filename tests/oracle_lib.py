@@ -51,6 +51,13 @@ def load():
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_fqranks_create.restype = C.c_void_p
+        lib.fo_fqranks_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        lib.fo_fqranks_destroy.argtypes = [C.c_void_p]
+        lib.fo_fqranks_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_fqranks_get.restype = C.c_void_p
+        lib.fo_fqranks_get.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_fqranks_hf_proc.argtypes = [C.c_void_p]
         lib.fo_frisys_create_ex.restype = C.c_void_p
         lib.fo_frisys_create_ex.argtypes = lib.fo_frisys_create.argtypes + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double]
         lib.fo_frifull_create.restype = C.c_void_p
@@ -407,3 +414,43 @@ def adjust_probs(vals, n_loc, exp_loc, n_tot, tot_norm):
     nl = C.c_uint32(n_loc)
     nn = lib.fo_adjust_probs(v.ctypes.data, v.size, C.byref(nl), exp_loc, n_tot, tot_norm, fl.ctypes.data)
     return v, nl.value, nn, fl
+
+
+class OracleFciqmcRanks:
+    """P in-process ranks of fo::Fciqmc sharing one communicator -- fciqmc_mol under `mpiexec -n P` (a generator per rank, seeded
+    seed + rank in mt mode; the counter stream does not depend on the rank)."""
+
+    def __init__(self, n_ranks, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU"):
+        self.lib = load()
+        self.n_ranks = n_ranks
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.h = self.lib.fo_fqranks_create(n_ranks, mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed,
+                                            int(counter_rng) | (2 if distribution == "HB" else 0))
+        if not self.h:
+            raise RuntimeError("oracle fciqmc ranks: setup failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.fo_fqranks_destroy(self.h)
+            self.h = None
+
+    def iterate(self, n):
+        """-> logs[n_ranks, n]"""
+        logs = np.zeros((self.n_ranks, n), dtype=FQLOG_DTYPE)
+        if self.lib.fo_fqranks_iterate(self.h, n, _p(logs)):
+            raise RuntimeError("oracle fciqmc ranks failed")
+        return logs
+
+    @property
+    def hf_proc(self):
+        return self.lib.fo_fqranks_hf_proc(self.h)
+
+    def vector(self, r):
+        h = self.lib.fo_fqranks_get(self.h, r)
+        n = self.lib.fo_fciqmc_vec(h, None, None, 0)
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        v = np.zeros(max(n, 1))
+        self.lib.fo_fciqmc_vec(h, _p(d), _p(v), d.size)
+        return d[:n], v[:n]

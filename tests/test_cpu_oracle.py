@@ -158,6 +158,41 @@ def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
     assert golden_io.vec_hash(d, v) == rows[-1][8]
 
 
+def _read_fq_rows(name, rank=None):
+    rows = []
+    with open(os.path.join(golden_io.GOLD, name + ".traj" + ("" if rank is None else f".r{rank}"))) as f:
+        for ln in f:
+            if ln.startswith("#"):
+                continue
+            t = ln.split()
+            rows.append((float.fromhex(t[1]), float.fromhex(t[2]), float.fromhex(t[3]), float.fromhex(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[8]), int(t[9], 16)))
+    return rows
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_mpi_runs"]))
+def test_oracle_fciqmc_ranks_reproduce_reference_under_mpiexec(oracle, mols, name):
+    """fciqmc_mol sharded over ranks (a generator per process, one all-to-all of the spawns per iteration, walker totals and
+    projections summed in rank order): every rank of the in-process oracle against what the same rank of the reference logged
+    under mpiexec -- shard sizes, local counts, digests; shift and walker number everywhere; the projected energy on the rank
+    that owns HF (the others keep their own terms in the reference)."""
+    r = golden_io.manifest()["fciqmc_mpi_runs"][name]
+    P = r["n_ranks"]
+    orc = oracle.OracleFciqmcRanks(P, mols(r["shape"]), epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"],
+                                   initiator=r["initiator"], seed=r["seed"], counter_rng=False, distribution=r["distribution"])
+    logs = orc.iterate(r["n_iter"])
+    hf = orc.hf_proc
+    for k in range(P):
+        rows = _read_fq_rows(name, k)
+        for i, row in enumerate(rows):
+            lg = logs[k, i]
+            assert (float(lg["norm"]), float(lg["shift"])) == row[2:4], (name, k, i)
+            assert (int(lg["n_nonz"]), int(lg["n_ini"]), int(lg["curr_size"]), int(lg["n_spawn"])) == row[4:8], (name, k, i)
+            if k == hf:
+                assert (float(lg["numer"]), float(lg["denom"])) == row[:2], (name, k, i)
+        d, v = orc.vector(k)
+        assert golden_io.vec_hash(d, v) == rows[-1][8], (name, k)
+
+
 @pytest.mark.parametrize("dist", ["NU", "HB"])
 def test_fciqmc_counter_stream_is_statistically_the_reference_stream(oracle, mols, dist):
     """the counter-based uniform stream the GPU replays cannot reproduce the reference's mt19937
