@@ -430,7 +430,6 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_norm(VecDev V, double *out) {
 void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
     if (p->max_dets == 0 || p->target_walkers == 0) throw FriesError("max_dets and target_walkers must be positive");
-    if (c->n_ranks > 1) throw FriesError("fciqmc_mol is one rank for now");
     c->fq = *p; c->fq_mode = true;
     c->eps = p->epsilon; c->target_norm = p->target_walkers; c->en_shift = 0; c->last_one_norm = 0; c->iterat = 0;
     c->mt.seed(p->seed);
@@ -438,10 +437,14 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     for (auto &x : c->proc_scr) x = c->mt();        // fciqmc_mol.cpp:126-128
     for (auto &x : c->vec_scr) x = c->mt();         // :134-136
     if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
-    uint32_t spawn_length = p->target_walkers * 2;      // :107 with one rank
-    c->adder_cap = spawn_length;
+    uint32_t spawn_length = p->target_walkers * 2;      // what a rank can spawn and receive; the reference's Adder holds
+    c->adder_cap = p->target_walkers / c->n_ranks / c->n_ranks * 2;      // target / n_procs^2 * 2 per destination (:107)
+    if (!c->d_proc_scr) c->d_proc_scr = fr_alloc<uint32_t>(64);
+    FR_HIP(hipMemcpyAsync(c->d_proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size(), hipMemcpyHostToDevice, c->stream));
+    c->hf_proc = fr_host_idx_to_proc(c, c->hf_det);
     fr_vec_alloc(c, &c->vec, p->max_dets);
     fr_spawn_alloc(c, spawn_length + 4096);
+    fr_xch_alloc(c, spawn_length + 4096);
     fr_vcomp_alloc(c, p->max_dets);                 // dots
     FqWork &Q = c->fqw;
     Q.cap_d = p->max_dets; Q.cap_a = spawn_length + 4096;
@@ -454,12 +457,14 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     Q.o1cnt = p->heat_bath ? fr_alloc<uint32_t>((size_t)Q.cap_d * c->n_elec) : nullptr;
     if (p->heat_bath && (c->n_elec > 32 || c->n_orb - c->n_elec / 2 > 32)) throw FriesError("heat-bath sampling supports at most 32 electrons / 32 virtual orbitals per spin");
     fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
-    double v = 100; uint8_t one = 1; uint32_t n1 = 1;       // :239-243
-    FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
-    FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
-    FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
-    FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
-    fr_vec_merge(c, &c->vec, 1, true);
+    if (c->rank == c->hf_proc) {                             // :239-243
+        double v = 100; uint8_t one = 1; uint32_t n1 = 1;
+        FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.ini, &one, 1, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &n1, 4, hipMemcpyHostToDevice, c->stream));
+        fr_vec_merge(c, &c->vec, 1, true);
+    }
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
 }
 
@@ -490,8 +495,10 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     uint32_t n_spawn = 0;
     FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));
-    if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder");
-    if (n_spawn) fr_vec_merge(c, &c->vec, n_spawn, true);           // one perform_add into the column itself (:413)
+    uint32_t n_merge = n_spawn;
+    if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn, true);  // one all-to-all per iteration; the spawns keep their order (:413)
+    else if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder");
+    if (n_merge) fr_vec_merge(c, &c->vec, n_merge, true);           // one perform_add into the column itself (:413)
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) throw FriesError("device error in the FCIQMC merge (capacity, hash table or electron count)");
     double norm = 0;
@@ -500,8 +507,18 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
         unsigned gn = fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK);
         if (gn > 1024) gn = 1024;
         FR_LAUNCH(c, "k_fq_norm", k_fq_norm, dim3(gn), dim3(FR_BLOCK), c->vec, Q.norm);
-        FR_HIP(hipMemcpyAsync(&norm, Q.norm, 8, hipMemcpyDeviceToHost, st));
-        FR_HIP(hipStreamSynchronize(st));
+        if (c->use_comm) {          // sum_mpi of the local walker numbers, in rank order (:417)
+            FR_HIP(hipMemcpyAsync(c->comm.small_send, Q.norm, 8, hipMemcpyDeviceToDevice, st));
+            const double *all = (const double *)fr_allgather(c, 8);
+            double h[FR_MAX_RANKS];
+            FR_HIP(hipMemcpyAsync(h, all, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+            for (int q = 0; q < c->n_ranks; q++) norm += h[q];
+        }
+        else {
+            FR_HIP(hipMemcpyAsync(&norm, Q.norm, 8, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+        }
         double damp = 0.05 / c->eps / 10;
         if (c->last_one_norm) { c->en_shift -= damp * log(norm / c->last_one_norm); c->last_one_norm = norm; }
         if (c->last_one_norm == 0 && norm > c->target_norm) c->last_one_norm = norm;

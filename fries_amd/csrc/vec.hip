@@ -439,7 +439,7 @@ __device__ __forceinline__ uint32_t fr_proc_of(det_t d, const uint32_t *scr, uin
 }
 
 // bucket = 2 * destination + initiator flag; counts per 256-element tile
-__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt, uint32_t hh_sites) {
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt, uint32_t hh_sites, int one_pass) {
     __shared__ uint32_t wcnt[4][FR_XCH_MAXB];
     const uint32_t n = *S.n_spawn;
     const uint32_t nb = 2 * n_ranks;
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_
     uint32_t k = 0xFFu;
     if (j < n) {
         uint32_t owner = hh_sites ? (uint32_t)(fr_hh_hash(S.det[j], scr, hh_sites) % n_ranks) : fr_proc_of(S.det[j], scr, n_ranks);
-        k = 2 * owner + (S.ini[j] ? 1u : 0u); key[j] = (uint8_t)k;
+        k = 2 * owner + ((S.ini[j] && !one_pass) ? 1u : 0u); key[j] = (uint8_t)k;
     }
     const int w = threadIdx.x >> 6;
     for (uint32_t b = 0; b < nb; b++) {
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_scan(SpawnBuf S, uint32_t n_ra
 
 struct XchRec { det_t det; double val; };
 
-__global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n_ranks, const uint8_t *key, const uint32_t *tile_off, const uint32_t *bucket, XchRec *out, uint32_t cap_recs, uint32_t *err) {
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n_ranks, const uint8_t *key, const uint32_t *tile_off, const uint32_t *bucket, XchRec *out, uint32_t cap_recs, uint32_t *err, int one_pass) {
     __shared__ uint32_t wcnt[4][FR_XCH_MAXB];
     const uint32_t n = *S.n_spawn;
     const uint32_t nb = 2 * n_ranks;
@@ -508,7 +508,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n
     if (j < n) {
         for (int ww = 0; ww < w; ww++) my_rank += wcnt[ww][k];
         uint32_t o = bucket[nb + k] + tile_off[(size_t)blockIdx.x * nb + k] + my_rank;
-        if (o < cap_recs) { XchRec r; r.det = S.det[j]; r.val = S.val[j]; out[o] = r; }
+        if (o < cap_recs) {
+            XchRec r; r.det = S.det[j]; r.val = S.val[j];
+            // one pass (fciqmc_mol): initiator and non-initiator spawns keep their order, so the flag rides inside the (integer) walker
+            // count: 2 v + sgn(v) * flag, exact for |v| < 2^51
+            if (one_pass) r.val = 2.0 * r.val + ((S.ini[j] ? 1.0 : 0.0) * (r.val > 0 ? 1.0 : -1.0));
+            out[o] = r;
+        }
         else atomicOr(err, FR_ERR_SPAWN_CAP);
     }
 }
@@ -516,13 +522,20 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n
 // seg[s] = {first record, number of pass-0 records, number of records} of source s in the receive buffer
 struct XchSegs { uint32_t n_src; uint32_t first[FR_MAX_RANKS], n0[FR_MAX_RANKS], cnt[FR_MAX_RANKS]; };
 
-__global__ void __launch_bounds__(FR_BLOCK) k_xch_unpack(SpawnBuf S, const XchRec *in, XchSegs G, uint32_t n_recv) {
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_unpack(SpawnBuf S, const XchRec *in, XchSegs G, uint32_t n_recv, int one_pass) {
     uint32_t j = blockIdx.x * FR_BLOCK + threadIdx.x;
     if (j == 0) *S.n_spawn = n_recv;
     if (j >= n_recv) return;
     uint32_t s = 0;
     while (s + 1 < G.n_src && j >= G.first[s + 1]) s++;
     XchRec r = in[j];
+    if (one_pass) {
+        const double a = fabs(r.val);
+        const double flag = a - 2.0 * floor(a * 0.5);           // 1 for an initiator spawn
+        S.det[j] = r.det; S.ini[j] = flag != 0 ? 1 : 0;
+        S.val[j] = (r.val - (r.val > 0 ? flag : -flag)) * 0.5;
+        return;
+    }
     S.det[j] = r.det; S.val[j] = r.val; S.ini[j] = (j - G.first[s]) >= G.n0[s] ? 1 : 0;
 }
 
@@ -540,7 +553,7 @@ void fr_xch_alloc(FriesCtx *c, uint32_t cap) {
 
 // Ships the n_local spawns in c->sp to their owners; on return c->sp holds what this rank received, in the
 // reference's arrival order.  Returns the number received.
-uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local) {
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, bool one_pass) {
     SpawnBuf &S = c->sp;
     hipStream_t st = c->stream;
     const int P = c->n_ranks;
@@ -549,9 +562,9 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local) {
     unsigned g = fr_blocks(n_local ? n_local : 1, FR_BLOCK);
     uint32_t cap_recs = (uint32_t)(c->comm.big_bytes / sizeof(XchRec));
     if (n_local == 0) FR_HIP(hipMemsetAsync(S.n_spawn, 0, 4, st));
-    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites);
+    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites, one_pass ? 1 : 0);
     FR_LAUNCH(c, "k_xch_scan", k_xch_scan, dim3(1), dim3(FR_BLOCK), S, (uint32_t)P, S.xcnt, S.xoff, S.xbucket, (uint32_t *)c->comm.small_send);
-    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err);
+    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err, one_pass ? 1 : 0);
     const uint32_t *all = (const uint32_t *)fr_allgather(c, nb * 4);
     std::vector<uint32_t> cnt((size_t)P * nb);
     FR_HIP(hipMemcpyAsync(cnt.data(), all, cnt.size() * 4, hipMemcpyDeviceToHost, st));
@@ -574,6 +587,6 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local) {
     if (n_recv > S.cap || n_recv > cap_recs) throw FriesError("received spawns exceed the spawn buffer");
     if (c->comm.alltoallv(c->comm.user, sb.data(), rb.data(), (void *)st)) throw FriesError("fries_comm.alltoallv failed");
     c->n_collectives++;
-    FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv);
+    FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv, one_pass ? 1 : 0);
     return (uint32_t)n_recv;
 }

@@ -149,7 +149,9 @@ int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
 int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
 
 /* ---- fciqmc_mol: FCIQMC with the near-uniform or the heat-bath excitation generator (FRIES_bin/fciqmc_mol.cpp), HF trial
- * vector, start from 100 walkers on HF, one rank.  The reference's sequential mt19937 stream cannot be replayed in parallel;
+ * vector, start from 100 walkers on HF; one rank or hash-sharded ranks (fries_set_comm: one all-to-all of the spawns per
+ * iteration; n_nonz / n_ini in the log are this rank's, norm and the projections global).  The reference's sequential mt19937
+ * stream cannot be replayed in parallel;
  * the engine draws from a counter-based stream keyed by (seed, iteration, determinant, attempt, purpose) -- the same uniforms
  * in distribution -- which the CPU oracle shares, and the oracle's functions and loop are pinned against the reference on the
  * reference's own stream (oracle/ref_harness.cpp: fciqmc).  Walker numbers are exact integers in the vector's doubles. */

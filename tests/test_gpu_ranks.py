@@ -94,3 +94,24 @@ def test_pivotal_compression_over_ranks(name, budget, tmp_path):
         total += rep["piv_nonzero"]
     assert 0 < total <= budget
     assert res.returncode == 0, res.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_mpi_runs"]))
+def test_fciqmc_over_ranks(name, tmp_path):
+    """fciqmc_mol hash-sharded over 2 and 3 ranks (near-uniform and heat-bath generators): one all-to-all of the spawns per iteration
+    with initiator and non-initiator spawns in their original order, walker totals and projections summed in rank order; every
+    rank's shard equals the in-process rank oracle's (which is pinned against the reference under mpiexec in the CPU suite)."""
+    r = golden_io.manifest()["fciqmc_mpi_runs"][name]
+    P = r["n_ranks"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "gloo", str(tmp_path)]
+    res = _run_ranks(cmd, env, 300)
+    for k in range(P):
+        fn = tmp_path / f"rank{k}.json"
+        assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+        rep = json.loads(fn.read_text())
+        assert rep["ok"], rep["fails"]
+        assert rep["n_alltoallv"] == rep["iters"]
+    assert res.returncode == 0, res.stderr[-4000:]
