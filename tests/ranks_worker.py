@@ -121,7 +121,7 @@ def fciqmc_ranks(name, r, rank, world, dev, out_dir, dist, torch):
     from fries_amd.comm import TorchComm
     from fries_amd.engine import FriEngine
     import oracle_lib
-    assert r["n_ranks"] == world
+    assert r["n_ranks"] == world or world == 1        # world 1: the same configuration through a one-rank communicator (RCCL test)
     mol = fcidump.synthetic(r["shape"])
     n_it = min(r["n_iter"], 100)
     comm = TorchComm(2 * r["target_walkers"] + 4096, torch.device("cuda", dev))

@@ -115,3 +115,18 @@ def test_fciqmc_over_ranks(name, tmp_path):
         assert rep["ok"], rep["fails"]
         assert rep["n_alltoallv"] == rep["iters"]
     assert res.returncode == 0, res.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_fciqmc_one_rank_communicator_over_rccl(tmp_path):
+    """backend "nccl" (RCCL) with a world of one: the order-preserving spawn exchange and the walker-total all-gather run as real
+    RCCL collectives under the engine's stream, and the run must equal the one-rank oracle."""
+    name = "fciqmc_n2_p2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "nccl", str(tmp_path)]
+    res = _run_ranks(cmd, dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), 300)
+    fn = tmp_path / "rank0.json"
+    assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+    rep = json.loads(fn.read_text())
+    assert rep["ok"], rep["fails"]
+    assert rep["n_alltoallv"] == rep["iters"]
