@@ -309,13 +309,13 @@ static void frifull_iterate(FriesCtx *c, fries_iter_log *lg) {
 // the driver's optional inputs; all three must precede fries_frisys_setup
 extern "C" int fries_set_trial_vector(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n) {
     FR_API_BEGIN
-    if (h->c.vec.dets) throw FriesError("fries_set_trial_vector must be called before fries_frisys_setup");
+    if (h->c.vec.dets) throw FriesError("fries_set_trial_vector must be called before the driver's setup");
     h->c.in_trial_det.assign(dets, dets + n); h->c.in_trial_val.assign(vals, vals + n);
     FR_API_END
 }
 extern "C" int fries_set_initial_vector(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n) {
     FR_API_BEGIN
-    if (h->c.vec.dets) throw FriesError("fries_set_initial_vector must be called before fries_frisys_setup");
+    if (h->c.vec.dets) throw FriesError("fries_set_initial_vector must be called before the driver's setup");
     h->c.in_ini_det.assign(dets, dets + n); h->c.in_ini_val.assign(vals, vals + n);
     FR_API_END
 }

@@ -457,7 +457,25 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     Q.o1cnt = p->heat_bath ? fr_alloc<uint32_t>((size_t)Q.cap_d * c->n_elec) : nullptr;
     if (p->heat_bath && (c->n_elec > 32 || c->n_orb - c->n_elec / 2 > 32)) throw FriesError("heat-bath sampling supports at most 32 electrons / 32 virtual orbitals per spin");
     fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
-    if (c->rank == c->hf_proc) {                             // :239-243
+    if (!c->in_ini_det.empty()) {                            // --ini_vec (:226-237): integer walkers, entries add()ed in file order from rank 0
+        std::vector<det_t> d; std::vector<double> v;
+        for (size_t i = 0; i < c->in_ini_det.size(); i++) {
+            const double w = (double)(int)c->in_ini_val[i];
+            if (w != 0 && fr_host_idx_to_proc(c, c->in_ini_det[i]) == c->rank) { d.push_back(c->in_ini_det[i]); v.push_back(w); }
+        }
+        uint32_t m = (uint32_t)d.size();
+        if (m >= c->adder_cap) throw FriesError("the initial vector fills the Adder (the reference would store the filling entry twice): raise --target");
+        if (m) {
+            std::vector<uint8_t> f(m, 1);
+            FR_HIP(hipMemcpyAsync(c->sp.det, d.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
+            fr_vec_merge(c, &c->vec, m, true);
+            FR_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    else if (c->rank == c->hf_proc) {                        // :239-243
         double v = 100; uint8_t one = 1; uint32_t n1 = 1;
         FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
         FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));

@@ -269,6 +269,22 @@ void fr_h_trial_setup(FriesCtx *c) {
         }
         if (src.empty()) throw FriesError("the trial vector holds no non-zero element");
         fr_h_apply_list(c, src, val, od, ov, nullptr, nullptr);
+        if (c->fq_mode) {
+            // fciqmc_mol.cpp:163-170 stores every entry with `while (!trial_vec.add(...)) trial_vec.perform_add(0)`; add() reports a full
+            // Adder AFTER storing, so the entry that fills it is stored again.  trial_vec's Adder holds exactly as many entries as the
+            // file has, so its last entry counts twice in the trial vector (but once in H * trial): the reference's denominators.
+            size_t stored = 0;
+            for (size_t i = 0; i < c->in_trial_det.size(); i++) {
+                if (c->in_trial_val[i] == 0) continue;
+                stored++;
+                if (stored == c->in_trial_det.size()) {
+                    size_t j = 0;
+                    while (src[j] != c->in_trial_det[i]) j++;
+                    val[j] += c->in_trial_val[i];
+                    stored = 1;
+                }
+            }
+        }
     }
     c->n_trial = (uint32_t)src.size(); c->n_htrial = (uint32_t)od.size();
     c->tr_det = fr_alloc<det_t>(src.size()); c->tr_val = fr_alloc<double>(src.size());

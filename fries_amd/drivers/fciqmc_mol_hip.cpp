@@ -1,7 +1,7 @@
 // fciqmc_mol on the MI355X engine (FRIES_bin/fciqmc_mol.cpp, --distribution NU or HB) over the C ABI.
 //
 //   fciqmc_mol_hip --fcidump_path F --point_group D2h --distribution NU|HB --target W --max_dets N --epsilon E
-//                  [--initiator I] [--max_iter K] [--result_dir DIR/] [--seed S] [--device D]
+//                  [--initiator I] [--max_iter K] [--result_dir DIR/] [--ini_vec PREFIX] [--trial_vec PREFIX] [--seed S] [--device D]
 //
 // Output files as the reference's (fciqmc_mol.cpp:262-300, 415-445): projnum.txt, projden.txt, nini.txt every iteration; S.txt,
 // N.txt (walkers), nnonz.txt every 10 iterations; params.txt.
@@ -26,6 +26,9 @@ int main(int argc, char **argv) {
         fries_fciqmc_params p{std::stod(kv["epsilon"]), kv.count("target") ? (uint32_t)std::stoul(kv["target"]) : 0u,
                               kv.count("initiator") ? (uint32_t)std::stoul(kv["initiator"]) : 0u, (uint32_t)std::stoul(kv["max_dets"]), seed,
                               kv["distribution"] == "HB" ? 1 : 0, 0};
+        std::vector<uint64_t> tdets; std::vector<double> tvals;
+        if (kv.count("trial_vec")) { load_vec_txt(kv["trial_vec"], tdets, tvals); ck(fries_set_trial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }      // fciqmc_mol.cpp:150-177
+        if (kv.count("ini_vec")) { load_vec_txt(kv["ini_vec"], tdets, tvals); ck(fries_set_initial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }          // :226-237
         ck(fries_fciqmc_setup(ctx, &p));
         const uint32_t max_iter = kv.count("max_iter") ? (uint32_t)std::stoul(kv["max_iter"]) : 1000000u;
         std::ofstream num_file(rd + "projnum.txt", std::ofstream::app), den_file(rd + "projden.txt", std::ofstream::app), shift_file(rd + "S.txt", std::ofstream::app),

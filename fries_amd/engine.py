@@ -226,11 +226,16 @@ class FriEngine:
         self.max_dets = max_dets
 
     # ---- fciqmc_mol
-    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, distribution="NU"):
+    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, distribution="NU", trial=None, ini=None):
         """fciqmc_mol with the near-uniform excitation generator (FRIES_bin/fciqmc_mol.cpp, --distribution NU): HF trial vector,
         100 walkers on HF to start; uniforms from a counter-based stream (see csrc/fciqmc.hip)."""
         if distribution not in ("NU", "HB"):
             raise RuntimeError('"dist_str" argument must be either "NU" or "HB"')
+        for pair, fn in ((trial, self.lib.fries_set_trial_vector), (ini, self.lib.fries_set_initial_vector)):
+            if pair is not None:
+                d = np.ascontiguousarray(pair[0], dtype=np.uint64)
+                v = np.ascontiguousarray(pair[1], dtype=np.float64)
+                self._ck(fn(self.h, _ptr(d), _ptr(v), min(d.size, v.size)))
         p = FciqmcParams(epsilon, target_walkers, initiator, max_dets, seed, 1 if distribution == "HB" else 0, 0)
         self._ck(self.lib.fries_fciqmc_setup(self.h, C.byref(p)))
         self.max_dets = max_dets

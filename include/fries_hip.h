@@ -100,7 +100,9 @@ typedef struct {
     uint32_t err;
 } fries_iter_log;
 
-/* Optional inputs of the frisys_mol driver, each before fries_frisys_setup:
+/* Optional inputs of the frisys_mol and fciqmc_mol drivers, each before fries_frisys_setup / fries_fciqmc_setup (for fciqmc_mol the
+ * initial values are walker numbers, and the last entry of the trial file counts twice in the trial vector, as in the
+ * reference's `while (!add) perform_add` loop, fciqmc_mol.cpp:163-170):
  *   --trial_vec (frisys_mol.cpp:157-181): the vector the energy is projected on, entries add()ed in the given order;
  *   --ini_vec   (:264-274): the starting vector instead of 100 x HF, entries add()ed in the given order (from rank 0);
  *   --ham_shift (:95-98): the offset subtracted from every diagonal element instead of the HF energy (pass ham_shift - core_en). */

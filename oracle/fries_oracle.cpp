@@ -2150,6 +2150,45 @@ void Fciqmc::setup() {
     unsigned spawn_length = par.target_walkers / cm.size / cm.size * 2;      // :107
     sol.init(par.max_dets, spawn_length, n_elec, 1, cm, proc_scr.data());
     hf_proc = sol.idx_to_proc(hf_det);
+    if (!trial_in_det.empty()) {
+        // --trial_vec (:150-177).  Every entry goes in through `while (!vec.add(...)) vec.perform_add(0)`: add() returns false when
+        // the entry it just stored filled the Adder, and the loop then stores it a second time.  trial_vec's Adder holds exactly
+        // n_trial entries, so the last entry of the file enters the trial vector twice (htrial_vec's is far larger): reproduced.
+        size_t n_trial = trial_in_det.size(), n_ex = (size_t)n_orb * n_orb * n_elec * n_elec;
+        Vec tv, ht;
+        tv.init(n_trial, n_trial, n_elec, 1, cm, proc_scr.data());
+        ht.init(n_trial * n_ex / cm.size, n_trial * n_ex / cm.size, n_elec, 2, cm, proc_scr.data());
+        if (cm.rank == 0) for (size_t i = 0; i < n_trial; i++) {
+            while (!tv.add(trial_in_det[i], trial_in_val[i], 1)) tv.perform_add(0);
+            while (!ht.add(trial_in_det[i], trial_in_val[i], 1)) ht.perform_add(0);
+        }
+        tv.perform_add(0); ht.perform_add(0);
+        h_op_offdiag(ht, ht.curr_size, sys, 1, 1.0);
+        ht.cur = 0;
+        h_op_diag(ht, 0, 0, 1, sys);
+        ht.add_vecs(0, 1);
+        auto gather = [&](Vec &v, std::vector<det_t> &od, std::vector<double> &ov) {
+            std::vector<std::vector<uint8_t>> snd(cm.size), rcv;
+            size_t n = v.curr_size;
+            std::vector<uint8_t> mine(n * 16);
+            if (n) { memcpy(mine.data(), v.dets.data(), n * 8); memcpy(mine.data() + n * 8, v.vals[0].data(), n * 8); }
+            for (int d = 0; d < cm.size; d++) snd[d] = mine;
+            if (cm.size == 1) rcv = snd; else cm.alltoallv(snd, rcv);
+            od.clear(); ov.clear();
+            for (int sr = 0; sr < cm.size; sr++) {
+                size_t k = rcv[sr].size() / 16, o = od.size();
+                od.resize(o + k); ov.resize(o + k);
+                if (k) { memcpy(&od[o], rcv[sr].data(), k * 8); memcpy(&ov[o], rcv[sr].data() + k * 8, k * 8); }
+            }
+        };
+        gather(tv, trial_det, trial_val);
+        gather(ht, htrial_det, htrial_val);
+        std::vector<uint8_t> ex;
+        size_t n_doub = doub_ex_symm(hf_det, tmp, n_elec, n_orb, ex, sys.symm.irrep.data());
+        size_t n_sing2 = count_singex(hf_det, tmp, n_elec, sys.symm);
+        p_doub = (double)n_doub / (n_sing2 + n_doub);
+    }
+    else {
     // trial = HF, H trial by enumeration on the rank that owns HF, then replicated (:148-191), as in frisys_mol
     trial_det = {hf_det}; trial_val = {1.0};
     {
@@ -2197,7 +2236,9 @@ void Fciqmc::setup() {
         size_t n_sing2 = count_singex(hf_det, tmp, n_elec, sys.symm);
         p_doub = (double)n_doub / (n_sing2 + n_doub);
     }
-    if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);      // :239-243
+    }
+    if (!ini_det.empty()) { if (cm.rank == 0) for (size_t i = 0; i < ini_det.size(); i++) while (!sol.add(ini_det[i], ini_val[i], 1)) sol.perform_add(0); }      // :226-237
+    else if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);      // :239-243
     sol.perform_add(0);
     if (par.heat_bath) sys.hb.set_up(sys.ints);       // :310-313
     en_shift = 0; last_norm = 0; iterat = 0;

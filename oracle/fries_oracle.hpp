@@ -406,6 +406,9 @@ struct Fciqmc {
     std::vector<FciqmcLog> log;
     Comm cm;                    // ranks: every process seeds its own generator (par.seed + rank), rank 0's scrambler is broadcast
     int hf_proc = 0;
+    // --trial_vec / --ini_vec (fciqmc_mol.cpp:150-177, 226-241): text vectors, added with `while (!add) perform_add` loops
+    std::vector<det_t> trial_in_det, ini_det;
+    std::vector<double> trial_in_val; std::vector<int> ini_val;
     void setup();
     void iterate(unsigned n);
 };

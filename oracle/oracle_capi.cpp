@@ -405,6 +405,23 @@ void *fo_fciqmc_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, c
     f->setup();
     return f;
 }
+// the same with --trial_vec / --ini_vec (n == 0: default)
+void *fo_fciqmc_create_ex(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                          double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int flags,
+                          const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const int32_t *in_val, size_t n_in) {
+    Fciqmc *f = new Fciqmc();
+    f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0;
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.target_walkers = target_walkers; f->par.init_thresh = init_thresh; f->par.max_dets = max_dets; f->par.seed = seed;
+    if (n_tr) { f->trial_in_det.assign(tr_det, tr_det + n_tr); f->trial_in_val.assign(tr_val, tr_val + n_tr); }
+    if (n_in) { f->ini_det.assign(in_det, in_det + n_in); f->ini_val.assign(in_val, in_val + n_in); }
+    f->setup();
+    return f;
+}
 void fo_fciqmc_destroy(void *h) { delete (Fciqmc *)h; }
 int fo_fciqmc_iterate(void *h, uint32_t n, FqLog *logs) {
     Fciqmc *f = (Fciqmc *)h;

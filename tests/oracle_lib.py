@@ -51,6 +51,9 @@ def load():
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_compress_vec_piv.argtypes = [C.c_void_p, C.c_uint32]
+        lib.fo_fciqmc_create_ex.restype = C.c_void_p
+        lib.fo_fciqmc_create_ex.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_fqranks_create.restype = C.c_void_p
         lib.fo_fqranks_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         lib.fo_fqranks_destroy.argtypes = [C.c_void_p]
@@ -365,14 +368,21 @@ class OracleFciqmc:
     reference's sequential mt19937 stream (pinned against the reference loop); counter_rng=True uses the counter-based
     stream the GPU replays."""
 
-    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU"):
+    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU", trial=None, ini=None):
         self.lib = load()
         if distribution not in ("NU", "HB"):
             raise RuntimeError('"dist_str" argument must be either "NU" or "HB"')
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
-        self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, int(counter_rng) | (2 if distribution == "HB" else 0))
+        flags = int(counter_rng) | (2 if distribution == "HB" else 0)
+        if trial is None and ini is None:
+            self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, flags)
+        else:
+            td, tv = (np.ascontiguousarray(trial[0], dtype=np.uint64), np.ascontiguousarray(trial[1], dtype=np.float64)) if trial is not None else (np.zeros(1, np.uint64), np.zeros(1))
+            idd, iv = (np.ascontiguousarray(ini[0], dtype=np.uint64), np.ascontiguousarray(ini[1], dtype=np.int32)) if ini is not None else (np.zeros(1, np.uint64), np.zeros(1, np.int32))
+            self.h = self.lib.fo_fciqmc_create_ex(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, flags,
+                                                  _p(td), _p(tv), td.size if trial is not None else 0, _p(idd), _p(iv), idd.size if ini is not None else 0)
 
     def __del__(self):
         if getattr(self, "h", None):

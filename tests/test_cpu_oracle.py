@@ -147,8 +147,13 @@ def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
                 continue
             t = ln.split()
             rows.append((float.fromhex(t[1]), float.fromhex(t[2]), float.fromhex(t[3]), float.fromhex(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[8]), int(t[9], 16)))
+    kw = {}
+    if "trial" in r:        # --trial_vec / --ini_vec: text vectors through the reference's reader; the last trial entry counts twice there
+        kw["trial"] = golden_io.read_text_vector(r["trial"])
+    if "ini" in r:
+        kw["ini"] = golden_io.read_text_vector(r["ini"])
     orc = oracle.OracleFciqmc(mols(r["shape"]), epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"],
-                              seed=r["seed"], counter_rng=False, distribution=r["distribution"])
+                              seed=r["seed"], counter_rng=False, distribution=r["distribution"], **kw)
     logs = orc.iterate(r["n_iter"])
     for i, row in enumerate(rows):
         lg = logs[i]

@@ -667,3 +667,42 @@ def test_cli_driver_text_vectors_and_ham_shift(mols, tmp_path):
         for i in range(n_it):
             row = g["rows"][i]
             assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10 and int(nk[i]) == row["nkept"]
+
+
+def test_fciqmc_trial_and_initial_vectors(oracle, mols, tmp_path):
+    """fciqmc_mol --trial_vec / --ini_vec on the device (engine and command-line driver) against the restatement on the counter
+    stream; the restatement's mt19937 mode reproduces the reference run with the same files (CPU suite), including the last
+    trial entry counting twice in the denominators."""
+    import subprocess
+    from fries_amd import build
+    from fries_amd.engine import FriEngine
+    mol = mols("N2")
+    trial = golden_io.read_text_vector("n2_trial_")
+    ini = golden_io.read_text_vector("n2_fq_ini_")
+    par = dict(epsilon=0.004, target_walkers=20000, max_dets=100000, initiator=2, seed=9, distribution="NU")
+    orc = oracle.OracleFciqmc(mol, counter_rng=True, trial=trial, ini=ini, **par)
+    n_it = 120
+    lo = orc.iterate(n_it)
+    eng = FriEngine(mol)
+    eng.setup_fciqmc(trial=trial, ini=ini, **par)
+    lg = eng.iterate_fciqmc(n_it)
+    for f in ("n_nonz", "n_ini", "curr_size", "n_spawn"):
+        assert np.array_equal(lg[f].astype(np.int64), lo[f].astype(np.int64)), f
+    # (a 25-term projection is summed block-parallel on the device: 1e-12 relative instead of bit for bit)
+    assert np.all(np.abs(lg["denom"] - lo["denom"]) <= 1e-12 * np.abs(lo["denom"])) and np.array_equal(lg["shift"], lo["shift"])
+    assert np.all(np.abs(lg["numer"] - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    d, v = eng.vector(); od, ov = orc.vector()
+    assert np.array_equal(v, ov) and np.array_equal(d[v != 0], od[ov != 0])
+    eng.close()
+    # the driver reads the same files
+    fc = str(tmp_path / "n2.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "fq") + "/"
+    os.makedirs(out)
+    res = subprocess.run([build.DRIVERS["fciqmc_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", "NU", "--target", "20000",
+                          "--max_dets", "100000", "--epsilon", "0.004", "--initiator", "2", "--max_iter", "60", "--result_dir", out, "--seed", "9",
+                          "--trial_vec", os.path.join(golden_io.GOLD, "n2_trial_"), "--ini_vec", os.path.join(golden_io.GOLD, "n2_fq_ini_")],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    den = np.loadtxt(out + "projden.txt"); num = np.loadtxt(out + "projnum.txt")
+    assert np.all(np.abs(den - lo["denom"][:60]) <= 1e-12 * np.abs(lo["denom"][:60])) and np.all(np.abs(num - lo["numer"][:60]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"][:60])))
