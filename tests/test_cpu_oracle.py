@@ -373,6 +373,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(dll, s), s
 
 
+def test_facade_header_and_drivers_compile_on_the_host(tmp_path):
+    """include/fries_facade.hpp and the C++ drivers are plain host C++17 over the C ABI: they must compile without hipcc."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "fries_facade.hpp"\nint main() { fries_hip::Matrix<double> m(2, 2); m(1, 1) = 1; double s = 0, l = 0; fries_hip::adjust_shift(&s, 2.0, &l, 1.0, 0.1); return (int)m(0, 0); }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for drv in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip", "frifull_mol_hip"):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(root, "fries_amd", "drivers", drv + ".cpp")], capture_output=True, text=True)
+        assert r.returncode == 0, (drv, r.stderr[-2000:])
+
+
 def test_engine_fails_loudly_without_gpu(mols):
     """No CPU fallback: without a HIP device the engine refuses to start."""
     from fries_amd import engine
