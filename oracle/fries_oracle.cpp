@@ -1788,6 +1788,7 @@ void FrisysHH::setup() {
     for (auto &x : proc_scr) x = mt();     // frisys_hh.cpp:80-83
     for (auto &x : vec_scr) x = mt();      // :88-91
     unsigned spawn_length = par.vec_nonz * 4 / cm.size;     // :94
+    if (full) { size_t sl = (size_t)n_elec * 4 * par.max_dets / cm.size; spawn_length = sl > 200000 ? 200000u : (unsigned)sl; }      // frifull_hh.cpp:91-95
     sol.hh_sites = L; sol.hh_ph_bits = par.ph_bits; sol.vec_scr = vec_scr.data(); sol.n_buckets = par.max_dets;
     sol.init(par.max_dets, spawn_length, n_elec, 2, cm, proc_scr.data());      // the Adder gets spawn_length here (:100), not adder_size
     neel = gen_neel_det_1D(L, n_elec);
@@ -1810,6 +1811,60 @@ void FrisysHH::iterate(unsigned n_iter) {
     uint8_t nb[2 * 65];
     for (unsigned it = 0; it < n_iter; it++, iterat++) {
         HHLog lg{};
+        size_t vec_size = sol.curr_size;
+        if (full) {
+            // frifull_hh.cpp:187-263: every hop and every phonon move of every stored state, in batches of about one Adder
+            size_t det_idx = 0, n_add = 0;
+            int num_added = 1;
+            const size_t vec_size_f = sol.curr_size;
+            const size_t adder_size = sol.adder_cap - n_elec * 4;
+            sol.cur = 1;
+            sol.zero_cur();
+            while (num_added > 0) {
+                num_added = 0;
+                const std::vector<double> &before = sol.vals[0];
+                while (det_idx < vec_size_f && (size_t)num_added < adder_size) {
+                    const double cur_el = before[det_idx];
+                    if (cur_el == 0) { det_idx++; continue; }
+                    const det_t cur = sol.dets[det_idx];
+                    const uint8_t ini = fabs(cur_el) > par.init_thresh;
+                    find_neighbors_1D(cur, L, n_elec, nb);
+                    for (unsigned k = 0; k < nb[0]; k++) {                    // hub_all: hops to the right, then to the left
+                        unsigned o = nb[k + 1];
+                        sol.add((cur & ~((det_t)1 << o)) | ((det_t)1 << (o + 1)), eps * hub_t * cur_el, ini);
+                    }
+                    for (unsigned k = 0; k < nb[n_elec + 1]; k++) {
+                        unsigned o = nb[n_elec + 1 + k + 1];
+                        sol.add((cur & ~((det_t)1 << o)) | ((det_t)1 << (o - 1)), eps * hub_t * cur_el, ini);
+                    }
+                    num_added += nb[0] + nb[n_elec + 1];
+                    uint8_t ph[64];
+                    decode_phonons(cur, L, par.ph_bits, ph);
+                    const uint8_t *occ = sol.orbs_at(det_idx);
+                    det_t nd;
+                    for (unsigned e = 0; e < n_elec / 2; e++) {               // spin-up electrons; a doubly occupied site couples twice
+                        unsigned site = occ[e];
+                        unsigned pn = ph[site];
+                        int doubly = (int)((cur >> (site + L)) & 1);
+                        if (pn > 0) { det_from_ph(cur, &nd, L, par.ph_bits, site, -1); sol.add(nd, -eps * par.g * sqrt((double)pn) * (doubly + 1) * cur_el, ini); num_added++; }
+                        if (pn + 1 < (1u << par.ph_bits)) { det_from_ph(cur, &nd, L, par.ph_bits, site, +1); sol.add(nd, -eps * par.g * sqrt((double)(pn + 1)) * (doubly + 1) * cur_el, ini); num_added++; }
+                    }
+                    for (unsigned e = n_elec / 2; e < n_elec; e++) {          // spin-down electrons on sites without a spin-up one
+                        unsigned site = occ[e] - L;
+                        if ((cur >> site) & 1) continue;
+                        unsigned pn = ph[site];
+                        if (pn > 0) { det_from_ph(cur, &nd, L, par.ph_bits, site, -1); sol.add(nd, -eps * par.g * sqrt((double)pn) * cur_el, ini); num_added++; }
+                        if (pn + 1 < (1u << par.ph_bits)) { det_from_ph(cur, &nd, L, par.ph_bits, site, +1); sol.add(nd, -eps * par.g * sqrt((double)(pn + 1)) * cur_el, ini); num_added++; }
+                    }
+                    det_idx++;
+                }
+                n_add += (size_t)num_added;
+                num_added = cm.sum(num_added);
+                sol.perform_add(0);
+            }
+            lg.num_success = n_add;
+        }
+        else {
         // :187-204 electron hop vs phonon
         for (size_t i = 0; i < sol.curr_size; i++) {
             double w = fabs(sol.vals[0][i]);
@@ -1835,7 +1890,7 @@ void FrisysHH::iterate(unsigned n_iter) {
         std::vector<double> &before = sol.vals[0];
         sol.cur = 1;
         sol.zero_cur();
-        size_t vec_size = sol.curr_size;
+        vec_size = sol.curr_size;
         for (int add_ini = 0; add_ini < 2; add_ini++) {       // :233-300
             int num_added = 1;
             size_t s = 0;
@@ -1878,6 +1933,7 @@ void FrisysHH::iterate(unsigned n_iter) {
                 sol.perform_add(0);
                 num_added = cm.sum(num_added);
             }
+        }
         }
         if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
         // diagonal :311-320

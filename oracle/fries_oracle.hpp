@@ -329,6 +329,7 @@ struct HHLog { double numer, denom, shift, norm; uint32_t nkept; int n_nonz; siz
 // FRIES_bin/frisys_hh.cpp:27-380, seed injected instead of the wall clock (:66-68)
 struct FrisysHH {
     HHParams par;
+    bool full = false;          // frifull_hh (FRIES_bin/frifull_hh.cpp): H applied in full instead of the two compressions
     std::mt19937 mt;
     std::vector<uint32_t> proc_scr, vec_scr;
     Vec sol;

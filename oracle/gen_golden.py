@@ -75,6 +75,12 @@ HH_RUNS = {
     "hh_l8_m5000_p3": (3, 40, 7, 8, 8, 0.01, 4.0, 1.0, 0.5, -2.0, 5000, 50000, 1.0, 2500.0),
 }
 
+# frifull_hh (Hubbard-Holstein Hamiltonian applied in full): same tuple as HH_RUNS
+HHFULL_RUNS = {
+    "hhfull_l6_m300": (1, 60, 5, 6, 6, 0.01, 2.0, 0.5, 0.3, -3.0, 300, 200000, 1.0, 150.0),
+    "hhfull_l8_m500_ini0": (1, 40, 7, 8, 8, 0.01, 4.0, 1.0, 0.5, -2.0, 500, 400000, 0.0, 250.0),
+}
+
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
@@ -201,6 +207,13 @@ def main():
             subprocess.run(cmd, check=True)
             manifest["hh_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
                                              gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+    manifest["hhfull_runs"] = {}
+    for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HHFULL_RUNS.items():
+        out = os.path.join(GOLD, name + ".traj")
+        cmd = [HARNESS, "hh", str(n_iter), str(seed), str(n_elec), str(n_sites), repr(eps), repr(U), repr(omega), repr(g), repr(gs), str(vnz), str(maxd), repr(ini), repr(tgt), out]
+        subprocess.run(cmd, check=True, env=dict(os.environ, FRIES_HH_FULL="1"))
+        manifest["hhfull_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
+                                              gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

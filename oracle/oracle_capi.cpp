@@ -343,12 +343,13 @@ int fo_idx_to_proc(void *h, uint64_t det) { return ((Frisys *)h)->sol.idx_to_pro
 // ---- frisys_hh: P in-process ranks (P = 1: plain)
 struct OracleHH { std::vector<std::unique_ptr<FrisysHH>> fr; };
 void *fo_hh_create(uint32_t n_ranks, uint32_t n_elec, uint32_t n_sites, double eps, double U, double omega, double g, double gs_energy,
-                   double target, double init, uint32_t vec_nonz, uint32_t max_dets, uint32_t seed) {
+                   double target, double init, uint32_t vec_nonz, uint32_t max_dets, uint32_t seed, int full) {
     OracleHH *R = new OracleHH();
     for (uint32_t r = 0; r < n_ranks; r++) {
         FrisysHH *f = new FrisysHH();
         f->par.n_elec = n_elec; f->par.n_sites = n_sites; f->par.eps = eps; f->par.U = U; f->par.omega = omega; f->par.g = g; f->par.hf_en = gs_energy;
         f->par.target_norm = target; f->par.init_thresh = init; f->par.vec_nonz = vec_nonz; f->par.max_dets = max_dets; f->par.seed = seed;
+        f->full = full != 0;       // frifull_hh instead of frisys_hh
         R->fr.emplace_back(f);
     }
     try {

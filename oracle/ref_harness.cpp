@@ -837,7 +837,9 @@ static int run_hh(int argc, char **argv) {
     std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
     for (auto &x : proc_scrambler) x = mt_obj();
     for (auto &x : vec_scrambler) x = mt_obj();
+    const bool full = getenv("FRIES_HH_FULL") != nullptr;        // frifull_hh.cpp instead of frisys_hh.cpp
     unsigned spawn_length = target_nonz * 4 / n_procs;
+    if (full) { size_t sl = (size_t)n_elec * 4 * max_n_dets / n_procs; spawn_length = sl > 200000 ? 200000u : (unsigned)sl; }      // frifull_hh.cpp:91-95
     uint8_t ph_bits = 3;
     std::function<double(const uint8_t *)> diag_shortcut = [hub_len](const uint8_t *det) { return hub_diag((uint8_t *)det, hub_len); };
     HubHolVec<double> sol_vec(max_n_dets, spawn_length, hub_len, ph_bits, n_elec, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
@@ -868,6 +870,7 @@ static int run_hh(int argc, char **argv) {
     const bool lock = n_procs == 1;
     if (lock) {
         fr.par.n_elec = n_elec; fr.par.n_sites = hub_len; fr.par.ph_bits = ph_bits; fr.par.eps = eps; fr.par.U = hub_u; fr.par.omega = ph_freq; fr.par.g = elec_ph;
+        fr.full = full;
         fr.par.hf_en = hf_en; fr.par.target_norm = target_norm; fr.par.init_thresh = init_thresh; fr.par.vec_nonz = target_nonz; fr.par.max_dets = max_n_dets; fr.par.seed = seed;
         fr.setup();
         CHECK(fr.neel == to_u64(neel_det, det_size), "neel det %" PRIx64 " %" PRIx64, (uint64_t)fr.neel, (uint64_t)to_u64(neel_det, det_size));
@@ -922,8 +925,61 @@ static int run_hh(int argc, char **argv) {
     FILE *f = fopen(fn, "w");
     fprintf(f, "# golden trajectory from the reference (frisys_hh.cpp loop, %d rank(s), rank %d); cols: it numer denom norm shift nkept n_nonz curr_size num_success digest\n", n_procs, proc_rank);
     fprintf(f, "# ref_proc %u neel %016" PRIx64 "\n", ref_proc, (uint64_t)to_u64(neel_det, det_size));
+    uint8_t (*spawn_orbs)[2] = (uint8_t (*)[2])malloc(sizeof(uint8_t) * n_elec * 2 * 2);
     for (unsigned iterat = 0; iterat < n_iter; iterat++) {
         size_t det_idx;
+        size_t num_success = 0, vec_size = sol_vec.curr_size();
+        if (full) {         // frifull_hh.cpp:187-263
+            det_idx = 0;
+            int num_added = 1;
+            size_t adder_size = sol_vec.adder_size() - n_elec * 4;
+            double *vals_before_mult = sol_vec.values();
+            sol_vec.set_curr_vec_idx(1);
+            sol_vec.zero_vec();
+            while (num_added > 0) {
+                num_added = 0;
+                while (det_idx < vec_size && (size_t)num_added < adder_size) {
+                    double curr_el = vals_before_mult[det_idx];
+                    if (curr_el == 0) { det_idx++; continue; }
+                    uint8_t *curr_det = sol_vec.indices()[det_idx];
+                    int ini_flag = fabs(curr_el) > init_thresh;
+                    size_t n_success = hub_all(n_elec, neighb_orbs[det_idx], spawn_orbs);
+                    for (size_t ex_idx = 0; ex_idx < n_success; ex_idx++) {
+                        memcpy(new_det, curr_det, det_size);
+                        zero_bit(new_det, spawn_orbs[ex_idx][0]);
+                        set_bit(new_det, spawn_orbs[ex_idx][1]);
+                        sol_vec.add(new_det, eps * hub_t * curr_el, ini_flag);
+                    }
+                    num_added += n_success;
+                    uint8_t *curr_occ = sol_vec.orbs_at_pos(det_idx);
+                    uint8_t *curr_phonons = sol_vec.phonons_at_pos(det_idx);
+                    for (size_t elec_idx = 0; elec_idx < n_elec / 2; elec_idx++) {
+                        uint8_t site = curr_occ[elec_idx];
+                        uint8_t phonon_num = curr_phonons[site];
+                        int doubly_occ = read_bit(curr_det, site + hub_len);
+                        if (phonon_num > 0) { sol_vec.det_from_ph(curr_det, new_det, site, -1); sol_vec.add(new_det, -eps * elec_ph * sqrt(phonon_num) * (doubly_occ + 1) * curr_el, ini_flag); num_added++; }
+                        if (phonon_num + 1 < (1 << ph_bits)) { sol_vec.det_from_ph(curr_det, new_det, site, +1); sol_vec.add(new_det, -eps * elec_ph * sqrt(phonon_num + 1) * (doubly_occ + 1) * curr_el, ini_flag); num_added++; }
+                    }
+                    for (size_t elec_idx = n_elec / 2; elec_idx < n_elec; elec_idx++) {
+                        uint8_t site = curr_occ[elec_idx] - n_orb;
+                        int doubly_occ = read_bit(curr_det, site);
+                        if (!doubly_occ) {
+                            uint8_t phonon_num = curr_phonons[site];
+                            if (phonon_num > 0) { sol_vec.det_from_ph(curr_det, new_det, site, -1); sol_vec.add(new_det, -eps * elec_ph * sqrt(phonon_num) * curr_el, ini_flag); num_added++; }
+                            if (phonon_num + 1 < (1 << ph_bits)) { sol_vec.det_from_ph(curr_det, new_det, site, +1); sol_vec.add(new_det, -eps * elec_ph * sqrt(phonon_num + 1) * curr_el, ini_flag); num_added++; }
+                        }
+                    }
+                    det_idx++;
+                }
+                num_success += (size_t)num_added;
+                num_added = sum_mpi(num_added, proc_rank, n_procs);
+                sol_vec.perform_add(0);
+                sol_vec.set_curr_vec_idx(0);
+                vals_before_mult = sol_vec.values();
+                sol_vec.set_curr_vec_idx(1);
+            }
+        }
+        else {
         for (det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
             double *curr_el = sol_vec[det_idx];
             double weight = fabs(*curr_el);
@@ -943,11 +999,11 @@ static int run_hh(int argc, char **argv) {
         }
         if (proc_rank == 0) rn_sys = mt_obj() / (1. + UINT32_MAX);
         comp_len = comp_sub(comp_vec2.data(), comp_len, ndiv_vec.data(), subwt_mem, keep_idx, NULL, target_nonz, wt_remain.data(), rn_sys, comp_vec1.data(), comp_idx);
-        size_t num_success = comp_len;
+        num_success = comp_len;
         double *vals_before_mult = sol_vec.values();
         sol_vec.set_curr_vec_idx(1);
         sol_vec.zero_vec();
-        size_t vec_size = sol_vec.curr_size();
+        vec_size = sol_vec.curr_size();
         for (int add_ini = 0; add_ini < 2; add_ini++) {
             int num_added = 1;
             size_t samp_idx = 0;
@@ -991,6 +1047,7 @@ static int run_hh(int argc, char **argv) {
                 sol_vec.set_curr_vec_idx(1);
                 num_added = sum_mpi(num_added, proc_rank, n_procs);
             }
+        }
         }
         size_t new_max_dets = sol_vec.max_size();
         if (new_max_dets > max_n_dets) { keep_exact.resize(new_max_dets, false); srt_arr.resize(new_max_dets); max_n_dets = new_max_dets; }

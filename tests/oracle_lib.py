@@ -89,7 +89,7 @@ def load():
         lib.fo_ranks_hf_proc.argtypes = [C.c_void_p]
         lib.fo_idx_to_proc.argtypes = [C.c_void_p, C.c_uint64]
         lib.fo_hh_create.restype = C.c_void_p
-        lib.fo_hh_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_double] * 7 + [C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.fo_hh_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_double] * 7 + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         lib.fo_hh_destroy.argtypes = [C.c_void_p]
         lib.fo_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.fo_hh_vec.restype = C.c_size_t
@@ -325,10 +325,10 @@ class OracleRanks:
 class OracleHH:
     """fo::FrisysHH -- the CPU restatement of frisys_hh (1-D Hubbard-Holstein), on n_ranks in-process ranks."""
 
-    def __init__(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, n_ranks=1):
+    def __init__(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, n_ranks=1, full=False):
         self.lib = load()
         self.n_ranks = n_ranks
-        self.h = self.lib.fo_hh_create(n_ranks, n_elec, n_sites, eps, U, omega, g, gs_energy, target_norm, initiator, vec_nonz, max_dets, seed)
+        self.h = self.lib.fo_hh_create(n_ranks, n_elec, n_sites, eps, U, omega, g, gs_energy, target_norm, initiator, vec_nonz, max_dets, seed, int(full))
         if not self.h:
             raise RuntimeError("oracle HH setup failed")
 

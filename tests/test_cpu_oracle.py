@@ -248,13 +248,16 @@ def _hh_params(r):
                 vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
 
 
-@pytest.mark.parametrize("name", sorted(golden_io.manifest()["hh_runs"]))
+_HH_ALL = dict(golden_io.manifest()["hh_runs"], **golden_io.manifest()["hhfull_runs"])
+
+
+@pytest.mark.parametrize("name", sorted(_HH_ALL))
 def test_oracle_hubbard_holstein_reproduces_reference(oracle, name):
-    """frisys_hh (1-D Hubbard-Holstein) restatement against the reference's own loop, one rank and under mpiexec -n 3:
+    """frisys_hh and frifull_hh (1-D Hubbard-Holstein) restated against the reference's own loops, one rank and under mpiexec -n 3:
     every logged scalar bit for bit and the digest of every shard."""
-    r = golden_io.manifest()["hh_runs"][name]
+    r = _HH_ALL[name]
     P = r["n_ranks"]
-    orc = oracle.OracleHH(n_ranks=P, **_hh_params(r))
+    orc = oracle.OracleHH(n_ranks=P, full=name in golden_io.manifest()["hhfull_runs"], **_hh_params(r))
     logs = orc.iterate(r["n_iter"])
     if P == 1:
         logs = logs[None, :]
