@@ -133,6 +133,7 @@ struct FriesCtx {
     fries_hh_params hh{};
     uint32_t *d_vec_scr = nullptr;
     det_t *hh_fdet = nullptr; double *hh_ovlp = nullptr;
+    unsigned long long *hhf_cnt = nullptr;      // frifull_hh: {adds tried, adds written} of the iteration
     uint32_t adder_cap = 0;                  // the reference's Adder capacity per destination (frisys_mol.cpp:109-110)
     uint64_t n_collectives = 0;
     // system
@@ -192,7 +193,7 @@ struct FriesCtx {
 // vec.hip
 void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap);
 void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out);
-void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool same_column);
+void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool same_column, bool arrival_order = false);
 void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n);
 void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap);

@@ -399,6 +399,9 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); hipFree(pv.tile_dd); }
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
     if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); hipFree(h->c.full_list); }
+    if (h->c.hh_fdet) hipFree(h->c.hh_fdet);
+    if (h->c.hh_ovlp) hipFree(h->c.hh_ovlp);
+    if (h->c.hhf_cnt) hipFree(h->c.hhf_cnt);
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
     if (h->c.stream) hipStreamDestroy(h->c.stream);
     delete h;

@@ -83,6 +83,101 @@ __global__ void __launch_bounds__(FR_BLOCK) k_hh_compact(CompWork W, VecDev V, S
     if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) *S.n_spawn = o;
 }
 
+// frifull_hh (FRIES_bin/frifull_hh.cpp:187-263): the off-diagonal part of the Hamiltonian applied in full.  The adds of one
+// stored state, in the reference's order: hops to the right, hops to the left (eps * t * value), then for every spin-up electron the
+// phonon moves -1 / +1 on its site (twice the coupling on a doubly occupied site), then the same for the spin-down electrons on
+// sites without a spin-up one.  Returns the number of adds written (zero values never reach the Adder, vec_utils.hpp:418-431);
+// *tried counts what the reference's num_added counts.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t fr_hhf_emit(det_t cur, double cur_el, unsigned L, unsigned n_elec, double eps, double g, det_t *o_det, double *o_val, uint32_t *tried) {
+    uint32_t n = 0, t = 0;
+    const det_t El = cur & ((1ull << (2 * L)) - 1ull);
+    det_t r0 = El & ~(El >> 1); r0 &= ~(1ull << (L - 1)); r0 &= ~(1ull << (2 * L - 1));
+    det_t r1 = El & (~El << 1); r1 &= ~(1ull << L); r1 &= ~1ull;
+    const double hop = eps * 1.0 * cur_el;
+    for (det_t m = r0; m; m &= m - 1) {
+        unsigned o = (unsigned)__ffsll((long long)m) - 1;
+        t++;
+        if (hop != 0) { if (WRITE) { o_det[n] = (cur & ~(1ull << o)) | (1ull << (o + 1)); o_val[n] = hop; } n++; }
+    }
+    for (det_t m = r1; m; m &= m - 1) {
+        unsigned o = (unsigned)__ffsll((long long)m) - 1;
+        t++;
+        if (hop != 0) { if (WRITE) { o_det[n] = (cur & ~(1ull << o)) | (1ull << (o - 1)); o_val[n] = hop; } n++; }
+    }
+    const det_t up = El & ((1ull << L) - 1ull), dn = El >> L;
+    for (int sp = 0; sp < 2; sp++) {
+        for (det_t m = sp ? (dn & ~up) : up; m; m &= m - 1) {
+            unsigned site = (unsigned)__ffsll((long long)m) - 1;
+            unsigned pn = fr_hh_ph(cur, L, site);
+            const unsigned sh = 2 * L + FR_HH_PH_BITS * site;
+            const int mult = sp ? 1 : (int)((dn >> site) & 1) + 1;
+            if (pn > 0) {
+                double v = sp ? -eps * g * sqrt((double)pn) * cur_el : -eps * g * sqrt((double)pn) * mult * cur_el;
+                t++;
+                if (v != 0) { if (WRITE) { o_det[n] = cur - (1ull << sh); o_val[n] = v; } n++; }
+            }
+            if (pn + 1 < (1u << FR_HH_PH_BITS)) {
+                double v = sp ? -eps * g * sqrt((double)(pn + 1)) * cur_el : -eps * g * sqrt((double)(pn + 1)) * mult * cur_el;
+                t++;
+                if (v != 0) { if (WRITE) { o_det[n] = cur + (1ull << sh); o_val[n] = v; } n++; }
+            }
+        }
+    }
+    if (tried) *tried = t;
+    return n;
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_hhf_count(VecDev V, double eps, double g, uint32_t *pcnt, unsigned long long *totals) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const unsigned L = V.hh_sites, n_elec = V.hh_nelec;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0, tried = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        double v = V.v0[i];
+        if (v == 0) continue;
+        uint32_t t;
+        cnt += fr_hhf_emit<false>(V.dets[i], v, L, n_elec, eps, g, nullptr, nullptr, &t);
+        tried += t;
+    }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    uint32_t bt = fr_block_sum_u32(tried, shu);
+    if (threadIdx.x == 0) { pcnt[blockIdx.x] = bc; if (bt) atomicAdd(&totals[0], (unsigned long long)bt); if (bc) atomicAdd(&totals[1], (unsigned long long)bc); }
+}
+
+__global__ void __launch_bounds__(FR_BLOCK) k_hhf_write(VecDev V, SpawnBuf S, double eps, double g, double init_thresh, const uint32_t *pcnt) {
+    __shared__ uint32_t shu[4];
+    const uint32_t n = V.st->curr_size;
+    const unsigned L = V.hh_sites, n_elec = V.hh_nelec;
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t tsum = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        double v = V.v0[i];
+        if (v != 0) tsum += fr_hhf_emit<false>(V.dets[i], v, L, n_elec, eps, g, nullptr, nullptr, nullptr);
+    }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t o = off + incl - tsum;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        double v = V.v0[i];
+        if (v == 0) continue;
+        uint32_t k = fr_hhf_emit<true>(V.dets[i], v, L, n_elec, eps, g, S.det + o, S.val + o, nullptr);     // (the host checked the total against the capacity)
+        const uint8_t ini = fabs(v) > init_thresh;          // strict here (frifull_hh.cpp:201), >= in frisys_hh
+        for (uint32_t q = 0; q < k; q++) S.ini[o + q] = ini;
+        o += k;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == FR_BLOCK - 1) *S.n_spawn = o;
+}
+
 // v0 <- v0 (1 - eps (U n_double + omega n_phonon - E_ref - S)) for the elements that existed before the merge, v0 += v1
 // (frisys_hh.cpp:311-321); publishes per-block sums of |v0| like k_death_clone
 __global__ void __launch_bounds__(FR_BLOCK) k_hh_death_clone(VecDev V, VcompBuf B, uint32_t vec_size_before, double eps, double shift, double hub_u, double omega, double hf_en, uint32_t n_samp) {
@@ -194,13 +289,18 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     FR_HIP(hipMemcpyAsync(c->d_vec_scr, c->vec_scr.data(), 4 * c->vec_scr.size(), hipMemcpyHostToDevice, c->stream));
     if (!c->d_hb) { c->d_hb = fr_alloc<HbTables>(1); FR_HIP(hipMemsetAsync(c->d_hb, 0, sizeof(HbTables), c->stream)); }     // unused by uniform stages, but staged
     c->adder_cap = (uint32_t)((uint64_t)p->vec_nonz * 4 / c->n_ranks);      // the Adder gets spawn_length here (:94, :100)
+    if (p->full && c->n_ranks > 1) throw FriesError("frifull_hh runs on one rank here (its Adder flushes interleave the ranks' adds batch by batch)");
     fr_vec_alloc(c, &c->vec, p->max_dets);
     c->vec.hh_sites = L; c->vec.hh_nelec = p->n_elec; c->vec.hh_buckets = p->max_dets; c->vec.hh_scr = c->d_vec_scr;
     fr_hbpp_alloc(c, wcap);
     // un-normalised stage-1 rows make comb repairs the rule rather than the exception (comp_kernels.hpp: k_sys_prop)
     c->W.prop = 1; c->W.kend = fr_alloc<uint32_t>(wcap); c->W.act[0] = fr_alloc<uint32_t>(wcap + 1); c->W.act[1] = fr_alloc<uint32_t>(wcap + 1); c->W.act_n = fr_alloc<uint32_t>(2);
-    fr_spawn_alloc(c, p->vec_nonz + 4096);
+    // frifull_hh: at most 4 n_elec adds per stored state (2 hops and 2 phonon moves per electron), vec_nonz states after a compression
+    const uint64_t sp_need = p->full ? (uint64_t)4 * p->n_elec * ((uint64_t)p->vec_nonz + 64) + 4096 : (uint64_t)p->vec_nonz + 4096;
+    if (sp_need > 0x7fffffffull) throw FriesError("vec_nonz too large for the spawn list");
+    fr_spawn_alloc(c, (uint32_t)sp_need);
     fr_xch_alloc(c, p->vec_nonz + 4096);
+    if (p->full) c->hhf_cnt = fr_alloc<unsigned long long>(2);
     fr_vcomp_alloc(c, p->max_dets);
     c->hh_fdet = fr_alloc<det_t>(wcap);
     c->hh_ovlp = fr_alloc<double>(4);
@@ -228,25 +328,43 @@ void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg) {
     const fries_hh_params &P = c->hh;
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     fr_vec_maybe_rebuild(c, &c->vec);
-    double rn[2];
-    rn[0] = hh_uni(c->mt); rn[1] = hh_uni(c->mt);       // every rank seeds alike; the reference broadcasts rank 0's draws
-    fr_hh_apply(c, c->vec_nonz, rn);
     uint32_t vec_size = c->h_vst.curr_size;
-    // spawning (:226-300)
-    CompWork &W = c->W;
-    uint32_t bound = c->num_success ? c->num_success : 1;
-    unsigned grid = fr_blocks(bound, FR_TILE);
-    double *f_val = W.S;
-    FR_LAUNCH(c, "k_hh_eval", k_hh_eval, dim3(grid), dim3(FR_BLOCK), W, c->vec, 1, c->eps, f_val, c->hh_fdet, W.pcnt[0]);
-    FR_LAUNCH(c, "k_hh_compact", k_hh_compact, dim3(grid), dim3(FR_BLOCK), W, c->vec, c->sp, 1, f_val, c->hh_fdet, W.pcnt[0], c->init_thresh);
     uint32_t n_spawn = 0;
-    FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
-    FR_HIP(hipStreamSynchronize(st));
-    if (n_spawn > c->sp.cap) throw FriesError("spawn buffer too small");
+    if (P.full) {
+        // frifull_hh.cpp:187-263: the whole off-diagonal action, one ordered add list (the reference's Adder flushes only cut it)
+        unsigned long long tot[2] = {0, 0};
+        if (vec_size) {
+            const unsigned gt = fr_blocks(vec_size, FR_TILE);
+            FR_HIP(hipMemsetAsync(c->hhf_cnt, 0, 16, st));
+            FR_LAUNCH(c, "k_hhf_count", k_hhf_count, dim3(gt), dim3(FR_BLOCK), c->vec, c->eps, P.g, c->sp.pcnt, c->hhf_cnt);
+            FR_HIP(hipMemcpyAsync(tot, c->hhf_cnt, 16, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+            if (tot[1] > c->sp.cap) throw FriesError("frifull_hh: more adds than the spawn list holds (more than vec_nonz + 64 stored states?)");
+            if (tot[1]) FR_LAUNCH(c, "k_hhf_write", k_hhf_write, dim3(gt), dim3(FR_BLOCK), c->vec, c->sp, c->eps, P.g, c->init_thresh, c->sp.pcnt);
+        }
+        n_spawn = (uint32_t)tot[1];
+        c->num_success = (uint32_t)tot[0];
+        c->comp_len[0] = c->comp_len[1] = 0;
+    }
+    else {
+        double rn[2];
+        rn[0] = hh_uni(c->mt); rn[1] = hh_uni(c->mt);       // every rank seeds alike; the reference broadcasts rank 0's draws
+        fr_hh_apply(c, c->vec_nonz, rn);
+        // spawning (:226-300)
+        CompWork &W = c->W;
+        uint32_t bound = c->num_success ? c->num_success : 1;
+        unsigned grid = fr_blocks(bound, FR_TILE);
+        double *f_val = W.S;
+        FR_LAUNCH(c, "k_hh_eval", k_hh_eval, dim3(grid), dim3(FR_BLOCK), W, c->vec, 1, c->eps, f_val, c->hh_fdet, W.pcnt[0]);
+        FR_LAUNCH(c, "k_hh_compact", k_hh_compact, dim3(grid), dim3(FR_BLOCK), W, c->vec, c->sp, 1, f_val, c->hh_fdet, W.pcnt[0], c->init_thresh);
+        FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        if (n_spawn > c->sp.cap) throw FriesError("spawn buffer too small");
+    }
     if (vec_size) FR_HIP(hipMemsetAsync(c->vec.v1, 0, 8 * (size_t)vec_size, st));      // set_curr_vec_idx(1); zero_vec() (:227-228)
     uint32_t n_merge = n_spawn;
     if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn);
-    if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false);
+    if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false, P.full != 0);
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) throw FriesError("device error in the Hubbard-Holstein merge (capacity, hash table or electron count)");
     // diagonal (:309-321)

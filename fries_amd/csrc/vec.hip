@@ -52,6 +52,7 @@ void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
 // mode 0: frisys_mol's merge (target column 1, origin column 0).  Modes 1 / 2: perform_add into the
 // origin column itself -- first the initiator spawns claim slots (1), then the others look up (2), so
 // that a non-initiator never misses a determinant an earlier initiator spawn of the same batch created.
+// mode 3: like 0, but the list is ONE arrival order (frifull_hh adds initiators and the others interleaved), no pass bit in the sort key.
 __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec, int mode) {
     const uint32_t n = *S.n_spawn;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
                         if (hv & FR_NEWBIT) atomicMin(&V.hvals[found], FR_NEWBIT | j);   // being created in this merge
                         S.slot[j] = found;
                     }
-                    else if (mode == 0) {
+                    else if (mode == 0 || mode == 3) {
                         // non-initiator spawns only reach determinants that were present before this merge and are
                         // non-zero in the origin column (vec_utils.hpp:617, 632-637)
                         if ((hv & FR_NEWBIT) || V.v0[hv] == 0) S.slot[j] = FR_NOPOS;
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, cons
     if (k == drop_key) return;
     uint32_t pos = k >> 1;
     if (t > 0 && (key[t - 1] >> 1) == pos) return;
-    if (mode == 0) {
+    if (mode == 0 || mode == 3) {
         double acc = V.v1[pos];
         for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) acc += S.val[pay[u]];
         V.v1[pos] = acc;
@@ -303,7 +304,7 @@ static int bits_for(uint32_t x) { int b = 0; while ((1ull << b) <= x) b++; retur
 
 // Adds the spawn list (c->sp, length *sp.n_spawn <= n_bound) to column 1 of the vector with
 // the reference's two-pass initiator rule relative to column 0.
-void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool same_column) {
+void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool same_column, bool arrival_order) {
     if (n_bound == 0) return;
     SpawnBuf &S = c->sp;
     hipStream_t st = c->stream;
@@ -312,7 +313,7 @@ void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool same_column) {
     uint32_t nblk_alloc = FR_MAX_PART;
     int nbits = bits_for(2u * v->cap + 1u);
     uint32_t drop_key = (nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
-    const int mode = same_column ? 1 : 0;
+    const int mode = same_column ? 1 : (arrival_order ? 3 : 0);
     FR_LAUNCH(c, "k_spawn_lookup", k_spawn_lookup, dim3(g1), dim3(FR_BLOCK), *v, S, c->n_elec, mode);
     if (same_column) FR_LAUNCH(c, "k_spawn_lookup", k_spawn_lookup, dim3(g1), dim3(FR_BLOCK), *v, S, c->n_elec, 2);
     FR_LAUNCH(c, "k_spawn_first", k_spawn_first, dim3(gt), dim3(FR_BLOCK), *v, S);

@@ -1,6 +1,7 @@
-// frisys_hh on the MI355X engine (FRIES_bin/frisys_hh.cpp) over the C ABI.
+// frisys_hh and frifull_hh on the MI355X engine (FRIES_bin/frisys_hh.cpp, FRIES_bin/frifull_hh.cpp) over the C ABI.
 //
 //   frisys_hh_hip --params_path P --vec_nonz N --max_dets N [--target T] [--initiator I] [--max_iter K] [--result_dir DIR/] [--seed S] [--device D]
+//                 [--full 1]      (frifull_hh: the Hamiltonian applied in full instead of compressed)
 //
 // P is the reference's parameter file (parse_hh_input, FRIES/io_utils.cpp:320-405): the keywords n_elec, lat_len, n_dim, eps, U,
 // omega, g, gs_energy, each on its own line followed by its value.  Outputs (frisys_hh.cpp:127-160, 330-347): projnum.txt,
@@ -31,7 +32,8 @@ int main(int argc, char **argv) {
         std::cout << "seed on process 0 is " << seed << std::endl;
         fries_hh_params p{(uint32_t)val["n_elec"], (uint32_t)val["lat_len"], val["eps"], val["U"], val["omega"], val["g"], val["gs_energy"],
                           kv.count("target") ? std::stod(kv["target"]) : 0.0, kv.count("initiator") ? std::stod(kv["initiator"]) : 0.0,
-                          (uint32_t)std::stoul(kv["vec_nonz"]), (uint32_t)std::stoul(kv["max_dets"]), seed, 0};
+                          (uint32_t)std::stoul(kv["vec_nonz"]), (uint32_t)std::stoul(kv["max_dets"]), seed,
+                          (uint32_t)(kv.count("full") ? std::stoul(kv["full"]) != 0 : 0)};
         ck(fries_hh_setup(ctx, &p));
         const uint32_t max_iter = kv.count("max_iter") ? (uint32_t)std::stoul(kv["max_iter"]) : 1000000u;
         std::ofstream num_file(rd + "projnum.txt", std::ofstream::app), den_file(rd + "projden.txt", std::ofstream::app), shift_file(rd + "S.txt", std::ofstream::app),

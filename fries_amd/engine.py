@@ -43,7 +43,7 @@ class HHParams(C.Structure):
     """struct fries_hh_params"""
     _fields_ = [("n_elec", C.c_uint32), ("n_sites", C.c_uint32), ("eps", C.c_double), ("U", C.c_double), ("omega", C.c_double), ("g", C.c_double),
                 ("gs_energy", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double), ("vec_nonz", C.c_uint32), ("max_dets", C.c_uint32),
-                ("seed", C.c_uint32), ("pad", C.c_uint32)]
+                ("seed", C.c_uint32), ("full", C.c_uint32)]
 
 
 class FciqmcParams(C.Structure):
@@ -258,9 +258,10 @@ class FriEngine:
         return logs
 
     # ---- frisys_hh
-    def setup_hh(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0):
-        """frisys_hh (FRIES_bin/frisys_hh.cpp): 1-D Hubbard-Holstein chain, open boundaries, t = 1, start from 100 x Neel."""
-        p = HHParams(n_elec, n_sites, eps, U, omega, g, gs_energy, target_norm, initiator, vec_nonz, max_dets, seed, 0)
+    def setup_hh(self, *, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, full=False):
+        """frisys_hh (FRIES_bin/frisys_hh.cpp): 1-D Hubbard-Holstein chain, open boundaries, t = 1, start from 100 x Neel.
+        full=True: frifull_hh (FRIES_bin/frifull_hh.cpp), the Hamiltonian applied in full instead of compressed."""
+        p = HHParams(n_elec, n_sites, eps, U, omega, g, gs_energy, target_norm, initiator, vec_nonz, max_dets, seed, 1 if full else 0)
         self._ck(self.lib.fries_hh_setup(self.h, C.byref(p)))
         self.max_dets = max_dets
 

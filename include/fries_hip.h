@@ -145,7 +145,9 @@ int fries_frifull_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs)
 typedef struct {
     uint32_t n_elec, n_sites;
     double eps, U, omega, g, gs_energy, target_norm, initiator;
-    uint32_t vec_nonz, max_dets, seed, pad;
+    uint32_t vec_nonz, max_dets, seed;
+    uint32_t full;      /* 0: frisys_hh.  1: frifull_hh (FRIES_bin/frifull_hh.cpp) -- every hop and phonon move of every stored state
+                         * instead of the two matrix compressions; num_success = number of adds; one rank only */
 } fries_hh_params;
 int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
 int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);

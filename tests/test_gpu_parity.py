@@ -433,16 +433,17 @@ def test_full_size_invariants_m1e6(Engine, mols):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(k for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] == 1))
+@pytest.mark.parametrize("name", sorted(k for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] == 1) + sorted(golden_io.manifest()["hhfull_runs"]))
 def test_hubbard_holstein_matches_reference(name):
-    """frisys_hh on the device against the reference's own loop (tests/golden/hh_*.traj): counts, norms, shifts and the
-    stored shard bit for bit; the projected-energy numerator (a block-parallel sum of signed terms) to 1e-10."""
+    """frisys_hh (hh_*) and frifull_hh (hhfull_*) on the device against the reference's own loops (tests/golden/hh*.traj): counts,
+    norms, shifts and the stored shard bit for bit; the projected-energy numerator (a block-parallel sum of signed terms) to 1e-10."""
     from fries_amd.engine import FriEngine
-    r = golden_io.manifest()["hh_runs"][name]
+    full = name in golden_io.manifest()["hhfull_runs"]
+    r = golden_io.manifest()["hhfull_runs" if full else "hh_runs"][name]
     g = golden_io.read_traj(name)
     eng = FriEngine(None)
     eng.setup_hh(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
-                 vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
+                 vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], full=full)
     logs = eng.iterate_hh(r["n_iter"])
     for i, row in enumerate(g["rows"]):
         lg = logs[i]
@@ -578,6 +579,23 @@ def test_cli_drivers_hh_and_fciqmc(oracle, mols, tmp_path):
         assert den[i] == row["denom"] and abs(num[i] - row["numer"]) <= 1e-10 * max(1.0, abs(row["numer"]))
     for k in range(n_it // 10):
         assert sh[k] == g["rows"][10 * k + 9]["shift"] and nm[k] == g["rows"][10 * k + 9]["norm"]
+    # ---- the same driver as frifull_hh (--full 1)
+    name = "hhfull_l6_m300"
+    r = golden_io.manifest()["hhfull_runs"][name]
+    g = golden_io.read_traj(name)
+    pf.write_text("n_elec\n%d\nlat_len\n%d\nn_dim\n1\neps\n%r\nU\n%r\nomega\n%r\ng\n%r\ngs_energy\n%r\n" % (r["n_elec"], r["n_sites"], r["eps"], r["U"], r["omega"], r["g"], r["gs_energy"]))
+    outf = str(tmp_path / "hhfull") + "/"
+    os.makedirs(outf)
+    res = subprocess.run([build.DRIVERS["frisys_hh_hip"], "--params_path", str(pf), "--vec_nonz", str(r["vec_nonz"]), "--max_dets", str(r["max_dets"]), "--target",
+                          repr(r["target_norm"]), "--initiator", repr(r["initiator"]), "--max_iter", str(n_it), "--result_dir", outf, "--seed", str(r["seed"]), "--full", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(outf + "projnum.txt"); den = np.loadtxt(outf + "projden.txt"); nm = np.loadtxt(outf + "norm.txt")
+    for i in range(n_it):
+        row = g["rows"][i]
+        assert den[i] == row["denom"] and abs(num[i] - row["numer"]) <= 1e-10 * max(1.0, abs(row["numer"]))
+    for k in range(n_it // 10):
+        assert nm[k] == g["rows"][10 * k + 9]["norm"]
     # ---- fciqmc_mol_hip
     mol = mols("Ne")
     fc = str(tmp_path / "ne.FCIDUMP")
