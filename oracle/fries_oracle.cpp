@@ -1473,6 +1473,211 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
     sc.vec_len = ns;
 }
 
+// ------------------------------------------------------------------ apply_HBPP_piv
+void HBPivScratch::init(size_t length, size_t n_subwt) {
+    len = length; vec_len = 0;
+    vec1.assign(length, 0); long_vec.assign(length * n_subwt, 0);
+    det_idx1.assign(length, 0); det_idx2.assign(length, 0); srt.assign(length * n_subwt, 0);
+    orb1.assign(length * 4, 0); orb2.assign(length * 4, 0); flag.assign(length * n_subwt, 0);
+    group.assign(length, 0);
+}
+
+// heat_bathPP.cpp:994-1012: the elements the compression did not zero, in order; fn(old_short, new_short, index in the group)
+template <class F>
+static size_t collapse_long(std::vector<double> &short_vec, const std::vector<double> &long_vec, size_t short_len, std::vector<uint8_t> &flag,
+                            const std::vector<uint16_t> &group, F fn) {
+    size_t n_short = 0, li = 0;
+    for (size_t si = 0; si < short_len; si++) {
+        for (size_t g = 0; g < group[si]; g++) {
+            if (!flag[li]) { short_vec[n_short] = long_vec[li]; fn(si, n_short, g); n_short++; }
+            flag[li] = 0;
+            li++;
+        }
+    }
+    return n_short;
+}
+
+void apply_HBPP_piv(const Vec &v, HBPivScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
+                    std::mt19937 &mt, uint32_t n_samp, bool unit_matrel, const Comm &cm) {
+    std::vector<double> &sv = sc.vec1, &lv = sc.long_vec;
+    size_t n_short = sc.vec_len;
+    std::vector<size_t> &di1 = sc.det_idx1, &di2 = sc.det_idx2;
+    uint8_t (*oi1)[4] = (uint8_t (*)[4])sc.orb1.data();
+    uint8_t (*oi2)[4] = (uint8_t (*)[4])sc.orb2.data();
+    std::vector<uint16_t> &grp = sc.group;
+    const unsigned n_elec = sys.n_elec, n_orb = sys.n_orb;
+    const HBInfo &hb = sys.hb;
+    const Symm &symm = sys.symm;
+    unsigned cts[N_IRREPS][2];
+
+    // ---- singles vs doubles (:1047-1067)
+    size_t n_long = 0;
+    for (size_t s = 0; s < n_short; s++) {
+        double w = fabs(sv[s]);
+        if (w > 0) { lv[n_long++] = w * p_doub; lv[n_long++] = w * (1 - p_doub); grp[s] = 2; }
+        else grp[s] = 0;
+    }
+    piv_comp_parallel(lv.data(), n_long, n_samp, sc.srt, sc.flag, mt, cm);
+    n_short = collapse_long(sv, lv, n_short, sc.flag, grp, [&](size_t o, size_t n, size_t g) { di2[n] = di1[o]; oi1[n][0] = (uint8_t)g; });
+    sc.stage_len[0] = n_short;
+
+    // ---- first occupied orbital (:1069-1101)
+    n_long = 0;
+    for (size_t s = 0; s < n_short; s++) {
+        const uint8_t *occ = v.orbs_at(di2[s]);
+        if (oi1[s][0] == 0) {
+            grp[s] = (uint16_t)(n_elec - new_hb);
+            double tw = calc_o1_probs(hb, &lv[n_long], n_elec, occ, new_hb);
+            for (size_t k = 0; k < n_elec - new_hb; k++) lv[n_long + k] *= sv[s] * (new_hb ? tw : 1);
+            n_long += n_elec - new_hb;
+        }
+        else {
+            count_symm_virt(cts, occ, n_elec, symm);
+            uint32_t n_occ = count_sing_allowed(occ, n_elec, symm, cts);
+            grp[s] = (uint16_t)n_occ;
+            for (size_t k = 0; k < n_occ; k++) lv[n_long + k] = sv[s] / n_occ;
+            n_long += n_occ;
+        }
+    }
+    piv_comp_parallel(lv.data(), n_long, n_samp, sc.srt, sc.flag, mt, cm);
+    n_short = collapse_long(sv, lv, n_short, sc.flag, grp, [&](size_t o, size_t n, size_t g) { di1[n] = di2[o]; oi2[n][0] = oi1[o][0]; oi2[n][1] = (uint8_t)g; });
+    sc.stage_len[1] = n_short;
+
+    // ---- unoccupied (single) / 2nd occupied (double) (:1103-1157)
+    n_long = 0;
+    for (size_t s = 0; s < n_short; s++) {
+        if (oi2[s][1] >= n_elec) { std::cerr << "Error: chosen occupied orbital (first) is out of bounds\n"; grp[s] = 0; continue; }
+        const uint8_t *occ = v.orbs_at(di1[s]);
+        if (oi2[s][0] == 0) {
+            double tw = 1;
+            uint16_t n_o2;
+            if (new_hb) { oi2[s][1]++; n_o2 = oi2[s][1]; tw = calc_o2_probs_half(hb, &lv[n_long], n_elec, occ, n_o2); }
+            else { n_o2 = (uint16_t)n_elec; calc_o2_probs(hb, &lv[n_long], n_elec, occ, oi2[s][1]); }
+            for (size_t k = 0; k < n_o2; k++) lv[n_long + k] *= tw * sv[s];
+            grp[s] = n_o2;
+            n_long += n_o2;
+        }
+        else {
+            count_symm_virt(cts, occ, n_elec, symm);
+            uint32_t n_virt = count_sing_virt(occ, n_elec, symm, cts, &oi2[s][1]);
+            if (n_virt == 0) grp[s] = 0;
+            else {
+                grp[s] = (uint16_t)n_virt;
+                oi2[s][3] = (uint8_t)n_virt;
+                for (size_t k = 0; k < n_virt; k++) lv[n_long + k] = sv[s] / n_virt;
+                n_long += n_virt;
+            }
+        }
+    }
+    piv_comp_parallel(lv.data(), n_long, n_samp, sc.srt, sc.flag, mt, cm);
+    n_short = collapse_long(sv, lv, n_short, sc.flag, grp, [&](size_t o, size_t n, size_t g) {
+        di2[n] = di1[o]; oi1[n][0] = oi2[o][0]; oi1[n][1] = oi2[o][1]; oi1[n][2] = (uint8_t)g;
+        if (oi2[o][0] == 1) oi1[n][3] = oi2[o][3];
+    });
+    sc.stage_len[2] = n_short;
+
+    // ---- 1st unoccupied (double) (:1159-1209)
+    n_long = 0;
+    for (size_t s = 0; s < n_short; s++) {
+        uint8_t o2u1 = oi1[s][2];
+        if (oi1[s][0] == 0) {
+            if (o2u1 >= n_elec) { std::cerr << "Error: chosen occupied orbital (second) is out of bounds\n"; grp[s] = 0; continue; }
+            const uint8_t *occ = v.orbs_at(di2[s]);
+            uint8_t o1_idx = oi1[s][1];
+            int o1_spin = o1_idx / (n_elec / 2);
+            int o2_spin = occ[o2u1] / n_orb;
+            double tw = calc_u1_probs(hb, &lv[n_long], occ[o1_idx], occ, n_elec, new_hb && (o1_spin == o2_spin));
+            uint32_t n_virt = n_orb - n_elec / 2;
+            grp[s] = (uint16_t)n_virt;
+            for (size_t k = 0; k < n_virt; k++) lv[n_long + k] *= sv[s] * (new_hb ? tw : 1);
+            n_long += n_virt;
+        }
+        else {
+            if (o2u1 >= oi1[s][3]) std::cerr << "Error: index of chosen virtual orbital exceeds maximum\n";
+            grp[s] = 1;         // the reference resets the group size after the error branch (:1192-1196)
+            lv[n_long++] = sv[s];
+        }
+    }
+    piv_comp_parallel(lv.data(), n_long, n_samp, sc.srt, sc.flag, mt, cm);
+    n_short = collapse_long(sv, lv, n_short, sc.flag, grp, [&](size_t o, size_t n, size_t g) {
+        di1[n] = di2[o]; oi2[n][0] = oi1[o][0]; oi2[n][1] = oi1[o][1]; oi2[n][2] = oi1[o][2];
+        oi2[n][3] = oi1[o][0] == 1 ? oi1[o][3] : (uint8_t)g;
+    });
+    sc.stage_len[3] = n_short;
+
+    // ---- 2nd unoccupied (double) (:1211-1252)
+    n_long = 0;
+    for (size_t s = 0; s < n_short; s++) {
+        size_t d = di1[s];
+        uint8_t o1_idx = oi2[s][1];
+        if (oi2[s][0] == 0) {
+            const uint8_t *occ = v.orbs_at(d);
+            uint8_t u1 = find_nth_virt(occ, o1_idx / (n_elec / 2), n_elec, n_orb, oi2[s][3]);
+            det_t cd = v.dets[d];
+            if (bit(cd, u1)) { std::cerr << "Error: occupied orbital chosen as 1st virtual\n"; grp[s] = 0; }
+            else {
+                oi2[s][3] = u1;
+                uint16_t n_probs;
+                double tw;
+                if (new_hb) tw = calc_u2_probs_half(hb, &lv[n_long], occ[o1_idx], occ[oi2[s][2]], u1, cd, symm, &n_probs);
+                else tw = calc_u2_probs(hb, &lv[n_long], occ[o1_idx], occ[oi2[s][2]], u1, symm, &n_probs);
+                for (size_t k = 0; k < n_probs; k++) lv[n_long + k] *= sv[s] * (new_hb ? tw : 1);
+                grp[s] = n_probs;
+                n_long += n_probs;
+            }
+        }
+        else { grp[s] = 1; lv[n_long++] = sv[s]; }
+    }
+    piv_comp_parallel(lv.data(), n_long, n_samp, sc.srt, sc.flag, mt, cm);
+    sc.stage_len[4] = 0;
+    for (size_t li = 0; li < n_long; li++) sc.stage_len[4] += !sc.flag[li];
+
+    // ---- decode, weight, matrix element, parity (:1254-1417, spin_parity == 0)
+    size_t old_len = n_short, li = 0;
+    n_short = 0;
+    for (size_t s = 0; s < old_len; s++) {
+        for (size_t g = 0; g < grp[s]; g++, li++) {
+            if (sc.flag[li]) { sc.flag[li] = 0; continue; }
+            size_t d = di1[s];
+            di2[n_short] = d;
+            const uint8_t *occ = v.orbs_at(d);
+            det_t cd = v.dets[d];
+            uint8_t o1_idx = oi2[s][1];
+            double tw, mel;
+            if (oi2[s][0] == 0) {
+                uint8_t o1 = occ[o1_idx], o2 = occ[oi2[s][2]], u1 = oi2[s][3];
+                uint8_t u2_ir = symm.irrep[o1 % n_orb] ^ symm.irrep[o2 % n_orb] ^ symm.irrep[u1 % n_orb];
+                uint8_t u2 = symm.lk(u2_ir, (unsigned)g + 1) + n_orb * (o2 / n_orb);
+                if (bit(cd, u2)) { if (new_hb) std::cerr << "Error: occupied orbital chosen as second virtual in unnormalized heat-bath\n"; continue; }
+                if (u1 == u2) { std::cerr << "Error: repeat virtual orbital chosen\n"; continue; }
+                if (u1 > u2) std::swap(u1, u2);
+                if (o1 > o2) std::swap(o1, o2);
+                oi1[n_short][0] = o1; oi1[n_short][1] = o2; oi1[n_short][2] = u1; oi1[n_short][3] = u2;
+                tw = new_hb ? calc_unnorm_wt(hb, oi1[n_short]) : calc_norm_wt(hb, oi1[n_short], occ, n_elec, cd, symm);
+                tw *= p_doub;
+                mel = unit_matrel ? 1.0 : doub_matrel_nosgn(oi1[n_short], sys.ints);
+                mel *= doub_parity(cd, oi1[n_short]);
+            }
+            else {
+                uint8_t o1 = occ[o1_idx];
+                oi1[n_short][0] = o1;
+                uint8_t u1 = virt_from_idx(cd, symm, symm.irrep[o1 % n_orb], n_orb * (o1 / n_orb), oi2[s][2]);
+                if (u1 == 255) { std::cerr << "Error: virtual orbital not found\n"; continue; }
+                oi1[n_short][1] = u1;
+                oi1[n_short][2] = oi1[n_short][3] = 0;
+                count_symm_virt(cts, occ, n_elec, symm);
+                unsigned n_occ = count_sing_allowed(occ, n_elec, symm, cts);
+                tw = (1 - p_doub) / n_occ / oi2[s][3];
+                mel = unit_matrel ? 1.0 : sing_matrel_nosgn(oi1[n_short], occ, sys.ints, n_elec);
+                mel *= sing_parity(cd, oi1[n_short]);
+            }
+            double el = lv[li] * mel / tw;
+            if (fabs(el) > 1e-12) { sv[n_short] = el; n_short++; }
+        }
+    }
+    sc.vec_len = n_short;
+}
+
 // ------------------------------------------------------------------ driver
 static inline double uni(std::mt19937 &mt) { return mt() / (1. + UINT32_MAX); }
 

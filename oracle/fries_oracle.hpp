@@ -240,6 +240,21 @@ struct MolSys {
 void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
                     const double rn[5], uint32_t n_samp, bool unit_matrel, const Comm &cm = Comm::self());
 
+// FRIES/Hamiltonians/heat_bathPP.hpp:303-311 (HBCompressPiv) and heat_bathPP.cpp:994-1419 (collapse_long_, apply_HBPP_piv) for
+// spin_parity == 0: every factor of the HB-PP factorisation is multiplied out into long_vec, compressed by
+// piv_comp_parallel (find_preserve + pivotal sampling, draws from mt) and collapsed back.  stage_len[k] = short length after stage k.
+struct HBPivScratch {
+    size_t len = 0, vec_len = 0;
+    std::vector<double> vec1, long_vec;
+    std::vector<size_t> det_idx1, det_idx2, srt;
+    std::vector<uint8_t> orb1, orb2, flag;
+    std::vector<uint16_t> group;
+    size_t stage_len[5] = {0, 0, 0, 0, 0};
+    void init(size_t length, size_t n_subwt);
+};
+void apply_HBPP_piv(const Vec &v, HBPivScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
+                    std::mt19937 &mt, uint32_t n_samp, bool unit_matrel, const Comm &cm = Comm::self());
+
 // ---------------------------------------------------------------- driver loop
 struct FrisysParams {
     double eps = 0.01, target_norm = 0, init_thresh = 0;

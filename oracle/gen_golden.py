@@ -82,7 +82,40 @@ HHFULL_RUNS = {
 }
 
 
+# apply_HBPP_piv (pivotal matrix compression) on the vector a golden frisys_mol run holds after n_iter iterations:
+# name -> (run in RUNS, n_iter, [(n_samp, generator seed), ...])
+HBPIV_RUNS = {
+    "hbpiv_ne_unnorm": ("ne_m2000_unnorm", 30, [(1500, 11), (400, 12), (6000, 13), (1, 14)]),
+    "hbpiv_h2o_hb": ("h2o_m5000_hb", 25, [(3000, 5), (700, 6)]),
+    "hbpiv_n2_unnorm": ("n2_m10000_unnorm_ini0", 20, [(8000, 1), (25000, 2)]),
+}
+
+
+def gen_hbpiv(manifest):
+    manifest["hbpiv_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (run, n_iter, cases) in HBPIV_RUNS.items():
+            shape, _, seed, eps, vnz, mnz, maxd, ini, tgt, dist, _ = RUNS[run]
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".txt")
+            cmd = [HARNESS, "hbpiv", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist, out]
+            for ns, ps in cases:
+                cmd += [str(ns), str(ps)]
+            subprocess.run(cmd, check=True)
+            manifest["hbpiv_runs"][name] = dict(run=run, n_iter=n_iter, cases=[list(c) for c in cases])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-hbpiv":     # add these fixtures to the existing manifest without re-running the rest
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        subprocess.run([HARNESS, "hbpp_all", os.path.join(GOLD, "hbpp_all.txt")], check=True)
+        gen_hbpiv(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     os.makedirs(GOLD, exist_ok=True)
     manifest = {"runs": {}, "ints": {}}
     subprocess.run([HARNESS, "unit"], check=True)
@@ -214,6 +247,7 @@ def main():
         subprocess.run(cmd, check=True, env=dict(os.environ, FRIES_HH_FULL="1"))
         manifest["hhfull_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
                                               gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+    gen_hbpiv(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

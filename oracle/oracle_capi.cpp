@@ -135,6 +135,23 @@ size_t fo_apply_hbpp_sys(void *h, uint32_t n_samp, const double *rn, int unit_ma
     if (cap >= n) for (size_t i = 0; i < n; i++) { pos[i] = (uint32_t)sc.det_idx2[i]; memcpy(orbs + 4 * i, &sc.orb1[4 * i], 4); vals[i] = sc.vec1[i]; }
     return n;
 }
+// apply_HBPP_piv on the handle's stored vector, drawing from the handle's generator (seed it with fo_frisys_restart)
+size_t fo_apply_hbpp_piv(void *h, uint32_t n_samp, int unit_matrel, uint32_t *pos, uint8_t *orbs, double *vals, size_t cap, uint64_t *stage_len) {
+    Frisys *f = (Frisys *)h;
+    HBPivScratch ps;
+    size_t n = f->sol.curr_size;
+    size_t len = (n > (size_t)n_samp ? n : (size_t)n_samp) * 2 + 64;
+    size_t ns = f->sys.n_elec > (f->sys.n_orb - f->sys.n_elec / 2) ? f->sys.n_elec : f->sys.n_orb - f->sys.n_elec / 2;
+    ps.init(len, ns);
+    std::copy(f->sol.vals[0].begin(), f->sol.vals[0].begin() + n, ps.vec1.begin());
+    for (size_t i = 0; i < n; i++) ps.det_idx1[i] = i;
+    ps.vec_len = n;
+    apply_HBPP_piv(f->sol, ps, f->sys, f->p_doub, f->par.new_hb, f->mt, n_samp, unit_matrel != 0);
+    size_t m = ps.vec_len;
+    if (cap >= m) for (size_t i = 0; i < m; i++) { pos[i] = (uint32_t)ps.det_idx2[i]; memcpy(orbs + 4 * i, &ps.orb1[4 * i], 4); vals[i] = ps.vec1[i]; }
+    if (stage_len) for (int k = 0; k < 5; k++) stage_len[k] = ps.stage_len[k];
+    return m;
+}
 void fo_set_p_doub(void *h, double p) { ((Frisys *)h)->p_doub = p; }
 // find_preserve + sys_comp + deletes on the handle's stored vector
 void fo_compress_vec(void *h, uint32_t n_samp, double rn, uint32_t *n_kept, double *glob_norm) {

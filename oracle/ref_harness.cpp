@@ -708,12 +708,86 @@ static int run_hbpp_all(const char *out) {
         fprintf(f, "%u %u %u %u %a\n", sv.orb_indices1[s][0], sv.orb_indices1[s][1], sv.orb_indices1[s][2], sv.orb_indices1[s][3], sv.vec1[s]);
     }
     CHECK(bad1 == 0, "|value| != 1 in %zu samples", bad1);
+    // second half of [new_hb_all] (:507-519): the pivotal variant with the same budget returns the same excitations
+    {
+        HBCompressPiv pv(n_ex, n_states);
+        pv.vec_len = 1; pv.det_indices1[0] = 0; pv.vec1[0] = 1;
+        std::mt19937 mt_piv = mt_obj;
+        apply_HBPP_piv(occ_orbs, dets, &pv, hbtens, &basis_symm, 0.95, true, mt_obj, n_ex, s1, d1, 0);
+        fo::HBPivScratch ps; ps.init(n_ex, n_states);
+        ps.vec_len = 1; ps.det_idx1[0] = 0; ps.vec1[0] = 1;
+        fo::apply_HBPP_piv(v, ps, sys, 0.95, true, mt_piv, n_ex, true);
+        CHECK(ps.vec_len == pv.vec_len && pv.vec_len == sv.vec_len, "hbpp_all piv len %zu %zu %zu", ps.vec_len, (size_t)pv.vec_len, (size_t)sv.vec_len);
+        CHECK(mt_piv() == mt_obj(), "hbpp_all piv generator state");
+        size_t badp = 0;
+        for (size_t s = 0; s < pv.vec_len && s < sv.vec_len; s++) {
+            if (fabs(fabs(pv.vec1[s]) - 1) > 1e-7 || memcmp(pv.orb_indices1[s], sv.orb_indices1[s], 4)) badp++;
+            CHECK(memcmp(pv.orb_indices1[s], &ps.orb1[4 * s], 4) == 0 && same_bits(pv.vec1[s], ps.vec1[s]) && pv.det_indices2[s] == ps.det_idx2[s], "hbpp_all piv sample %zu", s);
+        }
+        CHECK(badp == 0, "[new_hb_all] piv vs sys: %zu samples differ", badp);
+        fprintf(f, "PIV %zu\n", (size_t)pv.vec_len);
+        for (size_t s = 0; s < pv.vec_len; s++)
+            fprintf(f, "%u %u %u %u %a\n", pv.orb_indices1[s][0], pv.orb_indices1[s][1], pv.orb_indices1[s][2], pv.orb_indices1[s][3], pv.vec1[s]);
+    }
     // tensors, so the GPU test can run the same case without the FourDArr
     fprintf(f, "HB %a\n", hb.s_norm);
     auto dump = [&](const char *nm, const std::vector<double> &x) { fprintf(f, "%s %zu", nm, x.size()); for (double y : x) fprintf(f, " %a", y); fprintf(f, "\n"); };
     dump("s_tens", hb.s_tens); dump("d_diff", hb.d_diff); dump("d_same", hb.d_same); dump("exch_sqrt", hb.exch_sqrt); dump("diag_sqrt", hb.diag_sqrt); dump("exch_norms", hb.exch_norms);
     fclose(f);
     printf("HBPP_ALL n=%zu checks=%d fails=%d\n", (size_t)sv.vec_len, n_chk, n_fail);
+    return n_fail != 0;
+}
+
+// ------------------------------------------------------------------ apply_HBPP_piv on a populated vector
+// hbpiv <fcidump> <pg> <n_iter> <seed> <eps> <vec_nonz> <mat_nonz> <max_dets> <ini> <target> <dist> <out> <n_samp> <piv_seed> [<n_samp> <piv_seed> ...]
+// n_iter iterations of the reference's frisys_mol loop (oracle in lockstep), then for every (n_samp, piv_seed) the reference's
+// apply_HBPP_piv (heat_bathPP.cpp:1014-1419, spin_parity 0) and the restatement on that vector with generators seeded alike.
+static int run_hbpiv(int argc, char **argv) {
+    if (argc < 16) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10), mnz = strtoul(argv[8], 0, 10);
+    size_t max_dets = strtoull(argv[9], 0, 10); double ini = atof(argv[10]), tgt = atof(argv[11]);
+    int nhb = !strcmp(argv[12], "HB_unnorm");
+    const char *out = argv[13];
+    RefRun rr;
+    rr.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
+    fo::Frisys fr;
+    setup_oracle_from_ref(fr, rr, seed, max_dets);
+    for (unsigned it = 0; it < n_iter; it++) { rr.iterate(); fr.iterate(1); }
+    size_t n = rr.sol->curr_size();
+    CHECK(n == fr.sol.curr_size, "hbpiv vector sizes");
+    for (size_t i = 0; i < n; i++) CHECK(same_bits(rr.sol->values()[i], fr.sol.vals[0][i]), "hbpiv vector el %zu", i);
+    FILE *f = fopen(out, "w");
+    fprintf(f, "# apply_HBPP_piv through the reference after %u frisys_mol iterations; per case: CASE n_samp piv_seed n_out stage lengths, then pos o1 o2 u1 u2 value\n", n_iter);
+    const size_t n_states = rr.n_elec > (rr.n_orb - rr.n_elec / 2) ? rr.n_elec : rr.n_orb - rr.n_elec / 2;
+    for (int a = 14; a + 1 < argc; a += 2) {
+        uint32_t n_samp = strtoul(argv[a], 0, 10), pseed = strtoul(argv[a + 1], 0, 10);
+        size_t len = (n > (size_t)n_samp ? n : (size_t)n_samp) * 2 + 64;
+        HBCompressPiv pv(len, n_states);
+        std::copy(rr.sol->values(), rr.sol->values() + n, pv.vec1.begin());
+        for (size_t i = 0; i < n; i++) pv.det_indices1[i] = i;
+        pv.vec_len = n;
+        std::mt19937 m1(pseed), m2(pseed);
+        apply_HBPP_piv(rr.sol->occ_orbs(), rr.sol->indices(), &pv, rr.hb, rr.basis_symm, rr.p_doub, nhb, m1, n_samp, rr.sing_sc, rr.doub_sc, 0);
+        fo::HBPivScratch ps; ps.init(len, n_states);
+        std::copy(fr.sol.vals[0].begin(), fr.sol.vals[0].begin() + n, ps.vec1.begin());
+        for (size_t i = 0; i < n; i++) ps.det_idx1[i] = i;
+        ps.vec_len = n;
+        fo::apply_HBPP_piv(fr.sol, ps, fr.sys, fr.p_doub, nhb, m2, n_samp, false);
+        CHECK(ps.vec_len == pv.vec_len, "hbpiv n_samp %u len %zu %zu", n_samp, ps.vec_len, (size_t)pv.vec_len);
+        CHECK(m1() == m2(), "hbpiv n_samp %u generator state", n_samp);
+        size_t bad = 0;
+        for (size_t s = 0; s < pv.vec_len && s < ps.vec_len; s++)
+            if (memcmp(pv.orb_indices1[s], &ps.orb1[4 * s], 4) || !same_bits(pv.vec1[s], ps.vec1[s]) || pv.det_indices2[s] != ps.det_idx2[s]) bad++;
+        CHECK(bad == 0, "hbpiv n_samp %u: %zu samples differ", n_samp, bad);
+        fprintf(f, "CASE %u %u %zu %zu %zu %zu %zu %zu\n", n_samp, pseed, (size_t)pv.vec_len, ps.stage_len[0], ps.stage_len[1], ps.stage_len[2], ps.stage_len[3], ps.stage_len[4]);
+        for (size_t s = 0; s < pv.vec_len; s++)
+            fprintf(f, "%zu %u %u %u %u %a\n", (size_t)pv.det_indices2[s], pv.orb_indices1[s][0], pv.orb_indices1[s][1], pv.orb_indices1[s][2], pv.orb_indices1[s][3], pv.vec1[s]);
+        printf("HBPIV n_samp=%u seed=%u n_out=%zu stages %zu %zu %zu %zu %zu\n", n_samp, pseed, (size_t)pv.vec_len, ps.stage_len[0], ps.stage_len[1], ps.stage_len[2], ps.stage_len[3], ps.stage_len[4]);
+    }
+    fclose(f);
+    printf("HBPIV checks=%d fails=%d\n", n_chk, n_fail);
     return n_fail != 0;
 }
 
@@ -1356,6 +1430,7 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "unit")) rc = run_unit();
     else if (argc >= 3 && !strcmp(argv[1], "hbpp_all")) rc = run_hbpp_all(argv[2]);
     else if (argc >= 3 && !strcmp(argv[1], "piv")) rc = run_piv(argv[2]);
+    else if (argc >= 2 && !strcmp(argv[1], "hbpiv")) rc = run_hbpiv(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frifull")) rc = run_frifull(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);

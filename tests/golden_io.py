@@ -104,6 +104,25 @@ def read_piv_cases():
     return cases
 
 
+def read_hbpiv(name):
+    """tests/golden/<name>.txt: what the reference's apply_HBPP_piv returned on the vector of a golden run (oracle/ref_harness.cpp: run_hbpiv)."""
+    cases = []
+    with open(os.path.join(GOLD, name + ".txt")) as f:
+        cur = None
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "CASE":
+                cur = dict(n_samp=int(t[1]), seed=int(t[2]), n_out=int(t[3]), stage_len=[int(x) for x in t[4:9]], pos=[], orbs=[], val=[])
+                cases.append(cur)
+            else:
+                cur["pos"].append(int(t[0])); cur["orbs"].append([int(x) for x in t[1:5]]); cur["val"].append(float.fromhex(t[5]))
+    for c in cases:
+        c["pos"] = np.array(c["pos"], dtype=np.uint32); c["orbs"] = np.array(c["orbs"], dtype=np.uint8).reshape(-1, 4); c["val"] = np.array(c["val"])
+    return cases
+
+
 def read_text_vector(prefix):
     """<prefix>dets / <prefix>vals under tests/golden: the reference's text vector format (io_utils.cpp:447-482, 565-586)."""
     with open(os.path.join(GOLD, prefix + "dets")) as f:

@@ -47,6 +47,8 @@ def load():
         lib.fo_matrel_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.fo_apply_hbpp_sys.restype = C.c_size_t
         lib.fo_apply_hbpp_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_apply_hbpp_piv.restype = C.c_size_t
+        lib.fo_apply_hbpp_piv.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.fo_set_p_doub.argtypes = [C.c_void_p, C.c_double]
         lib.fo_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.fo_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -211,6 +213,16 @@ class OracleFrisys:
         vals = np.zeros(cap)
         n = self.lib.fo_apply_hbpp_sys(self.h, n_samp, _p(rn), int(unit_matrel), _p(pos), _p(orbs), _p(vals), cap)
         return pos[:n].copy(), orbs[:n].copy(), vals[:n].copy()
+
+    def apply_hbpp_piv(self, n_samp, unit_matrel=False, cap=None):
+        """apply_HBPP_piv on the stored vector with the handle's generator (restart(seed) first): positions, orbitals, values, stage lengths."""
+        cap = cap or (max(n_samp, self.vec_info()[0]) * 2 + 64)
+        pos = np.zeros(cap, dtype=np.uint32)
+        orbs = np.zeros((cap, 4), dtype=np.uint8)
+        vals = np.zeros(cap)
+        st = np.zeros(5, dtype=np.uint64)
+        n = self.lib.fo_apply_hbpp_piv(self.h, n_samp, int(unit_matrel), _p(pos), _p(orbs), _p(vals), cap, _p(st))
+        return pos[:n].copy(), orbs[:n].copy(), vals[:n].copy(), st
 
     def compress_vec(self, n_samp, rn):
         nk = C.c_uint32()

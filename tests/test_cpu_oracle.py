@@ -362,6 +362,26 @@ def test_oracle_pivotal_compression_known_answers(oracle):
         assert np.all((v != 0) | (fl == 1) | (np.array(cs["inp"]) == 0))
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["hbpiv_runs"]))
+def test_oracle_apply_hbpp_piv_matches_reference(oracle, mols, name):
+    """fo::apply_HBPP_piv (pivotal compression of every HB-PP factor) against what the reference's apply_HBPP_piv returned
+    (heat_bathPP.cpp:1014-1419) on the vector of a golden frisys_mol run: positions, orbitals and values bit for bit, stage lengths."""
+    import numpy as np
+    h = golden_io.manifest()["hbpiv_runs"][name]
+    r = golden_io.manifest()["runs"][h["run"]]
+    mol = fcidump.synthetic(r["shape"])
+    orc = oracle.OracleFrisys(mol, epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+                              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    orc.iterate(h["n_iter"])
+    cases = golden_io.read_hbpiv(name)
+    assert [[c["n_samp"], c["seed"]] for c in cases] == h["cases"]
+    for c in cases:
+        orc.restart(c["seed"])
+        pos, orbs, vals, st = orc.apply_hbpp_piv(c["n_samp"])
+        assert len(pos) == c["n_out"] and st.tolist() == c["stage_len"]
+        assert np.array_equal(pos, c["pos"]) and np.array_equal(orbs, c["orbs"]) and vals.tobytes() == c["val"].tobytes()
+
+
 def test_library_exports_every_declared_symbol():
     """libfries_hip.so loads on a GPU-less host and exports exactly what include/fries_hip.h declares."""
     from fries_amd import engine
