@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <random>
+#include <sstream>
 #include <stdexcept>
 
 struct FriesError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -94,6 +95,16 @@ struct PivBuf {
     void *tile_dd = nullptr;                                 // double-double tile sums / offsets of the parallel cut-point search
     uint64_t n_certified = 0, n_fallback = 0; uint32_t last_reason = 0;                // calls settled by the parallel search / by the sequential chain
 };
+// a plain device array compressed by the vector's pivotal kernels (apply_HBPP_piv's long_vec; pivotal.hip: fr_piv_comp_flat)
+struct FlatPiv {
+    uint32_t cap = 0;
+    double *vals = nullptr;         // the values, compressed in place
+    uint32_t *parent = nullptr;     // element of the short vector each value was expanded from
+    VecState *st = nullptr;
+    uint32_t *total = nullptr;      // [2] device scalars of the expansion / collapse
+    VcompBuf vc{};
+    PivBuf piv;
+};
 // ranks (include/fries_hip.h: fries_comm).  size == 1: no callbacks, the "gathered" block is the send block.
 struct fries_comm_ops {
     void *user; int32_t rank, size;
@@ -133,6 +144,8 @@ struct FriesCtx {
     fries_hh_params hh{};
     uint32_t *d_vec_scr = nullptr;
     det_t *hh_fdet = nullptr; double *hh_ovlp = nullptr;
+    FlatPiv flat;                   // apply_HBPP_piv
+    uint32_t *pv_goff = nullptr;    // first long index of every short element's group (W.cap)
     unsigned long long *hhf_cnt = nullptr;      // frifull_hh: {adds tried, adds written} of the iteration
     uint32_t adder_cap = 0;                  // the reference's Adder capacity per destination (frisys_mol.cpp:109-110)
     uint64_t n_collectives = 0;
@@ -212,6 +225,10 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
 void fr_unkept_norm(FriesCtx *c, uint32_t bound);
 // pivotal.hip
+void fr_piv_flat_reserve(FriesCtx *c, uint32_t cap);
+void fr_piv_flat_free(FriesCtx *c);
+void fr_piv_comp_flat(FriesCtx *c, uint32_t n, uint32_t compress_size);
+void fr_hbpp_piv_apply(FriesCtx *c, uint32_t n_samp, int unit_matrel, uint32_t stage_len[5]);
 void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *glob_norm);
 void fr_test_piv_adjust(FriesCtx *c, uint32_t *n_loc_io, double exp_loc, uint32_t n_tot, double tot_norm, double *new_norm, uint8_t *flags_out);
 // fciqmc.hip

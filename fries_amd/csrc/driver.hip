@@ -399,6 +399,8 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); hipFree(pv.tile_dd); }
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
     if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); hipFree(h->c.full_list); }
+    fr_piv_flat_free(&h->c);
+    if (h->c.pv_goff) hipFree(h->c.pv_goff);
     if (h->c.hh_fdet) hipFree(h->c.hh_fdet);
     if (h->c.hh_ovlp) hipFree(h->c.hh_ovlp);
     if (h->c.hhf_cnt) hipFree(h->c.hhf_cnt);
@@ -741,6 +743,25 @@ extern "C" int fries_apply_hbpp_sys(fries_ctx *h, uint32_t n_samp, const double 
     FR_API_END
 }
 
+extern "C" int fries_apply_hbpp_piv(fries_ctx *h, uint32_t n_samp, int unit_matrel, uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out,
+                                    uint32_t stage_len[5]) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (c->hh_mode || c->fq_mode || !c->W.cap) throw FriesError("fries_apply_hbpp_piv needs a context set up by fries_frisys_setup");
+    uint32_t sl[5] = {0, 0, 0, 0, 0};
+    fr_hbpp_piv_apply(c, n_samp, unit_matrel, sl);
+    size_t m = c->num_success;
+    if (n_out) *n_out = m;
+    if (stage_len) for (int k = 0; k < 5; k++) stage_len[k] = sl[k];
+    check_dev_err(c);
+    if (cap < m) throw FriesError("output buffer too small");
+    if (det_pos) FR_HIP(hipMemcpy(det_pos, c->c_pos, 4 * m, hipMemcpyDeviceToHost));
+    if (orbs) FR_HIP(hipMemcpy(orbs, c->c_orbs, 4 * m, hipMemcpyDeviceToHost));
+    if (vals) FR_HIP(hipMemcpy(vals, c->c_val, 8 * m, hipMemcpyDeviceToHost));
+    FR_API_END
+}
+
 extern "C" int fries_compress_vec(fries_ctx *h, uint32_t n_samp_in, double rn, uint32_t *n_kept, double *glob_norm) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;
@@ -783,6 +804,29 @@ extern "C" int fries_piv_stats(fries_ctx *h, uint64_t *n_certified, uint64_t *n_
     return (int)h->c.piv.last_reason;      // why the last fallback happened: 1 cut point near a border, 2 divmod, 4 walk, 8 candidate draw, 16 pass draw
 }
 extern "C" uint32_t fries_next_draw(fries_ctx *h) { return (uint32_t)h->c.mt(); }
+// the generator as std::mt19937's own text form (operator<< / operator>>): a caller that owns a std::mt19937, like the reference's
+// drivers, lends it to an operator whose number of draws depends on the data and takes it back afterwards
+extern "C" int fries_rng_set_state(fries_ctx *h, const char *text) {
+    FR_API_BEGIN
+    std::istringstream is(text ? text : "");
+    std::mt19937 m;
+    is >> m;
+    if (is.fail()) throw FriesError("fries_rng_set_state: not a std::mt19937 state");
+    h->c.mt = m;
+    FR_API_END
+}
+extern "C" int fries_rng_get_state(fries_ctx *h, char *buf, size_t cap, size_t *need) {
+    FR_API_BEGIN
+    std::ostringstream os;
+    os << h->c.mt;
+    const std::string s = os.str();
+    if (need) *need = s.size() + 1;
+    if (buf) {
+        if (cap < s.size() + 1) throw FriesError("fries_rng_get_state: buffer too small");
+        memcpy(buf, s.c_str(), s.size() + 1);
+    }
+    FR_API_END
+}
 
 __global__ void k_test_teeth(Teeth *t, double r0, double unit, uint32_t n, double *pos, const double *q, uint32_t nq, uint32_t *below) {
     if (blockIdx.x == 0 && threadIdx.x == 0) fr_build_teeth(t, r0, unit, n, 0.0);

@@ -527,3 +527,244 @@ void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]) {
     FR_HIP(hipStreamSynchronize(c->stream));
     c->num_success = c->comp_len[1];
 }
+
+// ------------------------------------------------------------------ apply_HBPP_piv (heat_bathPP.cpp:1014-1419, spin_parity 0)
+// Every factor of the HB-PP factorisation is multiplied out -- element e of the short vector becomes a group of values in
+// the long vector (long_vec) -- the long vector is compressed by piv_comp_parallel (find_preserve + pivotal sampling,
+// pivotal.hip) and collapsed back to the elements that were not zeroed (collapse_long_, :994-1012).  The short vector of a stage
+// is the same StageElems the systematic path builds (k_prep1 / k_prep: value incl. the factor's total weight, orbital code, row
+// cache): the products are the same numbers (p * (v * tot) == (v * tot) * p) and a group's size is the row length comp_sub sees,
+// or 0 where the reference leaves the group empty (:1061, :1108, :1133, :1167, :1222).
+struct PvLong { double *vals; uint32_t *parent; uint32_t *goff; uint8_t *del; uint32_t *total; };
+
+template <int STAGE, bool NEW_HB>
+__device__ __forceinline__ unsigned fr_pv_gsize(unsigned n_elec, unsigned n_orb, double val, uint32_t ndiv, uint32_t nsub) {
+    if (ndiv) return (val == 0 && ndiv == 1) ? 0u : ndiv;     // ndiv == 1 with a zero value is how k_prep marks an empty group
+    if (STAGE == 1) return 2;
+    if (STAGE == 2) return n_elec - (NEW_HB ? 1 : 0);
+    if (STAGE == 3) return NEW_HB ? nsub : n_elec;
+    if (STAGE == 4) return n_orb - n_elec / 2;
+    return nsub;
+}
+
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_pv_count(CompWork W, const HbTables *Tg, int cur, uint32_t *pcnt, uint32_t *total) {
+    __shared__ uint32_t shu[4];
+    const unsigned n_in = W.state[0].n_in;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    const StageElems E = W.el[cur];
+    const unsigned n_elec = Tg->n_elec, n_orb = Tg->n_orb;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        cnt += fr_pv_gsize<STAGE, NEW_HB>(n_elec, n_orb, E.val[e], E.ndiv[e], E.nsub[e]);
+    }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) { pcnt[blockIdx.x] = bc; if (bc) atomicAdd(total, bc); }
+}
+
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_pv_expand(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, const uint32_t *pcnt, PvLong L) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    const unsigned n_in = W.state[0].n_in;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    fr_stage_tables(&T, Tg);
+    const StageElems E = W.el[cur];
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    const unsigned n_elec = T.n_elec, n_orb = T.n_orb;
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t g[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        g[it] = e < n_in ? fr_pv_gsize<STAGE, NEW_HB>(n_elec, n_orb, E.val[e], E.ndiv[e], E.nsub[e]) : 0u;
+        tsum += g[it];
+    }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t o = off + incl - tsum;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + it;
+        if (e >= n_in) break;
+        L.goff[e] = o;
+        if (g[it] == 0) continue;
+        const double val = E.val[e];
+        const uint32_t nd = E.ndiv[e];
+        if (nd) {
+            const double part = val / nd;
+            for (uint32_t j = 0; j < nd; j++) { L.vals[o + j] = part; L.parent[o + j] = (uint32_t)e; }
+        }
+        else {
+            RowInfo ri = (STAGE == 1) ? fr_row1(W.row1) : fr_row_cached(E, e);
+            const det_t det = (STAGE == 1) ? 0ull : V.dets[E.pos[e]];
+            const uint32_t code = (STAGE == 1) ? 0u : E.code[e];
+            const uint32_t ge = g[it];
+            fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
+                if (s < ge) { L.vals[o + s] = w * val; L.parent[o + s] = (uint32_t)e; }
+            });
+        }
+        o += g[it];
+    }
+}
+
+// collapse_long_: the elements the compression did not zero become the next stage's emissions (source element, index in its group, value)
+__global__ void __launch_bounds__(FR_BLOCK) k_pv_ccount(PvLong L, uint32_t n_long, uint32_t *pcnt) {
+    __shared__ uint32_t shu[4];
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) { size_t l = base + it; if (l < n_long && !L.del[l]) cnt++; }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) pcnt[blockIdx.x] = bc;
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_pv_cwrite(CompWork W, PvLong L, uint32_t n_long, const uint32_t *pcnt, uint32_t out_cap, uint32_t *err) {
+    __shared__ uint32_t shu[4];
+    uint32_t off;
+    { uint32_t x = 0; for (unsigned i = threadIdx.x; i < blockIdx.x; i += blockDim.x) x += pcnt[i]; off = fr_block_sum_u32(x, shu); }
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t f[FR_ITEMS], tsum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) { size_t l = base + it; f[it] = (l < n_long && !L.del[l]) ? 1u : 0u; tsum += f[it]; }
+    uint32_t tot;
+    uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
+    uint32_t o = off + incl - tsum;
+    bool over = false;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t l = base + it;
+        if (l >= n_long) break;
+        if (f[it]) {
+            if (o < out_cap) { uint32_t e = L.parent[l]; W.e_wi[o] = e; W.e_sub[o] = (uint32_t)l - L.goff[e]; W.e_val[o] = L.vals[l]; }
+            else over = true;
+            o++;
+        }
+        L.del[l] = 0;
+    }
+    if (over) atomicOr(err, FR_ERR_SPAWN_CAP);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == FR_BLOCK - 1) { W.state[FR_MAX_ROUNDS + 1].n_out = o < out_cap ? o : out_cap; L.total[1] = o; }
+}
+
+// the last factor's survivors: orbitals, weight, matrix element with its sign, value (:1254-1417); f_val == 0 marks a dropped sample
+template <bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_final_eval_piv(CompWork W, VecDev V, SysDev S, int prev, double p_doub, int unit_matrel,
+                                                             double *f_val, uint32_t *f_orbs, uint32_t *pcnt) {
+    __shared__ HbTables T;
+    __shared__ uint32_t shu[4];
+    const unsigned n_in = W.state[FR_MAX_ROUNDS + 1].n_out;
+    const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    fr_stage_tables(&T, S.hb);
+    const StageElems P = W.el[prev];
+    const unsigned n_orb = T.n_orb;
+    size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;
+    uint32_t cnt = 0;
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t e = base + (size_t)it * FR_BLOCK;
+        if (e >= n_in) break;
+        uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
+        double val = W.e_val[e];
+        uint32_t pos = P.pos[wi], pc = P.code[wi];
+        det_t det = V.dets[pos];
+        unsigned o1_idx = fr_c(pc, 1);
+        double el = 0;
+        uint32_t orbs = 0;
+        if (fr_c(pc, 0) == 0) {
+            unsigned o1 = fr_nth_bit(det, o1_idx), o2 = fr_nth_bit(det, fr_c(pc, 2)), u1 = fr_c(pc, 3);
+            unsigned ir = T.irrep[o1 % n_orb] ^ T.irrep[o2 % n_orb] ^ T.irrep[u1 % n_orb];
+            unsigned u2 = T.lookup[ir][sub + 1] + n_orb * (o2 / n_orb);
+            if (!fr_bit(det, u2) && u1 != u2) {
+                if (u1 > u2) { unsigned t = u1; u1 = u2; u2 = t; }
+                if (o1 > o2) { unsigned t = o1; o1 = o2; o2 = t; }
+                orbs = fr_code(o1, o2, u1, u2);
+                double tw = NEW_HB ? fr_unnorm_wt(T, o1, o2, u1, u2) : fr_norm_wt(T, det, o1, o2, u1, u2);
+                tw *= p_doub;
+                double mel = unit_matrel ? 1.0 : fr_doub_matrel(o1, o2, u1, u2, S.eris, n_orb);
+                mel *= fr_doub_parity(det, o1, o2, u1, u2);
+                el = val * mel / tw;
+            }
+        }
+        else {
+            unsigned o1 = fr_nth_bit(det, o1_idx);
+            unsigned u1 = fr_virt_from_idx(T, det, T.irrep[o1 % n_orb], n_orb * (o1 / n_orb), fr_c(pc, 2));
+            if (u1 != 255) {
+                orbs = fr_code(o1, u1, 0, 0);
+                unsigned n_occ = fr_count_sing_allowed(T, det);
+                double tw = (1 - p_doub) / n_occ / fr_c(pc, 3);
+                double mel = unit_matrel ? 1.0 : fr_sing_matrel(det, o1, u1, S.h_core, S.eris, n_orb);
+                mel *= fr_sing_parity(det, o1, u1);
+                el = val * mel / tw;
+            }
+        }
+        if (!(fabs(el) > 1e-12)) el = 0;
+        f_val[e] = el; f_orbs[e] = orbs;
+        cnt += (el != 0);
+    }
+    uint32_t bc = fr_block_sum_u32(cnt, shu);
+    if (threadIdx.x == 0) pcnt[blockIdx.x] = bc;
+}
+
+template <int STAGE, bool NEW_HB>
+static uint32_t pv_stage(FriesCtx *c, int cur, uint32_t n_in, uint32_t n_samp) {
+    CompWork &W = c->W;
+    FlatPiv &F = c->flat;
+    hipStream_t st = c->stream;
+    const unsigned grid = fr_blocks(n_in ? n_in : 1, FR_TILE);
+    if (STAGE == 1) FR_LAUNCH(c, "k_prep1", k_prep1, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
+    else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
+    FR_HIP(hipMemsetAsync(F.total, 0, 8, st));
+    FR_LAUNCH(c, "k_pv_count", (k_pv_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->d_hb, cur, W.pcnt[0], F.total);
+    uint32_t n_long = 0;
+    FR_HIP(hipMemcpyAsync(&n_long, F.total, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    if (n_long == 0) {
+        FR_HIP(hipMemsetAsync(&W.state[FR_MAX_ROUNDS + 1].n_out, 0, 4, st));
+        return 0;
+    }
+    if (n_long > F.cap) fr_piv_flat_reserve(c, n_long + n_long / 4 + 1024);
+    PvLong L{F.vals, F.parent, c->pv_goff, F.vc.del, F.total};
+    FR_LAUNCH(c, "k_pv_expand", (k_pv_expand<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, W.pcnt[0], L);
+    fr_piv_comp_flat(c, n_long, n_samp);
+    L.del = F.vc.del;
+    const unsigned gl = fr_blocks(n_long, FR_TILE);
+    FR_LAUNCH(c, "k_pv_ccount", k_pv_ccount, dim3(gl), dim3(FR_BLOCK), L, n_long, W.pcnt[0]);
+    FR_LAUNCH(c, "k_pv_cwrite", k_pv_cwrite, dim3(gl), dim3(FR_BLOCK), W, L, n_long, W.pcnt[0], W.cap, c->d_err);
+    uint32_t n_out = 0;
+    FR_HIP(hipMemcpyAsync(&n_out, F.total + 1, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    if (n_out > W.cap) throw FriesError("pivotal matrix compression: more survivors than the work arrays hold");
+    return n_out;
+}
+
+template <bool NEW_HB>
+static void hbpp_piv_t(FriesCtx *c, uint32_t n_samp, int unit_matrel, uint32_t stage_len[5]) {
+    CompWork &W = c->W;
+    hipStream_t st = c->stream;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    uint32_t n = c->h_vst.curr_size;
+    if (n > W.cap) throw FriesError("vector larger than HB-PP work capacity");
+    if (!c->pv_goff) c->pv_goff = fr_alloc<uint32_t>(W.cap);
+    fr_piv_flat_reserve(c, 2 * (n > n_samp ? n : n_samp) + 1024);
+    n = pv_stage<1, NEW_HB>(c, 0, n, n_samp); stage_len[0] = n;
+    n = pv_stage<2, NEW_HB>(c, 1, n, n_samp); stage_len[1] = n;
+    n = pv_stage<3, NEW_HB>(c, 0, n, n_samp); stage_len[2] = n;
+    n = pv_stage<4, NEW_HB>(c, 1, n, n_samp); stage_len[3] = n;
+    n = pv_stage<5, NEW_HB>(c, 0, n, n_samp); stage_len[4] = n;
+    const unsigned grid = fr_blocks(n ? n : 1, FR_TILE);
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    double *f_val = W.S; uint32_t *f_orbs = W.kin;
+    FR_LAUNCH(c, "k_final_eval_piv", (k_final_eval_piv<NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
+    FR_LAUNCH(c, "k_final_compact", k_final_compact, dim3(grid), dim3(FR_BLOCK), W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
+    FR_HIP(hipMemcpyAsync(&c->num_success, c->d_nsucc, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+}
+
+void fr_hbpp_piv_apply(FriesCtx *c, uint32_t n_samp, int unit_matrel, uint32_t stage_len[5]) {
+    if (c->new_hb) hbpp_piv_t<true>(c, n_samp, unit_matrel, stage_len);
+    else hbpp_piv_t<false>(c, n_samp, unit_matrel, stage_len);
+}

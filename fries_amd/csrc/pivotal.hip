@@ -471,14 +471,16 @@ static uint32_t piv_budget(FriesCtx *c, const std::vector<double> &norms, uint32
     return got[c->rank];
 }
 
-void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *glob_norm_out) {
+// flat: c->vec / c->vc / c->piv stand for a plain array (fr_piv_comp_flat) -- no second column, no deletes afterwards
+static void piv_comp_core(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *glob_norm_out, bool flat) {
     VcompBuf &B = c->vc;
     hipStream_t st = c->stream;
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     const uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
     const uint32_t save = c->vec_nonz;
     c->vec_nonz = compress_size;
-    fr_death_clone(c, 0);                    // publishes the |v| block sums; column 1 is zero so values are unchanged
+    if (flat) fr_abs_sums(c);
+    else fr_death_clone(c, 0);               // publishes the |v| block sums; column 1 is zero so values are unchanged
     c->vec_nonz = save;
     uint32_t n_samp = compress_size;
     double gn = 0;
@@ -569,8 +571,72 @@ void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *
         }
         if (hs.end_pos < bound) FR_LAUNCH(c, "k_piv_tail", k_piv_tail, dim3(fr_blocks(bound - hs.end_pos, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, P);
     }
+    if (flat) return;
     fr_vec_delete_flagged(c, &c->vec, B.del, bound);         // compress_vecs: vec_utils.cpp:25-30
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
+}
+
+void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *glob_norm_out) { piv_comp_core(c, compress_size, n_kept, glob_norm_out, false); }
+
+// piv_comp_parallel (compress_utils.cpp:354-386) of a plain device array of n values (apply_HBPP_piv's long_vec): afterwards
+// F.vals holds the compressed values and F.vc.del[i] == 1 marks the elements that ended up zero.  The array rides through the same
+// kernels as the solution vector: for the duration of the call it IS c->vec (a VecDev whose only live members are v0 and st).
+void fr_piv_flat_reserve(FriesCtx *c, uint32_t cap) {
+    FlatPiv &F = c->flat;
+    if (F.cap >= cap) return;
+    if (fr_blocks(cap, FR_TILE) > FR_MAX_PART) throw FriesError("pivotal matrix compression: a factor expands to more elements than the work arrays index (8.3e6)");
+    if (F.cap) {
+        FR_HIP(hipStreamSynchronize(c->stream));
+        FR_HIP(hipFree(F.vals)); FR_HIP(hipFree(F.parent));
+        VcompBuf &B = F.vc;
+        FR_HIP(hipFree(B.keep)); FR_HIP(hipFree(B.del)); FR_HIP(hipFree(B.S));
+        for (int h = 0; h < 2; h++) { FR_HIP(hipFree(B.psum[h])); FR_HIP(hipFree(B.pcnt[h])); }
+        FR_HIP(hipFree(B.state)); FR_HIP(hipFree(B.teeth)); FR_HIP(hipFree(B.dots)); FR_HIP(hipFree(B.fix_list));
+        FR_HIP(hipFree(B.seq.tiles)); FR_HIP(hipFree(B.seq.subs)); FR_HIP(hipFree(B.seq.total)); FR_HIP(hipFree(B.gnorm));
+    }
+    F.vals = fr_alloc<double>(cap); F.parent = fr_alloc<uint32_t>(cap);
+    if (!F.st) { F.st = fr_alloc<VecState>(1); F.total = fr_alloc<uint32_t>(2); }
+    std::swap(c->vc, F.vc);
+    c->vc = VcompBuf{};
+    fr_vcomp_alloc(c, cap);
+    std::swap(c->vc, F.vc);
+    F.cap = cap;
+}
+void fr_piv_flat_free(FriesCtx *c) {
+    FlatPiv &F = c->flat;
+    if (!F.cap) return;
+    hipFree(F.vals); hipFree(F.parent); hipFree(F.st); hipFree(F.total);
+    VcompBuf &B = F.vc;
+    hipFree(B.keep); hipFree(B.del); hipFree(B.S);
+    for (int h = 0; h < 2; h++) { hipFree(B.psum[h]); hipFree(B.pcnt[h]); }
+    hipFree(B.state); hipFree(B.teeth); hipFree(B.dots); hipFree(B.fix_list);
+    hipFree(B.seq.tiles); hipFree(B.seq.subs); hipFree(B.seq.total); hipFree(B.gnorm);
+    PivBuf &P = F.piv;
+    if (P.start) { hipFree(P.start); hipFree(P.carry); hipFree(P.U); hipFree(P.unit); hipFree(P.scal); }
+    if (P.tile_dd) hipFree(P.tile_dd);
+    F = FlatPiv{};
+}
+void fr_piv_comp_flat(FriesCtx *c, uint32_t n, uint32_t compress_size) {
+    FlatPiv &F = c->flat;
+    if (n > F.cap) throw FriesError("fr_piv_comp_flat: array longer than reserved");
+    VecState hs{};
+    hs.curr_size = n;
+    FR_HIP(hipMemcpyAsync(F.st, &hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));        // hs is a host temporary
+    VecDev fv{};
+    fv.cap = F.cap; fv.v0 = F.vals; fv.st = F.st;
+    struct Swap {       // the solution vector comes back whatever happens
+        FriesCtx *c; FlatPiv &F; VecDev fv; VecState saved;
+        Swap(FriesCtx *c_, FlatPiv &F_, VecDev v) : c(c_), F(F_), fv(v), saved(c_->h_vst) { std::swap(c->vec, fv); std::swap(c->vc, F.vc); std::swap(c->piv, F.piv); }
+        ~Swap() {
+            std::swap(c->vec, fv); std::swap(c->vc, F.vc); std::swap(c->piv, F.piv); c->h_vst = saved;
+            // the statistics of fries_piv_stats count these calls, too
+            c->piv.n_certified += F.piv.n_certified; c->piv.n_fallback += F.piv.n_fallback;
+            if (F.piv.n_fallback) c->piv.last_reason = F.piv.last_reason;
+            F.piv.n_certified = F.piv.n_fallback = 0;
+        }
+    } guard(c, F, fv);
+    piv_comp_core(c, compress_size, nullptr, nullptr, true);
 }
 
 // test hook: adjust_probs alone on column 0 with nothing preserved (compress_utils.cpp:606-681)

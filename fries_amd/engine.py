@@ -20,7 +20,7 @@ EXPORTS = [
     "fries_last_error", "fries_device_count", "fries_ctx_create", "fries_ctx_destroy", "fries_set_molecule",
     "fries_get_hb_tensor", "fries_set_hb_tensor", "fries_hf_energy", "fries_matrel_batch", "fries_frisys_setup",
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
-    "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_compress_vec",
+    "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_apply_hbpp_piv", "fries_rng_set_state", "fries_rng_get_state", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
@@ -96,6 +96,9 @@ def load_library() -> C.CDLL:
     lib.fries_htrial_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fries_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.fries_vec_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_rng_set_state.argtypes = [C.c_void_p, C.c_char_p]
+    lib.fries_rng_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.fries_apply_hbpp_piv.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.fries_apply_hbpp_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_size_t), C.c_void_p]
     lib.fries_compress_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
@@ -326,6 +329,29 @@ class FriEngine:
         self._ck(self.lib.fries_apply_hbpp_sys(self.h, n_samp, _ptr(rn), int(unit_matrel), _ptr(pos), _ptr(orbs), _ptr(vals), cap, C.byref(m), _ptr(cl)))
         k = m.value
         return pos[:k].copy(), orbs[:k].copy(), vals[:k].copy(), cl
+
+    def rng_state(self) -> str:
+        """The driver generator in std::mt19937's text form."""
+        need = C.c_size_t()
+        self._ck(self.lib.fries_rng_get_state(self.h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        self._ck(self.lib.fries_rng_get_state(self.h, buf, need.value, None))
+        return buf.value.decode()
+
+    def set_rng_state(self, text: str):
+        self._ck(self.lib.fries_rng_set_state(self.h, text.encode()))
+
+    def apply_hbpp_piv(self, n_samp: int, unit_matrel: bool = False):
+        """apply_HBPP_piv (heat_bathPP.cpp:1014-1419) on the stored vector; the uniforms come from the engine's generator (restart(seed))."""
+        cap = n_samp + 4096
+        pos = np.zeros(cap, dtype=np.uint32)
+        orbs = np.zeros((cap, 4), dtype=np.uint8)
+        vals = np.zeros(cap)
+        m = C.c_size_t()
+        sl = np.zeros(5, dtype=np.uint32)
+        self._ck(self.lib.fries_apply_hbpp_piv(self.h, n_samp, int(unit_matrel), _ptr(pos), _ptr(orbs), _ptr(vals), cap, C.byref(m), _ptr(sl)))
+        k = m.value
+        return pos[:k].copy(), orbs[:k].copy(), vals[:k].copy(), sl
 
     def compress_vec(self, n_samp: int, rn: float):
         nk = C.c_uint32()

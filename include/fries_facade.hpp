@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <random>
+#include <sstream>
 #include <stdexcept>
 #include <vector>
 
@@ -141,6 +142,38 @@ inline void apply_HBPP_sys(DistVec<double> &vec, HBCompressSys *comp_vecs, std::
     uint32_t comp_len[5];
     ck(fries_apply_hbpp_sys(vec.engine().ctx(), n_samp, rn, 0, pos.data(), comp_vecs->orb_indices1.data(), comp_vecs->vec1.data(), cap, &n_out, comp_len));
     for (size_t i = 0; i < n_out; i++) comp_vecs->det_indices2[i] = pos[i];
+    comp_vecs->vec_len = n_out;
+}
+// FRIES/Hamiltonians/heat_bathPP.hpp:303-311
+struct HBCompressPiv {
+    std::vector<double> vec1;
+    std::vector<size_t> det_indices1, det_indices2;
+    Matrix<uint8_t> orb_indices1;
+    size_t vec_len = 0;
+    size_t stage_len[5] = {0, 0, 0, 0, 0};      // elements after each of the five compressions (not in the reference's struct)
+    HBCompressPiv(size_t length, size_t /*n_states*/) : vec1(length), det_indices1(length), det_indices2(length), orb_indices1(length, 4) {}
+};
+// the caller's generator travels to the device context and back (the number of draws depends on the data)
+inline void lend_generator(Engine &eng, std::mt19937 &mt_obj) { std::ostringstream os; os << mt_obj; ck(fries_rng_set_state(eng.ctx(), os.str().c_str())); }
+inline void return_generator(Engine &eng, std::mt19937 &mt_obj) {
+    size_t need = 0;
+    ck(fries_rng_get_state(eng.ctx(), nullptr, 0, &need));
+    std::vector<char> buf(need);
+    ck(fries_rng_get_state(eng.ctx(), buf.data(), buf.size(), nullptr));
+    std::istringstream is(buf.data());
+    is >> mt_obj;
+}
+// FRIES/Hamiltonians/heat_bathPP.cpp:1014-1419 (spin_parity 0) on the vector's column 0
+inline void apply_HBPP_piv(DistVec<double> &vec, HBCompressPiv *comp_vecs, std::mt19937 &mt_obj, uint32_t n_samp) {
+    const size_t cap = comp_vecs->vec1.size();
+    std::vector<uint32_t> pos(cap);
+    size_t n_out = 0;
+    uint32_t sl[5];
+    lend_generator(vec.engine(), mt_obj);
+    ck(fries_apply_hbpp_piv(vec.engine().ctx(), n_samp, 0, pos.data(), comp_vecs->orb_indices1.data(), comp_vecs->vec1.data(), cap, &n_out, sl));
+    return_generator(vec.engine(), mt_obj);
+    for (size_t i = 0; i < n_out; i++) comp_vecs->det_indices2[i] = pos[i];
+    for (int k = 0; k < 5; k++) comp_vecs->stage_len[k] = sl[k];
     comp_vecs->vec_len = n_out;
 }
 // FRIES/compress_utils.cpp:29-105: the preserved set stays on the device until sys_comp

@@ -200,6 +200,12 @@ int fries_htrial_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t c
  * tests/test_hamiltonian.cpp:493-500. */
 int fries_apply_hbpp_sys(fries_ctx *ctx, uint32_t n_samp, const double rn[5], int unit_matrel,
                          uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out, uint32_t comp_len[5]);
+/* apply_HBPP_piv (heat_bathPP.cpp:1014-1419, spin_parity 0): every factor multiplied out into the long vector, compressed by
+ * piv_comp_parallel to n_samp elements and collapsed; outputs as comp_scratch->{det_indices2, orb_indices1, vec1}.  The uniforms
+ * come from the context's generator in the reference's order (seed it with fries_frisys_restart), because their number
+ * depends on the data.  stage_len[k] = elements after the k-th compression.  One factor may expand to at most 8.3e6 values. */
+int fries_apply_hbpp_piv(fries_ctx *ctx, uint32_t n_samp, int unit_matrel,
+                         uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out, uint32_t stage_len[5]);
 /* find_preserve + sys_comp on column 0 (compress_utils.cpp:29-105, 283-327) followed by the deletes
  * of frisys_mol.cpp:534-539 */
 int fries_compress_vec(fries_ctx *ctx, uint32_t n_samp, double rn, uint32_t *n_kept, double *glob_norm);
@@ -215,6 +221,11 @@ int fries_piv_stats(fries_ctx *ctx, uint64_t *n_certified, uint64_t *n_fallback)
 /* the next raw draw of the context's mt19937 (advances it): lets a caller interleave its own draws as the reference's
  * drivers do, and tests check the generator's position */
 uint32_t fries_next_draw(fries_ctx *ctx);
+/* the generator in std::mt19937's text form (operator<< / operator>>), so that a caller owning a std::mt19937 as the reference's
+ * drivers do (frisys_mol.cpp:104-106) can lend it to fries_apply_hbpp_piv / fries_compress_vec_piv and take it back.
+ * get: buf may be NULL to query the size (*need, with the terminator; about 6.9 kB) */
+int fries_rng_set_state(fries_ctx *ctx, const char *text);
+int fries_rng_get_state(fries_ctx *ctx, char *buf, size_t cap, size_t *need);
 
 /* Restart: re-seed the driver RNG, restore the energy shift / last norm / iteration count -- the part of
  * --load_dir that is not the vector (frisys_mol.cpp:257-263, 284-286); pair with fries_vec_load. */

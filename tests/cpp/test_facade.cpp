@@ -3,7 +3,8 @@
 //   (2) the frisys_mol iteration (FRIES_bin/frisys_mol.cpp:405-552) assembled from the operator-level calls -- apply_HBPP_sys,
 //       the two-pass initiator add, death/cloning, find_preserve, adjust_shift, the dots, sys_comp -- with the spawns built on
 //       the host exactly as the reference's loop builds them, compared iteration by iteration with the fused
-//       fries_frisys_iterate of a second engine started from the same seed.
+//       fries_frisys_iterate of a second engine started from the same seed;
+//   (3) apply_HBPP_piv through the facade with the caller's std::mt19937.
 // usage: test_facade <FCIDUMP> <point group> <n_iter>
 #include "../../include/fries_facade.hpp"
 #include "../../fries_amd/drivers/driver_common.hpp"
@@ -112,6 +113,25 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < n && i < other.curr_size(); i++)
             if (memcmp(sol_vec[i], other[i], 8) || (*sol_vec[i] != 0 && memcmp(sol_vec.indices()[i], other.indices()[i], det_size))) bad++;
         REQUIRE(bad == 0);
+        // ---- (3) apply_HBPP_piv with the caller's generator (as subsp_mol.cpp:537 calls it): the generator travels to the context and
+        //      back; the second engine holds the same vector and draws from its own generator seeded alike
+        {
+            const uint32_t n_piv = 1500;
+            HBCompressPiv piv_vecs(n_piv + 4096, n_states);
+            std::mt19937 pm(77);
+            apply_HBPP_piv(sol_vec, &piv_vecs, pm, n_piv);
+            REQUIRE(piv_vecs.vec_len > 0 && piv_vecs.vec_len <= n_piv && piv_vecs.stage_len[0] <= n_piv);
+            fries_hip::ck(fries_frisys_restart(eng_fused.ctx(), 77, 0.0, 0.0, 0));
+            std::vector<uint32_t> pos(n_piv + 4096); std::vector<uint8_t> orbs(4 * (n_piv + 4096)); std::vector<double> vals(n_piv + 4096);
+            size_t m = 0; uint32_t sl[5];
+            fries_hip::ck(fries_apply_hbpp_piv(eng_fused.ctx(), n_piv, 0, pos.data(), orbs.data(), vals.data(), pos.size(), &m, sl));
+            REQUIRE(m == piv_vecs.vec_len);
+            size_t badp = 0;
+            for (size_t i = 0; i < m && i < piv_vecs.vec_len; i++)
+                if (pos[i] != piv_vecs.det_indices2[i] || memcmp(&orbs[4 * i], piv_vecs.orb_indices1[i], 4) || memcmp(&vals[i], &piv_vecs.vec1[i], 8)) badp++;
+            REQUIRE(badp == 0);
+            REQUIRE(pm() == fries_next_draw(eng_fused.ctx()));        // the caller's generator came back advanced by exactly the draws made
+        }
         printf("FACADE checks=%d fails=%d iterations=%u final n_nonz=%d\n", n_chk, n_fail, n_iter, sol_vec.n_nonz());
     } catch (std::exception &ex) { fprintf(stderr, "Exception: %s\n", ex.what()); return 3; }
     return n_fail != 0;

@@ -58,7 +58,8 @@ def vec_hash(dets, vals):
 
 
 def read_hbpp_all():
-    out = dict(orbs=[], vals=[], tens={})
+    out = dict(orbs=[], vals=[], piv_orbs=[], piv_vals=[], tens={})
+    ko, kv = "orbs", "vals"
     with open(os.path.join(GOLD, "hbpp_all.txt")) as f:
         for ln in f:
             t = ln.split()
@@ -68,15 +69,19 @@ def read_hbpp_all():
                 out["rn"] = [float.fromhex(x) for x in t[1:6]]
             elif t[0] == "N":
                 out["n"] = int(t[1])
+            elif t[0] == "PIV":      # the pivotal half of the reference test: same samples from apply_HBPP_piv
+                out["piv_n"] = int(t[1]); ko, kv = "piv_orbs", "piv_vals"
             elif t[0] == "HB":
                 out["tens"]["s_norm"] = [float.fromhex(t[1])]
             elif t[0] in ("s_tens", "d_diff", "d_same", "exch_sqrt", "diag_sqrt", "exch_norms"):
                 out["tens"][t[0]] = [float.fromhex(x) for x in t[2:]]
             else:
-                out["orbs"].append([int(x) for x in t[:4]])
-                out["vals"].append(float.fromhex(t[4]))
-    out["orbs"] = np.array(out["orbs"], dtype=np.uint8)
-    out["vals"] = np.array(out["vals"])
+                out[ko].append([int(x) for x in t[:4]])
+                out[kv].append(float.fromhex(t[4]))
+    for k in ("orbs", "piv_orbs"):
+        out[k] = np.array(out[k], dtype=np.uint8).reshape(-1, 4)
+    for k in ("vals", "piv_vals"):
+        out[k] = np.array(out[k])
     return out
 
 

@@ -304,6 +304,10 @@ def test_oracle_new_hb_all_known_answer(oracle, mols):
     assert pos.size == g["n"] == 984
     assert np.array_equal(orbs, g["orbs"]) and np.array_equal(vals, g["vals"])
     assert np.all(np.abs(np.abs(vals) - 1) < 1e-7)
+    # second half of the reference test (:507-519): apply_HBPP_piv with the same budget returns the same excitations
+    assert g["piv_n"] == 984 and np.array_equal(g["piv_orbs"], g["orbs"])
+    ppos, porbs, pvals, _ = orc.apply_hbpp_piv(n_ex, unit_matrel=True)
+    assert np.array_equal(porbs, g["piv_orbs"]) and pvals.tobytes() == g["piv_vals"].tobytes() and np.all(ppos == 0)
 
 
 def test_fcidump_parser_matches_reference_parser(mols, tmp_path):

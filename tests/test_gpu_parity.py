@@ -131,6 +131,34 @@ def test_new_hb_all_known_answer_on_gpu(Engine, mols):
     pos, orbs, vals, _ = eng.apply_hbpp_sys(n_ex, g["rn"], unit_matrel=True)
     assert pos.size == 984 and np.all(pos == 0)
     assert sorted(map(tuple, orbs.tolist())) == sorted(map(tuple, g["orbs"].tolist()))
+    # second half of the reference test (:507-519): the pivotal variant with the same budget keeps everything, too
+    ppos, porbs, pvals, sl = eng.apply_hbpp_piv(n_ex, unit_matrel=True)
+    assert ppos.size == 984 and np.all(ppos == 0) and np.all(np.abs(np.abs(pvals) - 1) < 1e-7)
+    assert np.array_equal(porbs, orbs)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["hbpiv_runs"]))
+def test_apply_hbpp_piv_matches_reference(Engine, name):
+    """apply_HBPP_piv on the device (every HB-PP factor multiplied out, pivotal compression, collapse) against what the reference's
+    function returned on the vector of a golden frisys_mol run (tests/golden/hbpiv_*.txt): positions, orbitals, values bit for bit and
+    the length after every compression; budgets below, near and above the number of elements."""
+    h = golden_io.manifest()["hbpiv_runs"][name]
+    r = golden_io.manifest()["runs"][h["run"]]
+    mol = fcidump.synthetic(r["shape"])
+    eng = Engine(mol)
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"],
+              target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    logs = eng.iterate(h["n_iter"])
+    g = golden_io.read_traj(h["run"])
+    assert float(logs[-1]["norm"]) == g["rows"][h["n_iter"] - 1]["norm"]
+    for c in golden_io.read_hbpiv(name):
+        eng.restart(c["seed"])
+        pos, orbs, vals, sl = eng.apply_hbpp_piv(c["n_samp"])
+        assert sl.tolist() == c["stage_len"], (name, c["n_samp"], sl.tolist(), c["stage_len"])
+        assert len(pos) == c["n_out"]
+        assert np.array_equal(pos, c["pos"]) and np.array_equal(orbs, c["orbs"])
+        assert vals.tobytes() == c["val"].tobytes(), (name, c["n_samp"], int(np.sum(vals != c["val"])))
     eng.close()
 
 
