@@ -50,6 +50,7 @@ struct StageElems {      // one ping-pong half
     uint32_t *nsub;      // row length (jagged stages)
     double *rinv;        // cached 1 / norm of the element's row (non-uniform elements)
     uint32_t *raux;      // cached RowInfo::aux
+    det_t *det;          // the parent's determinant, copied at prep time: every replay reads it coalesced instead of gathering V.dets[pos]
 };
 
 struct CompWork {
@@ -199,7 +200,7 @@ __device__ __forceinline__ void fr_load_elems(const CompWork &W, const VecDev &V
         if (e >= n_in) x[it].v = 0;
     }
 #pragma unroll
-    for (int it = 0; it < N; it++) x[it].det = (STAGE != 1 && x[it].nd == 0 && x[it].v != 0) ? V.dets[x[it].pos] : 0ull;
+    for (int it = 0; it < N; it++) { const size_t e = base + it; x[it].det = (STAGE != 1) ? E.det[e < n_in ? e : last] : 0ull; }
 }
 
 // Returns the number of emissions; *k advances over consumed teeth.  When EMIT, writes

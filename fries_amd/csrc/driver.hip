@@ -384,7 +384,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     VecDev &v = h->c.vec;
     hipFree(v.dets); hipFree(v.v0); hipFree(v.v1); hipFree(v.diag); hipFree(v.active); hipFree(v.free_stack); hipFree(v.hkeys); hipFree(v.hvals); hipFree(v.st);
     CompWork &W = h->c.W;
-    for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
+    for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.el[k].rinv); hipFree(W.el[k].raux); hipFree(W.el[k].det); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
     hipFree(W.wt_remain); hipFree(W.keep); hipFree(W.S); hipFree(W.kin); hipFree(W.cnt); hipFree(W.e_wi); hipFree(W.e_sub); hipFree(W.e_val); hipFree(W.state); hipFree(W.teeth); hipFree(W.fix_list);
     hipFree(h->c.c_pos); hipFree(h->c.c_orbs); hipFree(h->c.c_val); hipFree(h->c.d_nsucc);
     SpawnBuf &s = h->c.sp;

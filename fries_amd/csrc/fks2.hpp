@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         double wr = v;
         uint32_t kp = (final && live) ? W.keep[e] : 0u;
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
-        if (STAGE != 1 && live && nd == 0 && v > 0) { code = E.code[e]; det = V.dets[E.pos[e]]; ri = fr_row_cached(E, e); }
+        if (STAGE != 1 && live && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
         if (final) {
             double lastwf = 0;
             Pfx nx;

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep(CompWork W, VecDev V, const H
             }
             else { code = fr_code(1, o1_idx, o2_idx, fr_c(pc, 3)); ndiv = 1; }
         }
-        E.val[e] = val; E.pos[e] = pos; E.code[e] = code; E.ndiv[e] = ndiv; E.nsub[e] = nsub; E.rinv[e] = rinv; E.raux[e] = raux;
+        E.val[e] = val; E.pos[e] = pos; E.code[e] = code; E.ndiv[e] = ndiv; E.nsub[e] = nsub; E.rinv[e] = rinv; E.raux[e] = raux; E.det[e] = det;
         W.wt_remain[e] = val; W.keep[e] = 0;
         sum += val;
     }
@@ -266,7 +266,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     for (int h = 0; h < 2; h++) {
         W.el[h].val = fr_alloc<double>(cap); W.el[h].pos = fr_alloc<uint32_t>(cap); W.el[h].code = fr_alloc<uint32_t>(cap);
         W.el[h].ndiv = fr_alloc<uint32_t>(cap); W.el[h].nsub = fr_alloc<uint32_t>(cap);
-        W.el[h].rinv = fr_alloc<double>(cap); W.el[h].raux = fr_alloc<uint32_t>(cap);
+        W.el[h].rinv = fr_alloc<double>(cap); W.el[h].raux = fr_alloc<uint32_t>(cap); W.el[h].det = fr_alloc<det_t>(cap);
         W.psum[h] = fr_alloc<double>(FR_MAX_PART); W.pcnt[h] = fr_alloc<uint32_t>(FR_MAX_PART);
     }
     W.wt_remain = fr_alloc<double>(cap); W.keep = fr_alloc<uint32_t>(cap); W.S = fr_alloc<double>(cap);
