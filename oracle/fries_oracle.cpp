@@ -2398,7 +2398,7 @@ void Fciqmc::setup() {
     hf_det = gen_hf_det(n_orb, n_elec);
     occ_list(hf_det, tmp);
     sys.hf_en = diag_matrel(tmp, sys.ints, n_elec);
-    mt.seed(par.seed + (uint32_t)cm.rank);          // fciqmc_mol.cpp:102-104: one generator per process
+    mt.seed(par.seed + (uint32_t)cm.rank);          // fciqmc_mol.cpp:102-104: one generator per process (frimulti_mol.cpp:84-86 alike)
     proc_scr.assign(2 * n_orb, 0); vec_scr.resize(2 * n_orb);
     if (cm.rank == 0) for (auto &x : proc_scr) x = mt();     // :123-131, then MPI_Bcast
     if (cm.size > 1) {
@@ -2409,6 +2409,7 @@ void Fciqmc::setup() {
     for (auto &x : vec_scr) x = mt();      // :134-136
     if (par.counter_rng) { rng.mt = nullptr; rng.seed = par.seed; } else rng.mt = &mt;
     unsigned spawn_length = par.target_walkers / cm.size / cm.size * 2;      // :107
+    if (par.multi) spawn_length = par.mat_nonz * 2 / cm.size / cm.size;     // frimulti_mol.cpp:89
     sol.init(par.max_dets, spawn_length, n_elec, 1, cm, proc_scr.data());
     hf_proc = sol.idx_to_proc(hf_det);
     if (!trial_in_det.empty()) {
@@ -2503,6 +2504,14 @@ void Fciqmc::setup() {
     sol.perform_add(0);
     if (par.heat_bath) sys.hb.set_up(sys.ints);       // :310-313
     en_shift = 0; last_norm = 0; iterat = 0;
+    if (par.multi) {                                   // frimulti_mol.cpp:227-233
+        loc_norms.assign(cm.size, 0);
+        double mine = sol.local_norm();
+        cm.allgather(&mine, loc_norms.data(), sizeof(double));
+        glob_norm = 0;
+        for (int p = 0; p < cm.size; p++) glob_norm += loc_norms[p];
+        srt.assign(sol.max_size, 0); keep.assign(sol.max_size, 0);
+    }
 }
 void Fciqmc::iterate(unsigned n_iter) {
     const unsigned n_elec = sys.n_elec;
@@ -2597,6 +2606,94 @@ void Fciqmc::iterate(unsigned n_iter) {
             for (int q = 0; q < cm.size; q++) { lg.numer += all[2 * q]; lg.denom += all[2 * q + 1]; }
         }
         lg.shift = en_shift; lg.norm = glob_norm; lg.n_nonz = n_nonz; lg.n_ini = n_ini; lg.curr_size = sol.curr_size; lg.n_spawn = n_spawn;
+        log.push_back(lg);
+    }
+}
+
+// frimulti_mol.cpp:296-425.  Only --distribution HB gets past the reference's argument check (:38-46: both branches compare with
+// "HB"), so the doubles always come from hb_doub_multi and the singles from sing_multin.
+void Fciqmc::iterate_multi(unsigned n_iter) {
+    const unsigned n_elec = sys.n_elec;
+    const double eps = par.eps;
+    const unsigned shift_interval = 10;
+    const double shift_damping = 0.05;
+    std::vector<uint8_t> orbs; std::vector<double> probs; std::vector<uint32_t> att;
+    for (unsigned it = 0; it < n_iter; it++, iterat++) {
+        FciqmcLog lg{};
+        uint32_t n_ini = 0; size_t n_spawn = 0;
+        double rn_sys = mt() / (1. + UINT32_MAX);          // rank 0's draw, broadcast (:301-305); one rank here
+        const unsigned curr_mat_samp = iterat < 10 ? par.mat_nonz / 10 : par.mat_nonz;
+        double lbound = seed_sys(loc_norms.data(), &rn_sys, curr_mat_samp, cm);
+        if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
+        for (size_t d = 0; d < sol.curr_size; d++) {
+            double &cur = sol.vals[0][d];
+            const double weight = fabs(cur);
+            if (weight == 0) continue;
+            unsigned n_walk = 0;
+            lbound += weight;
+            while (rn_sys < lbound) { n_walk++; rn_sys += glob_norm / curr_mat_samp; }
+            double colsamp_wt = weight / (glob_norm / curr_mat_samp);
+            if (colsamp_wt > 1) colsamp_wt = 1;
+            const int ini = weight > par.init_thresh_f;
+            n_ini += ini;
+            const det_t det = sol.dets[d];
+            const uint8_t *occ = sol.orbs_at(d);
+            unsigned counts[N_IRREPS][2];
+            count_symm_virt(counts, occ, n_elec, sys.symm);
+            rng.begin(iterat, det, 0, RNG_BIN);
+            unsigned n_doub = bin_sample(n_walk, p_doub, rng);
+            unsigned n_sing = n_walk - n_doub;
+            if (orbs.size() < 4 * (size_t)n_walk + 4) { orbs.resize(4 * (size_t)n_walk + 4); probs.resize(n_walk + 1); att.resize(n_walk + 1); }
+            unsigned nn = hb_doub_multi(det, occ, n_elec, sys.symm, sys.hb, n_doub, rng, iterat, orbs.data(), probs.data(), att.data());
+            for (unsigned w = 0; w < nn; w++) {
+                double m = doub_matrel_nosgn(&orbs[4 * w], sys.ints);
+                if (fabs(m) > 1e-9) {
+                    det_t nd = det;
+                    m *= -eps / probs[w] / p_doub / n_walk * cur * doub_det_parity(&nd, &orbs[4 * w]) / colsamp_wt;
+                    if (!sol.add(nd, m, (uint8_t)ini)) throw std::runtime_error("Insufficient memory allocated in adder.");
+                    n_spawn++;
+                }
+            }
+            unsigned m_allow[64], delta_s;
+            nu_sing_setup(occ, n_elec, sys.symm, counts, m_allow, &delta_s);
+            unsigned ns = delta_s == n_elec ? 0 : n_sing;
+            for (unsigned j = 0; j < ns; j++) {
+                rng.begin(iterat, det, j, RNG_SING);
+                nu_sing_sample(det, occ, n_elec, sys.symm, m_allow, delta_s, rng, &orbs[2 * j], &probs[j]);
+            }
+            for (unsigned w = 0; w < ns; w++) {
+                double m = sing_matrel_nosgn(&orbs[2 * w], occ, sys.ints, n_elec);
+                if (fabs(m) > 1e-9) {
+                    det_t nd = det;
+                    m *= -eps / probs[w] / (1 - p_doub) / n_walk * cur * sing_det_parity(&nd, &orbs[2 * w]) / colsamp_wt;
+                    if (!sol.add(nd, m, (uint8_t)ini)) throw std::runtime_error("Insufficient memory allocated in adder.");
+                    n_spawn++;
+                }
+            }
+            if (std::isnan(sol.diag[d])) sol.diag[d] = diag_matrel(occ, sys.ints, n_elec) - sys.hf_en;
+            cur *= 1 - eps * (sol.diag[d] - en_shift);
+        }
+        sol.perform_add(0);
+        if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
+        unsigned n_samp = par.vec_nonz;
+        double mine = find_preserve(sol.vals[0].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm, cm);
+        nkept = par.vec_nonz - n_samp;
+        if ((iterat + 1) % shift_interval == 0) adjust_shift(&en_shift, glob_norm, &last_norm, par.target_norm, shift_damping / shift_interval / eps);
+        lg.numer = sol.dot(htrial_det, htrial_val);
+        lg.denom = sol.dot(trial_det, trial_val);
+        if (cm.size > 1) {
+            std::vector<double> all(2 * (size_t)cm.size);
+            double mine2[2] = {lg.numer, lg.denom};
+            cm.allgather(mine2, all.data(), 16);
+            lg.numer = 0; lg.denom = 0;
+            for (int q = 0; q < cm.size; q++) { lg.numer += all[2 * q]; lg.denom += all[2 * q + 1]; }
+        }
+        rn_sys = mt() / (1. + UINT32_MAX);
+        cm.allgather(&mine, loc_norms.data(), sizeof(double));
+        sys_comp(sol.vals[0].data(), sol.curr_size, loc_norms.data(), n_samp, keep, rn_sys, cm);
+        // :416-421: the test `indices()[det_idx] != hf_det` compares addresses, so it is always true and HF is deleted like any other
+        for (size_t i = 0; i < sol.curr_size; i++) if (keep[i]) { sol.del_at_pos(i); keep[i] = 0; }
+        lg.shift = en_shift; lg.norm = glob_norm; lg.n_nonz = sol.n_nonz; lg.n_ini = n_ini; lg.curr_size = sol.curr_size; lg.n_spawn = n_spawn;
         log.push_back(lg);
     }
 }

@@ -403,6 +403,11 @@ struct FciqmcParams {
     uint32_t seed = 0;
     bool counter_rng = false;
     bool heat_bath = false;         // --distribution HB (hb_doub_multi for the doubles) instead of NU
+    // frimulti_mol (FRIES_bin/frimulti_mol.cpp): FRI with multinomial matrix compression -- real-valued vector, the number of samples
+    // per column from one systematic comb over |v|, the vector compressed to vec_nonz by find_preserve + sys_comp
+    bool multi = false;
+    uint32_t vec_nonz = 0, mat_nonz = 0;
+    double target_norm = 0, init_thresh_f = 0;
 };
 struct FciqmcLog { double numer, denom, shift, norm; int n_nonz; uint32_t n_ini; size_t curr_size, n_spawn; };
 // FRIES_bin/fciqmc_mol.cpp:35-480, HF trial vector, HF start; numer / denom are the rank-ordered sums every rank would see on
@@ -425,8 +430,13 @@ struct Fciqmc {
     // --trial_vec / --ini_vec (fciqmc_mol.cpp:150-177, 226-241): text vectors, added with `while (!add) perform_add` loops
     std::vector<det_t> trial_in_det, ini_det;
     std::vector<double> trial_in_val; std::vector<int> ini_val;
+    // frimulti_mol state: every rank's norm after the last compression, the global norm before it (frimulti_mol.cpp:227-233, 393, 414)
+    std::vector<double> loc_norms; double glob_norm = 0;
+    std::vector<size_t> srt; std::vector<uint8_t> keep;
+    uint32_t nkept = 0;
     void setup();
     void iterate(unsigned n);
+    void iterate_multi(unsigned n);      // frimulti_mol.cpp:296-425
 };
 
 // runs fn(rank) on `size` in-process ranks that share one communicator (fn receives its Comm)

@@ -91,6 +91,25 @@ HBPIV_RUNS = {
 }
 
 
+# frimulti_mol (multinomial matrix compression, --distribution HB), one rank: name -> (shape, n_iter, seed, eps, vec_nonz, mat_nonz, max_dets, initiator, target)
+MULTI_RUNS = {
+    "multi_ne_m1000": ("Ne", 60, 11, 0.01, 1000, 5000, 50000, 1.0, 500.0),
+    "multi_n2_m5000_ini0": ("N2", 40, 3, 0.01, 5000, 20000, 200000, 0.0, 2500.0),
+}
+
+
+def gen_multi(manifest):
+    manifest["multi_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt) in MULTI_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([HARNESS, "frimulti", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), out], check=True)
+            manifest["multi_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+
+
 def gen_hbpiv(manifest):
     manifest["hbpiv_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -108,6 +127,13 @@ def gen_hbpiv(manifest):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-multi":
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_multi(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-hbpiv":     # add these fixtures to the existing manifest without re-running the rest
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
@@ -248,6 +274,7 @@ def main():
         manifest["hhfull_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
                                               gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
     gen_hbpiv(manifest)
+    gen_multi(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

@@ -440,12 +440,28 @@ void *fo_fciqmc_create_ex(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps
     f->setup();
     return f;
 }
+// frimulti_mol: the same object in its multinomial mode (fo::Fciqmc::iterate_multi); flags bit 0 = counter-based uniforms
+void *fo_frimulti_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                         double eps, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, double initiator, double target_norm, int flags) {
+    Fciqmc *f = new Fciqmc();
+    f->par.heat_bath = true; f->par.counter_rng = (flags & 1) != 0;
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.max_dets = max_dets; f->par.seed = seed;
+    f->par.multi = true; f->par.vec_nonz = vec_nonz; f->par.mat_nonz = mat_nonz; f->par.init_thresh_f = initiator; f->par.target_norm = target_norm;
+    f->setup();
+    return f;
+}
+uint32_t fo_frimulti_nkept(void *h) { return ((Fciqmc *)h)->nkept; }
 void fo_fciqmc_destroy(void *h) { delete (Fciqmc *)h; }
 int fo_fciqmc_iterate(void *h, uint32_t n, FqLog *logs) {
     Fciqmc *f = (Fciqmc *)h;
     try {
         for (uint32_t i = 0; i < n; i++) {
-            f->iterate(1);
+            if (f->par.multi) f->iterate_multi(1); else f->iterate(1);
             if (logs) {
                 const FciqmcLog &l = f->log.back();
                 logs[i].numer = l.numer; logs[i].denom = l.denom; logs[i].shift = l.shift; logs[i].norm = l.norm; logs[i].n_nonz = l.n_nonz;

@@ -1424,6 +1424,169 @@ static int run_fciqmc(int argc, char **argv) {
     return n_fail != 0;
 }
 
+// ------------------------------------------------------------------ frimulti_mol: reference loop vs the oracle in mt mode
+// ref_harness frimulti <fcidump> <pg> <n_iter> <seed> <eps> <vec_nonz> <mat_nonz> <max_dets> <initiator> <target> <out>
+// FRIES_bin/frimulti_mol.cpp:84-425 with the FCIDUMP reader and SymmERIs in place of its legacy --hf_path / FourDArr inputs (the same
+// library functions otherwise); --distribution HB, the only one its argument check lets through (:38-46).  One rank.
+static int run_frimulti(int argc, char **argv) {
+    if (argc < 13) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t target_nonz = strtoul(argv[7], 0, 10), matr_samp = strtoul(argv[8], 0, 10);
+    uint32_t max_n_dets = strtoul(argv[9], 0, 10); double init_thresh = atof(argv[10]), target_norm = atof(argv[11]);
+    int n_procs = 1, proc_rank = 0;
+    MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
+    MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
+    if (n_procs != 1) { fprintf(stderr, "frimulti: one rank\n"); return 2; }
+    fcidump_input *in_data = parse_fcidump(path, pg);
+    unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
+    size_t det_size = CEILING(2 * n_orb, 8);
+    unsigned n_elec_unf = n_elec, tot_orb = n_orb;
+    uint8_t *symm = in_data->symm;
+    Matrix<double> *h_core = in_data->hcore; SymmERIs *eris = &in_data->eris;
+    uint8_t tmp_orbs[64], hf_det[8] = {0};
+    gen_hf_bitstring(n_orb, n_elec, hf_det);
+    find_bits(hf_det, tmp_orbs, det_size);
+    double hf_en = diag_matrel(tmp_orbs, tot_orb, *eris, *h_core, n_frz, n_elec);
+    std::mt19937 mt_obj(seed);
+    unsigned spawn_length = matr_samp * 2 / n_procs / n_procs;       // :89
+    std::function<double(const uint8_t *)> diag_shortcut = [tot_orb, eris, h_core, n_frz, n_elec, hf_en](const uint8_t *occ) { return diag_matrel(occ, tot_orb, *eris, *h_core, n_frz, n_elec) - hf_en; };
+    SymmInfo symm_basis(symm, n_orb);
+    unsigned unocc_symm_cts[n_irreps][2];
+    std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
+    for (auto &x : proc_scrambler) x = mt_obj();
+    for (auto &x : vec_scrambler) x = mt_obj();
+    DistVec<double> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 1, proc_scrambler, vec_scrambler);
+    unsigned max_spawn = matr_samp;
+    std::vector<uint8_t> spawn_orbs_v(4 * (size_t)max_spawn + 64); std::vector<double> spawn_probs(max_spawn + 16);
+    uint8_t (*sing_orbs)[2] = (uint8_t (*)[2])spawn_orbs_v.data();
+    uint8_t (*doub_orbs)[4] = (uint8_t (*)[4])spawn_orbs_v.data();
+    size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
+    DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
+    DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1);
+    trial_vec.perform_add(0); htrial_vec.perform_add(0);
+    trial_vec.collect_procs();
+    std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
+    for (size_t i = 0; i < trial_vec.curr_size(); i++) trial_hashes[i] = sol_vec.idx_to_hash(trial_vec.indices()[i], tmp_orbs);
+    std::vector<uint8_t> scratch(4 * n_ex);
+    h_op_offdiag(htrial_vec, symm, tot_orb, *eris, *h_core, scratch.data(), scratch.size(), n_frz, n_elec_unf, 1, 1, 0);
+    htrial_vec.set_curr_vec_idx(0);
+    h_op_diag(htrial_vec, 0, 0, 1);
+    htrial_vec.add_vecs(0, 1);
+    htrial_vec.collect_procs();
+    std::vector<uintmax_t> htrial_hashes(htrial_vec.curr_size());
+    for (size_t i = 0; i < htrial_vec.curr_size(); i++) htrial_hashes[i] = sol_vec.idx_to_hash(htrial_vec.indices()[i], tmp_orbs);
+    sol_vec.gen_orb_list(hf_det, tmp_orbs);
+    size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, (uint8_t (*)[4])scratch.data(), symm);
+    size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
+    double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
+    sol_vec.add(hf_det, 100, 1);
+    sol_vec.perform_add(0);
+    double loc_norms[1], glob_norm;
+    loc_norms[0] = sol_vec.local_norm();
+    glob_norm = loc_norms[0];
+    hb_info *hb_probs = set_up(tot_orb, n_orb, *eris);
+
+    fo::Fciqmc fq;
+    fq.sys.n_orb = n_orb; fq.sys.n_elec = n_elec;
+    fill_oracle_ints(fq.sys.ints, *eris, *h_core, n_orb);
+    fq.sys.symm.init(symm, n_orb);
+    fq.par.eps = eps; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false; fq.par.heat_bath = true;
+    fq.par.multi = true; fq.par.vec_nonz = target_nonz; fq.par.mat_nonz = matr_samp; fq.par.target_norm = target_norm; fq.par.init_thresh_f = init_thresh;
+    fq.setup();
+    CHECK(same_bits(fq.p_doub, p_doub), "frimulti p_doub");
+
+    double en_shift = 0, last_one_norm = 0;
+    const double shift_damping = 0.05; const unsigned shift_interval = 10;
+    std::vector<size_t> srt_arr(max_n_dets); std::vector<bool> keep_exact(max_n_dets, false);
+    FILE *f = fopen(argv[12], "w");
+    fprintf(f, "# golden trajectory from the reference's frimulti_mol loop (1 rank, HB); cols: it numer denom norm shift nkept n_nonz curr_size n_spawn n_ini digest\n");
+    for (unsigned iterat = 0; iterat < n_iter; iterat++) {
+        size_t n_ini = 0, n_spawn = 0;
+        double rn_sys = mt_obj() / (1. + UINT32_MAX);
+        unsigned curr_mat_samp = (iterat < 10) ? matr_samp / 10 : matr_samp;
+        double lbound = seed_sys(loc_norms, &rn_sys, curr_mat_samp);
+        for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
+            double *curr_el = sol_vec[det_idx];
+            uint8_t *curr_det = sol_vec.indices()[det_idx];
+            double weight = fabs(*curr_el);
+            if (weight == 0) continue;
+            unsigned n_walk = 0;
+            lbound += weight;
+            while (rn_sys < lbound) { n_walk++; rn_sys += glob_norm / (curr_mat_samp); }
+            double colsamp_wt = weight / (glob_norm / curr_mat_samp);
+            if (colsamp_wt > 1) colsamp_wt = 1;
+            int ini_flag = weight > init_thresh;
+            n_ini += ini_flag;
+            uint8_t *occ_orbs = sol_vec.orbs_at_pos(det_idx);
+            count_symm_virt(unocc_symm_cts, occ_orbs, n_elec_unf, &symm_basis);
+            unsigned n_doub = bin_sample(n_walk, p_doub, mt_obj);
+            unsigned n_sing = n_walk - n_doub;
+            if (n_doub > max_spawn || n_sing / 2 > max_spawn) { fprintf(stderr, "harness: max_spawn exceeded\n"); return 2; }
+            n_doub = hb_doub_multi(curr_det, occ_orbs, n_elec_unf, &symm_basis, hb_probs, n_doub, mt_obj, doub_orbs, spawn_probs.data());
+            uint8_t new_det[8];
+            for (size_t w = 0; w < n_doub; w++) {
+                double matr_el = doub_matr_el_nosgn(doub_orbs[w], tot_orb, *eris, n_frz);
+                if (fabs(matr_el) > 1e-9) {
+                    memcpy(new_det, curr_det, det_size);
+                    matr_el *= -eps / spawn_probs[w] / p_doub / n_walk * (*curr_el) * doub_det_parity(new_det, doub_orbs[w]) / colsamp_wt;
+                    if (!sol_vec.add(new_det, matr_el, ini_flag)) { fprintf(stderr, "harness: adder full\n"); return 2; }
+                    n_spawn++;
+                }
+            }
+            n_sing = sing_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_sing, mt_obj, sing_orbs, spawn_probs.data());
+            for (size_t w = 0; w < n_sing; w++) {
+                double matr_el = sing_matr_el_nosgn(sing_orbs[w], occ_orbs, tot_orb, *eris, *h_core, n_frz, n_elec_unf);
+                if (fabs(matr_el) > 1e-9) {
+                    memcpy(new_det, curr_det, det_size);
+                    matr_el *= -eps / spawn_probs[w] / (1 - p_doub) / n_walk * (*curr_el) * sing_det_parity(new_det, sing_orbs[w]) / colsamp_wt;
+                    if (!sol_vec.add(new_det, matr_el, ini_flag)) { fprintf(stderr, "harness: adder full\n"); return 2; }
+                    n_spawn++;
+                }
+            }
+            double diag_el = sol_vec.matr_el_at_pos(det_idx);
+            *curr_el *= 1 - eps * (diag_el - en_shift);
+        }
+        sol_vec.perform_add(0);
+        unsigned n_samp = target_nonz;
+        loc_norms[0] = find_preserve(sol_vec.values(), srt_arr, keep_exact, sol_vec.curr_size(), &n_samp, &glob_norm);
+        unsigned nkept = target_nonz - n_samp;
+        if ((iterat + 1) % shift_interval == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, target_norm, shift_damping / shift_interval / eps);
+        double numer = sol_vec.dot(htrial_vec.indices(), htrial_vec.values(), htrial_vec.curr_size(), htrial_hashes);
+        double denom = sol_vec.dot(trial_vec.indices(), trial_vec.values(), trial_vec.curr_size(), trial_hashes);
+        rn_sys = mt_obj() / (1. + UINT32_MAX);
+        sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, keep_exact, rn_sys);
+        for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
+            if (keep_exact[det_idx] && sol_vec.indices()[det_idx] != hf_det) {        // an address comparison, as in the reference (:417)
+                sol_vec.del_at_pos(det_idx);
+                keep_exact[det_idx] = 0;
+            }
+        }
+        fq.iterate_multi(1);
+        const fo::FciqmcLog &lg = fq.log.back();
+        CHECK(same_bits(lg.numer, numer) && same_bits(lg.denom, denom), "frimulti it %u numer/denom %a %a | %a %a", iterat, lg.numer, numer, lg.denom, denom);
+        CHECK(same_bits(lg.norm, glob_norm) && same_bits(lg.shift, en_shift), "frimulti it %u norm/shift", iterat);
+        CHECK(fq.nkept == nkept && lg.n_nonz == sol_vec.n_nonz() && lg.curr_size == sol_vec.curr_size() && lg.n_spawn == n_spawn && lg.n_ini == n_ini,
+              "frimulti it %u counts nkept %u/%u nnz %d/%d size %zu/%zu spawn %zu/%zu ini %u/%zu", iterat, fq.nkept, nkept, lg.n_nonz, sol_vec.n_nonz(), lg.curr_size,
+              (size_t)sol_vec.curr_size(), lg.n_spawn, n_spawn, lg.n_ini, n_ini);
+        size_t bad = 0, nmin = std::min(lg.curr_size, (size_t)sol_vec.curr_size());
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < nmin; i++) {
+            double rv = sol_vec.values()[i];
+            fo::det_t rd = to_u64(sol_vec.indices()[i], det_size);
+            if (!same_bits(rv, fq.sol.vals[0][i])) bad++;
+            if (rv != 0 && rd != fq.sol.dets[i]) bad++;
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        CHECK(bad == 0, "frimulti it %u vector mismatch in %zu slots", iterat, bad);
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, glob_norm, en_shift, nkept, sol_vec.n_nonz(), (size_t)sol_vec.curr_size(), n_spawn, n_ini, hsh);
+    }
+    fclose(f);
+    printf("FRIMULTI iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, sol_vec.n_nonz());
+    return n_fail != 0;
+}
+
 int main(int argc, char **argv) {
     MPI_Init(NULL, NULL);
     int rc = 2;
@@ -1431,6 +1594,7 @@ int main(int argc, char **argv) {
     else if (argc >= 3 && !strcmp(argv[1], "hbpp_all")) rc = run_hbpp_all(argv[2]);
     else if (argc >= 3 && !strcmp(argv[1], "piv")) rc = run_piv(argv[2]);
     else if (argc >= 2 && !strcmp(argv[1], "hbpiv")) rc = run_hbpiv(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "frimulti")) rc = run_frimulti(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frifull")) rc = run_frifull(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);

@@ -109,6 +109,19 @@ def read_piv_cases():
     return cases
 
 
+def read_multi_traj(name):
+    """tests/golden/multi_*.traj: the reference's frimulti_mol loop (oracle/ref_harness.cpp: run_frimulti)."""
+    rows = []
+    with open(os.path.join(GOLD, name + ".traj")) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            rows.append(dict(it=int(t[0]), numer=float.fromhex(t[1]), denom=float.fromhex(t[2]), norm=float.fromhex(t[3]), shift=float.fromhex(t[4]), nkept=int(t[5]),
+                             n_nonz=int(t[6]), curr_size=int(t[7]), n_spawn=int(t[8]), n_ini=int(t[9]), hash=int(t[10], 16)))
+    return rows
+
+
 def read_hbpiv(name):
     """tests/golden/<name>.txt: what the reference's apply_HBPP_piv returned on the vector of a golden run (oracle/ref_harness.cpp: run_hbpiv)."""
     cases = []

@@ -419,6 +419,28 @@ class OracleFciqmc:
         return self.lib.fo_fciqmc_p_doub(self.h)
 
 
+class OracleMulti(OracleFciqmc):
+    """fo::Fciqmc in its frimulti_mol mode (FRIES_bin/frimulti_mol.cpp, --distribution HB): counter_rng=False is the reference's mt19937
+    stream (pinned against the reference loop), counter_rng=True the counter-based stream the GPU replays."""
+
+    def __init__(self, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, initiator=0.0, target_norm=0.0, seed=0, counter_rng=False):
+        self.lib = load()
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.lib.fo_frimulti_create.restype = C.c_void_p
+        self.lib.fo_frimulti_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_double, C.c_double, C.c_int]
+        self.lib.fo_frimulti_nkept.restype = C.c_uint32
+        self.lib.fo_frimulti_nkept.argtypes = [C.c_void_p]
+        self.h = self.lib.fo_frimulti_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, vec_nonz, mat_nonz, max_dets, seed, float(initiator), float(target_norm),
+                                             int(counter_rng))
+
+    @property
+    def nkept(self):
+        return self.lib.fo_frimulti_nkept(self.h)
+
+
 def piv_comp(vals, compress_size, seed):
     """fo::piv_comp_parallel (one rank) on a copy of vals: (new values, delete flags, the generator's next draw)."""
     lib = load()

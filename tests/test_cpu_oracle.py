@@ -386,6 +386,26 @@ def test_oracle_apply_hbpp_piv_matches_reference(oracle, mols, name):
         assert np.array_equal(pos, c["pos"]) and np.array_equal(orbs, c["orbs"]) and vals.tobytes() == c["val"].tobytes()
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["multi_runs"]))
+def test_oracle_frimulti_matches_reference(oracle, name):
+    """fo::Fciqmc::iterate_multi on the reference's mt19937 stream against the trajectory of the reference's frimulti_mol loop
+    (tests/golden/multi_*.traj): every scalar bit for bit, the counts, and the digest of the stored vector."""
+    r = golden_io.manifest()["multi_runs"][name]
+    rows = golden_io.read_multi_traj(name)
+    mol = fcidump.synthetic(r["shape"])
+    orc = oracle.OracleMulti(mol, epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], initiator=r["initiator"],
+                             target_norm=r["target_norm"], seed=r["seed"])
+    for row in rows:
+        lg = orc.iterate(1)[0]
+        for f in ("numer", "denom", "norm", "shift"):
+            assert float(lg[f]) == row[f], (name, row["it"], f)
+        for f in ("n_nonz", "curr_size", "n_spawn", "n_ini"):
+            assert int(lg[f]) == row[f], (name, row["it"], f)
+        assert orc.nkept == row["nkept"]
+    d, v = orc.vector()
+    assert golden_io.vec_hash(d, v) == rows[-1]["hash"]
+
+
 def test_library_exports_every_declared_symbol():
     """libfries_hip.so loads on a GPU-less host and exports exactly what include/fries_hip.h declares."""
     from fries_amd import engine
