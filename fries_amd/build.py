@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 DRIVER = os.path.join(HERE, "frisys_mol_hip")
 FACADE_TEST = os.path.join(HERE, "..", "tests", "cpp", "test_facade")
-DRIVERS = {name: os.path.join(HERE, name) for name in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip", "frifull_mol_hip")}
+DRIVERS = {name: os.path.join(HERE, name) for name in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip", "frifull_mol_hip", "frimulti_mol_hip")}
 
 
 def build_drivers(force: bool = False) -> str:

@@ -322,6 +322,51 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
     fr_vec_delete_flagged(c, &c->vec, B.del, bound);
 }
 
+// ------------------------------------------------------------------ frimulti_mol: samples per column (frimulti_mol.cpp:301-322)
+// One comb over the in-order running sum of |v|: first tooth from seed_sys with the norms the last compression left (one rank: the
+// in-order sum itself), spacing = the one-norm BEFORE that compression / n_teeth -- two different numbers in the reference, kept apart.
+// n_walk[i] = teeth in (S_{i-1}, S_i]... strictly: teeth below S_i minus teeth below S_{i-1} (`while (rn_sys < lbound)`).
+__global__ void k_mc_teeth(VcompBuf B, double rn, double prev_glob, uint32_t n_teeth, double *unit_out) {
+    const double T = *B.seq.total;
+    const double G = prev_glob < 0 ? T : prev_glob;
+    double r0 = rn * (T / n_teeth);
+    r0 += T / n_teeth * (int)(0.0 * n_teeth / T);
+    const double unit = G / n_teeth;
+    fr_build_teeth(B.teeth, r0, unit, n_teeth + 64, 0.0);
+    unit_out[0] = unit; unit_out[1] = T;
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_mc_walk(VecDev V, VcompBuf B, uint32_t *n_walk, uint32_t *err) {
+    __shared__ SeqShared seqsh;
+    __shared__ Teeth Tsh;
+    const unsigned n = V.st->curr_size;
+    const unsigned nblk = (n + FR_TILE - 1) / FR_TILE;
+    if (blockIdx.x >= nblk) return;
+    fr_stage_teeth(&Tsh, B.teeth);
+    const Teeth *th = &Tsh;
+    AccAbs acc{V.v0, V.st};
+    double Sx[4], Sprev;
+    fr_seq_prefix4(B.seq, acc, blockIdx.x, &seqsh, Sx, &Sprev);
+    size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
+    uint32_t kprev = fr_teeth_below(th, Sprev);
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        size_t i = base + it;
+        if (i >= n) break;
+        uint32_t k = fr_teeth_below(th, Sx[it]);
+        n_walk[i] = k - kprev;
+        if (k >= th->kmax) atomicOr(err, FR_ERR_SPAWN_CAP);      // the comb ran past its table: the vector's norm moved by more than 64 sampling units
+        kprev = k;
+    }
+}
+void fr_multi_walks(FriesCtx *c, double rn, double prev_glob_norm, uint32_t n_teeth, uint32_t *n_walk, double *unit_out) {
+    VcompBuf &B = c->vc;
+    const uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
+    AccAbs aa{c->vec.v0, c->vec.st};
+    run_seq(c, B.seq, aa, bound);
+    FR_LAUNCH(c, "k_mc_teeth", k_mc_teeth, dim3(1), dim3(1), B, rn, prev_glob_norm, n_teeth, unit_out);
+    FR_LAUNCH(c, "k_mc_walk", k_mc_walk, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, n_walk, c->d_err);
+}
+
 // block 0: <H trial | v>, block 1: <trial | v>
 __global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, const double *hv, uint32_t nh, const det_t *td, const double *tv, uint32_t nt, double *out) {
     __shared__ double shd[4];

@@ -124,6 +124,8 @@ struct FqWork {
     double *sp_val; det_t *sp_det; uint8_t *sp_ini;
     double *norm;
     uint32_t *o1cnt;            // heat-bath generator: samples per first occupied electron, [determinant][electron]
+    // frimulti_mol (multinomial matrix compression): samples per column from the systematic comb, real-valued spawns
+    int multi; uint32_t *n_walk; double samp_unit, init_f;
 };
 
 struct FriesCtx {
@@ -138,6 +140,7 @@ struct FriesCtx {
     // FCIQMC driver (fciqmc.hip)
     bool fq_mode = false;
     fries_fciqmc_params fq{};
+    fries_frimulti_params fm{};
     FqWork fqw{};
     // Hubbard-Holstein driver (hh.hip)
     bool hh_mode = false, hh_keep0 = false;
@@ -235,6 +238,9 @@ void fr_test_piv_adjust(FriesCtx *c, uint32_t *n_loc_io, double exp_loc, uint32_
 void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p);
 void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg);
 // hh.hip
+void fr_multi_setup(FriesCtx *c, const fries_frimulti_params *p);
+void fr_multi_iterate(FriesCtx *c, fries_fciqmc_log *lg);
+void fr_multi_walks(FriesCtx *c, double rn, double prev_glob_norm, uint32_t n_teeth, uint32_t *n_walk, double *unit_out);
 void fr_hh_setup(FriesCtx *c, const fries_hh_params *p);
 void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg);
 void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]);

@@ -67,11 +67,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
     if (d < n) {
         const double cur = V.v0[d];
         const int cur_i = (int)cur;
-        const unsigned n_walk = (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        // frimulti_mol: real weights; the column's sample number comes from the comb (k_mc_walk) and may be zero
+        const unsigned n_walk = Q.multi ? (cur != 0 ? Q.n_walk[d] : 0u) : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
         uint32_t n_doub = 0, n_sing = 0;
         double new_val = 0;
-        if (n_walk) {
-            nz = 1; ini = n_walk > init_thresh;
+        if (Q.multi ? cur != 0 : n_walk != 0) {
+            nz = 1; ini = Q.multi ? fabs(cur) > Q.init_f : n_walk > init_thresh;
             const int sign = cur_i < 0 ? -1 : 1;
             const det_t det = V.dets[d];
             double dg = V.diag[d];
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
                 // the counter-based stream is addressable by draw index, so the draws can be split over lanes
                 uint32_t slot = atomicAdd(&Q.totals[3], 1u);
                 Q.heavy[slot] = d;
-                n_doub = 0; n_sing = 0; new_val = cur;
+                n_doub = 0; n_sing = 0; new_val = Q.multi ? cur * (1 - eps * (dg - shift)) : cur;
             }
             else {
                 FqRng rng;
@@ -90,13 +91,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
                 n_sing = n_walk - n_doub;
                 // sing_multin returns nothing when no electron has a symmetry-allowed excitation (near_uniform.cpp:293-295)
                 if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
-                const double m = (1 - eps * (dg - shift)) * sign;
-                const int flr = (int)floor(m);
-                const double prob = m - flr;
-                int ret = flr * (int)n_walk;
-                rng.begin(seed, iter, det, 0, FQ_DEATH);
-                for (unsigned i = 0; i < n_walk; i++) ret += rng.uni() < prob;
-                new_val = (double)ret;
+                if (Q.multi) new_val = cur * (1 - eps * (dg - shift));       // frimulti_mol.cpp:379-380
+                else {
+                    const double m = (1 - eps * (dg - shift)) * sign;
+                    const int flr = (int)floor(m);
+                    const double prob = m - flr;
+                    int ret = flr * (int)n_walk;
+                    rng.begin(seed, iter, det, 0, FQ_DEATH);
+                    for (unsigned i = 0; i < n_walk; i++) ret += rng.uni() < prob;
+                    new_val = (double)ret;
+                }
                 if (Q.o1cnt) {          // heat-bath doubles: how many samples chose each electron as o1 (heat_bathPP.cpp:614-625)
                     const unsigned ne = T.n_elec;
                     double p1[32]; FqAlias A;
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy(VecDev V, SysDev S, FqWor
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t d = Q.heavy[h];
         const int cur_i = (int)V.v0[d];
-        const unsigned n_walk = (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        const unsigned n_walk = Q.multi ? Q.n_walk[d] : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
         const int sign = cur_i < 0 ? -1 : 1;
         const det_t det = V.dets[d];
         FqRng rb, rd;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy(VecDev V, SysDev S, FqWor
             uint32_t n_sing = n_walk - n_doub;
             if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
             Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing;
-            Q.new_val[d] = (double)(flr * (int)n_walk + (int)n_live);
+            if (!Q.multi) Q.new_val[d] = (double)(flr * (int)n_walk + (int)n_live);
         }
         if (Q.o1cnt) {
             __shared__ FqAlias As;
@@ -219,10 +223,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
         while (Q.n_att[lo] == 0 && lo > 0) lo--;       // cannot happen (an empty determinant never owns an attempt), kept for safety
         const uint32_t d = lo, i = a - Q.att_off[d], n_doub = Q.n_doub[d];
         const det_t det = V.dets[d];
-        const int cur_i = (int)V.v0[d];
-        const unsigned n_walk = (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        const double cur_f = V.v0[d];
+        const int cur_i = (int)cur_f;
+        const unsigned n_walk = Q.multi ? Q.n_walk[d] : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
         const int sign = cur_i < 0 ? -1 : 1;
-        sp_ini = n_walk > init_thresh;
+        sp_ini = Q.multi ? fabs(cur_f) > Q.init_f : n_walk > init_thresh;
+        // frimulti_mol.cpp:317-320: the column's weight relative to one sampling unit, at most 1
+        double colw = 1;
+        if (Q.multi) { colw = fabs(cur_f) / Q.samp_unit; if (colw > 1) colw = 1; }
         const unsigned n_orb = T.n_orb, n_elec = T.n_elec;
         SymCounts sc; fr_count_symm_virt(sc, T, det);
         FqRng rng;
@@ -265,6 +273,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
                         const unsigned a1 = o1 < o2 ? o1 : o2, a2 = o1 < o2 ? o2 : o1, b1 = u1 < u2 ? u1 : u2, b2 = u1 < u2 ? u2 : u1;
                         const double prob = fr_norm_wt(T, det, a1, a2, b1, b2);
                         double m = fr_doub_matrel(a1, a2, b1, b2, S.eris, n_orb);
+                        if (Q.multi) {          // a real-valued weight instead of a rounded walker (frimulti_mol.cpp:350-358)
+                            if (fabs(m) > 1e-9) {
+                                m *= -eps / prob / p_doub / n_walk * cur_f * fr_doub_parity(det, a1, a2, b1, b2) / colw;
+                                sp_val = m;
+                                sp_det = (det & ~(1ull << a1) & ~(1ull << a2)) | (1ull << b1) | (1ull << b2);
+                            }
+                        }
+                        else {
                         m *= eps / prob / p_doub;
                         rng.begin(seed, iter, det, att, FQ_ROUND_D);
                         const int flr = (int)floor(m);
@@ -273,6 +289,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
                             sp *= -fr_doub_parity(det, a1, a2, b1, b2) * sign;
                             sp_val = (double)sp;
                             sp_det = (det & ~(1ull << a1) & ~(1ull << a2)) | (1ull << b1) | (1ull << b2);
+                        }
                         }
                     }
                 }
@@ -378,6 +395,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
             }
             const double prob = 1. / m_allow[elec] / (n_elec - delta_s);
             double m = fr_sing_matrel(det, occ_orb, orbital, S.h_core, S.eris, n_orb);
+            if (Q.multi) {              // frimulti_mol.cpp:365-374
+                if (fabs(m) > 1e-9) {
+                    m *= -eps / prob / (1 - p_doub) / n_walk * cur_f * fr_sing_parity(det, occ_orb, orbital) / colw;
+                    sp_val = m;
+                    sp_det = (det & ~(1ull << occ_orb)) | (1ull << orbital);
+                }
+            }
+            else {
             m *= eps / prob / (1 - p_doub);
             rng.begin(seed, iter, det, j, FQ_ROUND_S);
             const int flr = (int)floor(m);
@@ -386,6 +411,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
                 sp *= -fr_sing_parity(det, occ_orb, orbital) * sign;
                 sp_val = (double)sp;
                 sp_det = (det & ~(1ull << occ_orb)) | (1ull << orbital);
+            }
             }
         }
         Q.sp_val[a] = sp_val; Q.sp_det[a] = sp_det; Q.sp_ini[a] = (uint8_t)sp_ini;
@@ -547,6 +573,91 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     if (lg) {
         lg->numer = c->numer; lg->denom = c->denom; lg->shift = c->en_shift; lg->norm = norm;
         lg->n_nonz = (int32_t)tot[1]; lg->n_ini = tot[2]; lg->curr_size = c->h_vst.curr_size; lg->n_spawn = n_spawn;
+        uint32_t e = 0;
+        FR_HIP(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+        lg->err = e | c->h_vst.err; lg->n_attempts = A;
+    }
+}
+
+
+// ------------------------------------------------------------------ frimulti_mol (FRIES_bin/frimulti_mol.cpp:84-425), --distribution HB, one rank
+void fr_multi_setup(FriesCtx *c, const fries_frimulti_params *p) {
+    if (c->use_comm && c->n_ranks > 1) throw FriesError("frimulti_mol runs on one rank here");
+    if (p->vec_nonz == 0 || p->mat_nonz < 10 || p->max_dets == 0) throw FriesError("vec_nonz, max_dets must be positive and mat_nonz at least 10 (the first iterations use a tenth of it)");
+    fries_fciqmc_params q{};
+    q.epsilon = p->epsilon; q.target_walkers = p->mat_nonz; q.initiator = 0; q.max_dets = p->max_dets; q.seed = p->seed; q.heat_bath = 1;
+    fr_fq_setup(c, &q);                 // scramblers, vector, work arrays, H * trial, 100 x HF -- as there (frimulti_mol.cpp:84-233)
+    c->fm = *p;
+    c->target_norm = p->target_norm; c->init_thresh = p->initiator; c->vec_nonz = p->vec_nonz; c->mat_nonz = p->mat_nonz;
+    c->adder_cap = p->mat_nonz * 2;     // :89
+    FqWork &Q = c->fqw;
+    Q.multi = 1; Q.n_walk = fr_alloc<uint32_t>(Q.cap_d); Q.init_f = p->initiator; Q.samp_unit = 1;
+    if (!c->W.kin) c->W.kin = fr_alloc<uint32_t>(p->max_dets);          // fr_sys_comp's tooth indices
+    if (!c->d_norms_keep) { c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1); }
+    c->glob_norm = -1;                  // no compression yet: the first comb is spaced by the norm of the start vector (:227-233)
+}
+
+void fr_multi_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
+    hipStream_t st = c->stream;
+    const fries_frimulti_params &P = c->fm;
+    FqWork &Q = c->fqw;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_vec_maybe_rebuild(c, &c->vec);
+    const uint32_t n = c->h_vst.curr_size;
+    if (n > Q.cap_d) throw FriesError("vector larger than the work arrays");
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    // samples per column (:301-322)
+    double rn_sys = c->mt() / (1. + UINT32_MAX);
+    const uint32_t curr_mat_samp = c->iterat < 10 ? P.mat_nonz / 10 : P.mat_nonz;
+    fr_multi_walks(c, rn_sys, c->glob_norm, curr_mat_samp, Q.n_walk, c->vc.dots);
+    const unsigned gd = fr_blocks(n ? n : 1, FR_BLOCK);
+    FR_HIP(hipMemsetAsync(&Q.totals[3], 0, 4, st));
+    const unsigned long long seed = c->fq.seed, iter = c->iterat;
+    FR_LAUNCH(c, "k_fq_count", k_fq_count, dim3(gd), dim3(FR_BLOCK), c->vec, S, Q, seed, iter, c->p_doub, c->eps, c->en_shift, 0u);
+    FR_LAUNCH(c, "k_fq_heavy", k_fq_heavy, dim3(512), dim3(FR_BLOCK), c->vec, S, Q, seed, iter, c->p_doub, c->eps, c->en_shift);
+    FR_LAUNCH(c, "k_fq_blocksum", k_fq_blocksum, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
+    FR_LAUNCH(c, "k_fq_offsets", k_fq_offsets, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
+    uint32_t tot[3];
+    double unit_T[2];
+    FR_HIP(hipMemcpyAsync(tot, Q.totals, 12, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipMemcpyAsync(unit_T, c->vc.dots, 16, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    const uint32_t A = tot[0];
+    if (A > Q.cap_a) throw FriesError("Insufficient memory allocated in adder");
+    FqWork Qa = Q;
+    Qa.samp_unit = unit_T[0];
+    const unsigned ga = fr_blocks(A ? A : 1, FR_BLOCK);
+    FR_LAUNCH(c, "k_fq_attempt", k_fq_attempt, dim3(ga), dim3(FR_BLOCK), c->vec, S, Qa, seed, iter, c->p_doub, c->eps, 0u);
+    FR_LAUNCH(c, "k_fq_compact", k_fq_compact, dim3(ga), dim3(FR_BLOCK), Q, c->sp);
+    FR_LAUNCH(c, "k_fq_apply", k_fq_apply, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
+    uint32_t n_spawn = 0;
+    FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder.");
+    if (n_spawn) fr_vec_merge(c, &c->vec, n_spawn, true);           // perform_add(0) into the column itself (:382)
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (c->h_vst.err) throw FriesError("device error in the merge (capacity, hash table or electron count)");
+    // compression (:385-421)
+    fr_abs_sums(c);
+    uint32_t n_samp = P.vec_nonz;
+    double glob_norm = 0;
+    fr_find_preserve(c, &n_samp, &glob_norm);
+    c->glob_norm = glob_norm;
+    c->nkept = P.vec_nonz - n_samp;
+    if ((c->iterat + 1) % 10 == 0) {
+        double damp = 0.05 / 10 / c->eps;
+        if (c->last_one_norm) { c->en_shift -= damp * log(glob_norm / c->last_one_norm); c->last_one_norm = glob_norm; }
+        if (c->last_one_norm == 0 && glob_norm > c->target_norm) c->last_one_norm = glob_norm;
+    }
+    fr_dots(c, &c->numer, &c->denom);
+    rn_sys = c->mt() / (1. + UINT32_MAX);
+    fr_sys_comp(c, n_samp, rn_sys);        // incl. the deletes; the reference's HF test compares addresses (:417), so HF goes like any other
+    c->iterat++;
+    c->tot_iters++; c->tot_spawns += n_spawn;
+    if (lg) {
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+        lg->numer = c->numer; lg->denom = c->denom; lg->shift = c->en_shift; lg->norm = glob_norm;
+        lg->n_nonz = c->h_vst.n_nonz; lg->n_ini = tot[2]; lg->curr_size = c->h_vst.curr_size; lg->n_spawn = n_spawn;
         uint32_t e = 0;
         FR_HIP(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
         lg->err = e | c->h_vst.err; lg->n_attempts = A;

@@ -22,7 +22,7 @@ EXPORTS = [
     "fries_frisys_iterate", "fries_p_doub", "fries_kernel_launches", "fries_vec_info", "fries_vec_download",
     "fries_vec_add", "fries_vec_load", "fries_htrial_download", "fries_apply_hbpp_sys", "fries_apply_hbpp_piv", "fries_rng_set_state", "fries_rng_get_state", "fries_compress_vec",
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
-    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate",
+    "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate", "fries_frimulti_setup", "fries_frimulti_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
 ]
@@ -44,6 +44,12 @@ class HHParams(C.Structure):
     _fields_ = [("n_elec", C.c_uint32), ("n_sites", C.c_uint32), ("eps", C.c_double), ("U", C.c_double), ("omega", C.c_double), ("g", C.c_double),
                 ("gs_energy", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double), ("vec_nonz", C.c_uint32), ("max_dets", C.c_uint32),
                 ("seed", C.c_uint32), ("full", C.c_uint32)]
+
+
+class FrimultiParams(C.Structure):
+    """struct fries_frimulti_params"""
+    _fields_ = [("epsilon", C.c_double), ("target_norm", C.c_double), ("initiator", C.c_double), ("vec_nonz", C.c_uint32), ("mat_nonz", C.c_uint32),
+                ("max_dets", C.c_uint32), ("seed", C.c_uint32)]
 
 
 class FciqmcParams(C.Structure):
@@ -120,6 +126,8 @@ def load_library() -> C.CDLL:
     lib.fries_prof_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fries_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
     lib.fries_get_scramblers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_frimulti_setup.argtypes = [C.c_void_p, C.POINTER(FrimultiParams)]
+    lib.fries_frimulti_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_fciqmc_setup.argtypes = [C.c_void_p, C.POINTER(FciqmcParams)]
     lib.fries_fciqmc_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_frifull_setup.argtypes = [C.c_void_p, C.POINTER(FrifullParams)]
@@ -246,6 +254,18 @@ class FriEngine:
     def iterate_fciqmc(self, n_iter: int):
         logs = np.zeros(n_iter, dtype=FCIQMC_LOG_DTYPE)
         self._ck(self.lib.fries_fciqmc_iterate(self.h, n_iter, _ptr(logs)))
+        return logs
+
+    # ---- frimulti_mol
+    def setup_multi(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0):
+        """frimulti_mol (FRIES_bin/frimulti_mol.cpp, --distribution HB): multinomial matrix compression, systematic vector compression."""
+        p = FrimultiParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed)
+        self._ck(self.lib.fries_frimulti_setup(self.h, C.byref(p)))
+        self.max_dets = max_dets
+
+    def iterate_multi(self, n_iter: int):
+        logs = np.zeros(n_iter, dtype=FCIQMC_LOG_DTYPE)
+        self._ck(self.lib.fries_frimulti_iterate(self.h, n_iter, _ptr(logs)))
         return logs
 
     # ---- frifull_mol

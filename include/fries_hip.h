@@ -175,6 +175,21 @@ typedef struct {
 int fries_fciqmc_setup(fries_ctx *ctx, const fries_fciqmc_params *p);
 int fries_fciqmc_iterate(fries_ctx *ctx, uint32_t n_iter, fries_fciqmc_log *logs);
 
+/* ---- frimulti_mol: FRI with multinomial matrix compression (FRIES_bin/frimulti_mol.cpp), --distribution HB (the only one the
+ * reference's argument check lets through, :38-46): every iteration one systematic comb over |v| gives each column its number of
+ * samples (:301-322), the samples are drawn with hb_doub_multi / sing_multin and spawn real-valued weights (:343-376), the
+ * diagonal acts in place (:379-380), and the vector is compressed to vec_nonz by find_preserve + sys_comp (:385-421).  The first ten
+ * iterations use mat_nonz / 10 samples (:306).  Random numbers as for fciqmc_mol: the two comb offsets per iteration come from the
+ * mt19937, the sampling from the counter-based stream shared with the CPU oracle, whose loop is pinned against the reference on the
+ * reference's stream (oracle/ref_harness.cpp: frimulti).  One rank.  Log: norm = one-norm before the compression (norm.txt),
+ * n_nonz / curr_size after it, n_spawn = adds, n_attempts = samples. */
+typedef struct {
+    double epsilon, target_norm, initiator;
+    uint32_t vec_nonz, mat_nonz, max_dets, seed;
+} fries_frimulti_params;
+int fries_frimulti_setup(fries_ctx *ctx, const fries_frimulti_params *p);
+int fries_frimulti_iterate(fries_ctx *ctx, uint32_t n_iter, fries_fciqmc_log *logs);
+
 /* DistVec accessors (FRIES/vec_utils.hpp:506-535): positions [0, curr_size) incl. holes (value 0) */
 int fries_vec_info(fries_ctx *ctx, uint32_t *curr_size, int32_t *n_nonz, uint32_t *n_free);
 int fries_vec_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);

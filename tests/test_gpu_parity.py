@@ -583,6 +583,53 @@ def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,n_it", [("multi_ne_m1000", 60), ("multi_n2_m5000_ini0", 40)])
+def test_frimulti_matches_oracle_counter_stream(oracle, name, n_it):
+    """frimulti_mol (multinomial matrix compression) on the device against the CPU restatement, both on the counter-based uniform stream,
+    in the configurations whose mt19937 runs are pinned against the reference loop (tests/golden/multi_*.traj, CPU suite): samples per
+    column from the comb, every spawn weight, the compressed vector -- norms, shifts, counts and the stored values bit for bit."""
+    from fries_amd.engine import FriEngine
+    r = golden_io.manifest()["multi_runs"][name]
+    mol = fcidump.synthetic(r["shape"])
+    par = dict(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], initiator=r["initiator"], target_norm=r["target_norm"], seed=r["seed"])
+    orc = oracle.OracleMulti(mol, counter_rng=True, **par)
+    eng = FriEngine(mol)
+    eng.setup_multi(**par)
+    assert eng.p_doub == orc.p_doub
+    lo = orc.iterate(n_it)
+    lg = eng.iterate_multi(n_it)
+    assert int(lg["err"].max()) == 0
+    for f in ("n_nonz", "n_ini", "curr_size", "n_spawn"):
+        assert np.array_equal(lg[f].astype(np.int64), lo[f].astype(np.int64)), (name, f, np.nonzero(lg[f].astype(np.int64) != lo[f].astype(np.int64))[0][:5])
+    assert np.array_equal(lg["norm"], lo["norm"]) and np.array_equal(lg["shift"], lo["shift"]) and np.array_equal(lg["denom"], lo["denom"])
+    assert np.all(np.abs(lg["numer"] - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    gd, gv = eng.vector()
+    od, ov = orc.vector()
+    assert gd.size == od.size and np.array_equal(gv, ov)
+    nz = ov != 0
+    assert np.array_equal(gd[nz], od[nz])
+    assert int(lo["n_nonz"][-1]) == r["vec_nonz"] and int(lo["n_spawn"].sum()) > 10 * r["vec_nonz"]
+    eng.close()
+    if name != "multi_ne_m1000":
+        return
+    # the command-line driver writes the same numbers
+    import subprocess, tempfile
+    from fries_amd import build
+    with tempfile.TemporaryDirectory() as tmp:
+        fc = os.path.join(tmp, "mol.FCIDUMP")
+        fcidump.write_fcidump(fc, mol)
+        out = os.path.join(tmp, "out") + "/"
+        os.makedirs(out)
+        res = subprocess.run([build.DRIVERS["frimulti_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", "HB", "--vec_nonz", str(r["vec_nonz"]),
+                              "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--epsilon", repr(r["epsilon"]), "--target", repr(r["target_norm"]),
+                              "--initiator", repr(r["initiator"]), "--max_iter", str(n_it), "--result_dir", out, "--seed", str(r["seed"])], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+        num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nm = np.loadtxt(out + "norm.txt"); nini = np.loadtxt(out + "nini.txt")
+        assert np.array_equal(den, lo["denom"]) and np.all(np.abs(num - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+        assert np.array_equal(nm, lo["norm"][9::10]) and np.array_equal(nini.astype(np.int64), lo["n_ini"].astype(np.int64))
+
+
+@pytest.mark.gpu
 def test_cli_drivers_hh_and_fciqmc(oracle, mols, tmp_path):
     """frisys_hh_hip against the reference's golden trajectory (its parameter-file format included) and fciqmc_mol_hip against the
     CPU restatement on the counter stream: the files the drivers write."""
