@@ -2526,11 +2526,15 @@ void Fciqmc::iterate(unsigned n_iter) {
             double &cur = sol.vals[0][d];
             int cur_i = (int)cur;
             unsigned n_walk = (unsigned)abs(cur_i);
+            if (par.fp) {                                   // fciqmc_fp_mol.cpp:342: one draw for every stored position, zeros included
+                rng.begin(iterat, sol.dets[d], 0, RNG_NWALK);
+                n_walk = (unsigned)round_binomially(fabs(cur), 1, rng);
+            }
             if (n_walk == 0) continue;
             n_nonz++;
             int ini = n_walk > par.init_thresh;
             n_ini += ini;
-            int sign = cur_i < 0 ? -1 : 1;
+            int sign = par.fp ? 1 - 2 * (cur < 0) : (cur_i < 0 ? -1 : 1);
             const det_t det = sol.dets[d];
             const uint8_t *occ = sol.orbs_at(d);
             unsigned counts[N_IRREPS][2];
@@ -2550,8 +2554,8 @@ void Fciqmc::iterate(unsigned n_iter) {
             for (unsigned w = 0; w < nn; w++) {
                 double m = doub_matrel_nosgn(&orbs[4 * w], sys.ints);
                 m *= eps / probs[w] / p_doub;
-                rng.begin(iterat, det, att[w], RNG_ROUND_D);
-                int sp = round_binomially(m, 1, rng);
+                double sp = m;                              // fciqmc_fp_mol.cpp:385-390: only small spawns are rounded
+                if (!par.fp || fabs(m) < 0.01) { rng.begin(iterat, det, att[w], RNG_ROUND_D); sp = round_binomially(m, 1, rng); }
                 if (sp != 0) {
                     det_t nd = det;
                     sp *= -doub_det_parity(&nd, &orbs[4 * w]) * sign;
@@ -2570,8 +2574,8 @@ void Fciqmc::iterate(unsigned n_iter) {
             for (unsigned w = 0; w < ns; w++) {
                 double m = sing_matrel_nosgn(&orbs[2 * w], occ, sys.ints, n_elec);
                 m *= eps / probs[w] / (1 - p_doub);
-                rng.begin(iterat, det, w, RNG_ROUND_S);
-                int sp = round_binomially(m, 1, rng);
+                double sp = m;
+                if (!par.fp || fabs(m) < 0.01) { rng.begin(iterat, det, w, RNG_ROUND_S); sp = round_binomially(m, 1, rng); }
                 if (sp != 0) {
                     det_t nd = det;
                     sp *= -sing_det_parity(&nd, &orbs[2 * w]) * sign;
@@ -2583,6 +2587,7 @@ void Fciqmc::iterate(unsigned n_iter) {
             // old one is still non-zero, so del_at_pos declines: a determinant left without walkers keeps its slot and its
             // hash entry with value 0 (only initiator spawns can revive it).  Reproduced: nothing is deleted here.
             if (std::isnan(sol.diag[d])) sol.diag[d] = diag_matrel(occ, sys.ints, n_elec) - sys.hf_en;
+            if (par.fp) { cur *= 1 - eps * (sol.diag[d] - en_shift); continue; }        // fciqmc_fp_mol.cpp:423-424
             double m = (1 - eps * (sol.diag[d] - en_shift)) * sign;
             rng.begin(iterat, det, 0, RNG_DEATH);
             int new_val = round_binomially(m, n_walk, rng);
@@ -2590,6 +2595,14 @@ void Fciqmc::iterate(unsigned n_iter) {
             cur = new_val;
         }
         sol.perform_add(0);
+        if (par.fp) {                                       // fciqmc_fp_mol.cpp:428-441
+            for (size_t d = 0; d < sol.curr_size; d++) {
+                double &c = sol.vals[0][d];
+                if (c == 0) continue;
+                if (fabs(c) < 1) { rng.begin(iterat, sol.dets[d], 0, RNG_COMP); c = round_binomially(c, 1, rng); }
+                if (c == 0) sol.del_at_pos(d);
+            }
+        }
         double glob_norm = 0;
         if ((iterat + 1) % shift_interval == 0) {          // :415-427
             glob_norm = cm.sum(sol.local_norm());

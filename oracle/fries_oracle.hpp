@@ -379,7 +379,7 @@ struct Rng {
     double uni();
     static uint64_t mix(uint64_t x);
 };
-enum { RNG_BIN = 0, RNG_DOUB = 1, RNG_SING = 2, RNG_ROUND_D = 3, RNG_ROUND_S = 4, RNG_DEATH = 5, RNG_HB_O1 = 6, RNG_HB_O2 = 7, RNG_HB_U1 = 8, RNG_HB_U2 = 9 };
+enum { RNG_BIN = 0, RNG_DOUB = 1, RNG_SING = 2, RNG_ROUND_D = 3, RNG_ROUND_S = 4, RNG_DEATH = 5, RNG_HB_O1 = 6, RNG_HB_O2 = 7, RNG_HB_U1 = 8, RNG_HB_U2 = 9, RNG_NWALK = 10, RNG_COMP = 11 };
 // FRIES/compress_utils.cpp:823-856 / 858-877 (one sample)
 void setup_alias(const double *probs, unsigned *aliases, double *alias_probs, size_t n_states);
 unsigned sample_alias_one(const unsigned *aliases, const double *alias_probs, size_t n_states, Rng &rng);
@@ -405,6 +405,9 @@ struct FciqmcParams {
     bool heat_bath = false;         // --distribution HB (hb_doub_multi for the doubles) instead of NU
     // frimulti_mol (FRIES_bin/frimulti_mol.cpp): FRI with multinomial matrix compression -- real-valued vector, the number of samples
     // per column from one systematic comb over |v|, the vector compressed to vec_nonz by find_preserve + sys_comp
+    // fciqmc_fp_mol (FRIES_bin/fciqmc_fp_mol.cpp): real-valued walkers -- |v| rounded stochastically to the number of spawning attempts,
+    // spawns below 0.01 rounded to integers and kept real otherwise, death in place, then every |v| < 1 rounded to -1 / 0 / 1
+    bool fp = false;
     bool multi = false;
     uint32_t vec_nonz = 0, mat_nonz = 0;
     double target_norm = 0, init_thresh_f = 0;

@@ -98,6 +98,26 @@ MULTI_RUNS = {
 }
 
 
+# fciqmc_fp_mol (real-valued walkers), one rank: name -> (shape, n_iter, seed, eps, target_walkers, max_dets, initiator, distribution)
+FCIQMC_FP_RUNS = {
+    "fciqmc_fp_ne": ("Ne", 250, 5, 0.005, 5000, 50000, 3, "NU"),
+    "fciqmc_fp_n2_hb": ("N2", 200, 9, 0.006, 20000, 200000, 2, "HB"),
+    "fciqmc_fp_h2o_ini0": ("H2O", 150, 11, 0.004, 10000, 200000, 0, "NU"),
+}
+
+
+def gen_fp(manifest):
+    manifest["fciqmc_fp_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (shape, n_iter, seed, eps, tw, maxd, ini, dist) in FCIQMC_FP_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([HARNESS, "fciqmc_fp", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
+            manifest["fciqmc_fp_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist, fp=True)
+
+
 def gen_multi(manifest):
     manifest["multi_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -127,10 +147,10 @@ def gen_hbpiv(manifest):
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--only-multi":
+    if len(sys.argv) > 1 and sys.argv[1] in ("--only-multi", "--only-fp"):
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
-        gen_multi(manifest)
+        (gen_multi if sys.argv[1] == "--only-multi" else gen_fp)(manifest)
         with open(os.path.join(GOLD, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
@@ -275,6 +295,7 @@ def main():
                                               gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
     gen_hbpiv(manifest)
     gen_multi(manifest)
+    gen_fp(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

@@ -412,7 +412,7 @@ struct FqLog { double numer, denom, shift, norm; int32_t n_nonz; uint32_t n_ini,
 void *fo_fciqmc_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                        double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int counter_rng) {
     Fciqmc *f = new Fciqmc();
-    f->par.heat_bath = (counter_rng & 2) != 0; counter_rng &= 1;        // bit 1 of the flag selects --distribution HB
+    f->par.heat_bath = (counter_rng & 2) != 0; f->par.fp = (counter_rng & 4) != 0; counter_rng &= 1;        // bit 1 of the flag selects --distribution HB, bit 2 fciqmc_fp_mol
     f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
     f->sys.ints.n_orb = n_orb;
     f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
@@ -428,7 +428,7 @@ void *fo_fciqmc_create_ex(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps
                           double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int flags,
                           const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const int32_t *in_val, size_t n_in) {
     Fciqmc *f = new Fciqmc();
-    f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0;
+    f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0; f->par.fp = (flags & 4) != 0;
     f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
     f->sys.ints.n_orb = n_orb;
     f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
@@ -486,7 +486,7 @@ void *fo_fqranks_create(uint32_t n_ranks, uint32_t n_orb, uint32_t n_elec, const
     OracleFqRanks *R = new OracleFqRanks();
     for (uint32_t r = 0; r < n_ranks; r++) {
         Fciqmc *f = new Fciqmc();
-        f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0;
+        f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0; f->par.fp = (flags & 4) != 0;
         f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
         f->sys.ints.n_orb = n_orb;
         f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);

@@ -1587,6 +1587,166 @@ static int run_frimulti(int argc, char **argv) {
     return n_fail != 0;
 }
 
+// ------------------------------------------------------------------ fciqmc_fp_mol: reference loop vs the oracle in mt mode
+// ref_harness fciqmc_fp <fcidump> <pg> <n_iter> <seed> <eps> <target_walkers> <max_dets> <initiator> <out> [NU|HB]
+// FRIES_bin/fciqmc_fp_mol.cpp:100-480 (real-valued walkers), HF trial vector, start from 100 x HF, one rank.
+static int run_fciqmc_fp(int argc, char **argv) {
+    if (argc < 11) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t target_walkers = strtoul(argv[7], 0, 10);
+    uint32_t max_n_dets = strtoul(argv[8], 0, 10); uint32_t init_thresh = strtoul(argv[9], 0, 10);
+    const bool heat_bath = argc > 11 && !strcmp(argv[11], "HB");
+    int n_procs = 1, proc_rank = 0;
+    MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
+    if (n_procs != 1) { fprintf(stderr, "fciqmc_fp: one rank\n"); return 2; }
+    fcidump_input *in_data = parse_fcidump(path, pg);
+    unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
+    size_t det_size = CEILING(2 * n_orb, 8);
+    unsigned n_elec_unf = n_elec, tot_orb = n_orb;
+    uint8_t *symm = in_data->symm;
+    Matrix<double> *h_core = in_data->hcore; SymmERIs *eris = &in_data->eris;
+    uint8_t tmp_orbs[64], hf_det[8] = {0};
+    gen_hf_bitstring(n_orb, n_elec, hf_det);
+    find_bits(hf_det, tmp_orbs, det_size);
+    double hf_en = diag_matrel(tmp_orbs, tot_orb, *eris, *h_core, n_frz, n_elec);
+    std::mt19937 mt_obj(seed);
+    unsigned spawn_length = target_walkers / n_procs / n_procs * 2;
+    std::function<double(const uint8_t *)> diag_shortcut = [tot_orb, eris, h_core, n_frz, n_elec, hf_en](const uint8_t *occ) { return diag_matrel(occ, tot_orb, *eris, *h_core, n_frz, n_elec) - hf_en; };
+    SymmInfo symm_basis(symm, n_orb);
+    unsigned unocc_symm_cts[n_irreps][2];
+    std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
+    for (auto &x : proc_scrambler) x = mt_obj();
+    for (auto &x : vec_scrambler) x = mt_obj();
+    DistVec<double> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 1, proc_scrambler, vec_scrambler);
+    unsigned max_spawn = 500000;
+    std::vector<uint8_t> spawn_orbs_v(4 * (size_t)max_spawn); std::vector<double> spawn_probs(max_spawn);
+    uint8_t (*sing_orbs)[2] = (uint8_t (*)[2])spawn_orbs_v.data();
+    uint8_t (*doub_orbs)[4] = (uint8_t (*)[4])spawn_orbs_v.data();
+    size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
+    DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
+    DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1);
+    trial_vec.perform_add(0); htrial_vec.perform_add(0);
+    trial_vec.collect_procs();
+    std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
+    for (size_t i = 0; i < trial_vec.curr_size(); i++) trial_hashes[i] = sol_vec.idx_to_hash(trial_vec.indices()[i], tmp_orbs);
+    h_op_offdiag(htrial_vec, symm, tot_orb, *eris, *h_core, spawn_orbs_v.data(), 4 * max_spawn, n_frz, n_elec_unf, 1, 1, 0);
+    htrial_vec.set_curr_vec_idx(0);
+    h_op_diag(htrial_vec, 0, 0, 1);
+    htrial_vec.add_vecs(0, 1);
+    htrial_vec.collect_procs();
+    std::vector<uintmax_t> htrial_hashes(htrial_vec.curr_size());
+    for (size_t i = 0; i < htrial_vec.curr_size(); i++) htrial_hashes[i] = sol_vec.idx_to_hash(htrial_vec.indices()[i], tmp_orbs);
+    sol_vec.gen_orb_list(hf_det, tmp_orbs);
+    size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, doub_orbs, symm);
+    size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
+    double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
+    sol_vec.add(hf_det, 100, 1);
+    sol_vec.perform_add(0);
+    double en_shift = 0, last_norm = 0, glob_norm = 0;
+    hb_info *hb_probs = heat_bath ? set_up(tot_orb, n_orb, *eris) : NULL;
+
+    fo::Fciqmc fq;
+    fq.sys.n_orb = n_orb; fq.sys.n_elec = n_elec;
+    fill_oracle_ints(fq.sys.ints, *eris, *h_core, n_orb);
+    fq.sys.symm.init(symm, n_orb);
+    fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
+    fq.par.heat_bath = heat_bath; fq.par.fp = true;
+    fq.setup();
+    CHECK(same_bits(fq.p_doub, p_doub), "fciqmc_fp p_doub");
+
+    FILE *f = fopen(argv[10], "w");
+    fprintf(f, "# golden trajectory from the reference's fciqmc_fp_mol loop (1 rank, %s); cols: it numer denom norm shift n_nonz n_ini curr_size n_spawn digest\n", heat_bath ? "HB" : "NU");
+    for (unsigned iterat = 0; iterat < n_iter; iterat++) {
+        int n_nonz = 0; size_t n_ini = 0, n_spawn = 0;
+        for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
+            double *curr_el = sol_vec[det_idx];
+            uint8_t *curr_det = sol_vec.indices()[det_idx];
+            unsigned n_walk = round_binomially(fabs(*curr_el), 1, mt_obj);
+            if (n_walk == 0) continue;
+            n_nonz++;
+            int ini_flag = n_walk > init_thresh;
+            n_ini += ini_flag;
+            int walk_sign = 1 - 2 * (*curr_el < 0);
+            uint8_t *occ_orbs = sol_vec.orbs_at_pos(det_idx);
+            count_symm_virt(unocc_symm_cts, occ_orbs, n_elec_unf, &symm_basis);
+            unsigned n_doub = bin_sample(n_walk, p_doub, mt_obj);
+            unsigned n_sing = n_walk - n_doub;
+            if (n_doub > max_spawn || n_sing > max_spawn) { fprintf(stderr, "harness: max_spawn exceeded\n"); return 2; }
+            if (heat_bath) n_doub = hb_doub_multi(curr_det, occ_orbs, n_elec_unf, &symm_basis, hb_probs, n_doub, mt_obj, doub_orbs, spawn_probs.data());
+            else n_doub = doub_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_doub, mt_obj, doub_orbs, spawn_probs.data());
+            uint8_t new_det[8];
+            for (size_t w = 0; w < n_doub; w++) {
+                double matr_el = doub_matr_el_nosgn(doub_orbs[w], tot_orb, *eris, n_frz);
+                matr_el *= eps / spawn_probs[w] / p_doub;
+                double spawn_walker;
+                if (fabs(matr_el) < 0.01) spawn_walker = round_binomially(matr_el, 1, mt_obj);
+                else spawn_walker = matr_el;
+                if (spawn_walker != 0) {
+                    memcpy(new_det, curr_det, det_size);
+                    spawn_walker *= -doub_det_parity(new_det, doub_orbs[w]) * walk_sign;
+                    if (!sol_vec.add(new_det, spawn_walker, ini_flag)) { fprintf(stderr, "adder full\n"); return 2; }
+                    n_spawn++;
+                }
+            }
+            n_sing = sing_multin(curr_det, occ_orbs, n_elec_unf, &symm_basis, unocc_symm_cts, n_sing, mt_obj, sing_orbs, spawn_probs.data());
+            for (size_t w = 0; w < n_sing; w++) {
+                double matr_el = sing_matr_el_nosgn(sing_orbs[w], occ_orbs, tot_orb, *eris, *h_core, n_frz, n_elec_unf);
+                matr_el *= eps / spawn_probs[w] / (1 - p_doub);
+                double spawn_walker;
+                if (fabs(matr_el) < 0.01) spawn_walker = round_binomially(matr_el, 1, mt_obj);
+                else spawn_walker = matr_el;
+                if (spawn_walker != 0) {
+                    memcpy(new_det, curr_det, det_size);
+                    spawn_walker *= -sing_det_parity(new_det, sing_orbs[w]) * walk_sign;
+                    if (!sol_vec.add(new_det, spawn_walker, ini_flag)) { fprintf(stderr, "adder full\n"); return 2; }
+                    n_spawn++;
+                }
+            }
+            double diag_el = sol_vec.matr_el_at_pos(det_idx);
+            *curr_el *= 1 - eps * (diag_el - en_shift);
+        }
+        sol_vec.perform_add(0);
+        for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {       // :428-441
+            double *curr_el = sol_vec[det_idx];
+            if (*curr_el == 0) continue;
+            if (fabs(*curr_el) < 1) *curr_el = round_binomially(*curr_el, 1, mt_obj);
+            if (*curr_el == 0) sol_vec.del_at_pos(det_idx);
+        }
+        double norm_out = 0;
+        if ((iterat + 1) % 10 == 0) {
+            glob_norm = sum_mpi(sol_vec.local_norm(), proc_rank, n_procs);
+            adjust_shift(&en_shift, glob_norm, &last_norm, target_walkers, 0.05 / eps / 10);
+            norm_out = glob_norm;
+        }
+        double numer = sol_vec.dot(htrial_vec.indices(), htrial_vec.values(), htrial_vec.curr_size(), htrial_hashes);
+        double denom = sol_vec.dot(trial_vec.indices(), trial_vec.values(), trial_vec.curr_size(), trial_hashes);
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < sol_vec.curr_size(); i++) {
+            double rv = sol_vec.values()[i];
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol_vec.indices()[i], det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        fprintf(f, "%u %a %a %a %a %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, norm_out, en_shift, n_nonz, n_ini, (size_t)sol_vec.curr_size(), n_spawn, hsh);
+        fq.iterate(1);
+        const fo::FciqmcLog &lg = fq.log.back();
+        CHECK(same_bits(lg.numer, numer) && same_bits(lg.denom, denom), "fciqmc_fp it %u numer/denom %a %a | %a %a", iterat, lg.numer, numer, lg.denom, denom);
+        CHECK(same_bits(lg.norm, norm_out) && same_bits(lg.shift, en_shift), "fciqmc_fp it %u norm/shift %a %a", iterat, lg.norm, norm_out);
+        CHECK(lg.n_nonz == n_nonz && lg.n_ini == n_ini && lg.curr_size == sol_vec.curr_size() && lg.n_spawn == n_spawn, "fciqmc_fp it %u counts nnz %d/%d ini %u/%zu size %zu/%zu spawn %zu/%zu",
+              iterat, lg.n_nonz, n_nonz, lg.n_ini, n_ini, lg.curr_size, (size_t)sol_vec.curr_size(), lg.n_spawn, n_spawn);
+        size_t bad = 0, nmin = std::min(lg.curr_size, (size_t)sol_vec.curr_size());
+        for (size_t i = 0; i < nmin; i++) {
+            double rv = sol_vec.values()[i];
+            if (!same_bits(rv, fq.sol.vals[0][i])) bad++;
+            if (rv != 0 && to_u64(sol_vec.indices()[i], det_size) != fq.sol.dets[i]) bad++;
+        }
+        CHECK(bad == 0, "fciqmc_fp it %u vector mismatch in %zu slots", iterat, bad);
+    }
+    fclose(f);
+    printf("FCIQMC_FP iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, sol_vec.n_nonz());
+    return n_fail != 0;
+}
+
 int main(int argc, char **argv) {
     MPI_Init(NULL, NULL);
     int rc = 2;
@@ -1595,6 +1755,7 @@ int main(int argc, char **argv) {
     else if (argc >= 3 && !strcmp(argv[1], "piv")) rc = run_piv(argv[2]);
     else if (argc >= 2 && !strcmp(argv[1], "hbpiv")) rc = run_hbpiv(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frimulti")) rc = run_frimulti(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "fciqmc_fp")) rc = run_fciqmc_fp(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frifull")) rc = run_frifull(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);

@@ -380,14 +380,15 @@ class OracleFciqmc:
     reference's sequential mt19937 stream (pinned against the reference loop); counter_rng=True uses the counter-based
     stream the GPU replays."""
 
-    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU", trial=None, ini=None):
+    def __init__(self, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU", trial=None, ini=None, fp=False):
+        """fp=True: fciqmc_fp_mol (FRIES_bin/fciqmc_fp_mol.cpp), real-valued walkers."""
         self.lib = load()
         if distribution not in ("NU", "HB"):
             raise RuntimeError('"dist_str" argument must be either "NU" or "HB"')
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
-        flags = int(counter_rng) | (2 if distribution == "HB" else 0)
+        flags = int(counter_rng) | (2 if distribution == "HB" else 0) | (4 if fp else 0)
         if trial is None and ini is None:
             self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, flags)
         else:

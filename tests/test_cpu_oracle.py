@@ -135,11 +135,17 @@ def test_sharding_hash_matches_reference_ranks(oracle, mols):
         assert nz.size > 0 and all(orc.idx_to_proc(x) == k for x in nz[:200])
 
 
-@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_runs"]))
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_runs"]) + sorted(golden_io.manifest()["fciqmc_fp_runs"]))
 def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
-    """fciqmc_mol (near-uniform and heat-bath generators) restated, consuming the reference's mt19937 stream: every logged scalar, the walker
-    counts and the digest of (position, determinant, walkers) against the reference's own loop."""
-    r = golden_io.manifest()["fciqmc_runs"][name]
+    """fciqmc_mol (near-uniform and heat-bath generators) and fciqmc_fp_mol (real-valued walkers, fciqmc_fp_*) restated, consuming the
+    reference's mt19937 stream: every logged scalar, the walker counts and the digest of (position, determinant, walkers) against the
+    reference's own loops."""
+    man = golden_io.manifest()
+    r = man["fciqmc_runs"][name] if name in man["fciqmc_runs"] else man["fciqmc_fp_runs"][name]
+    if r.get("fp"):
+        kw_fp = dict(fp=True)
+    else:
+        kw_fp = {}
     rows = []
     with open(os.path.join(golden_io.GOLD, name + ".traj")) as f:
         for ln in f:
@@ -153,7 +159,7 @@ def test_oracle_fciqmc_reproduces_reference(oracle, mols, name):
     if "ini" in r:
         kw["ini"] = golden_io.read_text_vector(r["ini"])
     orc = oracle.OracleFciqmc(mols(r["shape"]), epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"],
-                              seed=r["seed"], counter_rng=False, distribution=r["distribution"], **kw)
+                              seed=r["seed"], counter_rng=False, distribution=r["distribution"], **kw, **kw_fp)
     logs = orc.iterate(r["n_iter"])
     for i, row in enumerate(rows):
         lg = logs[i]
