@@ -358,6 +358,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_mc_walk(VecDev V, VcompBuf B, uint
         kprev = k;
     }
 }
+// exact in-order sum of |v| over the stored vector (DistVec::local_norm), to the host
+double fr_abs_norm(FriesCtx *c) {
+    const uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
+    AccAbs aa{c->vec.v0, c->vec.st};
+    run_seq(c, c->vc.seq, aa, bound);
+    double t = 0;
+    FR_HIP(hipMemcpyAsync(&t, c->vc.seq.total, 8, hipMemcpyDeviceToHost, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));
+    return t;
+}
 void fr_multi_walks(FriesCtx *c, double rn, double prev_glob_norm, uint32_t n_teeth, uint32_t *n_walk, double *unit_out) {
     VcompBuf &B = c->vc;
     const uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;

@@ -240,6 +240,7 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg);
 // hh.hip
 void fr_multi_setup(FriesCtx *c, const fries_frimulti_params *p);
 void fr_multi_iterate(FriesCtx *c, fries_fciqmc_log *lg);
+double fr_abs_norm(FriesCtx *c);
 void fr_multi_walks(FriesCtx *c, double rn, double prev_glob_norm, uint32_t n_teeth, uint32_t *n_walk, double *unit_out);
 void fr_hh_setup(FriesCtx *c, const fries_hh_params *p);
 void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg);

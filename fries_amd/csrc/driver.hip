@@ -542,7 +542,7 @@ extern "C" int fries_fciqmc_setup(fries_ctx *h, const fries_fciqmc_params *p) {
 extern "C" int fries_fciqmc_iterate(fries_ctx *h, uint32_t n_iter, fries_fciqmc_log *logs) {
     FR_API_BEGIN
     FR_HIP(hipSetDevice(h->c.device));
-    if (!h->c.fq_mode || h->c.fqw.multi) throw FriesError("fries_fciqmc_setup must be called first");
+    if (!h->c.fq_mode || h->c.fqw.multi == 1) throw FriesError("fries_fciqmc_setup must be called first");
     for (uint32_t i = 0; i < n_iter; i++) fr_fq_iterate(&h->c, logs ? &logs[i] : nullptr);
     check_dev_err(&h->c);
     FR_API_END
@@ -559,7 +559,7 @@ extern "C" int fries_frimulti_setup(fries_ctx *h, const fries_frimulti_params *p
 extern "C" int fries_frimulti_iterate(fries_ctx *h, uint32_t n_iter, fries_fciqmc_log *logs) {
     FR_API_BEGIN
     FR_HIP(hipSetDevice(h->c.device));
-    if (!h->c.fq_mode || !h->c.fqw.multi) throw FriesError("fries_frimulti_setup must be called first");
+    if (!h->c.fq_mode || h->c.fqw.multi != 1) throw FriesError("fries_frimulti_setup must be called first");
     for (uint32_t i = 0; i < n_iter; i++) fr_multi_iterate(&h->c, logs ? &logs[i] : nullptr);
     check_dev_err(&h->c);
     FR_API_END

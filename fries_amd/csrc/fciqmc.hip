@@ -25,7 +25,8 @@ struct FqRng {
     __device__ __forceinline__ unsigned choose(unsigned nmax) { return (unsigned)(uni() * nmax); }     // near_uniform.cpp:41-44
 };
 #define FQ_HEAVY 128u
-enum { FQ_BIN = 0, FQ_DOUB = 1, FQ_SING = 2, FQ_ROUND_D = 3, FQ_ROUND_S = 4, FQ_DEATH = 5, FQ_HB_O1 = 6, FQ_HB_O2 = 7, FQ_HB_U1 = 8, FQ_HB_U2 = 9 };
+enum { FQ_BIN = 0, FQ_DOUB = 1, FQ_SING = 2, FQ_ROUND_D = 3, FQ_ROUND_S = 4, FQ_DEATH = 5, FQ_HB_O1 = 6, FQ_HB_O2 = 7, FQ_HB_U1 = 8, FQ_HB_U2 = 9, FQ_NWALK = 10, FQ_COMP = 11 };
+// FqWork::multi: 0 fciqmc_mol (integer walkers), 1 frimulti_mol, 2 fciqmc_fp_mol (real-valued walkers)
 
 // alias method (compress_utils.cpp:823-877) on a probability row of at most 32 states
 struct FqAlias { uint8_t alias[32]; double prob[32]; };
@@ -68,12 +69,21 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
         const double cur = V.v0[d];
         const int cur_i = (int)cur;
         // frimulti_mol: real weights; the column's sample number comes from the comb (k_mc_walk) and may be zero
-        const unsigned n_walk = Q.multi ? (cur != 0 ? Q.n_walk[d] : 0u) : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        unsigned n_walk = Q.multi == 1 ? (cur != 0 ? Q.n_walk[d] : 0u) : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+        if (Q.multi == 2) {      // fciqmc_fp_mol.cpp:342: |v| rounded stochastically to the number of spawning attempts
+            n_walk = 0;
+            if (cur != 0) {
+                FqRng r0; r0.begin(seed, iter, V.dets[d], 0, FQ_NWALK);
+                const double a = fabs(cur); const int flr = (int)floor(a);
+                n_walk = (unsigned)(flr + (r0.uni() < a - flr ? 1 : 0));
+            }
+            Q.n_walk[d] = n_walk;
+        }
         uint32_t n_doub = 0, n_sing = 0;
-        double new_val = 0;
-        if (Q.multi ? cur != 0 : n_walk != 0) {
-            nz = 1; ini = Q.multi ? fabs(cur) > Q.init_f : n_walk > init_thresh;
-            const int sign = cur_i < 0 ? -1 : 1;
+        double new_val = Q.multi == 2 ? cur : 0;        // a real-valued walker without attempts is left alone (:343-345)
+        if (Q.multi == 1 ? cur != 0 : n_walk != 0) {
+            nz = 1; ini = Q.multi == 1 ? fabs(cur) > Q.init_f : n_walk > init_thresh;
+            const int sign = cur < 0 ? -1 : 1;
             const det_t det = V.dets[d];
             double dg = V.diag[d];
             if (dg != dg) { dg = fr_diag_matrel(det, S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[d] = dg; }
@@ -226,11 +236,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
         const double cur_f = V.v0[d];
         const int cur_i = (int)cur_f;
         const unsigned n_walk = Q.multi ? Q.n_walk[d] : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
-        const int sign = cur_i < 0 ? -1 : 1;
-        sp_ini = Q.multi ? fabs(cur_f) > Q.init_f : n_walk > init_thresh;
+        const int sign = cur_f < 0 ? -1 : 1;
+        sp_ini = Q.multi == 1 ? fabs(cur_f) > Q.init_f : n_walk > init_thresh;
         // frimulti_mol.cpp:317-320: the column's weight relative to one sampling unit, at most 1
         double colw = 1;
-        if (Q.multi) { colw = fabs(cur_f) / Q.samp_unit; if (colw > 1) colw = 1; }
+        if (Q.multi == 1) { colw = fabs(cur_f) / Q.samp_unit; if (colw > 1) colw = 1; }
+        const bool keep_real = Q.multi == 2;           // fciqmc_fp_mol.cpp:385-390: only spawns below 0.01 are rounded
         const unsigned n_orb = T.n_orb, n_elec = T.n_elec;
         SymCounts sc; fr_count_symm_virt(sc, T, det);
         FqRng rng;
@@ -273,7 +284,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
                         const unsigned a1 = o1 < o2 ? o1 : o2, a2 = o1 < o2 ? o2 : o1, b1 = u1 < u2 ? u1 : u2, b2 = u1 < u2 ? u2 : u1;
                         const double prob = fr_norm_wt(T, det, a1, a2, b1, b2);
                         double m = fr_doub_matrel(a1, a2, b1, b2, S.eris, n_orb);
-                        if (Q.multi) {          // a real-valued weight instead of a rounded walker (frimulti_mol.cpp:350-358)
+                        if (Q.multi == 1) {     // a real-valued weight instead of a rounded walker (frimulti_mol.cpp:350-358)
                             if (fabs(m) > 1e-9) {
                                 m *= -eps / prob / p_doub / n_walk * cur_f * fr_doub_parity(det, a1, a2, b1, b2) / colw;
                                 sp_val = m;
@@ -282,12 +293,15 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
                         }
                         else {
                         m *= eps / prob / p_doub;
-                        rng.begin(seed, iter, det, att, FQ_ROUND_D);
-                        const int flr = (int)floor(m);
-                        int sp = flr + (rng.uni() < m - flr ? 1 : 0);
+                        double sp = m;
+                        if (!keep_real || fabs(m) < 0.01) {
+                            rng.begin(seed, iter, det, att, FQ_ROUND_D);
+                            const int flr = (int)floor(m);
+                            sp = (double)(flr + (rng.uni() < m - flr ? 1 : 0));
+                        }
                         if (sp != 0) {
                             sp *= -fr_doub_parity(det, a1, a2, b1, b2) * sign;
-                            sp_val = (double)sp;
+                            sp_val = sp;
                             sp_det = (det & ~(1ull << a1) & ~(1ull << a2)) | (1ull << b1) | (1ull << b2);
                         }
                         }
@@ -363,12 +377,15 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
                 const unsigned o1 = orb2, o2 = orb1, u1 = unocc1 < unocc2 ? unocc1 : unocc2, u2 = unocc1 < unocc2 ? unocc2 : unocc1;
                 double m = fr_doub_matrel(o1, o2, u1, u2, S.eris, n_orb);
                 m *= eps / prob / p_doub;
-                rng.begin(seed, iter, det, i, FQ_ROUND_D);
-                const int flr = (int)floor(m);
-                int sp = flr + (rng.uni() < m - flr ? 1 : 0);
+                double sp = m;
+                if (!keep_real || fabs(m) < 0.01) {
+                    rng.begin(seed, iter, det, i, FQ_ROUND_D);
+                    const int flr = (int)floor(m);
+                    sp = (double)(flr + (rng.uni() < m - flr ? 1 : 0));
+                }
                 if (sp != 0) {
                     sp *= -fr_doub_parity(det, o1, o2, u1, u2) * sign;
-                    sp_val = (double)sp;
+                    sp_val = sp;
                     sp_det = (det & ~(1ull << o1) & ~(1ull << o2)) | (1ull << u1) | (1ull << u2);
                 }
             }
@@ -395,7 +412,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
             }
             const double prob = 1. / m_allow[elec] / (n_elec - delta_s);
             double m = fr_sing_matrel(det, occ_orb, orbital, S.h_core, S.eris, n_orb);
-            if (Q.multi) {              // frimulti_mol.cpp:365-374
+            if (Q.multi == 1) {         // frimulti_mol.cpp:365-374
                 if (fabs(m) > 1e-9) {
                     m *= -eps / prob / (1 - p_doub) / n_walk * cur_f * fr_sing_parity(det, occ_orb, orbital) / colw;
                     sp_val = m;
@@ -404,12 +421,15 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_attempt(VecDev V, SysDev S, FqW
             }
             else {
             m *= eps / prob / (1 - p_doub);
-            rng.begin(seed, iter, det, j, FQ_ROUND_S);
-            const int flr = (int)floor(m);
-            int sp = flr + (rng.uni() < m - flr ? 1 : 0);
+            double sp = m;
+            if (!keep_real || fabs(m) < 0.01) {
+                rng.begin(seed, iter, det, j, FQ_ROUND_S);
+                const int flr = (int)floor(m);
+                sp = (double)(flr + (rng.uni() < m - flr ? 1 : 0));
+            }
             if (sp != 0) {
                 sp *= -fr_sing_parity(det, occ_orb, orbital) * sign;
-                sp_val = (double)sp;
+                sp_val = sp;
                 sp_det = (det & ~(1ull << occ_orb)) | (1ull << orbital);
             }
             }
@@ -453,6 +473,20 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_norm(VecDev V, double *out) {
     if (threadIdx.x == 0) atomicAdd(out, r);
 }
 
+// fciqmc_fp_mol.cpp:428-441: every |v| < 1 becomes -1, 0 or 1; what became 0 is deleted
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_fp_round(VecDev V, uint8_t *del, unsigned long long seed, unsigned long long iter) {
+    const uint32_t n = V.st->curr_size;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = V.v0[i];
+    if (v == 0 || !(fabs(v) < 1)) return;
+    FqRng r; r.begin(seed, iter, V.dets[i], 0, FQ_COMP);
+    const int flr = (int)floor(v);
+    const int nv = flr + (r.uni() < v - flr ? 1 : 0);
+    V.v0[i] = (double)nv;
+    if (nv == 0) del[i] = 1;
+}
+
 void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
     if (p->max_dets == 0 || p->target_walkers == 0) throw FriesError("max_dets and target_walkers must be positive");
@@ -481,6 +515,12 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     FR_HIP(hipMemsetAsync(Q.totals, 0, 16, c->stream));
     Q.sp_val = fr_alloc<double>(Q.cap_a); Q.sp_det = fr_alloc<det_t>(Q.cap_a); Q.sp_ini = fr_alloc<uint8_t>(Q.cap_a);
     Q.o1cnt = p->heat_bath ? fr_alloc<uint32_t>((size_t)Q.cap_d * c->n_elec) : nullptr;
+    Q.multi = 0; Q.n_walk = nullptr; Q.samp_unit = 1; Q.init_f = 0;
+    if (p->real_walkers) {             // fciqmc_fp_mol
+        if (c->use_comm && c->n_ranks > 1) throw FriesError("fciqmc_fp_mol runs on one rank here");
+        if (!c->in_ini_det.empty() || !c->in_trial_det.empty()) throw FriesError("fciqmc_fp_mol: --ini_vec / --trial_vec are not provided");
+        Q.multi = 2; Q.n_walk = fr_alloc<uint32_t>(Q.cap_d);
+    }
     if (p->heat_bath && (c->n_elec > 32 || c->n_orb - c->n_elec / 2 > 32)) throw FriesError("heat-bath sampling supports at most 32 electrons / 32 virtual orbitals per spin");
     fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
     if (!c->in_ini_det.empty()) {                            // --ini_vec (:226-237): integer walkers, entries add()ed in file order from rank 0
@@ -545,8 +585,20 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     if (n_merge) fr_vec_merge(c, &c->vec, n_merge, true);           // one perform_add into the column itself (:413)
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) throw FriesError("device error in the FCIQMC merge (capacity, hash table or electron count)");
+    if (Q.multi == 2) {
+        const uint32_t nb = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
+        FR_LAUNCH(c, "k_fq_fp_round", k_fq_fp_round, dim3(fr_blocks(nb, FR_BLOCK)), dim3(FR_BLOCK), c->vec, c->vc.del, (unsigned long long)P.seed, (unsigned long long)c->iterat);
+        fr_vec_delete_flagged(c, &c->vec, c->vc.del, nb);
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    }
     double norm = 0;
-    if ((c->iterat + 1) % 10 == 0) {                                // :415-427
+    if ((c->iterat + 1) % 10 == 0 && Q.multi == 2) {                // real values: the reference's in-order sum, exactly (local_norm, vec_utils.hpp:683-689)
+        norm = fr_abs_norm(c);
+        double damp = 0.05 / c->eps / 10;
+        if (c->last_one_norm) { c->en_shift -= damp * log(norm / c->last_one_norm); c->last_one_norm = norm; }
+        if (c->last_one_norm == 0 && norm > c->target_norm) c->last_one_norm = norm;
+    }
+    else if ((c->iterat + 1) % 10 == 0) {                           // :415-427
         FR_HIP(hipMemsetAsync(Q.norm, 0, 8, st));
         unsigned gn = fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK);
         if (gn > 1024) gn = 1024;

@@ -1,7 +1,8 @@
-// fciqmc_mol on the MI355X engine (FRIES_bin/fciqmc_mol.cpp, --distribution NU or HB) over the C ABI.
+// fciqmc_mol and fciqmc_fp_mol on the MI355X engine (FRIES_bin/fciqmc_mol.cpp, FRIES_bin/fciqmc_fp_mol.cpp, --distribution NU or HB) over the C ABI.
 //
 //   fciqmc_mol_hip --fcidump_path F --point_group D2h --distribution NU|HB --target W --max_dets N --epsilon E
 //                  [--initiator I] [--max_iter K] [--result_dir DIR/] [--ini_vec PREFIX] [--trial_vec PREFIX] [--seed S] [--device D]
+//                  [--fp 1]       (fciqmc_fp_mol: real-valued walkers; without --ini_vec / --trial_vec)
 //
 // Output files as the reference's (fciqmc_mol.cpp:262-300, 415-445): projnum.txt, projden.txt, nini.txt every iteration; S.txt,
 // N.txt (walkers), nnonz.txt every 10 iterations; params.txt.
@@ -25,7 +26,7 @@ int main(int argc, char **argv) {
         std::cout << "seed on process 0 is " << seed << std::endl;
         fries_fciqmc_params p{std::stod(kv["epsilon"]), kv.count("target") ? (uint32_t)std::stoul(kv["target"]) : 0u,
                               kv.count("initiator") ? (uint32_t)std::stoul(kv["initiator"]) : 0u, (uint32_t)std::stoul(kv["max_dets"]), seed,
-                              kv["distribution"] == "HB" ? 1 : 0, 0};
+                              kv["distribution"] == "HB" ? 1 : 0, (kv.count("fp") && std::stoul(kv["fp"]) != 0) ? 1 : 0};
         std::vector<uint64_t> tdets; std::vector<double> tvals;
         if (kv.count("trial_vec")) { load_vec_txt(kv["trial_vec"], tdets, tvals); ck(fries_set_trial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }      // fciqmc_mol.cpp:150-177
         if (kv.count("ini_vec")) { load_vec_txt(kv["ini_vec"], tdets, tvals); ck(fries_set_initial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }          // :226-237
@@ -37,7 +38,7 @@ int main(int argc, char **argv) {
         num_file.precision(17); den_file.precision(17); shift_file.precision(17);
         {
             std::ofstream param_f(rd + "params.txt");
-            param_f << "FCIQMC calculation\nFCIDUMP path: " << kv["fcidump_path"] << "\nepsilon (imaginary time step): " << p.epsilon << "\nTarget number of walkers "
+            param_f << (p.real_walkers ? "Non-integer FCIQMC calculation\nFCIDUMP path: " : "FCIQMC calculation\nFCIDUMP path: ") << kv["fcidump_path"] << "\nepsilon (imaginary time step): " << p.epsilon << "\nTarget number of walkers "
                     << p.target_walkers << "\nInitiator threshold: " << p.initiator << "\nInitializing calculation from HF unit vector\n";
         }
         for (uint32_t it = 0; it < max_iter; it++) {

@@ -55,7 +55,7 @@ class FrimultiParams(C.Structure):
 class FciqmcParams(C.Structure):
     """struct fries_fciqmc_params"""
     _fields_ = [("epsilon", C.c_double), ("target_walkers", C.c_uint32), ("initiator", C.c_uint32), ("max_dets", C.c_uint32), ("seed", C.c_uint32),
-                ("heat_bath", C.c_int32), ("pad", C.c_int32)]
+                ("heat_bath", C.c_int32), ("real_walkers", C.c_int32)]
 
 
 FCIQMC_LOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("norm", "f8"), ("n_nonz", "i4"), ("n_ini", "u4"), ("curr_size", "u4"),
@@ -237,7 +237,7 @@ class FriEngine:
         self.max_dets = max_dets
 
     # ---- fciqmc_mol
-    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, distribution="NU", trial=None, ini=None):
+    def setup_fciqmc(self, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, distribution="NU", trial=None, ini=None, fp=False):
         """fciqmc_mol with the near-uniform excitation generator (FRIES_bin/fciqmc_mol.cpp, --distribution NU): HF trial vector,
         100 walkers on HF to start; uniforms from a counter-based stream (see csrc/fciqmc.hip)."""
         if distribution not in ("NU", "HB"):
@@ -247,7 +247,7 @@ class FriEngine:
                 d = np.ascontiguousarray(pair[0], dtype=np.uint64)
                 v = np.ascontiguousarray(pair[1], dtype=np.float64)
                 self._ck(fn(self.h, _ptr(d), _ptr(v), min(d.size, v.size)))
-        p = FciqmcParams(epsilon, target_walkers, initiator, max_dets, seed, 1 if distribution == "HB" else 0, 0)
+        p = FciqmcParams(epsilon, target_walkers, initiator, max_dets, seed, 1 if distribution == "HB" else 0, 1 if fp else 0)      # fp: fciqmc_fp_mol
         self._ck(self.lib.fries_fciqmc_setup(self.h, C.byref(p)))
         self.max_dets = max_dets
 

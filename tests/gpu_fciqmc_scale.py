@@ -7,9 +7,10 @@ from fries_amd.engine import FriEngine
 shape = sys.argv[1] if len(sys.argv) > 1 else "N2"
 eps = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
 target = int(sys.argv[3]) if len(sys.argv) > 3 else 1000000
+fp = len(sys.argv) > 4 and sys.argv[4] == "fp"       # fciqmc_fp_mol: real-valued walkers
 mol = fcidump.synthetic(shape)
 eng = FriEngine(mol)
-eng.setup_fciqmc(epsilon=eps, target_walkers=target, max_dets=8 * target, initiator=3, seed=1)
+eng.setup_fciqmc(epsilon=eps, target_walkers=target, max_dets=8 * target, initiator=3, seed=1, fp=fp)
 t0 = time.time(); it = 0
 while it < 40000:
     lg = eng.iterate_fciqmc(500); it += 500

@@ -583,6 +583,51 @@ def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_fp_runs"]))
+def test_fciqmc_fp_matches_oracle_counter_stream(oracle, name, tmp_path):
+    """fciqmc_fp_mol (real-valued walkers) on the device against the CPU restatement, both on the counter-based uniform stream, in the
+    configurations whose mt19937 runs are pinned against the reference loop (tests/golden/fciqmc_fp_*.traj, CPU suite): attempts per
+    walker, real and rounded spawns, the +-1 rounding of small values and the deletes -- every stored double bit for bit."""
+    from fries_amd.engine import FriEngine
+    r = golden_io.manifest()["fciqmc_fp_runs"][name]
+    mol = fcidump.synthetic(r["shape"])
+    par = dict(epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"], fp=True)
+    n_it = r["n_iter"]
+    orc = oracle.OracleFciqmc(mol, counter_rng=True, **par)
+    eng = FriEngine(mol)
+    eng.setup_fciqmc(**par)
+    lo = orc.iterate(n_it)
+    lg = eng.iterate_fciqmc(n_it)
+    assert int(lg["err"].max()) == 0
+    for f in ("n_nonz", "n_ini", "curr_size", "n_spawn"):
+        assert np.array_equal(lg[f].astype(np.int64), lo[f].astype(np.int64)), (name, f, np.nonzero(lg[f].astype(np.int64) != lo[f].astype(np.int64))[0][:5])
+    assert np.array_equal(lg["shift"], lo["shift"]) and np.array_equal(lg["norm"], lo["norm"]) and np.array_equal(lg["denom"], lo["denom"])
+    assert np.all(np.abs(lg["numer"] - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    gd, gv = eng.vector()
+    od, ov = orc.vector()
+    assert gd.size == od.size and np.array_equal(gv, ov)
+    nz = ov != 0
+    assert np.array_equal(gd[nz], od[nz])
+    assert int(lo["n_nonz"][-1]) > 30 and np.any(ov != np.round(ov))          # the walkers spread, and some are not integers
+    eng.close()
+    if name != "fciqmc_fp_ne":
+        return
+    import subprocess
+    from fries_amd import build
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    res = subprocess.run([build.DRIVERS["fciqmc_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--target", str(r["target_walkers"]),
+                          "--max_dets", str(r["max_dets"]), "--epsilon", repr(r["epsilon"]), "--initiator", str(r["initiator"]), "--max_iter", str(n_it), "--result_dir", out,
+                          "--seed", str(r["seed"]), "--fp", "1"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nini = np.loadtxt(out + "nini.txt")
+    assert np.array_equal(den, lo["denom"]) and np.all(np.abs(num - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    assert np.array_equal(nini.astype(np.int64), lo["n_ini"].astype(np.int64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,n_it", [("multi_ne_m1000", 60), ("multi_n2_m5000_ini0", 40)])
 def test_frimulti_matches_oracle_counter_stream(oracle, name, n_it):
     """frimulti_mol (multinomial matrix compression) on the device against the CPU restatement, both on the counter-based uniform stream,
