@@ -56,7 +56,7 @@ void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
 __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec, int mode) {
     const uint32_t n = *S.n_spawn;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    bool created = false, counted = false;          // counters are bumped once per wave at the end (one address, ~1e6 lanes)
+    bool created = false, counted = false, reused = false;   // counters are bumped once per wave at the end (one address, ~1e6 lanes)
     bool bad_nelec = false, hash_full = false;
     if (j < n) {
         const det_t dd = S.det[j];
@@ -66,16 +66,25 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
             if ((uint32_t)__popcll(dd & emask) != n_elec) { bad_nelec = true; S.slot[j] = FR_NOPOS; }
             else {
                 const det_t d = fr_vec_key(V, dd);
-                uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS;
+                uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS, first_tomb = FR_NOPOS;
+                // A new entry takes the first tombstone of its probe chain once the chain has been walked to its end without finding the key
+                // (otherwise a determinant that is deleted and spawned again every iteration -- the rule in fciqmc_fp_mol, common in
+                // frisys_mol -- lengthens its own chain by one slot per incarnation until the next rebuild).  Every lane inserting d follows
+                // the same rule, so concurrent inserters of d meet at the same slot and the CAS (old == d) merges them.
                 for (uint32_t probe = 0; probe < V.hcap; probe++) {
                     det_t k = V.hkeys[s];
                     if (k == d) { found = s; break; }
+                    if (k == FR_TOMB_KEY && ini && first_tomb == FR_NOPOS) first_tomb = s;
                     if (k == FR_EMPTY_KEY) {
                         if (!ini) break;
-                        det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
-                        if (old == FR_EMPTY_KEY) { found = s; created = true; break; }
-                        if (old == d) { found = s; break; }
-                        // another determinant took the slot: keep probing from the next one
+                        const bool use_tomb = first_tomb != FR_NOPOS;
+                        const uint32_t tgt = use_tomb ? first_tomb : s;
+                        const det_t expect = use_tomb ? FR_TOMB_KEY : FR_EMPTY_KEY;
+                        det_t old = atomicCAS((unsigned long long *)&V.hkeys[tgt], (unsigned long long)expect, (unsigned long long)d);
+                        if (old == expect) { found = tgt; if (use_tomb) reused = true; else created = true; break; }
+                        if (old == d) { found = tgt; break; }
+                        // another determinant took the slot: probe on from the one after it
+                        s = tgt; first_tomb = FR_NOPOS;
                     }
                     s = (s + 1) & (V.hcap - 1);
                 }
@@ -100,9 +109,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
             }
         }
     }
-    const unsigned long long mc = __ballot(created), mn = __ballot(counted);
+    const unsigned long long mc = __ballot(created), mn = __ballot(counted), mr = __ballot(reused);
     if (fr_lane() == 0) {
         if (mc) atomicAdd(&V.st->n_used, (uint32_t)__popcll(mc));
+        if (mr) atomicSub(&V.st->n_tomb, (uint32_t)__popcll(mr));
         if (mn) atomicAdd(&V.st->nonini_occ_add, (unsigned long long)__popcll(mn));
     }
     if (__any(bad_nelec) && fr_lane() == 0) atomicOr(&V.st->err, FR_ERR_NELEC);
