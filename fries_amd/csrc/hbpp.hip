@@ -722,8 +722,9 @@ static uint32_t pv_stage(FriesCtx *c, int cur, uint32_t n_in, uint32_t n_samp) {
     uint32_t n_long = 0;
     FR_HIP(hipMemcpyAsync(&n_long, F.total, 4, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));
-    if (n_long == 0) {
+    if (n_long == 0) {          // nothing on this rank (or at all)
         FR_HIP(hipMemsetAsync(&W.state[FR_MAX_ROUNDS + 1].n_out, 0, 4, st));
+        if (c->use_comm) fr_piv_comp_flat(c, 0, n_samp);     // the other ranks' compression still needs this one in its collectives
         return 0;
     }
     if (n_long > F.cap) fr_piv_flat_reserve(c, n_long + n_long / 4 + 1024);

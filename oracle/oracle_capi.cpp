@@ -352,6 +352,32 @@ int fo_ranks_compress_piv(void *h, uint32_t n_samp) {
     } catch (std::exception &e) { fprintf(stderr, "fo_ranks_compress_piv: %s\n", e.what()); return 1; }
     return 0;
 }
+// apply_HBPP_piv over the ranks (every piv_comp_parallel inside is collective); returns this rank's samples
+size_t fo_ranks_apply_hbpp_piv(void *h, uint32_t n_samp, uint32_t rank, uint32_t *pos, uint8_t *orbs, double *vals, size_t cap, uint64_t *stage_len) {
+    OracleRanks *R = (OracleRanks *)h;
+    int P = (int)R->fr.size();
+    std::vector<HBPivScratch> ps(P);
+    try {
+        run_ranks(P, [&](const Comm &c) {
+            Frisys &f = *R->fr[c.rank];
+            f.cm = c; f.sol.cm = c;
+            size_t n = f.sol.curr_size;
+            size_t len = (n > (size_t)n_samp ? n : (size_t)n_samp) * 2 + 64;
+            size_t ns = f.sys.n_elec > (f.sys.n_orb - f.sys.n_elec / 2) ? f.sys.n_elec : f.sys.n_orb - f.sys.n_elec / 2;
+            HBPivScratch &s = ps[c.rank];
+            s.init(len, ns);
+            std::copy(f.sol.vals[0].begin(), f.sol.vals[0].begin() + n, s.vec1.begin());
+            for (size_t i = 0; i < n; i++) s.det_idx1[i] = i;
+            s.vec_len = n;
+            apply_HBPP_piv(f.sol, s, f.sys, f.p_doub, f.par.new_hb, f.mt, n_samp, false, c);
+        });
+    } catch (std::exception &e) { fprintf(stderr, "fo_ranks_apply_hbpp_piv: %s\n", e.what()); return (size_t)-1; }
+    HBPivScratch &s = ps[rank];
+    size_t m = s.vec_len;
+    if (cap >= m) for (size_t i = 0; i < m; i++) { pos[i] = (uint32_t)s.det_idx2[i]; memcpy(orbs + 4 * i, &s.orb1[4 * i], 4); vals[i] = s.vec1[i]; }
+    if (stage_len) for (int k = 0; k < 5; k++) stage_len[k] = s.stage_len[k];
+    return m;
+}
 void *fo_ranks_get(void *h, uint32_t rank) { return ((OracleRanks *)h)->fr[rank].get(); }   // a Frisys* for fo_frisys_vec etc.
 int fo_ranks_hf_proc(void *h) { return ((OracleRanks *)h)->fr[0]->hf_proc; }
 int fo_idx_to_proc(void *h, uint64_t det) { return ((Frisys *)h)->sol.idx_to_proc(det); }

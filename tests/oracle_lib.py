@@ -300,6 +300,16 @@ class OracleRanks:
         for r in range(self.n_ranks):
             self.lib.fo_frisys_restart(self._rank(r), seed, 0.0, 0.0, 0)
 
+    def apply_hbpp_piv(self, n_samp, rank, cap):
+        """apply_HBPP_piv over the ranks (collective); this rank's samples.  NOTE: every call advances every rank's generator."""
+        self.lib.fo_ranks_apply_hbpp_piv.restype = C.c_size_t
+        self.lib.fo_ranks_apply_hbpp_piv.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        pos = np.zeros(cap, dtype=np.uint32); orbs = np.zeros((cap, 4), dtype=np.uint8); vals = np.zeros(cap); st = np.zeros(5, dtype=np.uint64)
+        n = self.lib.fo_ranks_apply_hbpp_piv(self.h, n_samp, rank, _p(pos), _p(orbs), _p(vals), cap, _p(st))
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle apply_hbpp_piv over ranks failed")
+        return pos[:n].copy(), orbs[:n].copy(), vals[:n].copy(), st
+
     def compress_piv(self, n_samp):
         if self.lib.fo_ranks_compress_piv(self.h, n_samp):
             raise RuntimeError("oracle ranks: pivotal compression failed")

@@ -84,6 +84,22 @@ def main():
     if not res["fails"] and golden_io.vec_hash(d, v) != rows[-1]["hash"]:
         res["fails"].append(("digest",))
     # optionally: pivotal compression of the sharded vector (piv_comp_parallel over the ranks) against the in-process rank oracle
+    # optionally: apply_HBPP_piv over the ranks (every compression inside is collective) against the in-process rank oracle
+    hbpiv = int(os.environ.get("FRIES_RANKS_HBPIV", "0"))
+    if hbpiv and not hh and not res["fails"]:
+        import oracle_lib
+        orc = oracle_lib.OracleRanks(world, mol, epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"],
+                                     target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+        orc.iterate(len(rows))
+        eng.restart(4242)
+        orc.restart(4242)
+        pos, orbs, vals, sl = eng.apply_hbpp_piv(hbpiv)
+        opos, oorbs, ovals, osl = orc.apply_hbpp_piv(hbpiv, rank, hbpiv + 4096)
+        if not (len(pos) == len(opos) and np.array_equal(pos, opos) and np.array_equal(orbs, oorbs) and vals.tobytes() == ovals.tobytes()):
+            res["fails"].append(("apply_hbpp_piv over ranks", len(pos), len(opos)))
+        if sl.tolist() != osl.tolist():
+            res["fails"].append(("apply_hbpp_piv stage lengths", sl.tolist(), osl.tolist()))
+        res["hbpiv_samples"] = int(len(pos)); res["hbpiv_stages"] = sl.tolist()
     piv_budget = int(os.environ.get("FRIES_RANKS_PIV", "0"))
     if piv_budget and not hh and not res["fails"]:
         import oracle_lib

@@ -75,6 +75,28 @@ def test_one_rank_communicator_over_rccl(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,budget", [("n2_m10000_unnorm_p2", 4000), ("h2o_m5000_hb_p3", 2500)])
+def test_apply_hbpp_piv_over_ranks(name, budget, tmp_path):
+    """apply_HBPP_piv over a sharded vector: the five pivotal compressions inside are collective (preservation rounds, the budget
+    apportioned by rank 0, per-shard sampling); every rank's samples against the in-process rank oracle, bit for bit."""
+    r = golden_io.manifest()["mpi_runs"][name]
+    P = r["n_ranks"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", FRIES_RANKS_HBPIV=str(budget))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "gloo", str(tmp_path), "12"]
+    res = _run_ranks(cmd, env, 300)
+    total = 0
+    for k in range(P):
+        fn = tmp_path / f"rank{k}.json"
+        assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+        rep = json.loads(fn.read_text())
+        assert rep["ok"], rep["fails"]
+        total += rep["hbpiv_stages"][0]
+    assert 0 < total <= budget          # what the first compression kept over all ranks
+    assert res.returncode == 0, res.stderr[-4000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,budget", [("n2_m10000_unnorm_p2", 3000), ("h2o_m5000_hb_p3", 1500)])
 def test_pivotal_compression_over_ranks(name, budget, tmp_path):
     """compress_vecs over a sharded vector (piv_comp_parallel with piv_budget apportioning the samples among the ranks,
