@@ -214,7 +214,7 @@ void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint3
 void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap);
 void fr_xch_alloc(FriesCtx *c, uint32_t cap);
-uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, bool one_pass = false);
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass = 0);      // 0: two passes (frisys_mol); 1: one pass, flag inside an integer value; 2: one pass, flag in bit 63 of the index
 // hbpp.hip
 void fr_hbpp_alloc(FriesCtx *c, uint32_t cap);
 void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]);

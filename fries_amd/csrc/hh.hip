@@ -289,7 +289,7 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     FR_HIP(hipMemcpyAsync(c->d_vec_scr, c->vec_scr.data(), 4 * c->vec_scr.size(), hipMemcpyHostToDevice, c->stream));
     if (!c->d_hb) { c->d_hb = fr_alloc<HbTables>(1); FR_HIP(hipMemsetAsync(c->d_hb, 0, sizeof(HbTables), c->stream)); }     // unused by uniform stages, but staged
     c->adder_cap = (uint32_t)((uint64_t)p->vec_nonz * 4 / c->n_ranks);      // the Adder gets spawn_length here (:94, :100)
-    if (p->full && c->n_ranks > 1) throw FriesError("frifull_hh runs on one rank here (its Adder flushes interleave the ranks' adds batch by batch)");
+    if (p->full) { uint64_t sl = (uint64_t)p->n_elec * 4 * p->max_dets / c->n_ranks; c->adder_cap = sl > 200000 ? 200000u : (uint32_t)sl; }      // frifull_hh.cpp:91-95
     fr_vec_alloc(c, &c->vec, p->max_dets);
     c->vec.hh_sites = L; c->vec.hh_nelec = p->n_elec; c->vec.hh_buckets = p->max_dets; c->vec.hh_scr = c->d_vec_scr;
     fr_hbpp_alloc(c, wcap);
@@ -299,7 +299,7 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     const uint64_t sp_need = p->full ? (uint64_t)4 * p->n_elec * ((uint64_t)p->vec_nonz + 64) + 4096 : (uint64_t)p->vec_nonz + 4096;
     if (sp_need > 0x7fffffffull) throw FriesError("vec_nonz too large for the spawn list");
     fr_spawn_alloc(c, (uint32_t)sp_need);
-    fr_xch_alloc(c, p->vec_nonz + 4096);
+    fr_xch_alloc(c, (uint32_t)sp_need);
     if (p->full) c->hhf_cnt = fr_alloc<unsigned long long>(2);
     fr_vcomp_alloc(c, p->max_dets);
     c->hh_fdet = fr_alloc<det_t>(wcap);
@@ -344,6 +344,13 @@ void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg) {
         }
         n_spawn = (uint32_t)tot[1];
         c->num_success = (uint32_t)tot[0];
+        if (c->use_comm) {
+            // Over ranks the reference ships its adds in rounds of about one Adder (frifull_hh.cpp:91-95, 193, 258-262) and a receiver sees
+            // (round, source rank, order).  One round -- every rank below its Adder size -- is (source rank, order), what one exchange delivers.
+            uint64_t sl = (uint64_t)P.n_elec * 4 * P.max_dets / c->n_ranks;
+            if (sl > 200000) sl = 200000;
+            if (tot[0] + (uint64_t)P.n_elec * 4 >= sl) throw FriesError("frifull_hh over ranks: this shard fills its Adder (200000 adds) in one iteration; several rounds per iteration are not provided");
+        }
         c->comp_len[0] = c->comp_len[1] = 0;
     }
     else {
@@ -363,7 +370,7 @@ void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg) {
     }
     if (vec_size) FR_HIP(hipMemsetAsync(c->vec.v1, 0, 8 * (size_t)vec_size, st));      // set_curr_vec_idx(1); zero_vec() (:227-228)
     uint32_t n_merge = n_spawn;
-    if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn);
+    if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn, P.full ? 2 : 0);
     if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false, P.full != 0);
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) throw FriesError("device error in the Hubbard-Holstein merge (capacity, hash table or electron count)");

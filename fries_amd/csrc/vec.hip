@@ -523,7 +523,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n
             XchRec r; r.det = S.det[j]; r.val = S.val[j];
             // one pass (fciqmc_mol): initiator and non-initiator spawns keep their order, so the flag rides inside the (integer) walker
             // count: 2 v + sgn(v) * flag, exact for |v| < 2^51
-            if (one_pass) r.val = 2.0 * r.val + ((S.ini[j] ? 1.0 : 0.0) * (r.val > 0 ? 1.0 : -1.0));
+            if (one_pass == 1) r.val = 2.0 * r.val + ((S.ini[j] ? 1.0 : 0.0) * (r.val > 0 ? 1.0 : -1.0));
+            // one pass with real values (frifull_hh): the flag rides in bit 63 of the index, which no index of <= 31 orbitals / 12 sites uses
+            if (one_pass == 2 && S.ini[j]) r.det |= 1ull << 63;
             out[o] = r;
         }
         else atomicOr(err, FR_ERR_SPAWN_CAP);
@@ -540,6 +542,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_unpack(SpawnBuf S, const XchRe
     uint32_t s = 0;
     while (s + 1 < G.n_src && j >= G.first[s + 1]) s++;
     XchRec r = in[j];
+    if (one_pass == 2) {
+        S.det[j] = r.det & ~(1ull << 63); S.val[j] = r.val; S.ini[j] = (uint8_t)(r.det >> 63);
+        return;
+    }
     if (one_pass) {
         const double a = fabs(r.val);
         const double flag = a - 2.0 * floor(a * 0.5);           // 1 for an initiator spawn
@@ -564,7 +570,7 @@ void fr_xch_alloc(FriesCtx *c, uint32_t cap) {
 
 // Ships the n_local spawns in c->sp to their owners; on return c->sp holds what this rank received, in the
 // reference's arrival order.  Returns the number received.
-uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, bool one_pass) {
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass) {
     SpawnBuf &S = c->sp;
     hipStream_t st = c->stream;
     const int P = c->n_ranks;
@@ -573,9 +579,9 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, bool one_pass) {
     unsigned g = fr_blocks(n_local ? n_local : 1, FR_BLOCK);
     uint32_t cap_recs = (uint32_t)(c->comm.big_bytes / sizeof(XchRec));
     if (n_local == 0) FR_HIP(hipMemsetAsync(S.n_spawn, 0, 4, st));
-    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites, one_pass ? 1 : 0);
+    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites, one_pass);
     FR_LAUNCH(c, "k_xch_scan", k_xch_scan, dim3(1), dim3(FR_BLOCK), S, (uint32_t)P, S.xcnt, S.xoff, S.xbucket, (uint32_t *)c->comm.small_send);
-    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err, one_pass ? 1 : 0);
+    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err, one_pass);
     const uint32_t *all = (const uint32_t *)fr_allgather(c, nb * 4);
     std::vector<uint32_t> cnt((size_t)P * nb);
     FR_HIP(hipMemcpyAsync(cnt.data(), all, cnt.size() * 4, hipMemcpyDeviceToHost, st));
@@ -598,6 +604,6 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, bool one_pass) {
     if (n_recv > S.cap || n_recv > cap_recs) throw FriesError("received spawns exceed the spawn buffer");
     if (c->comm.alltoallv(c->comm.user, sb.data(), rb.data(), (void *)st)) throw FriesError("fries_comm.alltoallv failed");
     c->n_collectives++;
-    FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv, one_pass ? 1 : 0);
+    FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv, one_pass);
     return (uint32_t)n_recv;
 }

@@ -147,7 +147,8 @@ typedef struct {
     double eps, U, omega, g, gs_energy, target_norm, initiator;
     uint32_t vec_nonz, max_dets, seed;
     uint32_t full;      /* 0: frisys_hh.  1: frifull_hh (FRIES_bin/frifull_hh.cpp) -- every hop and phonon move of every stored state
-                         * instead of the two matrix compressions; num_success = number of adds; one rank only */
+                         * instead of the two matrix compressions; num_success = number of adds; over ranks as long as a shard's adds of one
+                         * iteration fit one Adder (200 000), as the reference ships them in one round then */
 } fries_hh_params;
 int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
 int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);

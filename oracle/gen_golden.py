@@ -79,6 +79,9 @@ HH_RUNS = {
 HHFULL_RUNS = {
     "hhfull_l6_m300": (1, 60, 5, 6, 6, 0.01, 2.0, 0.5, 0.3, -3.0, 300, 200000, 1.0, 150.0),
     "hhfull_l8_m500_ini0": (1, 40, 7, 8, 8, 0.01, 4.0, 1.0, 0.5, -2.0, 500, 400000, 0.0, 250.0),
+    # under mpiexec -n P (one Adder round per iteration at these sizes)
+    "hhfull_l8_m500_p2": (2, 40, 7, 8, 8, 0.01, 4.0, 1.0, 0.5, -2.0, 500, 400000, 1.0, 250.0),
+    "hhfull_l6_m300_ini0_p3": (3, 50, 5, 6, 6, 0.01, 2.0, 0.5, 0.3, -3.0, 300, 200000, 0.0, 150.0),
 }
 
 
@@ -118,6 +121,18 @@ def gen_fp(manifest):
             manifest["fciqmc_fp_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist, fp=True)
 
 
+def gen_hhfull(manifest):
+    manifest["hhfull_runs"] = {}
+    for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HHFULL_RUNS.items():
+        out = os.path.join(GOLD, name + ".traj")
+        cmd = [HARNESS, "hh", str(n_iter), str(seed), str(n_elec), str(n_sites), repr(eps), repr(U), repr(omega), repr(g), repr(gs), str(vnz), str(maxd), repr(ini), repr(tgt), out]
+        if n_ranks > 1:
+            cmd = [MPIEXEC, "-n", str(n_ranks)] + cmd
+        subprocess.run(cmd, check=True, env=dict(os.environ, FRIES_HH_FULL="1"))
+        manifest["hhfull_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
+                                              gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+
+
 def gen_multi(manifest):
     manifest["multi_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -147,10 +162,10 @@ def gen_hbpiv(manifest):
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] in ("--only-multi", "--only-fp"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("--only-multi", "--only-fp", "--only-hhfull"):
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
-        (gen_multi if sys.argv[1] == "--only-multi" else gen_fp)(manifest)
+        {"--only-multi": gen_multi, "--only-fp": gen_fp, "--only-hhfull": gen_hhfull}[sys.argv[1]](manifest)
         with open(os.path.join(GOLD, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
@@ -286,13 +301,7 @@ def main():
             subprocess.run(cmd, check=True)
             manifest["hh_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
                                              gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
-    manifest["hhfull_runs"] = {}
-    for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HHFULL_RUNS.items():
-        out = os.path.join(GOLD, name + ".traj")
-        cmd = [HARNESS, "hh", str(n_iter), str(seed), str(n_elec), str(n_sites), repr(eps), repr(U), repr(omega), repr(g), repr(gs), str(vnz), str(maxd), repr(ini), repr(tgt), out]
-        subprocess.run(cmd, check=True, env=dict(os.environ, FRIES_HH_FULL="1"))
-        manifest["hhfull_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
-                                              gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+    gen_hhfull(manifest)
     gen_hbpiv(manifest)
     gen_multi(manifest)
     gen_fp(manifest)

@@ -35,9 +35,10 @@ def main():
     man = golden_io.manifest()
     if name in man.get("fciqmc_mpi_runs", {}):
         return fciqmc_ranks(name, man["fciqmc_mpi_runs"][name], rank, world, dev, out_dir, dist, torch)
-    hh = name in man.get("hh_runs", {})
+    hh_full = name in man.get("hhfull_runs", {})
+    hh = hh_full or name in man.get("hh_runs", {})
     if hh:
-        r = man["hh_runs"][name]
+        r = man["hhfull_runs" if hh_full else "hh_runs"][name]
         assert r["n_ranks"] == world, (r["n_ranks"], world)
         g = golden_io.read_traj(name, rank=rank if world > 1 else None)
     elif name in man["mpi_runs"]:
@@ -50,10 +51,11 @@ def main():
         g = golden_io.read_traj(name)
     res = dict(rank=rank, ok=True, fails=[])
     if hh:
-        comm = TorchComm(r["vec_nonz"], torch.device("cuda", dev))
+        # frifull_hh ships every hop and phonon move: up to 4 n_elec adds per stored state
+        comm = TorchComm(4 * r["n_elec"] * (r["vec_nonz"] + 64) + 4096 if hh_full else r["vec_nonz"], torch.device("cuda", dev))
         eng = FriEngine(None, device=dev, comm=comm)
         eng.setup_hh(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"],
-                     vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
+                     vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], full=hh_full)
         step = eng.iterate_hh
     else:
         mol = fcidump.synthetic(r["shape"])

@@ -36,7 +36,8 @@ def _free_port():
     return p
 
 
-_RANK_RUNS = dict(golden_io.manifest()["mpi_runs"], **{k: v for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] > 1})
+_RANK_RUNS = dict(golden_io.manifest()["mpi_runs"], **{k: v for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] > 1},
+                  **{k: v for k, v in golden_io.manifest()["hhfull_runs"].items() if v["n_ranks"] > 1})
 
 
 @pytest.mark.gpu
