@@ -404,6 +404,7 @@ void fr_dots(FriesCtx *c, double *numer, double *denom) {
     FR_HIP(hipMemcpyAsync(h, src, 16 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
     FR_HIP(hipStreamSynchronize(c->stream));
     double nu = 0, de = 0;          // sum_mpi in rank order (frisys_mol.cpp:512-517)
+    if (c->dots_slot0_from_hf && P > 1) { h[0] = h[2 * c->hf_proc]; h[1] = h[2 * c->hf_proc + 1]; }      // fciqmc_fp_mol.cpp:461-462: slot 0 overwritten by the gathering rank
     for (int p = 0; p < P; p++) { nu += h[2 * p]; de += h[2 * p + 1]; }
     *numer = nu; *denom = de;
 }

@@ -141,6 +141,7 @@ struct FriesCtx {
     bool fq_mode = false;
     fries_fciqmc_params fq{};
     fries_frimulti_params fm{};
+    bool dots_slot0_from_hf = false;         // fciqmc_fp_mol's gather quirk (compress.hip: fr_dots)
     FqWork fqw{};
     // Hubbard-Holstein driver (hh.hip)
     bool hh_mode = false, hh_keep0 = false;

@@ -517,7 +517,8 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     Q.o1cnt = p->heat_bath ? fr_alloc<uint32_t>((size_t)Q.cap_d * c->n_elec) : nullptr;
     Q.multi = 0; Q.n_walk = nullptr; Q.samp_unit = 1; Q.init_f = 0;
     if (p->real_walkers) {             // fciqmc_fp_mol
-        if (c->use_comm && c->n_ranks > 1) throw FriesError("fciqmc_fp_mol runs on one rank here");
+        if (c->use_comm && c->n_ranks > 1 && 2 * c->n_orb > 63) throw FriesError("fciqmc_fp_mol over ranks needs bit 63 of the index for the initiator flag (at most 31 orbitals)");
+        c->dots_slot0_from_hf = true;      // fciqmc_fp_mol.cpp:461-462
         if (!c->in_ini_det.empty() || !c->in_trial_det.empty()) throw FriesError("fciqmc_fp_mol: --ini_vec / --trial_vec are not provided");
         Q.multi = 2; Q.n_walk = fr_alloc<uint32_t>(Q.cap_d);
     }
@@ -580,7 +581,7 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));
     uint32_t n_merge = n_spawn;
-    if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn, true);  // one all-to-all per iteration; the spawns keep their order (:413)
+    if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn, Q.multi == 2 ? 2 : 1);  // one all-to-all per iteration; the spawns keep their order (:413)
     else if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder");
     if (n_merge) fr_vec_merge(c, &c->vec, n_merge, true);           // one perform_add into the column itself (:413)
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
@@ -594,6 +595,15 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     double norm = 0;
     if ((c->iterat + 1) % 10 == 0 && Q.multi == 2) {                // real values: the reference's in-order sum, exactly (local_norm, vec_utils.hpp:683-689)
         norm = fr_abs_norm(c);
+        if (c->use_comm) {          // sum_mpi of the local norms, in rank order
+            FR_HIP(hipMemcpyAsync(c->comm.small_send, &norm, 8, hipMemcpyHostToDevice, st));
+            const double *all = (const double *)fr_allgather(c, 8);
+            double h[FR_MAX_RANKS];
+            FR_HIP(hipMemcpyAsync(h, all, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+            norm = 0;
+            for (int q = 0; q < c->n_ranks; q++) norm += h[q];
+        }
         double damp = 0.05 / c->eps / 10;
         if (c->last_one_norm) { c->en_shift -= damp * log(norm / c->last_one_norm); c->last_one_norm = norm; }
         if (c->last_one_norm == 0 && norm > c->target_norm) c->last_one_norm = norm;

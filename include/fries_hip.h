@@ -166,7 +166,8 @@ typedef struct {
     int32_t heat_bath;          /* 0: --distribution NU (near_uniform.cpp), 1: --distribution HB (hb_doub_multi, heat_bathPP.cpp:601-683) */
     int32_t real_walkers;       /* 0: fciqmc_mol.  1: fciqmc_fp_mol (FRIES_bin/fciqmc_fp_mol.cpp): real-valued walkers -- |v| rounded stochastically to
                                  * the number of attempts (:342), spawns below 0.01 rounded and kept real otherwise (:385-390), death in place (:423-424),
-                                 * then every |v| < 1 rounded to -1 / 0 / 1 and zeros deleted (:428-441); one rank, no text vectors */
+                                 * then every |v| < 1 rounded to -1 / 0 / 1 and zeros deleted (:428-441); ranks as for fciqmc_mol (incl. the
+                                 * gather at :461-462 that overwrites rank 0's projection terms with the HF owner's); no text vectors */
 } fries_fciqmc_params;
 typedef struct {
     double numer, denom;        /* projnum.txt / projden.txt */

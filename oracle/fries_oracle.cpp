@@ -2615,6 +2615,9 @@ void Fciqmc::iterate(unsigned n_iter) {
             std::vector<double> all(2 * (size_t)cm.size);
             double mine2[2] = {lg.numer, lg.denom};
             cm.allgather(mine2, all.data(), 16);
+            // fciqmc_fp_mol.cpp:461-462 overwrites slot 0 of the gathered terms with the gathering rank's own (rank 0's terms are lost and
+            // the HF owner's count twice unless it is rank 0): reproduced as the rank that owns HF sees it
+            if (par.fp) { all[0] = all[2 * (size_t)hf_proc]; all[1] = all[2 * (size_t)hf_proc + 1]; }
             lg.numer = 0; lg.denom = 0;
             for (int q = 0; q < cm.size; q++) { lg.numer += all[2 * q]; lg.denom += all[2 * q + 1]; }
         }

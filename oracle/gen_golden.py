@@ -109,7 +109,24 @@ FCIQMC_FP_RUNS = {
 }
 
 
+# fciqmc_fp_mol under mpiexec -n P: name -> (n_ranks, same tuple as FCIQMC_FP_RUNS)
+FCIQMC_FP_MPI_RUNS = {
+    "fciqmc_fp_n2_p2": (2, ("N2", 150, 9, 0.006, 20000, 200000, 2, "NU")),
+    "fciqmc_fp_h2o_hb_p3": (3, ("H2O", 120, 11, 0.004, 10000, 200000, 0, "HB")),
+}
+
+
 def gen_fp(manifest):
+    manifest["fciqmc_fp_mpi_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (n_ranks, (shape, n_iter, seed, eps, tw, maxd, ini, dist)) in FCIQMC_FP_MPI_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([MPIEXEC, "-n", str(n_ranks), HARNESS, "fciqmc_fp", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
+            manifest["fciqmc_fp_mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini,
+                                                        distribution=dist, fp=True)
     manifest["fciqmc_fp_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, (shape, n_iter, seed, eps, tw, maxd, ini, dist) in FCIQMC_FP_RUNS.items():

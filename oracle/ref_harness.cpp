@@ -1599,7 +1599,7 @@ static int run_fciqmc_fp(int argc, char **argv) {
     const bool heat_bath = argc > 11 && !strcmp(argv[11], "HB");
     int n_procs = 1, proc_rank = 0;
     MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
-    if (n_procs != 1) { fprintf(stderr, "fciqmc_fp: one rank\n"); return 2; }
+    MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
     fcidump_input *in_data = parse_fcidump(path, pg);
     unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
     size_t det_size = CEILING(2 * n_orb, 8);
@@ -1610,13 +1610,14 @@ static int run_fciqmc_fp(int argc, char **argv) {
     gen_hf_bitstring(n_orb, n_elec, hf_det);
     find_bits(hf_det, tmp_orbs, det_size);
     double hf_en = diag_matrel(tmp_orbs, tot_orb, *eris, *h_core, n_frz, n_elec);
-    std::mt19937 mt_obj(seed);
+    std::mt19937 mt_obj(seed + (uint32_t)proc_rank);      // one generator per process (fciqmc_fp_mol.cpp:108-110 seeds each from its clock)
     unsigned spawn_length = target_walkers / n_procs / n_procs * 2;
     std::function<double(const uint8_t *)> diag_shortcut = [tot_orb, eris, h_core, n_frz, n_elec, hf_en](const uint8_t *occ) { return diag_matrel(occ, tot_orb, *eris, *h_core, n_frz, n_elec) - hf_en; };
     SymmInfo symm_basis(symm, n_orb);
     unsigned unocc_symm_cts[n_irreps][2];
     std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
-    for (auto &x : proc_scrambler) x = mt_obj();
+    if (proc_rank == 0) for (auto &x : proc_scrambler) x = mt_obj();
+    MPI_Bcast(proc_scrambler.data(), 2 * n_orb, MPI_UNSIGNED, 0, MPI_COMM_WORLD);
     for (auto &x : vec_scrambler) x = mt_obj();
     DistVec<double> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 1, proc_scrambler, vec_scrambler);
     unsigned max_spawn = 500000;
@@ -1626,7 +1627,8 @@ static int run_fciqmc_fp(int argc, char **argv) {
     size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
     DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
     DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
-    trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1);
+    unsigned hf_proc = sol_vec.idx_to_proc(hf_det);
+    if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
     trial_vec.perform_add(0); htrial_vec.perform_add(0);
     trial_vec.collect_procs();
     std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
@@ -1642,9 +1644,10 @@ static int run_fciqmc_fp(int argc, char **argv) {
     size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, doub_orbs, symm);
     size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
     double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-    sol_vec.add(hf_det, 100, 1);
+    if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
     sol_vec.perform_add(0);
     double en_shift = 0, last_norm = 0, glob_norm = 0;
+    const bool lockstep = n_procs == 1;
     hb_info *hb_probs = heat_bath ? set_up(tot_orb, n_orb, *eris) : NULL;
 
     fo::Fciqmc fq;
@@ -1653,11 +1656,12 @@ static int run_fciqmc_fp(int argc, char **argv) {
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
     fq.par.heat_bath = heat_bath; fq.par.fp = true;
-    fq.setup();
-    CHECK(same_bits(fq.p_doub, p_doub), "fciqmc_fp p_doub");
+    if (lockstep) { fq.setup(); CHECK(same_bits(fq.p_doub, p_doub), "fciqmc_fp p_doub"); }
 
-    FILE *f = fopen(argv[10], "w");
-    fprintf(f, "# golden trajectory from the reference's fciqmc_fp_mol loop (1 rank, %s); cols: it numer denom norm shift n_nonz n_ini curr_size n_spawn digest\n", heat_bath ? "HB" : "NU");
+    std::string out_name(argv[10]);
+    if (n_procs > 1) out_name += ".r" + std::to_string(proc_rank);
+    FILE *f = fopen(out_name.c_str(), "w");
+    fprintf(f, "# golden trajectory from the reference's fciqmc_fp_mol loop (%d rank(s), %s); cols: it numer denom norm shift n_nonz n_ini curr_size n_spawn digest\n", n_procs, heat_bath ? "HB" : "NU");
     for (unsigned iterat = 0; iterat < n_iter; iterat++) {
         int n_nonz = 0; size_t n_ini = 0, n_spawn = 0;
         for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
@@ -1722,12 +1726,20 @@ static int run_fciqmc_fp(int argc, char **argv) {
         }
         double numer = sol_vec.dot(htrial_vec.indices(), htrial_vec.values(), htrial_vec.curr_size(), htrial_hashes);
         double denom = sol_vec.dot(trial_vec.indices(), trial_vec.values(), trial_vec.curr_size(), trial_hashes);
+        if (n_procs > 1) {      // :456-470: gathered on the rank that owns HF -- and slot 0 overwritten with that rank's own terms (:461-462)
+            double rn[64], rd[64];
+            MPI_Gather(&numer, 1, MPI_DOUBLE, rn, 1, MPI_DOUBLE, hf_proc, MPI_COMM_WORLD);
+            MPI_Gather(&denom, 1, MPI_DOUBLE, rd, 1, MPI_DOUBLE, hf_proc, MPI_COMM_WORLD);
+            rn[0] = numer; rd[0] = denom;
+            if ((int)hf_proc == proc_rank) { numer = 0; denom = 0; for (int q = 0; q < n_procs; q++) { numer += rn[q]; denom += rd[q]; } }
+        }
         uint64_t hsh = 1469598103934665603ull;
         for (size_t i = 0; i < sol_vec.curr_size(); i++) {
             double rv = sol_vec.values()[i];
             if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol_vec.indices()[i], det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
         }
         fprintf(f, "%u %a %a %a %a %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, norm_out, en_shift, n_nonz, n_ini, (size_t)sol_vec.curr_size(), n_spawn, hsh);
+        if (!lockstep) continue;
         fq.iterate(1);
         const fo::FciqmcLog &lg = fq.log.back();
         CHECK(same_bits(lg.numer, numer) && same_bits(lg.denom, denom), "fciqmc_fp it %u numer/denom %a %a | %a %a", iterat, lg.numer, numer, lg.denom, denom);
@@ -1743,7 +1755,7 @@ static int run_fciqmc_fp(int argc, char **argv) {
         CHECK(bad == 0, "fciqmc_fp it %u vector mismatch in %zu slots", iterat, bad);
     }
     fclose(f);
-    printf("FCIQMC_FP iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, sol_vec.n_nonz());
+    if (proc_rank == 0) printf("FCIQMC_FP ranks=%d hf_proc=%u iters=%u checks=%d fails=%d final n_nonz=%d\n", n_procs, hf_proc, n_iter, n_chk, n_fail, sol_vec.n_nonz());
     return n_fail != 0;
 }
 

@@ -475,14 +475,14 @@ class OracleFciqmcRanks:
     """P in-process ranks of fo::Fciqmc sharing one communicator -- fciqmc_mol under `mpiexec -n P` (a generator per rank, seeded
     seed + rank in mt mode; the counter stream does not depend on the rank)."""
 
-    def __init__(self, n_ranks, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU"):
+    def __init__(self, n_ranks, mol, *, epsilon, target_walkers, max_dets, initiator=0, seed=0, counter_rng=False, distribution="NU", fp=False):
         self.lib = load()
         self.n_ranks = n_ranks
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
         self.h = self.lib.fo_fqranks_create(n_ranks, mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed,
-                                            int(counter_rng) | (2 if distribution == "HB" else 0))
+                                            int(counter_rng) | (2 if distribution == "HB" else 0) | (4 if fp else 0))
         if not self.h:
             raise RuntimeError("oracle fciqmc ranks: setup failed")
 

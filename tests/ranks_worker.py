@@ -35,6 +35,8 @@ def main():
     man = golden_io.manifest()
     if name in man.get("fciqmc_mpi_runs", {}):
         return fciqmc_ranks(name, man["fciqmc_mpi_runs"][name], rank, world, dev, out_dir, dist, torch)
+    if name in man.get("fciqmc_fp_mpi_runs", {}):       # fciqmc_fp_mol: real-valued walkers
+        return fciqmc_ranks(name, man["fciqmc_fp_mpi_runs"][name], rank, world, dev, out_dir, dist, torch)
     hh_full = name in man.get("hhfull_runs", {})
     hh = hh_full or name in man.get("hh_runs", {})
     if hh:
@@ -144,10 +146,11 @@ def fciqmc_ranks(name, r, rank, world, dev, out_dir, dist, torch):
     n_it = min(r["n_iter"], 100)
     comm = TorchComm(2 * r["target_walkers"] + 4096, torch.device("cuda", dev))
     eng = FriEngine(mol, device=dev, comm=comm)
+    fp = bool(r.get("fp"))
     eng.setup_fciqmc(epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"], seed=r["seed"],
-                     distribution=r["distribution"])
+                     distribution=r["distribution"], fp=fp)
     orc = oracle_lib.OracleFciqmcRanks(world, mol, epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"],
-                                       seed=r["seed"], counter_rng=True, distribution=r["distribution"])
+                                       seed=r["seed"], counter_rng=True, distribution=r["distribution"], fp=fp)
     lo = orc.iterate(n_it)[rank]
     res = dict(rank=rank, ok=True, fails=[])
     lg = eng.iterate_fciqmc(n_it)

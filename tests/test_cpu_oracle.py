@@ -180,16 +180,17 @@ def _read_fq_rows(name, rank=None):
     return rows
 
 
-@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_mpi_runs"]))
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_mpi_runs"]) + sorted(golden_io.manifest().get("fciqmc_fp_mpi_runs", {})))
 def test_oracle_fciqmc_ranks_reproduce_reference_under_mpiexec(oracle, mols, name):
     """fciqmc_mol sharded over ranks (a generator per process, one all-to-all of the spawns per iteration, walker totals and
     projections summed in rank order): every rank of the in-process oracle against what the same rank of the reference logged
     under mpiexec -- shard sizes, local counts, digests; shift and walker number everywhere; the projected energy on the rank
     that owns HF (the others keep their own terms in the reference)."""
-    r = golden_io.manifest()["fciqmc_mpi_runs"][name]
+    man = golden_io.manifest()
+    r = man["fciqmc_mpi_runs"][name] if name in man["fciqmc_mpi_runs"] else man["fciqmc_fp_mpi_runs"][name]      # fciqmc_fp_*: real-valued walkers
     P = r["n_ranks"]
     orc = oracle.OracleFciqmcRanks(P, mols(r["shape"]), epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"],
-                                   initiator=r["initiator"], seed=r["seed"], counter_rng=False, distribution=r["distribution"])
+                                   initiator=r["initiator"], seed=r["seed"], counter_rng=False, distribution=r["distribution"], fp=bool(r.get("fp")))
     logs = orc.iterate(r["n_iter"])
     hf = orc.hf_proc
     for k in range(P):

@@ -119,13 +119,17 @@ def test_pivotal_compression_over_ranks(name, budget, tmp_path):
     assert res.returncode == 0, res.stderr[-4000:]
 
 
+_FQ_RANK_RUNS = dict(golden_io.manifest()["fciqmc_mpi_runs"], **golden_io.manifest().get("fciqmc_fp_mpi_runs", {}))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(golden_io.manifest()["fciqmc_mpi_runs"]))
+@pytest.mark.parametrize("name", sorted(_FQ_RANK_RUNS))
 def test_fciqmc_over_ranks(name, tmp_path):
-    """fciqmc_mol hash-sharded over 2 and 3 ranks (near-uniform and heat-bath generators): one all-to-all of the spawns per iteration
-    with initiator and non-initiator spawns in their original order, walker totals and projections summed in rank order; every
-    rank's shard equals the in-process rank oracle's (which is pinned against the reference under mpiexec in the CPU suite)."""
-    r = golden_io.manifest()["fciqmc_mpi_runs"][name]
+    """fciqmc_mol and fciqmc_fp_mol (fciqmc_fp_*: real-valued walkers) hash-sharded over 2 and 3 ranks (near-uniform and heat-bath
+    generators): one all-to-all of the spawns per iteration with initiator and non-initiator spawns in their original order, walker
+    totals and projections summed in rank order; every rank's shard equals the in-process rank oracle's (which is pinned against the
+    reference under mpiexec in the CPU suite)."""
+    r = _FQ_RANK_RUNS[name]
     P = r["n_ranks"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
