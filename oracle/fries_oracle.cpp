@@ -2637,7 +2637,14 @@ void Fciqmc::iterate_multi(unsigned n_iter) {
     for (unsigned it = 0; it < n_iter; it++, iterat++) {
         FciqmcLog lg{};
         uint32_t n_ini = 0; size_t n_spawn = 0;
-        double rn_sys = mt() / (1. + UINT32_MAX);          // rank 0's draw, broadcast (:301-305); one rank here
+        auto bcast0 = [&]() {                              // rank 0 draws, everybody receives (:301-305, :412-414 + compress_utils.cpp:291)
+            double mine = cm.rank == 0 ? mt() / (1. + UINT32_MAX) : 0.0;
+            if (cm.size == 1) return mine;
+            std::vector<double> all(cm.size);
+            cm.allgather(&mine, all.data(), sizeof(double));
+            return all[0];
+        };
+        double rn_sys = bcast0();
         const unsigned curr_mat_samp = iterat < 10 ? par.mat_nonz / 10 : par.mat_nonz;
         double lbound = seed_sys(loc_norms.data(), &rn_sys, curr_mat_samp, cm);
         if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
@@ -2704,7 +2711,7 @@ void Fciqmc::iterate_multi(unsigned n_iter) {
             lg.numer = 0; lg.denom = 0;
             for (int q = 0; q < cm.size; q++) { lg.numer += all[2 * q]; lg.denom += all[2 * q + 1]; }
         }
-        rn_sys = mt() / (1. + UINT32_MAX);
+        rn_sys = bcast0();
         cm.allgather(&mine, loc_norms.data(), sizeof(double));
         sys_comp(sol.vals[0].data(), sol.curr_size, loc_norms.data(), n_samp, keep, rn_sys, cm);
         // :416-421: the test `indices()[det_idx] != hf_det` compares addresses, so it is always true and HF is deleted like any other

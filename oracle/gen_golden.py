@@ -150,7 +150,24 @@ def gen_hhfull(manifest):
                                               gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
 
 
+# frimulti_mol under mpiexec -n P: name -> (n_ranks, same tuple as MULTI_RUNS)
+MULTI_MPI_RUNS = {
+    "multi_n2_m5000_p2": (2, ("N2", 40, 3, 0.01, 5000, 20000, 200000, 1.0, 2500.0)),
+    "multi_h2o_m3000_ini0_p3": (3, ("H2O", 40, 17, 0.005, 3000, 12000, 100000, 0.0, 1500.0)),
+}
+
+
 def gen_multi(manifest):
+    manifest["multi_mpi_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (n_ranks, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt)) in MULTI_MPI_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([MPIEXEC, "-n", str(n_ranks), HARNESS, "frimulti", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), out], check=True)
+            manifest["multi_mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd,
+                                                    initiator=ini, target_norm=tgt)
     manifest["multi_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt) in MULTI_RUNS.items():

@@ -482,6 +482,9 @@ void *fo_frimulti_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps,
     return f;
 }
 uint32_t fo_frimulti_nkept(void *h) { return ((Fciqmc *)h)->nkept; }
+// frimulti_mol over P in-process ranks: an OracleFqRanks whose members run iterate_multi (fo_fqranks_iterate dispatches on par.multi)
+void *fo_multiranks_create(uint32_t n_ranks, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                           double eps, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, double initiator, double target_norm, int flags);
 void fo_fciqmc_destroy(void *h) { delete (Fciqmc *)h; }
 int fo_fciqmc_iterate(void *h, uint32_t n, FqLog *logs) {
     Fciqmc *f = (Fciqmc *)h;
@@ -536,7 +539,7 @@ int fo_fqranks_iterate(void *h, uint32_t n, FqLog *logs) {
             Fciqmc &f = *R->fr[c.rank];
             f.cm = c; f.sol.cm = c;
             for (uint32_t i = 0; i < n; i++) {
-                f.iterate(1);
+                if (f.par.multi) f.iterate_multi(1); else f.iterate(1);
                 if (logs) {
                     const FciqmcLog &l = f.log.back();
                     FqLog &o = logs[(size_t)c.rank * n + i];
@@ -547,6 +550,26 @@ int fo_fqranks_iterate(void *h, uint32_t n, FqLog *logs) {
         });
     } catch (std::exception &e) { fprintf(stderr, "fo_fqranks_iterate: %s\n", e.what()); return 1; }
     return 0;
+}
+void *fo_multiranks_create(uint32_t n_ranks, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                           double eps, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, double initiator, double target_norm, int flags) {
+    OracleFqRanks *R = new OracleFqRanks();
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        Fciqmc *f = new Fciqmc();
+        f->par.heat_bath = true; f->par.counter_rng = (flags & 1) != 0;
+        f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+        f->sys.ints.n_orb = n_orb;
+        f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+        f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+        f->sys.symm.init(irreps, n_orb);
+        f->par.eps = eps; f->par.max_dets = max_dets; f->par.seed = seed;
+        f->par.multi = true; f->par.vec_nonz = vec_nonz; f->par.mat_nonz = mat_nonz; f->par.init_thresh_f = initiator; f->par.target_norm = target_norm;
+        R->fr.emplace_back(f);
+    }
+    try {
+        run_ranks((int)n_ranks, [&](const Comm &c) { Fciqmc &f = *R->fr[c.rank]; f.cm = c; f.setup(); });
+    } catch (std::exception &e) { fprintf(stderr, "fo_multiranks_create: %s\n", e.what()); delete R; return nullptr; }
+    return R;
 }
 void *fo_fqranks_get(void *h, uint32_t rank) { return ((OracleFqRanks *)h)->fr[rank].get(); }      // a Fciqmc* for fo_fciqmc_vec
 int fo_fqranks_hf_proc(void *h) { return ((OracleFqRanks *)h)->fr[0]->hf_proc; }

@@ -1437,7 +1437,6 @@ static int run_frimulti(int argc, char **argv) {
     int n_procs = 1, proc_rank = 0;
     MPI_Comm_size(MPI_COMM_WORLD, &n_procs);
     MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
-    if (n_procs != 1) { fprintf(stderr, "frimulti: one rank\n"); return 2; }
     fcidump_input *in_data = parse_fcidump(path, pg);
     unsigned n_elec = in_data->n_elec, n_frz = 0, n_orb = in_data->n_orb_;
     size_t det_size = CEILING(2 * n_orb, 8);
@@ -1448,13 +1447,14 @@ static int run_frimulti(int argc, char **argv) {
     gen_hf_bitstring(n_orb, n_elec, hf_det);
     find_bits(hf_det, tmp_orbs, det_size);
     double hf_en = diag_matrel(tmp_orbs, tot_orb, *eris, *h_core, n_frz, n_elec);
-    std::mt19937 mt_obj(seed);
+    std::mt19937 mt_obj(seed + (uint32_t)proc_rank);       // one generator per process (:84-86)
     unsigned spawn_length = matr_samp * 2 / n_procs / n_procs;       // :89
     std::function<double(const uint8_t *)> diag_shortcut = [tot_orb, eris, h_core, n_frz, n_elec, hf_en](const uint8_t *occ) { return diag_matrel(occ, tot_orb, *eris, *h_core, n_frz, n_elec) - hf_en; };
     SymmInfo symm_basis(symm, n_orb);
     unsigned unocc_symm_cts[n_irreps][2];
     std::vector<uint32_t> proc_scrambler(2 * n_orb), vec_scrambler(2 * n_orb);
-    for (auto &x : proc_scrambler) x = mt_obj();
+    if (proc_rank == 0) for (auto &x : proc_scrambler) x = mt_obj();
+    MPI_Bcast(proc_scrambler.data(), 2 * n_orb, MPI_UNSIGNED, 0, MPI_COMM_WORLD);
     for (auto &x : vec_scrambler) x = mt_obj();
     DistVec<double> sol_vec(max_n_dets, spawn_length, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 1, proc_scrambler, vec_scrambler);
     unsigned max_spawn = matr_samp;
@@ -1464,7 +1464,8 @@ static int run_frimulti(int argc, char **argv) {
     size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
     DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
     DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
-    trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1);
+    unsigned hf_proc = sol_vec.idx_to_proc(hf_det);
+    if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
     trial_vec.perform_add(0); htrial_vec.perform_add(0);
     trial_vec.collect_procs();
     std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
@@ -1481,11 +1482,14 @@ static int run_frimulti(int argc, char **argv) {
     size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, (uint8_t (*)[4])scratch.data(), symm);
     size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
     double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-    sol_vec.add(hf_det, 100, 1);
+    if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
     sol_vec.perform_add(0);
-    double loc_norms[1], glob_norm;
-    loc_norms[0] = sol_vec.local_norm();
-    glob_norm = loc_norms[0];
+    double loc_norms[64], glob_norm;
+    loc_norms[proc_rank] = sol_vec.local_norm();
+    MPI_Allgather(MPI_IN_PLACE, 0, MPI_DOUBLE, loc_norms, 1, MPI_DOUBLE, MPI_COMM_WORLD);
+    glob_norm = 0;
+    for (int q = 0; q < n_procs; q++) glob_norm += loc_norms[q];
+    const bool lockstep = n_procs == 1;
     hb_info *hb_probs = set_up(tot_orb, n_orb, *eris);
 
     fo::Fciqmc fq;
@@ -1494,17 +1498,20 @@ static int run_frimulti(int argc, char **argv) {
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false; fq.par.heat_bath = true;
     fq.par.multi = true; fq.par.vec_nonz = target_nonz; fq.par.mat_nonz = matr_samp; fq.par.target_norm = target_norm; fq.par.init_thresh_f = init_thresh;
-    fq.setup();
-    CHECK(same_bits(fq.p_doub, p_doub), "frimulti p_doub");
+    if (lockstep) { fq.setup(); CHECK(same_bits(fq.p_doub, p_doub), "frimulti p_doub"); }
 
     double en_shift = 0, last_one_norm = 0;
     const double shift_damping = 0.05; const unsigned shift_interval = 10;
     std::vector<size_t> srt_arr(max_n_dets); std::vector<bool> keep_exact(max_n_dets, false);
-    FILE *f = fopen(argv[12], "w");
-    fprintf(f, "# golden trajectory from the reference's frimulti_mol loop (1 rank, HB); cols: it numer denom norm shift nkept n_nonz curr_size n_spawn n_ini digest\n");
+    std::string out_name(argv[12]);
+    if (n_procs > 1) out_name += ".r" + std::to_string(proc_rank);
+    FILE *f = fopen(out_name.c_str(), "w");
+    fprintf(f, "# golden trajectory from the reference's frimulti_mol loop (HB; per rank under mpiexec); cols: it numer denom norm shift nkept n_nonz curr_size n_spawn n_ini digest\n");
     for (unsigned iterat = 0; iterat < n_iter; iterat++) {
         size_t n_ini = 0, n_spawn = 0;
-        double rn_sys = mt_obj() / (1. + UINT32_MAX);
+        double rn_sys = 0;
+        if (proc_rank == 0) rn_sys = mt_obj() / (1. + UINT32_MAX);
+        MPI_Bcast(&rn_sys, 1, MPI_DOUBLE, 0, MPI_COMM_WORLD);
         unsigned curr_mat_samp = (iterat < 10) ? matr_samp / 10 : matr_samp;
         double lbound = seed_sys(loc_norms, &rn_sys, curr_mat_samp);
         for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
@@ -1550,18 +1557,35 @@ static int run_frimulti(int argc, char **argv) {
         }
         sol_vec.perform_add(0);
         unsigned n_samp = target_nonz;
-        loc_norms[0] = find_preserve(sol_vec.values(), srt_arr, keep_exact, sol_vec.curr_size(), &n_samp, &glob_norm);
+        loc_norms[proc_rank] = find_preserve(sol_vec.values(), srt_arr, keep_exact, sol_vec.curr_size(), &n_samp, &glob_norm);
         unsigned nkept = target_nonz - n_samp;
         if ((iterat + 1) % shift_interval == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, target_norm, shift_damping / shift_interval / eps);
         double numer = sol_vec.dot(htrial_vec.indices(), htrial_vec.values(), htrial_vec.curr_size(), htrial_hashes);
         double denom = sol_vec.dot(trial_vec.indices(), trial_vec.values(), trial_vec.curr_size(), trial_hashes);
-        rn_sys = mt_obj() / (1. + UINT32_MAX);
+        if (n_procs > 1) {      // :399-409: gathered and added up in rank order on the rank that owns HF
+            double rnm[64], rdn[64];
+            MPI_Gather(&numer, 1, MPI_DOUBLE, rnm, 1, MPI_DOUBLE, hf_proc, MPI_COMM_WORLD);
+            MPI_Gather(&denom, 1, MPI_DOUBLE, rdn, 1, MPI_DOUBLE, hf_proc, MPI_COMM_WORLD);
+            if ((int)hf_proc == proc_rank) { numer = 0; denom = 0; for (int q = 0; q < n_procs; q++) { numer += rnm[q]; denom += rdn[q]; } }
+        }
+        if (proc_rank == 0) rn_sys = mt_obj() / (1. + UINT32_MAX);
+        MPI_Bcast(&rn_sys, 1, MPI_DOUBLE, 0, MPI_COMM_WORLD);        // (the reference relies on sys_comp's own broadcast, compress_utils.cpp:291)
+        MPI_Allgather(MPI_IN_PLACE, 0, MPI_DOUBLE, loc_norms, 1, MPI_DOUBLE, MPI_COMM_WORLD);
         sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, keep_exact, rn_sys);
         for (size_t det_idx = 0; det_idx < sol_vec.curr_size(); det_idx++) {
             if (keep_exact[det_idx] && sol_vec.indices()[det_idx] != hf_det) {        // an address comparison, as in the reference (:417)
                 sol_vec.del_at_pos(det_idx);
                 keep_exact[det_idx] = 0;
             }
+        }
+        if (!lockstep) {
+            uint64_t hs2 = 1469598103934665603ull;
+            for (size_t i = 0; i < sol_vec.curr_size(); i++) {
+                double rv = sol_vec.values()[i];
+                if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol_vec.indices()[i], det_size); hs2 = (hs2 ^ rd) * 1099511628211ull; hs2 = (hs2 ^ vb) * 1099511628211ull; hs2 = (hs2 ^ i) * 1099511628211ull; }
+            }
+            fprintf(f, "%u %a %a %a %a %u %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, glob_norm, en_shift, nkept, sol_vec.n_nonz(), (size_t)sol_vec.curr_size(), n_spawn, n_ini, hs2);
+            continue;
         }
         fq.iterate_multi(1);
         const fo::FciqmcLog &lg = fq.log.back();
@@ -1583,7 +1607,7 @@ static int run_frimulti(int argc, char **argv) {
         fprintf(f, "%u %a %a %a %a %u %d %zu %zu %zu %016" PRIx64 "\n", iterat, numer, denom, glob_norm, en_shift, nkept, sol_vec.n_nonz(), (size_t)sol_vec.curr_size(), n_spawn, n_ini, hsh);
     }
     fclose(f);
-    printf("FRIMULTI iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, sol_vec.n_nonz());
+    if (proc_rank == 0) printf("FRIMULTI ranks=%d hf_proc=%u iters=%u checks=%d fails=%d final n_nonz=%d\n", n_procs, hf_proc, n_iter, n_chk, n_fail, sol_vec.n_nonz());
     return n_fail != 0;
 }
 

@@ -109,10 +109,10 @@ def read_piv_cases():
     return cases
 
 
-def read_multi_traj(name):
-    """tests/golden/multi_*.traj: the reference's frimulti_mol loop (oracle/ref_harness.cpp: run_frimulti)."""
+def read_multi_traj(name, raw=False):
+    """tests/golden/multi_*.traj: the reference's frimulti_mol loop (oracle/ref_harness.cpp: run_frimulti).  raw: name is the file name."""
     rows = []
-    with open(os.path.join(GOLD, name + ".traj")) as f:
+    with open(os.path.join(GOLD, name if raw else name + ".traj")) as f:
         for line in f:
             t = line.split()
             if not t or t[0].startswith("#"):

@@ -509,3 +509,21 @@ class OracleFciqmcRanks:
         v = np.zeros(max(n, 1))
         self.lib.fo_fciqmc_vec(h, _p(d), _p(v), d.size)
         return d[:n], v[:n]
+
+
+class OracleMultiRanks(OracleFciqmcRanks):
+    """P in-process ranks of fo::Fciqmc in its frimulti_mol mode -- frimulti_mol under `mpiexec -n P`."""
+
+    def __init__(self, n_ranks, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, initiator=0.0, target_norm=0.0, seed=0, counter_rng=False):
+        self.lib = load()
+        self.n_ranks = n_ranks
+        irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+        hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+        er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        self.lib.fo_multiranks_create.restype = C.c_void_p
+        self.lib.fo_multiranks_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  C.c_uint32, C.c_double, C.c_double, C.c_int]
+        self.h = self.lib.fo_multiranks_create(n_ranks, mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, vec_nonz, mat_nonz, max_dets, seed, float(initiator),
+                                               float(target_norm), int(counter_rng))
+        if not self.h:
+            raise RuntimeError("oracle frimulti ranks: setup failed")

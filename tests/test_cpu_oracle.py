@@ -413,6 +413,30 @@ def test_oracle_frimulti_matches_reference(oracle, name):
     assert golden_io.vec_hash(d, v) == rows[-1]["hash"]
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("multi_mpi_runs", {})))
+def test_oracle_frimulti_ranks_reproduce_reference_under_mpiexec(oracle, name):
+    """frimulti_mol sharded over ranks (rank 0's comb offsets broadcast, the comb running through the ranks' norms in rank order, one
+    all-to-all of the spawns, collective vector compression): every rank of the in-process oracle against what the same rank of the
+    reference logged under mpiexec; the projections on the rank that owns HF."""
+    r = golden_io.manifest()["multi_mpi_runs"][name]
+    P = r["n_ranks"]
+    mol = fcidump.synthetic(r["shape"])
+    orc = oracle.OracleMultiRanks(P, mol, epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], initiator=r["initiator"],
+                                  target_norm=r["target_norm"], seed=r["seed"])
+    logs = orc.iterate(r["n_iter"])
+    hf = orc.hf_proc
+    for k in range(P):
+        rows = golden_io.read_multi_traj(name + ".traj.r%d" % k, raw=True)
+        for i, row in enumerate(rows):
+            lg = logs[k, i]
+            assert (float(lg["norm"]), float(lg["shift"])) == (row["norm"], row["shift"]), (name, k, i)
+            assert (int(lg["n_nonz"]), int(lg["curr_size"]), int(lg["n_spawn"]), int(lg["n_ini"])) == (row["n_nonz"], row["curr_size"], row["n_spawn"], row["n_ini"]), (name, k, i)
+            if k == hf:
+                assert (float(lg["numer"]), float(lg["denom"])) == (row["numer"], row["denom"]), (name, k, i)
+        d, v = orc.vector(k)
+        assert golden_io.vec_hash(d, v) == rows[-1]["hash"], (name, k)
+
+
 def test_library_exports_every_declared_symbol():
     """libfries_hip.so loads on a GPU-less host and exports exactly what include/fries_hip.h declares."""
     from fries_amd import engine
