@@ -326,13 +326,18 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
 // One comb over the in-order running sum of |v|: first tooth from seed_sys with the norms the last compression left (one rank: the
 // in-order sum itself), spacing = the one-norm BEFORE that compression / n_teeth -- two different numbers in the reference, kept apart.
 // n_walk[i] = teeth in (S_{i-1}, S_i]... strictly: teeth below S_i minus teeth below S_{i-1} (`while (rn_sys < lbound)`).
-__global__ void k_mc_teeth(VcompBuf B, double rn, double prev_glob, uint32_t n_teeth, double *unit_out) {
-    const double T = *B.seq.total;
+// norms: every rank's in-order |v| sum in rank order (one rank: its own); keep receives the lower ranks' for the prefix sums
+__global__ void k_mc_teeth(VcompBuf B, double rn, double prev_glob, uint32_t n_teeth, double *unit_out, const double *norms, int rank, int n_ranks, double *keep) {
+    double lbound0 = 0;             // seed_sys (compress_utils.cpp:107-127)
+    for (int p = 0; p < rank; p++) { lbound0 += norms[p]; keep[p] = norms[p]; }
+    double T = lbound0;
+    for (int p = rank; p < n_ranks; p++) T += norms[p];
     const double G = prev_glob < 0 ? T : prev_glob;
     double r0 = rn * (T / n_teeth);
-    r0 += T / n_teeth * (int)(0.0 * n_teeth / T);
+    r0 += T / n_teeth * (int)(lbound0 * n_teeth / T);
+    if (r0 < lbound0) r0 += T / n_teeth;
     const double unit = G / n_teeth;
-    fr_build_teeth(B.teeth, r0, unit, n_teeth + 64, 0.0);
+    fr_build_teeth(B.teeth, r0, unit, n_teeth + 64, lbound0);
     unit_out[0] = unit; unit_out[1] = T;
 }
 __global__ void __launch_bounds__(FR_BLOCK) k_mc_walk(VecDev V, VcompBuf B, uint32_t *n_walk, uint32_t *err) {
@@ -373,7 +378,17 @@ void fr_multi_walks(FriesCtx *c, double rn, double prev_glob_norm, uint32_t n_te
     const uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
     AccAbs aa{c->vec.v0, c->vec.st};
     run_seq(c, B.seq, aa, bound);
-    FR_LAUNCH(c, "k_mc_teeth", k_mc_teeth, dim3(1), dim3(1), B, rn, prev_glob_norm, n_teeth, unit_out);
+    const double *norms = B.seq.total;
+    if (c->use_comm) {          // loc_norms of the last compression = every rank's in-order sum now (frimulti_mol.cpp:227-229, 414)
+        FR_LAUNCH(c, "k_put_double", k_put_double, dim3(1), dim3(1), B.seq.total, (double *)c->comm.small_send);
+        norms = (const double *)fr_allgather(c, sizeof(double));
+    }
+    FR_LAUNCH(c, "k_mc_teeth", k_mc_teeth, dim3(1), dim3(1), B, rn, prev_glob_norm, n_teeth, unit_out, norms, c->rank, c->n_ranks, c->d_norms_keep);
+    if (c->rank > 0) {          // this rank's prefix sums continue the lower ranks' (the comb is global)
+        SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
+        SeqWork Q2 = B.seq; Q2.total = c->d_seq_scratch;
+        run_seq_from(c, Q2, aa, bound, from);
+    }
     FR_LAUNCH(c, "k_mc_walk", k_mc_walk, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, n_walk, c->d_err);
 }
 

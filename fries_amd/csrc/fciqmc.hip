@@ -644,14 +644,14 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
 
 // ------------------------------------------------------------------ frimulti_mol (FRIES_bin/frimulti_mol.cpp:84-425), --distribution HB, one rank
 void fr_multi_setup(FriesCtx *c, const fries_frimulti_params *p) {
-    if (c->use_comm && c->n_ranks > 1) throw FriesError("frimulti_mol runs on one rank here");
+    if (c->use_comm && c->n_ranks > 1 && 2 * c->n_orb > 63) throw FriesError("frimulti_mol over ranks needs bit 63 of the index for the initiator flag (at most 31 orbitals)");
     if (p->vec_nonz == 0 || p->mat_nonz < 10 || p->max_dets == 0) throw FriesError("vec_nonz, max_dets must be positive and mat_nonz at least 10 (the first iterations use a tenth of it)");
     fries_fciqmc_params q{};
     q.epsilon = p->epsilon; q.target_walkers = p->mat_nonz; q.initiator = 0; q.max_dets = p->max_dets; q.seed = p->seed; q.heat_bath = 1;
     fr_fq_setup(c, &q);                 // scramblers, vector, work arrays, H * trial, 100 x HF -- as there (frimulti_mol.cpp:84-233)
     c->fm = *p;
     c->target_norm = p->target_norm; c->init_thresh = p->initiator; c->vec_nonz = p->vec_nonz; c->mat_nonz = p->mat_nonz;
-    c->adder_cap = p->mat_nonz * 2;     // :89
+    c->adder_cap = p->mat_nonz * 2 / c->n_ranks / c->n_ranks;     // :89
     FqWork &Q = c->fqw;
     Q.multi = 1; Q.n_walk = fr_alloc<uint32_t>(Q.cap_d); Q.init_f = p->initiator; Q.samp_unit = 1;
     if (!c->W.kin) c->W.kin = fr_alloc<uint32_t>(p->max_dets);          // fr_sys_comp's tooth indices
@@ -695,8 +695,10 @@ void fr_multi_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     uint32_t n_spawn = 0;
     FR_HIP(hipMemcpyAsync(&n_spawn, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
     FR_HIP(hipStreamSynchronize(st));
-    if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder.");
-    if (n_spawn) fr_vec_merge(c, &c->vec, n_spawn, true);           // perform_add(0) into the column itself (:382)
+    uint32_t n_merge = n_spawn;
+    if (c->use_comm) n_merge = fr_spawn_exchange(c, n_spawn, 2);     // one all-to-all per iteration, arrival order = (source rank, add order)
+    else if (n_spawn >= c->adder_cap) throw FriesError("Insufficient memory allocated in adder.");
+    if (n_merge) fr_vec_merge(c, &c->vec, n_merge, true);           // perform_add(0) into the column itself (:382)
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) throw FriesError("device error in the merge (capacity, hash table or electron count)");
     // compression (:385-421)

@@ -185,7 +185,7 @@ int fries_fciqmc_iterate(fries_ctx *ctx, uint32_t n_iter, fries_fciqmc_log *logs
  * diagonal acts in place (:379-380), and the vector is compressed to vec_nonz by find_preserve + sys_comp (:385-421).  The first ten
  * iterations use mat_nonz / 10 samples (:306).  Random numbers as for fciqmc_mol: the two comb offsets per iteration come from the
  * mt19937, the sampling from the counter-based stream shared with the CPU oracle, whose loop is pinned against the reference on the
- * reference's stream (oracle/ref_harness.cpp: frimulti).  One rank.  Log: norm = one-norm before the compression (norm.txt),
+ * reference's stream (oracle/ref_harness.cpp: frimulti).  One rank or hash-sharded ranks (fries_set_comm).  Log: norm = one-norm before the compression (norm.txt),
  * n_nonz / curr_size after it, n_spawn = adds, n_attempts = samples. */
 typedef struct {
     double epsilon, target_norm, initiator;

@@ -35,6 +35,8 @@ def main():
     man = golden_io.manifest()
     if name in man.get("fciqmc_mpi_runs", {}):
         return fciqmc_ranks(name, man["fciqmc_mpi_runs"][name], rank, world, dev, out_dir, dist, torch)
+    if name in man.get("multi_mpi_runs", {}):           # frimulti_mol
+        return multi_ranks(name, man["multi_mpi_runs"][name], rank, world, dev, out_dir, dist, torch)
     if name in man.get("fciqmc_fp_mpi_runs", {}):       # fciqmc_fp_mol: real-valued walkers
         return fciqmc_ranks(name, man["fciqmc_fp_mpi_runs"][name], rank, world, dev, out_dir, dist, torch)
     hh_full = name in man.get("hhfull_runs", {})
@@ -172,6 +174,52 @@ def fciqmc_ranks(name, r, rank, world, dev, out_dir, dist, torch):
     res["ok"] = not res["fails"]
     res["n_allgather"] = comm.n_allgather; res["n_alltoallv"] = comm.n_alltoallv; res["iters"] = n_it
     res["walkers"] = float(np.abs(v).sum())
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f, default=str)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+    sys.exit(0 if res["ok"] else 1)
+
+
+def multi_ranks(name, r, rank, world, dev, out_dir, dist, torch):
+    """frimulti_mol sharded over the ranks on the device against the in-process rank oracle, both on the counter-based uniform stream (the
+    oracle's mt19937 mode is what is pinned against the reference under mpiexec): this rank's counts, shard, norms and shift at every
+    iteration, the projected energy within 1e-10."""
+    from fries_amd import fcidump
+    from fries_amd.comm import TorchComm
+    from fries_amd.engine import FriEngine
+    import oracle_lib
+    assert r["n_ranks"] == world
+    mol = fcidump.synthetic(r["shape"])
+    n_it = r["n_iter"]
+    par = dict(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], initiator=r["initiator"], target_norm=r["target_norm"], seed=r["seed"])
+    comm = TorchComm(2 * r["mat_nonz"] + 4096, torch.device("cuda", dev))
+    eng = FriEngine(mol, device=dev, comm=comm)
+    eng.setup_multi(**par)
+    orc = oracle_lib.OracleMultiRanks(world, mol, counter_rng=True, **par)
+    lo = orc.iterate(n_it)[rank]
+    res = dict(rank=rank, ok=True, fails=[])
+    lg = eng.iterate_multi(n_it)
+    for i in range(n_it):
+        for f in ("n_nonz", "n_ini", "curr_size", "n_spawn"):
+            if int(lg[f][i]) != int(lo[f][i]):
+                res["fails"].append((i, f, int(lg[f][i]), int(lo[f][i])))
+        for f in ("shift", "norm", "denom"):
+            if float(lg[f][i]) != float(lo[f][i]):
+                res["fails"].append((i, f, float(lg[f][i]), float(lo[f][i])))
+        if abs(float(lg["numer"][i]) - float(lo["numer"][i])) > 1e-10 * max(1.0, abs(float(lo["numer"][i]))):
+            res["fails"].append((i, "numer", float(lg["numer"][i]), float(lo["numer"][i])))
+        if int(lg["err"][i]):
+            res["fails"].append((i, "err", int(lg["err"][i])))
+        if len(res["fails"]) > 8:
+            break
+    d, v = eng.vector()
+    od, ov = orc.vector(rank)
+    if not res["fails"] and not (np.array_equal(v, ov) and np.array_equal(d[v != 0], od[ov != 0])):
+        res["fails"].append(("shard differs",))
+    res["ok"] = not res["fails"]
+    res["n_allgather"] = comm.n_allgather; res["n_alltoallv"] = comm.n_alltoallv; res["iters"] = n_it
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f, default=str)
     dist.barrier()

@@ -119,13 +119,13 @@ def test_pivotal_compression_over_ranks(name, budget, tmp_path):
     assert res.returncode == 0, res.stderr[-4000:]
 
 
-_FQ_RANK_RUNS = dict(golden_io.manifest()["fciqmc_mpi_runs"], **golden_io.manifest().get("fciqmc_fp_mpi_runs", {}))
+_FQ_RANK_RUNS = dict(golden_io.manifest()["fciqmc_mpi_runs"], **golden_io.manifest().get("fciqmc_fp_mpi_runs", {}), **golden_io.manifest().get("multi_mpi_runs", {}))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(_FQ_RANK_RUNS))
 def test_fciqmc_over_ranks(name, tmp_path):
-    """fciqmc_mol and fciqmc_fp_mol (fciqmc_fp_*: real-valued walkers) hash-sharded over 2 and 3 ranks (near-uniform and heat-bath
+    """fciqmc_mol, fciqmc_fp_mol (fciqmc_fp_*: real-valued walkers) and frimulti_mol (multi_*) hash-sharded over 2 and 3 ranks (near-uniform and heat-bath
     generators): one all-to-all of the spawns per iteration with initiator and non-initiator spawns in their original order, walker
     totals and projections summed in rank order; every rank's shard equals the in-process rank oracle's (which is pinned against the
     reference under mpiexec in the CPU suite)."""
