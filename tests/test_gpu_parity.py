@@ -461,7 +461,8 @@ def test_full_size_invariants_m1e6(Engine, mols):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(k for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] == 1) + sorted(golden_io.manifest()["hhfull_runs"]))
+@pytest.mark.parametrize("name", sorted(k for k, v in golden_io.manifest()["hh_runs"].items() if v["n_ranks"] == 1)
+                         + sorted(k for k, v in golden_io.manifest()["hhfull_runs"].items() if v["n_ranks"] == 1))
 def test_hubbard_holstein_matches_reference(name):
     """frisys_hh (hh_*) and frifull_hh (hhfull_*) on the device against the reference's own loops (tests/golden/hh*.traj): counts,
     norms, shifts and the stored shard bit for bit; the projected-energy numerator (a block-parallel sum of signed terms) to 1e-10."""
