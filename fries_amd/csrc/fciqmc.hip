@@ -130,19 +130,25 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_count(VecDev V, SysDev S, FqWor
     if (threadIdx.x == 0) { Q.blk_nz[blockIdx.x] = b_nz; Q.blk_ini[blockIdx.x] = b_ini; }
 }
 
-// determinants with more than FQ_HEAVY walkers, one workgroup each: the same draws as the lane loop above (draw i of a stream is
-// hash(key + (i + 1) * golden), whoever evaluates it), counted with a workgroup reduction
-__global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter, double p_doub,
-                                                       double eps, double shift) {
-    __shared__ HbTables T;
+// Determinants with more than FQ_HEAVY walkers: the same draws as the lane loop above (draw i of a stream is hash(key + (i + 1) * golden),
+// whoever evaluates it), spread over FQ_HSLICES workgroups per determinant; the counts are integers, so the atomic adds commute.
+// Pass A: the binomial split and the death draws (n_doub / n_att of a heavy determinant are zero when it starts and serve as the
+// accumulators).  Pass B: samples per first occupied electron (heat-bath generator), then the attempt number and the new value.
+#define FQ_HSLICES 32
+// workgroups sharing one heavy determinant: one per 8192 walkers (the per-workgroup set-up -- alias table, tables in LDS -- is not free)
+__device__ __forceinline__ unsigned fq_heavy_slices(unsigned n_walk) { unsigned s = (n_walk + 8191u) / 8192u; return s < 1u ? 1u : (s > FQ_HSLICES ? FQ_HSLICES : s); }
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy_a(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter, double p_doub,
+                                                         double eps, double shift) {
     __shared__ uint32_t shu[4];
-    fr_stage_tables(&T, S.hb);
     const uint32_t nh = Q.totals[3];
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t d = Q.heavy[h];
-        const int cur_i = (int)V.v0[d];
+        const double cur = V.v0[d];
+        const int cur_i = (int)cur;
         const unsigned n_walk = Q.multi ? Q.n_walk[d] : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
-        const int sign = cur_i < 0 ? -1 : 1;
+        const int sign = cur < 0 ? -1 : 1;
+        const unsigned ns = fq_heavy_slices(n_walk);
+        if (blockIdx.y >= ns) continue;
         const det_t det = V.dets[d];
         FqRng rb, rd;
         rb.begin(seed, iter, det, 0, FQ_BIN);
@@ -151,32 +157,70 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy(VecDev V, SysDev S, FqWor
         const int flr = (int)floor(m);
         const double prob = m - flr;
         uint32_t c_doub = 0, c_live = 0;
-        for (unsigned i = threadIdx.x; i < n_walk; i += blockDim.x) {
+        for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < n_walk; i += ns * blockDim.x) {
             rb.ctr = i; rd.ctr = i;         // uni() pre-increments: draw number i + 1 of each stream
             c_doub += rb.uni() < p_doub;
-            c_live += rd.uni() < prob;
+            if (!Q.multi) c_live += rd.uni() < prob;
         }
         __syncthreads();
-        const uint32_t n_doub = fr_block_sum_u32(c_doub, shu);
+        const uint32_t b_doub = fr_block_sum_u32(c_doub, shu);
         __syncthreads();
-        const uint32_t n_live = fr_block_sum_u32(c_live, shu);
-        if (threadIdx.x == 0) {
-            uint32_t n_sing = n_walk - n_doub;
-            if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
-            Q.n_doub[d] = n_doub; Q.n_att[d] = n_doub + n_sing;
-            if (!Q.multi) Q.new_val[d] = (double)(flr * (int)n_walk + (int)n_live);
-        }
+        const uint32_t b_live = fr_block_sum_u32(c_live, shu);
+        if (threadIdx.x == 0) { if (b_doub) atomicAdd(&Q.n_doub[d], b_doub); if (b_live) atomicAdd(&Q.n_att[d], b_live); }
+        if (Q.o1cnt && blockIdx.y == 0 && threadIdx.x < S.n_elec) Q.o1cnt[(size_t)d * S.n_elec + threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(FR_BLOCK) k_fq_heavy_b(VecDev V, SysDev S, FqWork Q, unsigned long long seed, unsigned long long iter,
+                                                         double eps, double shift) {
+    __shared__ HbTables T;
+    __shared__ FqAlias As;
+    __shared__ uint32_t hist[32];
+    fr_stage_tables(&T, S.hb);
+    const uint32_t nh = Q.totals[3];
+    const unsigned ne = T.n_elec;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t d = Q.heavy[h];
+        const unsigned ns = fq_heavy_slices(Q.multi ? Q.n_walk[d] : (unsigned)fabs(V.v0[d]));
+        if (blockIdx.y >= ns) continue;
+        const det_t det = V.dets[d];
+        const uint32_t n_doub = Q.n_doub[d];
         if (Q.o1cnt) {
-            __shared__ FqAlias As;
-            __shared__ uint32_t hist[32];
-            const unsigned ne = T.n_elec;
             if (threadIdx.x == 0) { double p1[32]; fq_o1_probs(T, det, p1); fq_setup_alias(As, p1, ne); }
             if (threadIdx.x < 32) hist[threadIdx.x] = 0;
             __syncthreads();
             FqRng r1;
-            for (unsigned i = threadIdx.x; i < n_doub; i += blockDim.x) { r1.begin(seed, iter, det, i, FQ_HB_O1); atomicAdd(&hist[fq_sample_alias(As, ne, r1)], 1u); }
+            // a lane per sample; the wave counts its samples per electron with ballots (lane k keeps the count of electron k): a few
+            // hundred thousand atomic adds onto n_elec LDS words serialise otherwise
+            uint32_t mine = 0;
+            const int lane = fr_lane();
+            for (unsigned i0 = blockIdx.y * blockDim.x; i0 < n_doub; i0 += ns * blockDim.x) {
+                const unsigned i = i0 + threadIdx.x;
+                unsigned e = 0xffu;
+                if (i < n_doub) { r1.begin(seed, iter, det, i, FQ_HB_O1); e = fq_sample_alias(As, ne, r1); }
+                for (unsigned k = 0; k < ne; k++) {
+                    const unsigned long long mk = __ballot(e == k);
+                    if ((unsigned)lane == k) mine += (uint32_t)__popcll(mk);
+                }
+            }
+            if ((unsigned)lane < ne && mine) atomicAdd(&hist[lane], mine);
             __syncthreads();
-            if (threadIdx.x < ne) Q.o1cnt[(size_t)d * ne + threadIdx.x] = hist[threadIdx.x];
+            if (threadIdx.x < ne && hist[threadIdx.x]) atomicAdd(&Q.o1cnt[(size_t)d * ne + threadIdx.x], hist[threadIdx.x]);
+        }
+        if (blockIdx.y == 0 && threadIdx.x == 0) {       // nobody else reads n_att / new_val of this determinant in this kernel
+            const double cur = V.v0[d];
+            const int cur_i = (int)cur;
+            const unsigned n_walk = Q.multi ? Q.n_walk[d] : (unsigned)(cur_i < 0 ? -cur_i : cur_i);
+            const int sign = cur < 0 ? -1 : 1;
+            const uint32_t n_live = Q.n_att[d];
+            uint32_t n_sing = n_walk - n_doub;
+            if (fr_count_sing_allowed(T, det) == 0) n_sing = 0;
+            Q.n_att[d] = n_doub + n_sing;
+            if (!Q.multi) {
+                const double m = (1 - eps * (V.diag[d] - shift)) * sign;
+                const int flr = (int)floor(m);
+                Q.new_val[d] = (double)(flr * (int)n_walk + (int)n_live);
+            }
         }
         __syncthreads();
     }
@@ -565,7 +609,8 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     const unsigned gd = fr_blocks(n ? n : 1, FR_BLOCK);
     FR_HIP(hipMemsetAsync(&Q.totals[3], 0, 4, st));
     FR_LAUNCH(c, "k_fq_count", k_fq_count, dim3(gd), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift, P.initiator);
-    FR_LAUNCH(c, "k_fq_heavy", k_fq_heavy, dim3(512), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift);
+    FR_LAUNCH(c, "k_fq_heavy_a", k_fq_heavy_a, dim3(128, FQ_HSLICES), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift);
+    FR_LAUNCH(c, "k_fq_heavy_b", k_fq_heavy_b, dim3(128, FQ_HSLICES), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->eps, c->en_shift);
     FR_LAUNCH(c, "k_fq_blocksum", k_fq_blocksum, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
     FR_LAUNCH(c, "k_fq_offsets", k_fq_offsets, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
     uint32_t tot[3];
@@ -676,7 +721,8 @@ void fr_multi_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     FR_HIP(hipMemsetAsync(&Q.totals[3], 0, 4, st));
     const unsigned long long seed = c->fq.seed, iter = c->iterat;
     FR_LAUNCH(c, "k_fq_count", k_fq_count, dim3(gd), dim3(FR_BLOCK), c->vec, S, Q, seed, iter, c->p_doub, c->eps, c->en_shift, 0u);
-    FR_LAUNCH(c, "k_fq_heavy", k_fq_heavy, dim3(512), dim3(FR_BLOCK), c->vec, S, Q, seed, iter, c->p_doub, c->eps, c->en_shift);
+    FR_LAUNCH(c, "k_fq_heavy_a", k_fq_heavy_a, dim3(128, FQ_HSLICES), dim3(FR_BLOCK), c->vec, S, Q, seed, iter, c->p_doub, c->eps, c->en_shift);
+    FR_LAUNCH(c, "k_fq_heavy_b", k_fq_heavy_b, dim3(128, FQ_HSLICES), dim3(FR_BLOCK), c->vec, S, Q, seed, iter, c->eps, c->en_shift);
     FR_LAUNCH(c, "k_fq_blocksum", k_fq_blocksum, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
     FR_LAUNCH(c, "k_fq_offsets", k_fq_offsets, dim3(gd), dim3(FR_BLOCK), c->vec, Q);
     uint32_t tot[3];
