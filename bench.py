@@ -10,6 +10,11 @@ Steady state is reached by a restart, like the reference's --load_dir: a filler 
 initiator 0 populates m determinants in a few dozen iterations, its vector is rescaled to the
 target norm and loaded into the measured engine (and, for the CPU baseline, into the oracle).
 
+`--gpus N`: STRONG scaling -- the same global m hash-sharded over N ranks, one per MI355X, RCCL; `value` is the global
+iterations/s.  Without a launcher around it (WORLD_SIZE unset) and N > 1 the script starts its own N ranks with
+torch.distributed.run before touching a GPU; it refuses to run when fewer than N GPUs are visible or when the process group's
+size is not N.  At N == 8 (or --config4 1) BASELINE config 4 (H2O-shaped, m = 1e7 over the ranks) is timed as well (key `config4`).
+
 Prints ONE JSON line (rank 0).  Extra keys: spawns_per_s, roofline, cpu_baseline, parity.
 """
 from __future__ import annotations
@@ -118,55 +123,29 @@ def cpu_baseline(args, mol, par, dets, vals, run_seed, m):
     return cb, {f: [x for x in lo[f]] for f in ("numer", "denom", "norm", "nkept", "n_nonz", "curr_size", "num_success")}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--m", type=int, default=int(os.environ.get("FRIES_BENCH_M", "1000000")), help="nonzeros per GPU")
-    ap.add_argument("--shape", default="N2")
-    ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: sized to ~20 s; 0: skip)")
-    ap.add_argument("--profile-steps", type=int, default=5)
-    ap.add_argument("--backend", default=os.environ.get("FRIES_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        device = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(device)
-        dist.init_process_group(args.backend)
-    elif os.environ.get("FRIES_BENCH_FORCE_COMM"):
-        # one rank, but every collective goes through RCCL: what the callbacks cost without any link latency
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-        device = 0
-        torch.cuda.set_device(0)
-        dist.init_process_group(args.backend, rank=0, world_size=1)
-    else:
-        dist = None
-        device = 0
-
+def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, primary):
+    """One timed run of the frisys_mol loop on a hash-sharded vector of m_glob non-zeros over `world` ranks.  Strong scaling:
+    m_glob is the GLOBAL budget (vec_nonz = mat_nonz = target), whatever the number of ranks -- the run
+    `mpiexec -n N frisys_mol --vec_nonz m --mat_nonz m` does, one rank per MI355X.  -> result dict on rank 0, None elsewhere."""
     from fries_amd import fcidump
     from fries_amd.engine import FriEngine
 
-    m = args.m
-    mol = fcidump.synthetic(args.shape)
+    mol = fcidump.synthetic(shape)
     seed = 20250215
-    # Weak scaling: m determinants PER GPU.  N ranks hold one hash-sharded vector with vec_nonz = mat_nonz = target = N * m
-    # (determinants routed by the reference's proc hash, spawns exchanged with an RCCL all-to-all, every sum_mpi an
-    # all-gather added in rank order) -- the run `mpiexec -n N frisys_mol` would do, one rank per MI355X.
-    m_glob = world * m
+    # per-rank capacity: 4 m / N slots plus slack for the hash's load imbalance (a few sigma of a binomial) -- the reference
+    # sizes every rank's table with the same --max_dets
+    max_dets = int(4 * m_glob / world * (1.0 if world == 1 else 1.15)) + (0 if world == 1 else 65536)
     comm = None
     if dist is not None:
-        from fries_amd.comm import TorchComm
-        comm = TorchComm(m_glob, torch.device("cuda", device))
-    dets, vals = build_state(mol, m_glob, 4 * m, seed, device, comm, dist)
-    par = dict(epsilon=0.01, vec_nonz=m_glob, mat_nonz=m_glob, max_dets=4 * m, target_norm=float(m_glob), initiator=1.0, seed=seed, distribution="HB_unnorm")
+        import torch
+        if args.transport == "rccl":
+            from fries_amd.comm import RcclComm
+            comm = RcclComm(m_glob, device, dist)
+        else:
+            from fries_amd.comm import TorchComm
+            comm = TorchComm(m_glob, torch.device("cuda", device))
+    dets, vals = build_state(mol, m_glob, max_dets, seed, device, comm, dist)
+    par = dict(epsilon=0.01, vec_nonz=m_glob, mat_nonz=m_glob, max_dets=max_dets, target_norm=float(m_glob), initiator=1.0, seed=seed, distribution="HB_unnorm")
     eng = FriEngine(mol, device=device, comm=comm)
     eng.setup(**par)
     eng.vec_load(dets, vals)            # this rank's shard
@@ -179,16 +158,17 @@ def main():
             import torch
             torch.cuda.synchronize()
 
-    first_logs = eng.iterate(args.warmup) if args.warmup else None
+    first_logs = eng.iterate(warmup) if warmup else None
     c0 = eng.counters()
-    coll0 = (comm.n_allgather + comm.n_alltoallv) if comm is not None else 0
+    coll0 = comm.n_collectives() if comm is not None else 0
     barrier()
     t0 = time.perf_counter()
-    eng.iterate(args.steps, want_logs=False)
+    eng.iterate(steps, want_logs=False)
     eng.vec_info()                      # drains the engine's stream
     barrier()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
+    n_coll = (comm.n_collectives() - coll0) if comm is not None else 0
     if dist is not None:
         import torch
         t = torch.tensor([dt], device="cuda")
@@ -197,25 +177,34 @@ def main():
         sp = torch.tensor([float(c1["spawns"] - c0["spawns"])], device="cuda")
         dist.all_reduce(sp)
         spawns = float(sp.item())
+        world_seen, backend_seen = dist.get_world_size(), dist.get_backend()
     else:
         spawns = float(c1["spawns"] - c0["spawns"])
-    # whole-job rate in units of "one iteration of an m-determinant shard": N shards advance per global iteration
-    iters_per_s = world * args.steps / dt
-    n_coll = (comm.n_allgather + comm.n_alltoallv - coll0) if comm is not None else 0
+        world_seen, backend_seen = 1, None
+    iters_per_s = steps / dt            # GLOBAL iterations per second at fixed global m (BASELINE.json's metric)
+    if world == 1:
+        par_str = "1 GPU, 1 rank"
+    else:
+        par_str = (f"{world_seen} ranks ({backend_seen}, transport {args.transport}), one rank per MI355X, one hash-sharded vector of {m_glob} non-zeros "
+                   f"(~{m_glob // world} per GPU): one all-to-all of the spawns + rank-ordered all-gathers per iteration")
     result = {
         "metric": "fri_iterations_per_s", "value": iters_per_s, "unit": "iterations/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.shape} cc-pVDZ-shaped synthetic FCIDUMP, frisys_mol HB_unnorm, vec_nonz=mat_nonz=target={m}, initiator 1, eps 0.01, restart from a full vector",
-                   "m": m, "m_global": m_glob,
-                   "parallelism": "1 GPU" if world == 1 else f"{world} ranks, one hash-sharded vector of {m_glob} nonzeros ({m} per GPU), {args.backend} all-to-all + rank-ordered all-gathers; value = ranks x global iterations/s"},
-        "global_iterations_per_s": args.steps / dt,
+        "n_gpus": world_seen, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{shape} cc-pVDZ-shaped synthetic FCIDUMP, frisys_mol HB_unnorm, vec_nonz=mat_nonz=target={m_glob} (global, fixed as N grows), initiator 1, eps 0.01, restart from a full vector",
+                   "m": m_glob, "m_per_gpu": m_glob / world, "parallelism": par_str},
         "spawns_per_s": spawns / dt,
-        "kernel_launches_per_iter": (c1["launches"] - c0["launches"]) / args.steps,
-        "fks_replays_per_iter": (c1["fks_replays"] - c0["fks_replays"]) / args.steps,
+        "kernel_launches_per_iter": (c1["launches"] - c0["launches"]) / steps,
+        "fks_replays_per_iter": (c1["fks_replays"] - c0["fks_replays"]) / steps,
     }
+    if comm is not None:
+        result["collectives_per_iter"] = n_coll / max(1, steps)
+    if not primary:
+        eng.close()
+        return result if rank == 0 else None
 
     # ---- roofline of the dominant kernel, HIP events on the engine's stream (rank 0 times; every rank iterates)
+    m = m_glob
     info = eng.vec_info()
     cA = eng.counters()
     if rank == 0:
@@ -226,27 +215,27 @@ def main():
         rep = eng.prof_report()
         eng.prof_enable(False)
         cB = eng.counters()
-        if comm is not None:
-            result["collectives_per_iter"] = n_coll / max(1, args.steps)
         tot_ms = sum(v[0] for v in rep.values())
         dom = max(rep.items(), key=lambda kv: kv[1][0])
         name, (ms, calls) = dom
         avg_s = ms / calls * 1e-3
-        stage_elems = (cB["stage_elems"] - cA["stage_elems"]) / args.profile_steps      # elements over the five stages, per iteration
+        stage_elems = (cB["stage_elems"] - cA["stage_elems"]) / args.profile_steps      # elements over the five stages, per iteration (this rank)
         base = next((k for k in ALG_BYTES if name.startswith(k)), None)
         units = stage_elems / 5.0 if base else None      # elements one launch passes over (stage average)
         ach = ALG_BYTES[base](units) / avg_s / 1e9 if base else None
         # HBM bytes per launch from the PMC passes kept under profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # command, corrected as MI355X_MICROARCH.md prescribes); mean over the stage instantiations of the kernel
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                tk = json.load(f)["kernels"]
-            vals_t = [v["bytes_per_launch"] for k, v in tk.items() if k.startswith(name + "<") or k == name]
-            if vals_t and m == 1_000_000 and world == 1:
-                traffic = float(np.mean(vals_t))
-        except (OSError, KeyError, ValueError):
-            pass
+        for prof in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", prof)) as f:
+                    tk = json.load(f)["kernels"]
+                vals_t = [v["bytes_per_launch"] for k, v in tk.items() if k.startswith(name + "<") or k == name]
+                if vals_t and m == 1_000_000 and world == 1:
+                    traffic = float(np.mean(vals_t))
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                               "avg_launch_us": avg_s * 1e6, "calls_per_iter": calls / args.profile_steps,
@@ -258,15 +247,15 @@ def main():
             result["roofline"]["measured_copy_GBs"] = copy_gbs
             result["roofline"]["frac_of_measured_copy"] = (ach / copy_gbs) if ach else None
             result["iteration_frac_of_measured_copy"] = 312.0 * m * iters_per_s / world / 1e9 / copy_gbs
-            result["spawn_term_GBs"] = 64.0 * result["spawns_per_s"] / world / 1e9       # 64 B per spawn (assembly + merge)
+            result["spawn_term_GBs"] = 64.0 * result["spawns_per_s"] / world / 1e9       # 64 B per spawn (assembly + merge), per GPU
         except Exception as ex:      # the measurement is informative only
             result["roofline"]["measured_copy_GBs"] = None
             print("copy-bandwidth measurement skipped: %r" % (ex,), file=sys.stderr)
         result["kernel_time_ms_per_iter"] = tot_ms / args.profile_steps
         result["top_kernels"] = {k: {"ms_per_iter": v[0] / args.profile_steps, "calls_per_iter": v[1] / args.profile_steps}
                                  for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("FRIES_BENCH_TOPK", "8"))]}
-        # whole-iteration algorithmic traffic (~312 B per nonzero per iteration)
-        result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9      # per GPU
+        # whole-iteration algorithmic traffic (~312 B per nonzero per iteration), per GPU
+        result["iteration_alg_GBs"] = 312.0 * m * iters_per_s / world / 1e9
 
         # ---- CPU baseline on this box's host cores: the REAL reference (oracle/_ref, built from /root/reference by
         # oracle/Makefile and shipped as a binary) advanced from the same restart state and seed; the oracle port is the
@@ -274,15 +263,97 @@ def main():
         if args.cpu_iters != 0 and world == 1:
             result["cpu_baseline"], ref_log = cpu_baseline(args, mol, par, dets, vals, run_seed, m)
             if first_logs is not None and ref_log is not None:
-                k = min(len(ref_log["numer"]), args.warmup)
+                k = min(len(ref_log["numer"]), warmup)
                 same = all(int(first_logs[f][i]) == int(ref_log[f][i]) for i in range(k) for f in ("num_success", "n_nonz", "curr_size", "nkept"))
                 en_g = first_logs["numer"][:k] / first_logs["denom"][:k]
                 en_r = np.asarray(ref_log["numer"][:k]) / np.asarray(ref_log["denom"][:k])
                 result["parity"] = {"against": result["cpu_baseline"]["kind"], "iterations_compared": k, "counts_identical": bool(same),
                                     "energy_within_1e-10": bool(np.all(np.abs(en_g - en_r) < 1e-10)),
                                     "norm_bit_identical": bool(all(float(first_logs["norm"][i]) == float(ref_log["norm"][i]) for i in range(k)))}
-        print(json.dumps(result))
     eng.close()
+    return result if rank == 0 else None
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh worker processes (one per GPU, RCCL)
+    BEFORE this process touches a GPU, relay rank 0's JSON line, return the launcher's exit code."""
+    import socket
+    import subprocess
+    import torch        # device_count() does not initialise the GPU on this image
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to report a smaller job as n_gpus={args.gpus}\n")
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--m", type=int, default=int(os.environ.get("FRIES_BENCH_M", "1000000")), help="GLOBAL non-zeros (vec_nonz = mat_nonz = target), fixed as N grows")
+    ap.add_argument("--shape", default="N2")
+    ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: sized to ~20 s; 0: skip)")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--backend", default=os.environ.get("FRIES_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--transport", default=os.environ.get("FRIES_BENCH_TRANSPORT", "torch"), choices=["torch", "rccl"],
+                    help="how the engine's collectives travel for N > 1: torch.distributed callbacks, or the native librccl transport (csrc/comm_rccl)")
+    ap.add_argument("--config4", type=int, default=-1, help="also time BASELINE config 4 (H2O-shaped, m = 1e7 sharded over the ranks): -1 = only when N == 8")
+    args = ap.parse_args()
+
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(3)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if torch.cuda.device_count() < world:
+            sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible: one rank per GPU is the contract\n")
+            sys.exit(3)
+        device = local_rank
+        torch.cuda.set_device(device)
+        dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    elif os.environ.get("FRIES_BENCH_FORCE_COMM"):
+        # one rank, but every collective goes through RCCL: what the callbacks cost without any link latency
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        device = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group(args.backend, rank=0, world_size=1)
+    else:
+        dist = None
+        device = 0
+
+    result = run_workload(args, args.shape, args.m, world, rank, device, dist, args.steps, args.warmup, primary=True)
+    # BASELINE config 4 beside the headline: H2O-shaped, m = 1e7 hash-sharded over the ranks (default: only at N == 8)
+    want4 = args.config4 > 0 or (args.config4 < 0 and world == 8)
+    if want4:
+        r4 = run_workload(args, "H2O", int(os.environ.get("FRIES_BENCH_M4", "10000000")), world, rank, device, dist, max(5, args.steps // 2), min(args.warmup, 5), primary=False)
+        if rank == 0:
+            result["config4"] = {k: r4[k] for k in ("value", "unit", "ms_per_step", "spawns_per_s", "steps", "warmup", "config", "kernel_launches_per_iter", "collectives_per_iter") if k in r4}
+    if rank == 0:
+        print(json.dumps(result))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -79,6 +79,9 @@ class TorchComm:
         torch.cuda.set_stream(ext)
         self._bound = stream_ptr
 
+    def n_collectives(self) -> int:
+        return self.n_allgather + self.n_alltoallv
+
     def release(self):
         """Called before the engine's stream is destroyed: torch must not keep it as its current stream."""
         if self._bound is not None and self.device.type == "cuda":

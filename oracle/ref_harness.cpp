@@ -351,6 +351,8 @@ struct RefRun {
     std::function<double(uint8_t *)> doub_sc;
     std::vector<uint32_t> proc_scr, vec_scr;
     std::vector<fo::det_t> trial_in_det, ini_in_det; std::vector<double> trial_in_val, ini_in_val;      // what the text files held
+    size_t max_dets_ = 0, adder_size_ = 0;
+    std::function<double(const uint8_t *)> diag_sc_;
     // per-iteration record
     double numer, denom, glob_norm; unsigned nkept; size_t num_success;
 
@@ -378,6 +380,7 @@ struct RefRun {
         for (auto &x : proc_scr) x = mt();
         for (auto &x : vec_scr) x = mt();
         sol = new DistVec<double>(max_dets, adder_size, n_orb * 2, n_elec, n_procs, diag_sc, 2, proc_scr, vec_scr);
+        max_dets_ = max_dets; adder_size_ = adder_size; diag_sc_ = diag_sc;
         hf_proc = sol->idx_to_proc(hf_det);
         size_t n_states = n_elec > (n_orb - n_elec / 2) ? n_elec : n_orb - n_elec / 2;
         comp = new HBCompressSys(spawn_length, n_states);
@@ -429,6 +432,32 @@ struct RefRun {
         sol->perform_add(0);
         hb = set_up(n_orb, n_orb, *eris);
         srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
+    }
+
+    // A fresh solution vector holding (dets, vals) in positions 0..n-1 -- what DistVec::load / fries_vec_load leave behind
+    // (the old one's free-position stack would hand the positions out in reverse).  Every entry must belong to this rank.
+    void replace_vector(const std::vector<uint64_t> &dets, const std::vector<double> &vals) {
+        sol = new DistVec<double>(max_dets_, adder_size_, n_orb * 2, n_elec, n_procs, diag_sc_, 2, proc_scr, vec_scr);      // the old one is leaked, like the reference's own objects
+        size_t i = 0;
+        int more = 1;
+        while (more) {
+            while (i < dets.size()) {
+                uint8_t d[8]; memcpy(d, &dets[i], 8);
+                i++;
+                if (!sol->add(d, vals[i - 1], 1)) break;
+            }
+            sol->perform_add(0);
+            more = sum_mpi((int)(i < dets.size()), proc_rank, n_procs);
+        }
+        srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
+    }
+    uint64_t digest() const {
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < sol->curr_size(); i++) {
+            double rv = sol->values()[i];
+            if (rv != 0) { uint64_t vb; memcpy(&vb, &rv, 8); fo::det_t rd = to_u64(sol->indices()[i], det_size); hsh = (hsh ^ rd) * 1099511628211ull; hsh = (hsh ^ vb) * 1099511628211ull; hsh = (hsh ^ i) * 1099511628211ull; }
+        }
+        return hsh;
     }
 
     void iterate() {
@@ -888,6 +917,63 @@ static int run_restart(int argc, char **argv) {
     int sp = sum_mpi((int)(spawns / (n_iter ? n_iter : 1)), rr.proc_rank, rr.n_procs);
     if (rr.proc_rank == 0)
         printf("{\"kind\": \"reference\", \"ranks\": %d, \"iters\": %u, \"seconds\": %.6f, \"iters_per_s\": %.6f, \"spawns_per_iter\": %d, \"n_nonz\": %d}\n", rr.n_procs, n_iter, s, n_iter / s, sp, nn);
+    return 0;
+}
+
+
+// [mpiexec -n P] ref_harness pin <fcidump> <pg> <seed> <eps> <m> <max_dets> <HB|HB_unnorm> <run_seed> <n_iter> <out>
+// The BASELINE sizes, pinned: exactly what bench.py does, by the REAL reference.  (1) filler: frisys_mol from 100 x HF with
+// vec_nonz = mat_nonz = m, initiator 0, no norm control, in blocks of 5 iterations until the (global) number of non-zeros
+// reaches m, then 10 more; (2) restart: the non-zero entries, in storage order, scaled by m / one-norm (local norms summed in
+// storage order, then over the ranks in rank order), become positions 0..n-1 of a fresh vector, initiator 1, target norm m,
+// generator re-seeded with run_seed, shift 0; (3) n_iter iterations.  Every rank writes <out>[.r<rank>]: one row per
+// iteration of both phases with the digest of its shard, and the restart's scale factor.
+static int run_pin(int argc, char **argv) {
+    if (argc < 12) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    uint32_t seed = strtoul(argv[4], 0, 10); double eps = atof(argv[5]);
+    uint32_t m = strtoul(argv[6], 0, 10); size_t max_dets = strtoull(argv[7], 0, 10);
+    int nhb = !strcmp(argv[8], "HB_unnorm");
+    uint32_t run_seed = strtoul(argv[9], 0, 10); unsigned n_iter = atoi(argv[10]);
+    RefRun rr;
+    rr.setup(path, pg, seed, eps, m, m, max_dets, 0.0, 0.0, nhb);
+    char fn[1024];
+    if (rr.n_procs > 1) snprintf(fn, sizeof fn, "%s.r%d", argv[11], rr.proc_rank); else snprintf(fn, sizeof fn, "%s", argv[11]);
+    FILE *f = fopen(fn, "w");
+    fprintf(f, "# pinned run of the reference (ref_harness pin), %d rank(s), rank %d; rows: phase it numer denom norm shift nkept n_nonz curr_size num_success digest\n", rr.n_procs, rr.proc_rank);
+    fprintf(f, "# args: <fcidump> %s seed %u eps %s m %u max_dets %zu %s run_seed %u n_iter %u\n", pg, seed, argv[5], m, max_dets, argv[8], run_seed, n_iter);
+    fprintf(f, "# p_doub %a hf_en %a n_htrial %zu hf_proc %u\n", rr.p_doub, rr.hf_en, (size_t)rr.htrial->curr_size(), rr.hf_proc);
+    auto row = [&](const char *ph, unsigned it) {
+        fprintf(f, "%s %u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", ph, it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success, rr.digest());
+        fflush(f);
+    };
+    unsigned it = 0;
+    bool full = false;
+    for (int blk = 0; blk < 200 && !full; blk++) {
+        for (int k = 0; k < 5; k++, it++) { rr.iterate(); row("F", it); }
+        full = sum_mpi(rr.sol->n_nonz(), rr.proc_rank, rr.n_procs) >= (int)m;
+    }
+    for (int k = 0; k < 10; k++, it++) { rr.iterate(); row("F", it); }
+    std::vector<uint64_t> dets; std::vector<double> vals;
+    double loc = 0;
+    for (size_t i = 0; i < rr.sol->curr_size(); i++) {
+        double v = rr.sol->values()[i];
+        if (v != 0) { dets.push_back(to_u64(rr.sol->indices()[i], rr.det_size)); vals.push_back(v); loc += fabs(v); }
+    }
+    const double glob = sum_mpi(loc, rr.proc_rank, rr.n_procs);
+    const double scale = (double)m / glob;
+    for (auto &v : vals) v = v * scale;
+    fprintf(f, "RESTART %zu %a %a %a\n", dets.size(), loc, glob, scale);
+    rr.replace_vector(dets, vals);
+    rr.init_thresh = 1.0; rr.target = (double)m;
+    rr.mt.seed(run_seed); rr.en_shift = 0; rr.last_one_norm = 0; rr.iterat = 0;
+    MPI_Barrier(MPI_COMM_WORLD);
+    auto t0 = std::chrono::steady_clock::now();
+    for (unsigned k = 0; k < n_iter; k++) { rr.iterate(); row("R", k); }
+    MPI_Barrier(MPI_COMM_WORLD);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fclose(f);
+    if (rr.proc_rank == 0) printf("{\"kind\": \"reference\", \"mode\": \"pin\", \"ranks\": %d, \"filler_iters\": %u, \"iters\": %u, \"seconds\": %.3f, \"iters_per_s\": %.4f}\n", rr.n_procs, it, n_iter, sec, n_iter / sec);
     return 0;
 }
 
@@ -1797,6 +1883,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "pin")) rc = run_pin(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "hh")) rc = run_hh(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "fciqmc")) rc = run_fciqmc(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
