@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfries_hip.so")
-SOURCES = ["hbpp.hip", "vec.hip", "compress.hip", "pivotal.hip", "system.hip", "hh.hip", "fciqmc.hip", "driver.hip"]
+SOURCES = ["hbpp.hip", "vec.hip", "compress.hip", "pivotal.hip", "system.hip", "hh.hip", "fciqmc.hip", "driver.hip", "comm_native.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -117,3 +117,95 @@ class TorchComm:
             self.error = e
             traceback.print_exc(file=sys.stderr)
             return 1
+
+
+class _NativeComm:
+    """A transport of csrc/comm_native.hip behind the same attributes TorchComm offers the engine (struct, big_bytes,
+    counters, release): no Python in the collectives."""
+
+    def __init__(self, handle, lib, size, rank, big_bytes):
+        self.lib, self.h, self.size, self.rank, self.big_bytes = lib, handle, size, rank, big_bytes
+        self.struct = CommStruct()
+        if lib.fries_transport_comm(self.h, C.byref(self.struct)) != 0:
+            raise RuntimeError(lib.fries_last_error().decode())
+        self.error = None
+
+    def _counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.lib.fries_transport_counts(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    @property
+    def n_allgather(self):
+        return self._counts()[0]
+
+    @property
+    def n_alltoallv(self):
+        return self._counts()[1]
+
+    def n_collectives(self) -> int:
+        return sum(self._counts())
+
+    def release(self):
+        pass
+
+    def destroy(self):
+        if self.h:
+            self.lib.fries_transport_destroy(self.h)
+            self.h = None
+
+
+class RcclComm(_NativeComm):
+    """fries_comm on librccl directly (ncclAllGather / ncclAllToAllv on the engine's stream), one process per GPU.  The
+    128-byte communicator id is made by rank 0 and broadcast through the already initialised torch.distributed group
+    (bootstrap only: no torch call remains on the data path)."""
+
+    def __init__(self, mat_nonz: int, device: int, dist=None, group=None):
+        from .engine import load_library
+        lib = load_library()
+        rank, size = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
+        idb = (C.c_uint8 * 128)()
+        if rank == 0 and lib.fries_rccl_unique_id(idb) != 0:
+            raise RuntimeError(lib.fries_last_error().decode())
+        if dist is not None:
+            import torch
+            dev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.tensor(list(idb), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0, group=group)
+            idb = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        bb = big_bytes_for(mat_nonz)
+        if lib.fries_rccl_create(C.byref(h), idb, rank, size, device, bb) != 0:
+            raise RuntimeError(lib.fries_last_error().decode())
+        super().__init__(h, lib, size, rank, bb)
+
+
+class LocalGroup:
+    """`size` ranks as threads of this process (csrc/comm_native.hip, "local"): group.comm(rank, device) gives rank's
+    fries_comm; each rank's engine must then be driven from its own thread."""
+
+    def __init__(self, size: int, mat_nonz: int):
+        from .engine import load_library
+        self.lib = load_library()
+        self.size = size
+        self.big_bytes = big_bytes_for(mat_nonz)
+        self.g = C.c_void_p()
+        if self.lib.fries_local_group_create(C.byref(self.g), size, self.big_bytes) != 0:
+            raise RuntimeError(self.lib.fries_last_error().decode())
+        self.members = []
+
+    def comm(self, rank: int, device: int = 0) -> _NativeComm:
+        h = C.c_void_p()
+        if self.lib.fries_local_create(C.byref(h), self.g, rank, device) != 0:
+            raise RuntimeError(self.lib.fries_last_error().decode())
+        c = _NativeComm(h, self.lib, self.size, rank, self.big_bytes)
+        self.members.append(c)
+        return c
+
+    def destroy(self):
+        for c in self.members:
+            c.destroy()
+        self.members = []
+        if self.g:
+            self.lib.fries_local_group_destroy(self.g)
+            self.g = None

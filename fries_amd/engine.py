@@ -24,6 +24,7 @@ EXPORTS = [
     "fries_test_teeth", "fries_test_seqsum", "fries_frisys_restart", "fries_prof_enable", "fries_prof_count", "fries_prof_get", "fries_counters",
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate", "fries_frimulti_setup", "fries_frimulti_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
+    "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
     "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
 ]
 
@@ -135,6 +136,16 @@ def load_library() -> C.CDLL:
     lib.fries_hh_setup.argtypes = [C.c_void_p, C.POINTER(HHParams)]
     lib.fries_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fries_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.fries_rccl_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
+    lib.fries_local_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]
+    lib.fries_local_group_destroy.argtypes = [C.c_void_p]
+    lib.fries_local_group_destroy.restype = None
+    lib.fries_local_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]
+    lib.fries_transport_comm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fries_transport_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fries_transport_destroy.argtypes = [C.c_void_p]
+    lib.fries_transport_destroy.restype = None
     lib.fries_stream.restype = C.c_void_p
     lib.fries_stream.argtypes = [C.c_void_p]
     lib.fries_idx_to_proc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

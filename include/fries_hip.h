@@ -73,6 +73,26 @@ typedef struct {
     /* send_bytes[d] bytes of big_send go to rank d, recv_bytes[s] bytes arrive from rank s (host arrays of `size`) */
     int (*alltoallv)(void *user, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *stream);
 } fries_comm;
+/* Native transports that fill a fries_comm (csrc/comm_native.hip) -- the C++ counterpart of MPI_COMM_WORLD in the reference:
+ *   RCCL: one process per MI355X.  Rank 0 makes the 128-byte id (fries_rccl_unique_id) and the launcher hands it to every rank
+ *   (a file, MPI_Bcast, a TCP store: the drivers use a rendezvous file); fries_rccl_create joins the communicator on `device`.
+ *   The all-gather is ncclAllGather and the all-to-all ncclAllToAllv, both on the engine's stream.
+ *   local: `size` ranks = `size` host threads of one process, each driving its own context, on any devices; several ranks
+ *   may share one GPU (RCCL refuses that), so multi-rank runs can be checked on a one-GPU machine.  Every rank's thread must
+ *   enter each collective (the engine does); create the group once, then one transport per rank.
+ * big_bytes >= 16 x (mat_nonz + 4096), the same on every rank. */
+typedef struct fries_transport fries_transport;
+typedef struct fries_local_group fries_local_group;
+int fries_rccl_unique_id(uint8_t id[128]);
+int fries_rccl_create(fries_transport **out, const uint8_t id[128], int rank, int size, int device, uint64_t big_bytes);
+int fries_local_group_create(fries_local_group **out, int size, uint64_t big_bytes);
+void fries_local_group_destroy(fries_local_group *g);
+int fries_local_create(fries_transport **out, fries_local_group *g, int rank, int device);
+/* fills *comm for fries_set_comm; the transport must outlive the context */
+int fries_transport_comm(fries_transport *t, fries_comm *comm);
+int fries_transport_counts(fries_transport *t, uint64_t *n_allgather, uint64_t *n_alltoallv);
+void fries_transport_destroy(fries_transport *t);
+
 /* call between fries_set_molecule and fries_frisys_setup; without it the context is one rank */
 int fries_set_comm(fries_ctx *ctx, const fries_comm *comm);
 /* the HIP stream (hipStream_t) every kernel of this context is launched on */

@@ -179,6 +179,34 @@ def gen_multi(manifest):
             manifest["multi_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini, target_norm=tgt)
 
 
+# BASELINE sizes pinned by the reference (ref_harness pin: bench.py's filler + restart, then n_iter iterations with digests):
+# name -> (n_ranks, shape, seed, eps, m, max_dets per rank, distribution, run_seed, n_iter)
+PIN_RUNS = {
+    "pin_n2_m1e6": (1, "N2", 20250215, 0.01, 1000000, 4000000, "HB_unnorm", 777, 100),           # BASELINE config 2 = bench.py's workload
+    "pin_h2o_m1e7_p8": (8, "H2O", 20250215, 0.01, 10000000, 5815536, "HB_unnorm", 777, 24),      # BASELINE config 4: mpiexec -n 8
+}
+
+
+def gen_pin(manifest, only=None):
+    manifest.setdefault("pin_runs", {})
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (n_ranks, shape, seed, eps, m, maxd, dist, run_seed, n_iter) in PIN_RUNS.items():
+            if only and name not in only:
+                continue
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".pin")
+            cmd = [HARNESS, "pin", path, mol.point_group, str(seed), repr(eps), str(m), str(maxd), dist, str(run_seed), str(n_iter), out]
+            if n_ranks > 1:
+                cmd = [MPIEXEC, "-n", str(n_ranks)] + cmd
+            r = subprocess.run(cmd, check=True, capture_output=True, text=True)
+            timing = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            manifest["pin_runs"][name] = dict(n_ranks=n_ranks, shape=shape, seed=seed, epsilon=eps, m=m, max_dets=maxd, distribution=dist, run_seed=run_seed,
+                                              n_iter=n_iter, reference_iters_per_s_build_container=timing["iters_per_s"], filler_iters=timing["filler_iters"])
+            print("pin", name, timing, flush=True)
+
+
 def gen_hbpiv(manifest):
     manifest["hbpiv_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -196,6 +224,13 @@ def gen_hbpiv(manifest):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-pin":      # minutes of CPU each: the BASELINE sizes
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_pin(manifest, only=sys.argv[2:] or None)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] in ("--only-multi", "--only-fp", "--only-hhfull"):
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
@@ -339,6 +374,7 @@ def main():
     gen_hbpiv(manifest)
     gen_multi(manifest)
     gen_fp(manifest)
+    gen_pin(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

@@ -13,6 +13,17 @@ struct OracleLog { double numer, denom, shift, norm; uint32_t nkept; int32_t n_n
 
 extern "C" {
 
+// the per-iteration digest oracle/ref_harness.cpp logs: FNV-style over (determinant, value bits, position) of the non-zero entries
+uint64_t fo_vec_digest(const uint64_t *dets, const double *vals, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) {
+        if (vals[i] == 0) continue;
+        uint64_t vb; memcpy(&vb, &vals[i], 8);
+        h = (h ^ dets[i]) * 1099511628211ull; h = (h ^ vb) * 1099511628211ull; h = (h ^ (uint64_t)i) * 1099511628211ull;
+    }
+    return h;
+}
+
 void *fo_frisys_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                        double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm) {
     Frisys *f = new Frisys();

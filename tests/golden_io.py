@@ -46,6 +46,9 @@ def read_traj(name, rank=None):
 
 def vec_hash(dets, vals):
     """The FNV-style digest oracle/ref_harness.cpp writes per iteration: non-zero entries by position."""
+    if len(vals) > 20000:       # the C loop of the test-side oracle library; the Python loop below is the definition
+        import oracle_lib
+        return oracle_lib.vec_digest(dets, vals)
     mask = (1 << 64) - 1
     h = 1469598103934665603
     p = 1099511628211
@@ -149,3 +152,23 @@ def read_text_vector(prefix):
         vals = np.array([float(t) for t in f.read().split()])
     n = min(dets.size, vals.size)
     return dets[:n], vals[:n]
+
+
+def read_pin(name, rank=None):
+    """tests/golden/<name>.pin[.r<rank>] from `ref_harness pin`: the reference's filler run ("F" rows), the restart record
+    (entries kept, local / global one-norm, scale factor) and the measured run ("R" rows)."""
+    fill, run, restart, hdr = [], [], None, {}
+    with open(os.path.join(GOLD, name + ".pin" + ("" if rank is None else f".r{rank}"))) as f:
+        for ln in f:
+            t = ln.split()
+            if not t:
+                continue
+            if ln.startswith("# p_doub"):
+                hdr = dict(p_doub=float.fromhex(t[2]), hf_en=float.fromhex(t[4]), n_htrial=int(t[6]), hf_proc=int(t[8]))
+            elif t[0] == "RESTART":
+                restart = dict(n=int(t[1]), loc_norm=float.fromhex(t[2]), glob_norm=float.fromhex(t[3]), scale=float.fromhex(t[4]))
+            elif t[0] in ("F", "R"):
+                row = dict(it=int(t[1]), numer=float.fromhex(t[2]), denom=float.fromhex(t[3]), norm=float.fromhex(t[4]), shift=float.fromhex(t[5]),
+                           nkept=int(t[6]), n_nonz=int(t[7]), curr_size=int(t[8]), num_success=int(t[9]), hash=int(t[10], 16))
+                (fill if t[0] == "F" else run).append(row)
+    return dict(fill=fill, run=run, restart=restart, **hdr)

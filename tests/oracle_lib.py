@@ -32,6 +32,8 @@ def load():
         lib.fo_frisys_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         lib.fo_frisys_destroy.argtypes = [C.c_void_p]
+        lib.fo_vec_digest.restype = C.c_uint64
+        lib.fo_vec_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.fo_frisys_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.fo_frisys_p_doub.restype = C.c_double
         lib.fo_frisys_p_doub.argtypes = [C.c_void_p]
@@ -113,6 +115,13 @@ def load():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def vec_digest(dets, vals) -> int:
+    """The digest ref_harness logs per iteration (C loop: a 1e6-element vector takes milliseconds)."""
+    d = np.ascontiguousarray(dets, dtype=np.uint64)
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    return int(load().fo_vec_digest(_p(d), _p(v), min(d.size, v.size)))
 
 
 class OracleFrisys:
