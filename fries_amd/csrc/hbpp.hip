@@ -3,6 +3,7 @@
 // order-preserving compaction of the surviving samples.
 #include "ctx.hpp"
 #include "fks2.hpp"
+#include "fks_seq.hpp"
 
 // ------------------------------------------------------------------ stage preparation
 // Stage 1 elements are the stored vector elements (frisys_mol.cpp:414-420, heat_bathPP.cpp:714-727).
@@ -297,6 +298,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         FR_HIP(hipMemset(F.scal, 0, sizeof(FksScal)));
     }
     c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1);
+    c->fks_seq = fr_alloc<FksSeq>(1);
     c->c_pos = fr_alloc<uint32_t>(cap); c->c_orbs = fr_alloc<uint32_t>(cap); c->c_val = fr_alloc<double>(cap);
     c->d_nsucc = fr_alloc<uint32_t>(1);
     FR_HIP(hipMemset(W.state, 0, sizeof(CompState) * (FR_MAX_ROUNDS + 2)));
@@ -343,6 +345,46 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep_hh2(CompWork W, VecDev V, int
     if (threadIdx.x == 0) { W.psum[0][blockIdx.x] = bs; W.pcnt[0][blockIdx.x] = 0; }
 }
 
+// find_keep_sub of this stage in the reference's order (fks_seq.hpp): sweeps driven from the host, one sum_mpi before and one
+// after each, as in compress_utils.cpp:153-265
+template <int STAGE, bool NEW_HB>
+static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) {
+    CompWork &W = c->W;
+    hipStream_t st = c->stream;
+    const int P = c->n_ranks;
+    FksSeq *Q = c->fks_seq;
+    FR_LAUNCH(c, "k_fks_seq_reset", k_fks_seq_reset, dim3(grid < 1024 ? grid : 1024), dim3(FR_BLOCK), W, cur);
+    AccVal av{W.el[cur].val, &W.state[0]};
+    FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
+    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccVal>), dim3(1), dim3(FR_BLOCK), W.seq, av, fr_seq_from_zero());
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccVal>), dim3(1), dim3(64), W.seq, av, fr_seq_from_zero());
+    FR_LAUNCH(c, "k_fks_seq_begin", k_fks_seq_begin, dim3(1), dim3(1), W, Q, W.seq.total, (double *)c->comm.small_send);
+    AccWt acc{W.wt_remain, &W.state[0]};
+    for (int sweep = 0; ; sweep++) {
+        if (sweep > 4096) throw FriesError("sequential find_keep_sub did not terminate");
+        const double *alln = (const double *)fr_allgather(c, sizeof(double));
+        FR_LAUNCH(c, "k_fks_seq_norm", k_fks_seq_norm, dim3(1), dim3(1), Q, alln, P);
+        FR_LAUNCH(c, "k_fks_seq_sweep", (k_fks_seq_sweep<STAGE, NEW_HB>), dim3(1), dim3(64), W, c->d_hb, cur, c->p_doub, Q);
+        FR_LAUNCH(c, "k_fks_seq_put_k", k_fks_seq_put_k, dim3(1), dim3(1), Q, (uint32_t *)c->comm.small_send);
+        const uint32_t *allk = (const uint32_t *)fr_allgather(c, sizeof(uint32_t));
+        FR_LAUNCH(c, "k_fks_seq_post", k_fks_seq_post, dim3(1), dim3(1), Q, allk, P, (double *)c->comm.small_send);
+        FksSeq h;
+        FR_HIP(hipMemcpyAsync(&h, Q, sizeof(h), hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        if (!h.go) break;
+        if (h.resum) {      // loc_one_norm re-summed from wt_remain, in order (compress_utils.cpp:258-264)
+            FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+            FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
+            FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+            FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, fr_seq_from_zero());
+            FR_LAUNCH(c, "k_fks_seq_take_resum", k_fks_seq_take_resum, dim3(1), dim3(1), Q, W.seq.total, (double *)c->comm.small_send);
+        }
+    }
+    FR_LAUNCH(c, "k_fks_seq_end", k_fks_seq_end, dim3(1), dim3(1), Q, F);
+    c->n_fks_sequential++;
+}
+
 template <int STAGE, bool NEW_HB>
 static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, double rn, uint32_t *n_out_host, bool hh_stage2 = false) {
     CompWork &W = c->W;
@@ -373,9 +415,11 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // afterwards which replay was the first to reproduce its predecessor, and that count is the next iteration's first batch.
     int it = 0, batch = c->rounds_hint[STAGE], needed = 0;
     uint32_t hh[FR_MAX_ROUNDS];
-    while (!needed) {
+    FksScal hscal;
+    bool sequential = c->fks_force_seq;
+    while (!needed && !sequential) {
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
-        if (batch <= 0) throw FriesError("find_keep_sub replay did not settle within FR_MAX_ROUNDS iterations");
+        if (batch <= 0 || it >= 48) { sequential = true; break; }       // the replay does not settle (e.g. the reference's own 0/0 corner): walk the stage in order instead
         for (int k = 0; k < batch; k++) {
             if (c->dbg == 4) FR_LAUNCH(c, "k_fks_prologue", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, 1);
             FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
@@ -388,11 +432,20 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             it++;
         }
         FR_HIP(hipMemcpyAsync(hh, F.hist, 4 * (size_t)it, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipMemcpyAsync(&hscal, F.scal, sizeof(hscal), hipMemcpyDeviceToHost, st));
         FR_HIP(hipStreamSynchronize(st));
         for (int j = 1; j < it && !needed; j++) if (hh[j] == 0) needed = j + 1;      // replay 0 always counts as changed
         batch = 1;
+        if (hscal.overflow) sequential = true;
     }
-    c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
+    // A stage that removes (almost) all of its norm: the reference's running norm is then its own rounding noise, which only the
+    // in-order walk reproduces (fks_seq.hpp).  psG[0] / G_last are sums over the ranks, so every rank decides alike.
+    if (!sequential && !(hscal.G_last >= 1e-3 * hscal.psG[0]) && hscal.psG[0] > 0) sequential = true;
+    if (sequential) {
+        if (hscal.overflow) { uint32_t z = 0; FR_HIP(hipMemcpyAsync(c->d_err, &z, 4, hipMemcpyHostToDevice, st)); }     // FR_ERR_ROUNDS of the abandoned replay (nothing else can have raised a flag: the iteration checks d_err at its end)
+        run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
+    }
+    else c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
     c->fks_iters[STAGE] = it;
     if (c->dbg == 3) {
         FksScal hs; uint32_t hh[FR_MAX_ROUNDS + 2];
@@ -408,10 +461,12 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         fprintf(stderr, "\n");
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
-    FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
-    if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_PMAX), dim3(FR_BLOCK), F);
-    // settled: recompute every wt_remain with the budget of its last flagged sweep
-    FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
+    if (!sequential) {
+        FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
+        if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_PMAX), dim3(FR_BLOCK), F);
+        // settled: recompute every wt_remain with the budget of its last flagged sweep
+        FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
+    }
     AccWt acc{W.wt_remain, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
@@ -466,7 +521,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         CompState fs; FksScal hs;
         FR_HIP(hipMemcpy(&fs, &W.state[FR_MAX_ROUNDS + 1], sizeof(fs), hipMemcpyDeviceToHost));
         FR_HIP(hipMemcpy(&hs, F.scal, sizeof(hs), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[stage %d] n_in %u n_rem %u unit %.6g loc_norm %.6g G %.6g n_fix %u n_out %u n_pass %d replays %d\n", STAGE, fs.n_in, fs.n_rem, fs.unit, fs.loc_norm, fs.G, fs.n_fix, fs.n_out, hs.n_pass, it);
+        fprintf(stderr, "[stage %d rank %d] n_in %u n_rem %u unit %.17g loc_norm %.17g G %.6g n_fix %u n_out %u n_pass %d replays %d\n", STAGE, c->rank, fs.n_in, fs.n_rem, fs.unit, fs.loc_norm, fs.G, fs.n_fix, fs.n_out, hs.n_pass, it);
     }
 }
 

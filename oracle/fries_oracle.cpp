@@ -3,6 +3,8 @@
 // Compile with -ffp-contract=off: the parity contract is plain IEEE-754
 // double arithmetic in the reference's literal operation order (no FMA).
 #include "fries_oracle.hpp"
+#include <cstdlib>
+#include <cstdio>
 #include <mutex>
 #include <condition_variable>
 #include <thread>
@@ -982,7 +984,10 @@ size_t comp_sub(const double *values, size_t count, const uint32_t *n_div, SubWt
     std::vector<double> loc_norms(cm.size);
     double mine = find_keep_sub(values, n_div, sw, sub_sizes, count, &tmp_nsamp, wt_remain, cm);
     cm.allgather(&mine, loc_norms.data(), sizeof(double));   // :818
-    return sys_sub(values, n_div, sw, sub_sizes, count, tmp_nsamp, wt_remain, loc_norms.data(), rn, new_vals, new_idx, cm);
+    static const bool dbg = getenv("FRIES_ORACLE_DBG") != nullptr;
+    size_t n_out = sys_sub(values, n_div, sw, sub_sizes, count, tmp_nsamp, wt_remain, loc_norms.data(), rn, new_vals, new_idx, cm);
+    if (dbg) fprintf(stderr, "[oracle comp_sub rank %d] n_in %zu n_rem %u loc_norm %.17g n_out %zu\n", cm.rank, count, tmp_nsamp, mine, n_out);
+    return n_out;
 }
 
 void adjust_shift(double *shift, double one_norm, double *last_norm, double target_norm, double damp) {
@@ -1294,6 +1299,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         else ndiv[d] = 1;
     }
     comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[0], vec2.data(), cidx, cm);
+    sc.stage_len[0] = comp_len;
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- first occupied orbital (:736-770)
@@ -1316,6 +1322,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         }
     }
     comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[1], vec1.data(), cidx, cm);
+    sc.stage_len[1] = comp_len;
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- unoccupied (single) / 2nd occupied (double) (:772-816)
@@ -1348,6 +1355,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         }
     }
     comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, new_hb ? nsub.data() : nullptr, n_samp, wtr, rn[2], vec2.data(), cidx, cm);
+    sc.stage_len[2] = comp_len;
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- 1st unoccupied (double) (:818-864)
@@ -1383,6 +1391,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         }
     }
     comp_len = comp_sub(vec2.data(), comp_len, ndiv.data(), sw, nullptr, n_samp, wtr, rn[3], vec1.data(), cidx, cm);
+    sc.stage_len[3] = comp_len;
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- 2nd unoccupied (double) (:866-915)
@@ -1417,6 +1426,7 @@ void apply_HBPP_sys(const Vec &v, HBScratch &sc, const MolSys &sys, double p_dou
         else { oi2[s][3] = oi1[wi][3]; ndiv[s] = 1; }
     }
     comp_len = comp_sub(vec1.data(), comp_len, ndiv.data(), sw, nsub.data(), n_samp, wtr, rn[4], vec2.data(), cidx, cm);
+    sc.stage_len[4] = comp_len;
     if (comp_len > spawn_length) std::cerr << "Error: insufficient memory allocated for matrix compression.\n";
 
     // ---- decode, weight, matrix element, parity (:917-991)
@@ -1824,6 +1834,7 @@ void Frisys::iterate(unsigned n_iter) {
         apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz, false, cm);
         size_t comp_len = sc.vec_len;
         lg.num_success = comp_len;
+        for (int k = 0; k < 5; k++) lg.comp_len[k] = sc.stage_len[k];
 
         std::vector<double> &before = sol.vals[0];
         sol.cur = 1;

@@ -225,6 +225,7 @@ struct HBScratch {
     std::vector<uint32_t> ndiv;
     std::vector<size_t> comp_idx;            // len x 2
     SubWts sw;
+    size_t stage_len[5] = {0, 0, 0, 0, 0};    // elements after each of the five comp_sub calls of the last apply_HBPP_sys
     void init(size_t length, size_t n_subwt);
 };
 struct MolSys {

@@ -68,7 +68,7 @@ void fo_frisys_iterate(void *h, uint32_t n, OracleLog *logs) {
             OracleLog &o = logs[i];
             o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.nkept = l.nkept;
             o.n_nonz = l.n_nonz; o.curr_size = (uint32_t)l.curr_size; o.num_success = (uint32_t)l.num_success;
-            for (int k = 0; k < 5; k++) o.comp_len[k] = 0;
+            for (int k = 0; k < 5; k++) o.comp_len[k] = (uint32_t)l.comp_len[k];
             o.err = 0;
         }
     }
@@ -309,7 +309,7 @@ struct OracleRanks { std::vector<std::unique_ptr<Frisys>> fr; };
 static void fill_log(const IterLog &l, OracleLog &o) {
     o.numer = l.numer; o.denom = l.denom; o.shift = l.shift; o.norm = l.norm; o.nkept = l.nkept;
     o.n_nonz = l.n_nonz; o.curr_size = (uint32_t)l.curr_size; o.num_success = (uint32_t)l.num_success;
-    for (int k = 0; k < 5; k++) o.comp_len[k] = 0;
+    for (int k = 0; k < 5; k++) o.comp_len[k] = (uint32_t)l.comp_len[k];
     o.err = 0;
 }
 
