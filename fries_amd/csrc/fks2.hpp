@@ -50,7 +50,13 @@ struct FksSaved {
 
 struct Fks2Work {
     uint32_t nb8_cap;
-    uint32_t *dk8[2]; double *dg8[2], *ws8[2];   // [FR_FKS_PMAX][nb8_cap] group deltas; replay `it` writes buffer it & 1
+    uint32_t *dk8; double *dg8, *ws8;       // [FR_FKS_PMAX][nb8_cap] group deltas of the latest evaluation of every group
+    // Per (tile of FR_BLOCK elements, sweep): the inputs the tile was last evaluated with -- running norm and remaining budget at its
+    // first group -- and the smallest distance of any of its comparisons from flipping (in units of the norm).  A later replay whose
+    // inputs for the tile differ by less (same integers) cannot change any decision of the tile and skips it ("light" replays).
+    double *tG; float *tR, *tGm; uint32_t *tK; uint32_t *tNp;     // [ntile_cap][FR_FKS_PMAX] x4, [ntile_cap]: tR = tightest relative margin, tGm = smallest norm compared against
+    uint32_t *cdirty;                       // [FR_FKS_MAXCHUNK] it + 1 of the last replay that changed a delta inside the chunk
+    uint32_t ntile_cap;
     uint32_t *xk8; double *xg8;             // exclusive prefixes over the groups of a chunk, same shape
     uint32_t *ck; double *cg, *cw;          // [FR_FKS_PMAX][FR_FKS_MAXCHUNK] totals per chunk of 2048 groups
     uint32_t *ckx; double *cgx;             // exclusive prefixes of (ck, cg) over the chunks
@@ -118,6 +124,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Wo
     const CompState st0 = W.state[0];
     const double G0 = fr_sum_partials(W.psum[0], (st0.n_in + FR_TILE - 1) / FR_TILE, shd);
     for (int k = threadIdx.x; k < FR_MAX_ROUNDS + 2; k += blockDim.x) F.hist[k] = 0;
+    for (int k = threadIdx.x; k < FR_FKS_MAXCHUNK; k += blockDim.x) F.cdirty[k] = 0;
     if (threadIdx.x == 0) {
         FksScal *S = F.scal;
         S->G0 = G0; S->n0 = st0.n_rem; S->n_in = st0.n_in;
@@ -181,26 +188,37 @@ __device__ __forceinline__ double fr_grp8_running(double start, double c, int f)
 // decision would differ under a slightly smaller threshold.
 template <int STAGE, bool NEW_HB>
 __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32_t code, const RowInfo &ri, unsigned n_sub, double p_doub,
-                                            double cwf, double gl, uint32_t kp_in, uint32_t *kp_out, uint32_t *add, double *unkept_wt, double *max_unkept) {
+                                            double cwf, double gl, uint32_t kp_in, uint32_t *kp_out, uint32_t *add, double *unkept_wt, double *max_unkept, double *min_kept) {
     unsigned full = (n_sub / 8) * 8;
     uint32_t kk = kp_in, a = 0;
-    double wsum = 0, mu = 0;
+    double wsum = 0, mu = 0, mk = INFINITY;
     fr_row_visit<STAGE, NEW_HB>(T, det, code, ri, p_doub, [&](unsigned s, double w) {
         if (s >= n_sub || ((kk >> s) & 1u)) return;
         double sub_magn = cwf * w;
         double thr = s < full ? 1e-12 : 1e-10;      // compress_utils.cpp:213 / :233
-        if (sub_magn >= gl && fabs(sub_magn) > thr) { kk |= 1u << s; a++; }
+        if (sub_magn >= gl && fabs(sub_magn) > thr) { kk |= 1u << s; a++; mk = sub_magn < mk ? sub_magn : mk; }
         else { wsum += w; mu = sub_magn > mu ? sub_magn : mu; }
     });
-    *kp_out = kk; *add = a; *unkept_wt = wsum; *max_unkept = mu;
+    *kp_out = kk; *add = a; *unkept_wt = wsum; *max_unkept = mu; *min_kept = mk;
 }
 
 #define FR_FKS_TILES_PER_CHUNK (FR_FKS_CHUNK * 8 / FR_BLOCK)
 
-template <int STAGE, bool NEW_HB>
-__global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, VecDev V, const HbTables *Tg, int cur, int it, double p_doub, int final, int dbg = 0) {
+// MODE 0: early replays -- every tile, prefixes zero / from the warm start / from the previous replay, deltas written without
+//         comparison (the replay counts as changed), no margins recorded: the lean kernel.
+// MODE 1: late replays -- margins recorded, deltas compared with the stored ones (hist[it] / cdirty raised on a difference);
+//         with `light` a tile whose inputs moved by less than its tightest comparison tolerates is skipped.
+// MODE 2: final pass -- wt_remain with the budget of the last sweep that flagged the element.
+#define FR_FKS_TILE_MAXK 8192u      // a tile of FR_BLOCK elements preserves at most 32 sub-weights per element
+
+template <int STAGE, bool NEW_HB, int MODE>
+__global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
     __shared__ HbTables T;
     __shared__ FksScal S;
+    __shared__ uint32_t sm_r[FR_FKS_PMAX + 1];      // per sweep: smallest relative margin of the tile's comparisons, smallest norm compared against (float bits)
+    __shared__ uint32_t sm_gm[FR_FKS_PMAX + 1];
+    __shared__ double sm_G[FR_FKS_PMAX + 1];
+    __shared__ uint32_t sm_K[FR_FKS_PMAX + 1];
     {
         const uint32_t *src = (const uint32_t *)F.scal;
         uint32_t *dst = (uint32_t *)&S;
@@ -214,14 +232,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     const StageElems E = W.el[cur];
     const int n_pass = S.n_pass;
     const bool zp = S.zero_prefix != 0;
-    const bool warm0 = !final && zp && S.warm;               // replay 0 of a warm start: prefixes from the saved chunk totals
+    const bool warm0 = MODE == 0 && zp && S.warm;            // replay 0 of a warm start: prefixes from the saved chunk totals
     const int vup = S.valid_upto;
     const unsigned n_chunk_saved = warm0 ? F.saved->nchunk : 0u;
     const unsigned saved_nb8 = warm0 ? F.saved->nb8 : 0u;
     const double wsc = S.warm_scale;
-    uint32_t *const dk8 = F.dk8[it & 1];
-    double *const dg8 = F.dg8[it & 1], *const ws8 = F.ws8[it & 1];
+    uint32_t *const dk8 = F.dk8;
+    double *const dg8 = F.dg8, *const ws8 = F.ws8;
     const int lane = fr_lane(), f = lane & 7;
+    // a replay without comparison, or with a different number of sweeps than its predecessor, always counts as changed
+    if (MODE != 2 && (MODE == 0 || S.n_pass != S.valid_upto) && blockIdx.x == 0 && threadIdx.x == 0) F.hist[it] = 1u;
 
     for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const size_t e = (size_t)tile * FR_BLOCK + threadIdx.x;
@@ -229,6 +249,42 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         const bool in_grp = b < nb8;
         const bool live = e < n_in;
         const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
+        if (MODE == 1) {
+            // Light replay: has anything this tile's decisions depend on moved by more than its tightest comparison tolerates?
+            // Every comparison of the tile has the form  c * (budget - k) >= norm - g  with (k, g) = what the tile itself used up
+            // before that point.  If no decision of the tile changes, (k, g) stay as they were, so a change of the tile's inputs
+            // (budget: integer, norm) moves the left side by a factor within 1 +- eps1 and the right side within 1 +- eps2, and no
+            // comparison whose two sides differ by more than (eps1 + eps2) x the larger side can flip.
+            int ok = 1;
+            if (MODE == 1 && light) {
+                const int p = threadIdx.x;
+                const size_t b0 = (size_t)tile * (FR_BLOCK / 8);
+                if (p < n_pass) {
+                    double xg = 0.0; uint32_t xk = 0u;
+                    if (p <= vup) {
+                        const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
+                        xg = F.cgx[cx] + F.xg8[(size_t)p * stride + b0]; xk = F.ckx[cx] + F.xk8[(size_t)p * stride + b0];
+                    }
+                    const double G_in = S.psG[p] - xg; const uint32_t K_in = S.psN[p] - xk;
+                    const size_t tx = (size_t)tile * FR_FKS_PMAX + p;
+                    const uint32_t K_old = F.tK[tx]; const double G_old = F.tG[tx];
+                    const double gmin = (double)F.tGm[tx], rmar = (double)F.tR[tx];
+                    const uint32_t k_lo = K_in < K_old ? K_in : K_old, dk = K_in < K_old ? K_old - K_in : K_in - K_old;
+                    ok = 0;
+                    if (k_lo > 2u * FR_FKS_TILE_MAXK && gmin > 0) {
+                        const double eps1 = (double)dk / (double)(k_lo - FR_FKS_TILE_MAXK);
+                        const double eps2 = (fabs(G_in - G_old) + 1e-12 * S.psG[0]) / gmin;     // prefix sums carry ~1e-16 of the stage's norm
+                        ok = (eps1 + eps2) * 1.0001 < rmar;
+                    }
+                    if (dk == 0u && G_in == G_old) ok = 1;          // nothing moved at all
+                }
+                else if (p == FR_FKS_PMAX) ok = (F.tNp[tile] == (uint32_t)n_pass);
+            }
+            if (threadIdx.x <= FR_FKS_PMAX) { sm_r[threadIdx.x] = 0x7F800000u; sm_gm[threadIdx.x] = 0x7F800000u; }
+            ok = __syncthreads_and(ok);
+            if (dbg == 3 && threadIdx.x == 0 && it < FR_MAX_ROUNDS) { atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u); if (!(MODE == 1 && light && ok)) atomicAdd(&F.dbg_cnt[it * 4], 1u); }
+            if (MODE == 1 && light && ok) continue;
+        }
         const double chunk_frac = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
         // group start state of sweep p: what the groups before mine removed (norm) and used (samples) in that sweep
         // The loads are issued one sweep ahead and only added up when the sweep starts: any arithmetic on them here would make the
@@ -236,7 +292,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         struct Pfx { double a, b; uint32_t c, d; };
         auto prefix_issue = [&](int p, Pfx *o) {
             o->a = 0.0; o->b = 0.0; o->c = 0u; o->d = 0u;
-            if (warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
+            if (MODE == 0 && warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
                 double xg = 0.0; uint32_t xk = 0u;
                 if (F.sxk8 && b < saved_nb8 && my_chunk < n_chunk_saved) {       // stage 1: the same elements sat in this group last time
                     const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
@@ -265,10 +321,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         double v = live ? E.val[e] : 0.0;
         uint32_t nd = live ? E.ndiv[e] : 1u;
         double wr = v;
-        uint32_t kp = (final && live) ? W.keep[e] : 0u;
+        uint32_t kp = (MODE == 2 && live) ? W.keep[e] : 0u;
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
         if (STAGE != 1 && live && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
-        if (final) {
+        if (MODE == 2) {
             double lastwf = 0;
             Pfx nx;
             if (n_pass > 0) prefix_issue(0, &nx);
@@ -295,7 +351,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             }
             continue;
         }
-        if (dbg == 1) continue;
+        bool out_changed = false;
         float wmax = -1.0f;         // upper bound of the largest unpreserved normalised weight; < 0: row not looked at yet
         // (in this loop the sums are formed at once: measured faster than deferring them -- 62 vs 69 us -- while the final loop
         // above gains a third from deferring)
@@ -307,12 +363,17 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             const double xg = xg_n; const uint32_t xk = xk_n;
             if (p + 1 < n_pass) { prefix_issue(p + 1, &nx); xg_n = nx.a + nx.b; xk_n = nx.c + nx.d; }
             const double glob0 = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
+            if (MODE == 1 && threadIdx.x == 0) { sm_G[p] = glob0; sm_K[p] = S.psN[p] - xk; }       // the tile's inputs for this sweep
             // flags are taken against the group's start norm (compress_utils.cpp:172-180)
             double cw = v * wf;
             if (nd > 0) cw /= nd;
-            const bool flagged = live && wr > 0 && cw >= glob0;
+            const bool cmp = live && wr > 0;
+            const bool flagged = cmp && cw >= glob0;
+            // distance of my comparisons from flipping, relative to their larger side (float is plenty; rounded down)
+            float mr = INFINITY;
+            if (MODE == 1 && cmp) mr = (float)fabs(cw - glob0) * __frcp_rn((float)(cw > glob0 ? cw : glob0));
             // --- speculate with the start norm, then validate against the running norm
-            double change = 0, new_wr = wr, mu = 0;
+            double change = 0, new_wr = wr, mu = 0, mk = INFINITY;
             uint32_t add = 0, new_kp = kp;
             bool evaluated = false, skipped = false;
             double used_gl = glob0;
@@ -320,7 +381,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 if (nd > 0) { new_kp = kp | 1u; new_wr = 0; add = nd; change = v; }
                 else if (wmax >= 0 && cw * (double)wmax < glob0) skipped = true;
             }
-            bool need_eval = flagged && nd == 0 && !skipped && dbg != 2;
+            bool need_eval = flagged && nd == 0 && !skipped;
             double gl_mine = glob0;
             const bool any_flagged = __any(flagged);
             if (any_flagged) {
@@ -332,7 +393,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                     if (need_eval) {
                         unsigned n_sub = fr_row_len<STAGE, NEW_HB>(T, ri.nsub);
                         double uw;
-                        fr_fks2_row<STAGE, NEW_HB>(T, det, code, ri, n_sub, p_doub, cw, gl_mine, kp, &new_kp, &add, &uw, &mu);
+                        fr_fks2_row<STAGE, NEW_HB>(T, det, code, ri, n_sub, p_doub, cw, gl_mine, kp, &new_kp, &add, &uw, &mu, &mk);
                         // Remaining weight of the row inside the replay: value x (sum of the unpreserved normalised sub-weights).  The
                         // reference forms sum(value * budget * w_s) / budget (compress_utils.cpp:243-245), the same number up to rounding
                         // but dependent on the budget; that form is used for the final wt_remain (final pass, bit for bit), while the
@@ -352,6 +413,17 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                     }
                     if (!__any(need_eval)) break;
                 }
+                // the row comparisons, against the running norm they were finally decided with
+                if (MODE == 1 && flagged && nd == 0) {
+                    float m2;
+                    if (need_eval || !(gl_mine > 0)) m2 = 0.0f;          // the validation loop ran out of rounds / the norm is gone: never skip this tile
+                    else if (skipped) m2 = (float)(gl_mine - cw * (double)wmax) * __frcp_rn((float)gl_mine);
+                    else {
+                        m2 = (float)(gl_mine - mu) * __frcp_rn((float)gl_mine);
+                        if (mk < INFINITY) { const float m3 = (float)(mk - gl_mine) * __frcp_rn((float)mk); m2 = m3 < m2 ? m3 : m2; }
+                    }
+                    mr = m2 < mr ? m2 : mr;
+                }
             }
             // commit
             if (flagged && !skipped) {
@@ -359,6 +431,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 kp = new_kp; wr = new_wr;
             }
             else { add = 0; change = 0; }
+            // the tile's tightest comparison and smallest norm of this sweep: 8-lane minima, then one LDS atomic per group
+            if (MODE == 1) {
+                float gm = cmp ? (float)gl_mine * 0.99999f : INFINITY;      // gl_mine <= glob0: the smaller of my two right-hand sides
+                if (!(mr >= 0.0f)) mr = 0.0f;
+                if (!(gm >= 0.0f)) gm = 0.0f;
+                uint32_t ur = __float_as_uint(mr * 0.9999f), ug = __float_as_uint(gm), t;
+                t = fr_dpp_u32<FR_DPP_HMIRROR>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR1>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR2>(ur); ur = t < ur ? t : ur;
+                t = fr_dpp_u32<FR_DPP_HMIRROR>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR1>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR2>(ug); ug = t < ug ? t : ug;
+                if (f == 0 && ur != 0x7F800000u) { atomicMin(&sm_r[p], ur); atomicMin(&sm_gm[p], ug); }
+            }
             // group totals (a wave without a flagged lane, the usual case from the third sweep on, has nothing new to add up)
             uint32_t gk = 0; double gg = 0.0, gw = gw_last;
             if (any_flagged) {
@@ -369,7 +451,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             }
             if (f == 0 && in_grp) {
                 size_t ix = (size_t)p * stride + b;
-                dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw;
+                if (MODE == 1) {
+                    if (dk8[ix] != gk || __double_as_longlong(dg8[ix]) != __double_as_longlong(gg) || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
+                        dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw; out_changed = true;
+                    }
+                }
+                else { dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw; }
             }
         }
         // one sweep beyond: keeps nothing, but its wt_remain sum is what a re-summed norm would be
@@ -377,16 +464,34 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             const double gw = gw_last;
             if (f == 0 && in_grp) {
                 size_t ix = (size_t)n_pass * stride + b;
-                dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw;
+                if (MODE == 1) {
+                    if (dk8[ix] != 0u || __double_as_longlong(dg8[ix]) != 0ll || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
+                        dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw; out_changed = true;
+                    }
+                }
+                else { dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw; }
             }
         }
+        if (MODE == 1 && __any(out_changed) && lane == 0) {
+            if (F.hist[it] == 0) atomicOr(&F.hist[it], 1u);
+            F.cdirty[my_chunk] = (uint32_t)it + 1u;
+        }
         if (live) { W.keep[e] = kp; W.wt_remain[e] = wr; }
+        // what this evaluation was based on, for the light replays that follow
+        if (MODE != 1) continue;
+        __syncthreads();
+        if ((int)threadIdx.x < n_pass) {
+            const size_t tx = (size_t)tile * FR_FKS_PMAX + threadIdx.x;
+            F.tG[tx] = sm_G[threadIdx.x]; F.tK[tx] = sm_K[threadIdx.x];
+            F.tR[tx] = __uint_as_float(sm_r[threadIdx.x]); F.tGm[tx] = __uint_as_float(sm_gm[threadIdx.x]);
+        }
+        else if (threadIdx.x == FR_FKS_PMAX) F.tNp[tile] = (uint32_t)n_pass;
     }
 }
 
 // Exclusive prefixes over the 8-blocks inside chunks of 2048 groups (grid: chunks x sweeps); chunk totals go to
 // (ck, cg, cw).  Also compares this replay's deltas with the previous replay's and raises hist[it] on any difference.
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it) {
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it, int light) {
     __shared__ double shd[12];
     __shared__ uint32_t shu[4];
     const FksScal *S = F.scal;
@@ -396,32 +501,20 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
     const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
     const int n_pass = S->n_pass;
     const size_t stride = F.nb8_cap;            // a multiple of FR_FKS_CHUNK: every chunk of a sweep's row is fully addressable
+    // no delta of this chunk moved in this replay (and the sweeps are the same as before): its prefixes and totals stand
+    if (light && n_pass == S->valid_upto && F.cdirty[c] != (uint32_t)it + 1u) return;
     if (c < nchunk && p <= n_pass && p < FR_FKS_PMAX) {
-        const bool fresh = S->zero_prefix || p > S->valid_upto;      // nothing to compare with
         // thread t owns groups [8t, 8t + 8) of the chunk: 32 / 64 contiguous bytes per array, fetched as 16-byte vectors
         const size_t base = (size_t)p * stride + (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8;
         const unsigned left = (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8 < nb8 ? (unsigned)(nb8 - ((size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8)) : 0u;   // valid groups of mine
         uint32_t k[8]; double g[8], w[8];
         {
-            const uint4 *pk = (const uint4 *)(F.dk8[it & 1] + base);
+            const uint4 *pk = (const uint4 *)(F.dk8 + base);
             uint4 a = pk[0], bq = pk[1];
             k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = bq.x; k[5] = bq.y; k[6] = bq.z; k[7] = bq.w;
-            const double2 *pg = (const double2 *)(F.dg8[it & 1] + base), *pw = (const double2 *)(F.ws8[it & 1] + base);
+            const double2 *pg = (const double2 *)(F.dg8 + base), *pw = (const double2 *)(F.ws8 + base);
 #pragma unroll
             for (int j = 0; j < 4; j++) { double2 x = pg[j], y = pw[j]; g[2 * j] = x.x; g[2 * j + 1] = x.y; w[2 * j] = y.x; w[2 * j + 1] = y.y; }
-        }
-        bool diff = fresh;
-        if (!fresh) {
-            const uint4 *pk = (const uint4 *)(F.dk8[(it & 1) ^ 1] + base);
-            uint4 a = pk[0], bq = pk[1];
-            uint32_t kp[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
-            const double2 *pg = (const double2 *)(F.dg8[(it & 1) ^ 1] + base), *pw = (const double2 *)(F.ws8[(it & 1) ^ 1] + base);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                double2 x = pg[j], y = pw[j];
-                if ((unsigned)(2 * j) < left && (kp[2 * j] != k[2 * j] || __double_as_longlong(x.x) != __double_as_longlong(g[2 * j]) || __double_as_longlong(y.x) != __double_as_longlong(w[2 * j]))) diff = true;
-                if ((unsigned)(2 * j + 1) < left && (kp[2 * j + 1] != k[2 * j + 1] || __double_as_longlong(x.y) != __double_as_longlong(g[2 * j + 1]) || __double_as_longlong(y.y) != __double_as_longlong(w[2 * j + 1]))) diff = true;
-            }
         }
         uint32_t tk = 0; double tg = 0, tw = 0;
 #pragma unroll
@@ -448,7 +541,6 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
         if (threadIdx.x == 0) {
             F.ck[(size_t)p * FR_FKS_MAXCHUNK + c] = totk; F.cg[(size_t)p * FR_FKS_MAXCHUNK + c] = totg; F.cw[(size_t)p * FR_FKS_MAXCHUNK + c] = totw;
         }
-        if (__any(diff) && fr_lane() == 0 && F.hist[it] == 0) atomicOr(&F.hist[it], 1u);
     }
 }
 

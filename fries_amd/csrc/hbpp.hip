@@ -282,7 +282,12 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         Fks2Work &F = c->F2;
         F.nb8_cap = (uint32_t)(((size_t)cap / 8 + 2 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK * FR_FKS_CHUNK);     // whole chunks: k_fks_scan uses unguarded vector loads
         size_t n8 = (size_t)FR_FKS_PMAX * F.nb8_cap;
-        for (int h = 0; h < 2; h++) { F.dk8[h] = fr_alloc<uint32_t>(n8); F.dg8[h] = fr_alloc<double>(n8); F.ws8[h] = fr_alloc<double>(n8); }
+        F.dk8 = fr_alloc<uint32_t>(n8); F.dg8 = fr_alloc<double>(n8); F.ws8 = fr_alloc<double>(n8);
+        F.ntile_cap = (uint32_t)(((size_t)F.nb8_cap * 8 + FR_BLOCK - 1) / FR_BLOCK + 1);
+        F.tG = fr_alloc<double>((size_t)F.ntile_cap * FR_FKS_PMAX); F.tR = fr_alloc<float>((size_t)F.ntile_cap * FR_FKS_PMAX); F.tGm = fr_alloc<float>((size_t)F.ntile_cap * FR_FKS_PMAX);
+        F.tK = fr_alloc<uint32_t>((size_t)F.ntile_cap * FR_FKS_PMAX); F.tNp = fr_alloc<uint32_t>(F.ntile_cap);
+        F.cdirty = fr_alloc<uint32_t>(FR_FKS_MAXCHUNK);
+        FR_HIP(hipMemset(F.tNp, 0xff, 4 * (size_t)F.ntile_cap));
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
         F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
         F.ck = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cg = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cw = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
@@ -421,9 +426,15 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
         if (batch <= 0 || it >= 48) { sequential = true; break; }       // the replay does not settle (e.g. the reference's own 0/0 corner): walk the stage in order instead
         for (int k = 0; k < batch; k++) {
-            if (c->dbg == 4) FR_LAUNCH(c, "k_fks_prologue", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, 1);
-            FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
-            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it);
+            // replay 0 evaluates every tile; later replays only the tiles whose inputs moved by more than their tightest comparison allows
+            // The replay needs about as many rounds as the reference runs sweeps (a sweep's start state is only right once the sweep
+            // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
+            // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
+            const int rec_at = c->fks_no_light ? 1 : (c->rounds_hint[STAGE] > 3 ? c->rounds_hint[STAGE] - 2 : 1);
+            const int light = (it > rec_at && !c->fks_no_light) ? 1 : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
+            if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
+            else FR_LAUNCH(c, light ? "k_fks_sweep_light" : "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
+            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0);
             FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
             if (xr) {
                 const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
@@ -454,10 +465,10 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         fprintf(stderr, "[fks] stage %d n_in %u replays %d needed %d n_pass %d lane_evals %u wave_eval_rounds %u (per replay %.0f / %.0f) psN:", STAGE, hs.n_in, it, needed, hs.n_pass,
                 hh[FR_MAX_ROUNDS], hh[FR_MAX_ROUNDS + 1], hh[FR_MAX_ROUNDS] / (double)it, hh[FR_MAX_ROUNDS + 1] / (double)it);
         for (int p = 0; p < hs.n_pass; p++) fprintf(stderr, " %u", hs.psN[p]);
-        fprintf(stderr, "\n   groups changed per replay (dk | dg only | ws only | dg>1e-9):");
+        fprintf(stderr, "\n   tiles evaluated / tiles | - | - per replay:");
         std::vector<uint32_t> dc((size_t)FR_MAX_ROUNDS * 4);
         FR_HIP(hipMemcpy(dc.data(), F.dbg_cnt, dc.size() * 4, hipMemcpyDeviceToHost));
-        for (int k = 1; k < it; k++) fprintf(stderr, "  [%d] %u|%u|%u|%u", k, dc[k * 4], dc[k * 4 + 1], dc[k * 4 + 2], dc[k * 4 + 3]);
+        for (int k = 0; k < it; k++) fprintf(stderr, "  [%d] %u/%u chg %u", k, dc[k * 4], dc[k * 4 + 1], hh[k]);
         fprintf(stderr, "\n");
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
@@ -465,7 +476,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
         if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_PMAX), dim3(FR_BLOCK), F);
         // settled: recompute every wt_remain with the budget of its last flagged sweep
-        FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB>), dim3(gridE), dim3(FR_BLOCK), W, F, c->vec, c->d_hb, cur, it, c->p_doub, 1);
+        FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB, 2>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, 0);
     }
     AccWt acc{W.wt_remain, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
