@@ -129,7 +129,7 @@ static void run_seq(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound) {
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, fr_seq_from_zero());
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, fr_seq_from_zero());
 }
 // the chain again, starting from the lbound this rank inherits (classification and maps depend on the running sum's binade)
 template <class Acc>
@@ -137,7 +137,7 @@ static void run_seq_from(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound, SeqS
     unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(64), Q, acc, from);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
 }
 
 // exact in-order sum of the unpreserved |v| into vc.seq.total (what find_preserve returns, compress_utils.cpp:98-101)

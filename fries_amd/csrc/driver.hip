@@ -906,7 +906,7 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccArr>), dim3(1), dim3(64), Q, acc, from);
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_test_seq_apply", k_test_seq_apply, dim3(ntile), dim3(FR_BLOCK), Q, acc, dout);
     FR_HIP(hipStreamSynchronize(c->stream));
     FR_HIP(hipMemcpy(out_prefix, dout, 8 * (size_t)n, hipMemcpyDeviceToHost));

@@ -363,7 +363,7 @@ static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) 
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccVal>), dim3(1), dim3(FR_BLOCK), W.seq, av, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccVal>), dim3(1), dim3(64), W.seq, av, fr_seq_from_zero());
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccVal>), dim3(1), dim3(FR_BLOCK), W.seq, av, fr_seq_from_zero());
     FR_LAUNCH(c, "k_fks_seq_begin", k_fks_seq_begin, dim3(1), dim3(1), W, Q, W.seq.total, (double *)c->comm.small_send);
     AccWt acc{W.wt_remain, &W.state[0]};
     for (int sweep = 0; ; sweep++) {
@@ -382,7 +382,7 @@ static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) 
             FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
             FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
             FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-            FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, fr_seq_from_zero());
+            FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
             FR_LAUNCH(c, "k_fks_seq_take_resum", k_fks_seq_take_resum, dim3(1), dim3(1), Q, W.seq.total, (double *)c->comm.small_send);
         }
     }
@@ -482,7 +482,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
     FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), W.seq, acc, fr_seq_from_zero());
+    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
     const double *norms = W.seq.total;
     if (xr) {
         // every rank's remaining norm (compress_utils.cpp:817-818), then the in-order lbound chain again from this
@@ -497,7 +497,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_LAUNCH(c, "k_keep_norms", k_keep_norms, dim3(1), dim3(64), norms, P, c->d_norms_keep, W, F);
         FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
         FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc);
-        FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(64), Q2, acc, from);
+        FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
     }
     if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);

@@ -221,70 +221,134 @@ __device__ __forceinline__ long long fr_wave_incl_i64(long long v) {
     return v;
 }
 
+// What the chain needs about the tiles that may straddle a power of two, staged in LDS by the whole workgroup before wave 0
+// starts walking: their sub-tile records and the 64 elements of every sub-tile that has to be added one by one.  Fetched on
+// demand by the one walking wave, each of these costs a dependent global-load latency (~2 us) -- with ~15 such tiles per sum
+// that was most of the kernel's 70 us.
+#define FR_SEQ_DT_CAP 64            // dirty tiles staged (more are handled from global memory, correct but slow)
+#define FR_SEQ_DS_CAP 64            // dirty sub-tiles whose elements are staged
+struct SeqSubL { long long d0, d1; int e; uint32_t dirty; int slot; int pad; };
+struct SeqStage {
+    uint32_t n_dt, n_ds;
+    uint32_t dt_list[FR_SEQ_DT_CAP];
+    SeqSubL subs[FR_SEQ_DT_CAP * FR_SUBS_PER_TILE];
+    double elems[FR_SEQ_DS_CAP * 64];
+    uint32_t scan[8];
+};
+
+// all FR_BLOCK threads: ordered list of the first FR_SEQ_DT_CAP dirty tiles, their sub-tile records, the elements of their dirty sub-tiles
 template <class Acc>
-__device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start) {
+__device__ __forceinline__ void fr_seq_stage(const SeqWork &Q, const Acc &acc, SeqStage *sh) {
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
+    const unsigned per = (ntile + FR_BLOCK - 1) / FR_BLOCK;
+    const unsigned lo = threadIdx.x * per, hi = lo + per < ntile ? lo + per : ntile;
+    uint32_t cnt = 0;
+    for (unsigned t = lo; t < hi; t++) cnt += Q.tiles[t].dirty ? 1u : 0u;
+    uint32_t tot;
+    uint32_t o = fr_block_scan_u32(cnt, sh->scan, &tot) - cnt;
+    for (unsigned t = lo; t < hi && o < FR_SEQ_DT_CAP; t++) if (Q.tiles[t].dirty) sh->dt_list[o++] = t;
+    if (threadIdx.x == 0) { sh->n_dt = tot < FR_SEQ_DT_CAP ? tot : FR_SEQ_DT_CAP; sh->n_ds = 0; }
+    __syncthreads();
+    const unsigned n_dt = sh->n_dt;
+    for (unsigned i = threadIdx.x; i < n_dt * FR_SUBS_PER_TILE; i += FR_BLOCK) {
+        const unsigned t = sh->dt_list[i / FR_SUBS_PER_TILE], j = i % FR_SUBS_PER_TILE;
+        const SeqRec r = Q.subs[(size_t)t * FR_SUBS_PER_TILE + j];
+        SeqSubL l; l.d0 = r.d0; l.d1 = r.d1; l.e = r.e; l.dirty = r.dirty; l.slot = -1; l.pad = 0;
+        if (r.dirty && (size_t)t * FR_SEQ_TILE + (size_t)j * 64 < n) {
+            const uint32_t slot = atomicAdd(&sh->n_ds, 1u);
+            if (slot < FR_SEQ_DS_CAP) l.slot = (int)slot;
+        }
+        sh->subs[i] = l;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n_dt * FR_SUBS_PER_TILE * 64; i += FR_BLOCK) {
+        const unsigned si = i >> 6, k = i & 63;
+        const int slot = sh->subs[si].slot;         // uniform over the wave: 64 consecutive i share one sub-tile
+        if (slot < 0) continue;
+        const unsigned t = sh->dt_list[si / FR_SUBS_PER_TILE], j = si % FR_SUBS_PER_TILE;
+        const size_t e = (size_t)t * FR_SEQ_TILE + (size_t)j * 64 + k;
+        sh->elems[slot * 64 + k] = e < n ? acc.get(e) : 0.0;
+    }
+    __syncthreads();
+}
+
+#define FR_SEQ_LCHUNK 2048          // tile records staged per round
+struct SeqTileL { long long d0, d1; int e; uint32_t dirty; };
+
+// wave 0: walks tiles [c0, c1) whose records sit in tl[0, c1 - c0); *di_io = dirty tiles met so far == index into the staged list
+template <class Acc>
+__device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start, const SeqStage *sh, const SeqTileL *tl, unsigned c0, unsigned c1, unsigned *di_io) {
+    const unsigned n = acc.count();
     const int lane = fr_lane();
     double carry = start;
-    SeqRec nxt;
-    nxt.dirty = 1; nxt.e = 0; nxt.d0 = nxt.d1 = 0;
-    if ((unsigned)lane < ntile) nxt = Q.tiles[lane];
-    for (unsigned t0 = 0; t0 < ntile; t0 += 64) {
-        SeqRec r = nxt;
-        if (t0 + 64 + lane < ntile) nxt = Q.tiles[t0 + 64 + lane];          // in flight while this batch is consumed
-        const int n_here = (ntile - t0) < 64u ? (int)(ntile - t0) : 64;
-        // sub-tile records of the first four dirty tiles of the batch, fetched now (16 lanes each) so that their latency
-        // overlaps the clean runs before them
-        const unsigned long long dirty_mask = __ballot(lane < n_here && r.dirty != 0);
-        SeqRec pre;
-        pre.dirty = 1; pre.e = 0; pre.d0 = pre.d1 = 0;
-        {
-            unsigned long long dm = dirty_mask;
-            const int grp = lane >> 4;
-            for (int k = 0; k < grp && dm; k++) dm &= dm - 1;
-            if (dm) { const unsigned tt = t0 + (unsigned)(__ffsll((long long)dm) - 1); pre = Q.subs[(size_t)tt * FR_SUBS_PER_TILE + (lane & 15)]; }
-        }
-        int pos = 0, n_dirty_seen = 0;
+    unsigned di = *di_io;
+    const unsigned n_dt = sh->n_dt;
+    for (unsigned t0 = c0; t0 < c1; t0 += 64) {
+        SeqTileL r;
+        r.dirty = 1; r.e = 0; r.d0 = r.d1 = 0;
+        if (t0 + lane < c1) r = tl[t0 - c0 + lane];
+        const int n_here = (c1 - t0) < 64u ? (int)(c1 - t0) : 64;
+        int pos = 0;
         while (pos < n_here) {
             const int e0 = __builtin_amdgcn_readlane(r.e, pos);
             const unsigned dflag = (unsigned)__builtin_amdgcn_readlane((int)r.dirty, pos);
             const unsigned t = t0 + pos;
             if (dflag) {
-                // tile t may straddle a power of two: walk its sub-tiles (records fetched by lanes 0..15 at once)
-                SeqRec sr;
-                int src0 = 0;           // lane holding sub-tile 0's record
-                if (n_dirty_seen < 4) { sr = pre; src0 = 16 * n_dirty_seen; }
-                else {
-                    sr.dirty = 1; sr.e = 0; sr.d0 = sr.d1 = 0;
-                    if (lane < FR_SUBS_PER_TILE) sr = Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane];
+                // tile t may straddle a power of two: walk its sub-tiles -- runs of clean sub-tiles in one binade are composed by
+                // a scan over lanes (as for tiles), only a sub-tile that may straddle one is added element by element
+                const bool staged = di < n_dt;          // then sh->dt_list[di] == t
+                SeqSubL sl;
+                sl.dirty = 1; sl.e = 0; sl.d0 = sl.d1 = 0; sl.slot = -1; sl.pad = 0;
+                if (lane < FR_SUBS_PER_TILE) {
+                    if (staged) sl = sh->subs[di * FR_SUBS_PER_TILE + lane];
+                    else { const SeqRec q = Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane]; sl.d0 = q.d0; sl.d1 = q.d1; sl.e = q.e; sl.dirty = q.dirty; }
                 }
-                n_dirty_seen++;
                 if (lane == 0) Q.tiles[t].carry = carry;
-                for (int j = 0; j < FR_SUBS_PER_TILE; j++) {
-                    const size_t sidx = (size_t)t * FR_SUBS_PER_TILE + j;
-                    const size_t e_lo = (size_t)t * FR_SEQ_TILE + (size_t)j * 64;
-                    if (lane == 0) Q.subs[sidx].carry = carry;
-                    if (e_lo >= n) continue;
-                    const unsigned sd = (unsigned)__builtin_amdgcn_readlane((int)sr.dirty, src0 + j);
-                    if (!sd) {
-                        const int se = __builtin_amdgcn_readlane(sr.e, src0 + j);
-                        carry = fr_seq_apply_map(carry, se, fr_bcast_i64(sr.d0, src0 + j), fr_bcast_i64(sr.d1, src0 + j));
-                    }
-                    else {
+                const size_t t_lo = (size_t)t * FR_SEQ_TILE;
+                const int n_sub_here = (int)(((n - t_lo) + 63) / 64 < (size_t)FR_SUBS_PER_TILE ? ((n - t_lo) + 63) / 64 : (size_t)FR_SUBS_PER_TILE);
+                int jp = 0;
+                while (jp < n_sub_here) {
+                    const unsigned sd = (unsigned)__builtin_amdgcn_readlane((int)sl.dirty, jp);
+                    if (sd) {
+                        const size_t e_lo = t_lo + (size_t)jp * 64;
                         const size_t e_hi = e_lo + 64 < n ? e_lo + 64 : n;
-                        const double mine_a = (e_lo + lane < e_hi) ? acc.get(e_lo + lane) : 0.0;
+                        const int slot = __builtin_amdgcn_readlane(sl.slot, jp);
+                        if (lane == 0) Q.subs[(size_t)t * FR_SUBS_PER_TILE + jp].carry = carry;
+                        double mine_a;
+                        if (slot >= 0) mine_a = sh->elems[slot * 64 + lane];
+                        else mine_a = (e_lo + lane < e_hi) ? acc.get(e_lo + lane) : 0.0;
 #pragma unroll
                         for (int k = 0; k < 64; k++) carry = carry + fr_bcast_f64(mine_a, k);
+                        jp++;
+                        continue;
                     }
+                    const int se = __builtin_amdgcn_readlane(sl.e, jp);
+                    const unsigned long long okm = __ballot(lane >= jp && lane < n_sub_here && !sl.dirty && sl.e == se);
+                    const unsigned long long shm = okm >> jp;
+                    const int run = (~shm == 0ull) ? 64 : (__ffsll((long long)~shm) - 1);
+                    PMap m; m.d0 = sl.d0; m.d1 = sl.d1;
+                    if (lane < jp || lane >= jp + run) m = fr_pm_id();
+                    for (int off = 1; off < FR_SUBS_PER_TILE; off <<= 1) {              // inclusive ordered scan of maps over the 16 lanes
+                        PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
+                        if (lane >= off) m = fr_pm_compose(o, m);
+                    }
+                    PMap ex; ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
+                    if (lane == 0 || lane == jp) ex = fr_pm_id();
+                    if (lane >= jp && lane < jp + run) Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane].carry = fr_seq_apply_map(carry, se, ex.d0, ex.d1);
+                    const int last = jp + run - 1;
+                    carry = fr_seq_apply_map(carry, se, fr_bcast_i64(m.d0, last), fr_bcast_i64(m.d1, last));
+                    jp += run;
                 }
+                if (lane >= n_sub_here && lane < FR_SUBS_PER_TILE) Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane].carry = carry;
+                di++;
                 pos++;
                 continue;
             }
             // run of clean tiles in binade e0 starting at lane `pos`
             const unsigned long long ok = __ballot(lane >= pos && lane < n_here && !r.dirty && r.e == e0);
-            const unsigned long long sh = ok >> pos;
-            int run = (~sh == 0ull) ? 64 : (__ffsll((long long)~sh) - 1);        // lanes pos .. pos+run-1 (run >= 1)
+            const unsigned long long sh_ = ok >> pos;
+            int run = (~sh_ == 0ull) ? 64 : (__ffsll((long long)~sh_) - 1);        // lanes pos .. pos+run-1 (run >= 1)
             PMap m; m.d0 = r.d0; m.d1 = r.d1;
             if (lane < pos || lane >= pos + run) m = fr_pm_id();
             PMap ex;                                                             // exclusive map of my tile
@@ -309,13 +373,32 @@ __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double s
             pos += run;
         }
     }
+    *di_io = di;
     return carry;
 }
 
+// one workgroup: everybody stages (dirty tiles once, tile records in rounds of FR_SEQ_LCHUNK), wave 0 walks
 template <class Acc>
-__global__ void __launch_bounds__(64) k_seq_chain(SeqWork Q, Acc acc, SeqStart st) {
-    double tot = fr_seq_chain_wave(Q, acc, st.value());
-    if (threadIdx.x == 0) *Q.total = tot;
+__global__ void __launch_bounds__(FR_BLOCK) k_seq_chain(SeqWork Q, Acc acc, SeqStart st) {
+    __shared__ SeqStage sh;
+    __shared__ SeqTileL tl[FR_SEQ_LCHUNK];
+    fr_seq_stage(Q, acc, &sh);
+    const unsigned n = acc.count();
+    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
+    double carry = st.value();
+    unsigned di = 0;
+    for (unsigned c0 = 0; c0 < ntile; c0 += FR_SEQ_LCHUNK) {
+        const unsigned c1 = c0 + FR_SEQ_LCHUNK < ntile ? c0 + FR_SEQ_LCHUNK : ntile;
+        if (c0) __syncthreads();        // wave 0 is done with the previous round's records
+        for (unsigned t = c0 + threadIdx.x; t < c1; t += FR_BLOCK) {
+            const SeqRec q = Q.tiles[t];
+            SeqTileL l; l.d0 = q.d0; l.d1 = q.d1; l.e = q.e; l.dirty = q.dirty;
+            tl[t - c0] = l;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) carry = fr_seq_chain_wave(Q, acc, carry, &sh, tl, c0, c1, &di);
+    }
+    if (threadIdx.x == 0) *Q.total = carry;
 }
 
 // ---- S5: exact running sums for the 4 consecutive elements of this thread.
