@@ -217,6 +217,7 @@ void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out);
 void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_spawn_bound, bool same_column, bool arrival_order = false);
 void fr_vec_delete_flagged(FriesCtx *c, VecDev *v, const uint8_t *d_flags, uint32_t n);
 void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
+void fr_vec_reserve_hash(FriesCtx *c, VecDev *v, uint32_t n_new);
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap);
 void fr_xch_alloc(FriesCtx *c, uint32_t cap);
 uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass = 0);      // 0: two passes (frisys_mol); 1: one pass, flag inside an integer value; 2: one pass, flag in bit 63 of the index

@@ -54,7 +54,10 @@ struct VecState {           // lives in device memory, mirrored to the host on d
 };
 struct VecDev {
     uint32_t cap;           // max positions
-    uint32_t hcap;          // hash capacity, power of two
+    uint32_t hcap;          // hash slots in use, a power of two: sized to the live set (grown / shrunk at rebuilds), not to max_dets --
+                            // random probes into a table 16 x the live set miss every cache (223 MB of traffic per lookup pass at m = 1e6)
+    uint32_t hcap_max;      // slots allocated (host bookkeeping)
+    uint32_t used_ub;       // host-side upper bound of the occupied slots (exact after fr_vec_sync_state, + spawns after every merge)
     det_t *dets;
     double *v0, *v1;        // the two value columns (n_vecs == 2)
     double *diag;           // cached diagonal element - hf_en; NaN = not yet computed

@@ -15,7 +15,9 @@ void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
     v->cap = cap;
     uint32_t h = 1024;
     while (h < 2u * cap + 1024u) h <<= 1;
-    v->hcap = h;
+    v->hcap_max = h;
+    v->hcap = h < (1u << 14) ? h : (1u << 14);
+    v->used_ub = 0;
     v->dets = fr_alloc<det_t>(cap); v->v0 = fr_alloc<double>(cap); v->v1 = fr_alloc<double>(cap);
     v->diag = fr_alloc<double>(cap); v->active = fr_alloc<uint8_t>(cap); v->free_stack = fr_alloc<uint32_t>(cap);
     v->hkeys = fr_alloc<det_t>(h); v->hvals = fr_alloc<uint32_t>(h);
@@ -33,6 +35,7 @@ void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
 void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out) {
     FR_HIP(hipMemcpyAsync(out, v->st, sizeof(VecState), hipMemcpyDeviceToHost, c->stream));
     FR_HIP(hipStreamSynchronize(c->stream));
+    v->used_ub = out->n_used;
 }
 
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
@@ -319,6 +322,8 @@ void fr_vec_merge(FriesCtx *c, VecDev *v, uint32_t n_bound, bool same_column, bo
     SpawnBuf &S = c->sp;
     hipStream_t st = c->stream;
     if (n_bound > S.cap) throw FriesError("spawn list exceeds spawn buffer capacity");
+    fr_vec_reserve_hash(c, v, n_bound);
+    v->used_ub = (uint32_t)((uint64_t)v->used_ub + n_bound < 0xFFFFFFFFull ? v->used_ub + n_bound : 0xFFFFFFFFu);
     unsigned g1 = fr_blocks(n_bound, FR_BLOCK), gt = fr_blocks(n_bound, FR_TILE);
     uint32_t nblk_alloc = FR_MAX_PART;
     int nbits = bits_for(2u * v->cap + 1u);
@@ -417,12 +422,35 @@ __global__ void k_hash_reinsert(VecDev V) {
     atomicOr(&V.st->err, FR_ERR_HASH_FULL);
 }
 
-void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v) {
-    // host copy of the state must be current
-    if ((uint64_t)c->h_vst.n_used * 10 < (uint64_t)v->hcap * 6) return;
+// Clears the table and re-inserts every active position into a table of `want` slots (a power of two <= hcap_max).
+static void hash_rebuild(FriesCtx *c, VecDev *v, uint32_t want, uint32_t n_pos_bound) {
+    v->hcap = want;
     FR_HIP(hipMemsetAsync(v->hkeys, 0, sizeof(det_t) * v->hcap, c->stream));
     FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)v->hcap, c->stream));
-    FR_LAUNCH(c, "k_hash_reinsert", k_hash_reinsert, dim3(fr_blocks(c->h_vst.curr_size ? c->h_vst.curr_size : 1, FR_BLOCK)), dim3(FR_BLOCK), *v);
+    FR_LAUNCH(c, "k_hash_reinsert", k_hash_reinsert, dim3(fr_blocks(n_pos_bound ? n_pos_bound : 1, FR_BLOCK)), dim3(FR_BLOCK), *v);
+}
+static uint32_t hash_slots_for(const VecDev *v, uint64_t n_entries) {
+    static const int fill = getenv("FRIES_HASH_FILL") ? atoi(getenv("FRIES_HASH_FILL")) : 40;     // percent of the slots the entries may take
+    uint64_t want = 1u << 14;
+    while (want * (uint64_t)fill < n_entries * 100u && want < v->hcap_max) want <<= 1;
+    return (uint32_t)(want < v->hcap_max ? want : v->hcap_max);
+}
+
+void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v) {
+    // host copy of the state must be current.  Rebuild when tombstones + entries pass 60 % of the slots; the new size follows the live set.
+    if ((uint64_t)c->h_vst.n_used * 10 < (uint64_t)v->hcap * 6) return;
+    hash_rebuild(c, v, hash_slots_for(v, c->h_vst.curr_size), c->h_vst.curr_size);
+    v->used_ub = c->h_vst.curr_size;
+}
+
+// before a merge of up to n_new spawns: room for every one of them to be a new determinant
+void fr_vec_reserve_hash(FriesCtx *c, VecDev *v, uint32_t n_new) {
+    const uint64_t need = (uint64_t)v->used_ub + n_new;
+    if (need * 10 < (uint64_t)v->hcap * 7) return;
+    const uint32_t want = hash_slots_for(v, need);
+    if (want == v->hcap && want == v->hcap_max) return;          // as large as it gets: the rebuild-on-tombstones rule applies as before
+    hash_rebuild(c, v, want > v->hcap ? want : v->hcap, v->cap);       // positions in use are not known on the host here: launch over the capacity
+    // used_ub stays: an upper bound is all it has to be (the next sync makes it exact)
 }
 
 // ------------------------------------------------------------------ spawn exchange between ranks
