@@ -187,6 +187,25 @@ PIN_RUNS = {
 }
 
 
+# frisys_hh at a large budget, one rank, from 100 x Neel through the start-up regime into the compressed one (the 1-D stand-in for
+# BASELINE config 5): same tuple as HH_RUNS.  gs_energy -1 makes the population grow (with -7.5 it dies out at 900 states).
+# 150 iterations: zero-valued entries are never released in this driver (frisys_hh.cpp:321 vs frisys_mol.cpp:498), the table keeps
+# growing past the budget, and the reference itself segfaults at iteration 164 of this run.
+HH_SCALE_RUNS = {
+    "hh_l12_m1e6": (1, 150, 3, 12, 12, 0.005, 4.0, 1.0, 0.7, -1.0, 1000000, 8000000, 1.0, 250000.0),
+}
+
+
+def gen_hh_scale(manifest):
+    manifest["hh_scale_runs"] = {}
+    for name, (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs, vnz, maxd, ini, tgt) in HH_SCALE_RUNS.items():
+        out = os.path.join(GOLD, name + ".traj")
+        cmd = [HARNESS, "hh", str(n_iter), str(seed), str(n_elec), str(n_sites), repr(eps), repr(U), repr(omega), repr(g), repr(gs), str(vnz), str(maxd), repr(ini), repr(tgt), out]
+        subprocess.run(cmd, check=True)
+        manifest["hh_scale_runs"][name] = dict(n_ranks=n_ranks, n_iter=n_iter, seed=seed, n_elec=n_elec, n_sites=n_sites, eps=eps, U=U, omega=omega, g=g,
+                                               gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+
+
 def gen_pin(manifest, only=None):
     manifest.setdefault("pin_runs", {})
     with tempfile.TemporaryDirectory() as tmp:
@@ -224,6 +243,13 @@ def gen_hbpiv(manifest):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-hh-scale":
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_hh_scale(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-pin":      # minutes of CPU each: the BASELINE sizes
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
@@ -375,6 +401,7 @@ def main():
     gen_multi(manifest)
     gen_fp(manifest)
     gen_pin(manifest)
+    gen_hh_scale(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

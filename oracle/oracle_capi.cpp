@@ -518,6 +518,23 @@ size_t fo_fciqmc_vec(void *h, uint64_t *dets, double *vals, size_t cap) {
     return n;
 }
 double fo_fciqmc_p_doub(void *h) { return ((Fciqmc *)h)->p_doub; }
+// replaces the stored walkers: determinants land in positions 0..n-1 (what fries_vec_load does on the device), then the part of a
+// restart that is not the vector: shift, walker number at the last shift update, iteration count (the counter stream is keyed by it)
+void fo_fciqmc_load(void *h, const uint64_t *dets, const double *vals, size_t n, double en_shift, double last_norm, uint32_t iterat) {
+    Fciqmc *f = (Fciqmc *)h;
+    Vec &v = f->sol;
+    const size_t cap = v.max_size, ac = v.adder_cap;
+    const unsigned nv = v.n_vecs;
+    const Comm cm = v.cm; const uint32_t *ps = v.proc_scr;
+    v.init(cap, ac, f->sys.n_elec, nv, cm, ps);
+    uint8_t tmp[64];
+    for (size_t i = 0; i < n; i++) {
+        v.dets[i] = dets[i]; v.vals[0][i] = vals[i]; v.active[i] = 1; v.table[dets[i]] = (ptrdiff_t)i;
+        occ_list(dets[i], tmp); memcpy(&v.occ[i * v.n_elec], tmp, v.n_elec);
+    }
+    v.curr_size = n; v.n_nonz = (int)n;
+    f->en_shift = en_shift; f->last_norm = last_norm; f->iterat = iterat;
+}
 
 // ---- fciqmc_mol on P in-process ranks (the reference under mpiexec -n P: own generator per rank, one all-to-all per iteration)
 struct OracleFqRanks { std::vector<std::unique_ptr<Fciqmc>> fr; };

@@ -107,6 +107,7 @@ def load():
         lib.fo_fciqmc_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.fo_fciqmc_vec.restype = C.c_size_t
         lib.fo_fciqmc_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.fo_fciqmc_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_uint32]
         lib.fo_fciqmc_p_doub.restype = C.c_double
         lib.fo_fciqmc_p_doub.argtypes = [C.c_void_p]
         _lib = lib
@@ -437,6 +438,12 @@ class OracleFciqmc:
     @property
     def p_doub(self):
         return self.lib.fo_fciqmc_p_doub(self.h)
+
+    def load(self, dets, vals, en_shift=0.0, last_norm=0.0, iterat=0):
+        """Replaces the walkers (positions 0..n-1) and the shift / last walker number / iteration count."""
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        self.lib.fo_fciqmc_load(self.h, _p(d), _p(v), d.size, en_shift, last_norm, iterat)
 
 
 class OracleMulti(OracleFciqmc):

@@ -111,3 +111,69 @@ def test_native_rccl_transport_world_of_one():
     code = _RCCL_ONE.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "RCCL1 OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+@pytest.mark.parametrize("dist,n_it", [("NU", 50), ("HB", 50)])
+def test_fciqmc_1e6_walkers_matches_oracle(oracle, dist, n_it):
+    """BASELINE config 3 (fciqmc_mol, N2-shaped, 1e6 walkers): the device against the CPU restatement on the shared counter stream
+    for 50 iterations at that size -- walker numbers, positions, spawn counts, shift, every stored value.  The population is grown
+    on the device from 2e5 walkers on HF (300 iterations spread them over ~1e5 determinants) and multiplied up to >= 1e6 walkers, then both sides restart from that
+    vector (DistVec::load semantics: non-zero entries into positions 0..n-1, shift 0, iteration 0)."""
+    from fries_amd.engine import FriEngine
+    mol = fcidump.synthetic("N2")
+    par = dict(epsilon=0.02, target_walkers=1000000, max_dets=4000000, initiator=3, seed=1, distribution=dist)
+    hf = (1 << (mol.n_elec // 2)) - 1
+    hf = hf | (hf << mol.n_orb)
+    eng = FriEngine(mol)
+    eng.setup_fciqmc(ini=(np.array([hf], dtype=np.uint64), np.array([2.0e5])), **par)     # the reference's per-determinant spawn buffer holds 5e5 (fciqmc_mol.cpp:144)
+    lg = eng.iterate_fciqmc(300)
+    assert int(lg["err"].max()) == 0
+    d, v = eng.vector()
+    keep = v != 0
+    d, v = d[keep], v[keep]
+    v = v * np.ceil(1.0e6 / np.abs(v).sum())         # the same distribution with an integer multiple of the walkers: >= 1e6
+    walkers = float(np.abs(v).sum())
+    assert 1e6 <= walkers < 2.0e6 and d.size > 30000, (walkers, d.size)
+    eng.vec_load(d, v)
+    eng.restart(0, 0.0, 0.0, 0)
+    orc = oracle.OracleFciqmc(mol, counter_rng=True, **par)
+    orc.load(d, v, 0.0, 0.0, 0)
+    assert eng.p_doub == orc.p_doub
+    lg = eng.iterate_fciqmc(n_it)
+    lo = orc.iterate(n_it)
+    assert int(lg["err"].max()) == 0
+    for f in ("n_nonz", "n_ini", "curr_size", "n_spawn"):
+        assert np.array_equal(lg[f].astype(np.int64), lo[f].astype(np.int64)), (f, np.nonzero(lg[f].astype(np.int64) != lo[f].astype(np.int64))[0][:5])
+    assert np.array_equal(lg["shift"], lo["shift"]) and np.array_equal(lg["norm"], lo["norm"]) and np.array_equal(lg["denom"], lo["denom"])
+    assert np.all(np.abs(lg["numer"] - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
+    gd, gv = eng.vector()
+    od, ov = orc.vector()
+    assert gd.size == od.size and np.array_equal(gv, ov)
+    nz = ov != 0
+    assert np.array_equal(gd[nz], od[nz])
+    print(dist, "walkers", int(np.abs(gv).sum()), "determinants", int(np.count_nonzero(gv)), "attempts/iteration", int(lg["n_attempts"][-1]), "spawns/iteration", int(lg["n_spawn"][-1]))
+    eng.close()
+
+
+def test_frisys_hh_budget_1e6_matches_reference():
+    """The 1-D stand-in for BASELINE config 5 (frisys_hh; the reference has no 2-D lattice): L = 12 sites at half filling, budget
+    vec_nonz = 1e6, from 100 x Neel through the start-up regime, the regime where the second compression's comb needs ~1e4
+    repairs per stage (k_sys_prop) and into the compressed regime, against what the REAL reference logged
+    (tests/golden/hh_l12_m1e6.traj, `ref_harness hh`): counts, norms, shifts every iteration, the digest of the vector every 20."""
+    from fries_amd.engine import FriEngine
+    g = golden_io.read_traj("hh_l12_m1e6")
+    r = golden_io.manifest()["hh_scale_runs"]["hh_l12_m1e6"]
+    eng = FriEngine(None)
+    eng.setup_hh(n_elec=r["n_elec"], n_sites=r["n_sites"], eps=r["eps"], U=r["U"], omega=r["omega"], g=r["g"], gs_energy=r["gs_energy"], vec_nonz=r["vec_nonz"],
+                 max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"])
+    fails = []
+    for row in g["rows"]:
+        lg = eng.iterate_hh(1)[0]
+        pin_replay._check_row(lg, row, fails, "hh")
+        if row["it"] % 20 == 19 or row is g["rows"][-1]:
+            d, v = eng.vector()
+            if golden_io.vec_hash(d, v) != row["hash"]:
+                fails.append(("hh", row["it"], "digest"))
+        assert not fails, fails[:6]
+    assert g["rows"][-1]["n_nonz"] > 500000 and max(x["num_success"] for x in g["rows"]) == r["vec_nonz"]
+    eng.close()
