@@ -27,6 +27,28 @@
 #define FR_MAX_ROUNDS 600
 #define FR_FKS_PMAX 64          // sweeps tracked per replay (the reference needs 2-6 in steady state, more when the budget exceeds the elements)
 #define FR_FKS_TILE (FR_BLOCK * 8)  // elements per workgroup in k_fks_iter
+#define FR_MAX_FIX 8192         // comb repairs a stage may ask for through the short in-order walk (a handful in practice; frisys_hh's
+                                // thousands go through k_sys_prop); beyond it FR_ERR_BACKLOG
+
+// ascending sort of list[0, n), n <= FR_MAX_FIX, by the whole workgroup (bitonic over the next power of two; the tail is padded)
+__device__ __forceinline__ void fr_sort_fix_list(uint32_t *list, uint32_t n) {
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < m; i += blockDim.x) list[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = list[i], b = list[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { list[i] = b; list[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
 
 struct CompState {
     double G;            // remaining norm entering this round
@@ -290,7 +312,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
         if (k != fr_teeth_below(th, Se)) {      // the comb is not where the next lane assumes: repaired by k_sys_fixup / k_sys_prop
             uint32_t slot = atomicAdd(&fin->n_fix, 1u);
             if (W.prop) { if (e + 1 < n_in) W.act[0][atomicAdd(&W.act_n[0], 1u)] = (uint32_t)(e + 1); }
-            else if (slot < FR_MAX_PART) W.fix_list[slot] = (uint32_t)e;
+            else if (slot < FR_MAX_FIX) W.fix_list[slot] = (uint32_t)e;
         }
         Sprev = Se;
     }
@@ -301,16 +323,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
 // Repairs the (rare) elements after which the reference's comb lags behind lbound: walk
 // forward sequentially from each flagged element until the tooth index re-synchronises.
 template <int STAGE, bool NEW_HB>
-__global__ void k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err) {
+__global__ void __launch_bounds__(FR_BLOCK) k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err) {
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
     uint32_t nf = fin->n_fix;
     if (nf == 0) return;
-    if (nf > FR_MAX_PART) { atomicOr(err, FR_ERR_BACKLOG); nf = FR_MAX_PART; }
+    if (nf > FR_MAX_FIX) { if (threadIdx.x == 0) atomicOr(err, FR_ERR_BACKLOG); nf = FR_MAX_FIX; }
     const HbTables &T = *Tg;
     const Teeth *th = W.teeth;
     const unsigned n_in = fin->n_in;
-    // insertion sort of the short list (ascending element index)
-    for (uint32_t i = 1; i < nf; i++) { uint32_t x = W.fix_list[i]; int j = (int)i - 1; while (j >= 0 && W.fix_list[j] > x) { W.fix_list[j + 1] = W.fix_list[j]; j--; } W.fix_list[j + 1] = x; }
+    fr_sort_fix_list(W.fix_list, nf);       // ascending element index
+    if (threadIdx.x != 0) return;
     size_t done_upto = 0;
     for (uint32_t i = 0; i < nf; i++) {
         size_t e = W.fix_list[i];

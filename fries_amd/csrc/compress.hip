@@ -11,7 +11,7 @@ void fr_vcomp_alloc(FriesCtx *c, uint32_t cap) {
     B.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
     B.teeth = fr_alloc<Teeth>(1);
     B.dots = fr_alloc<double>(2);
-    B.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
+    B.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
     B.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); B.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); B.seq.total = fr_alloc<double>(1);
     B.gnorm = fr_alloc<double>(1);
     FR_HIP(hipMemsetAsync(B.keep, 0, cap, c->stream));
@@ -251,21 +251,22 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sc_apply(VecDev V, VcompBuf B, uin
         if (sel) k++;
         if (k != fr_teeth_below(th, Se)) {
             uint32_t slot = atomicAdd(&fin->n_fix, 1u);
-            if (slot < FR_MAX_PART) B.fix_list[slot] = (uint32_t)i;
+            if (slot < FR_MAX_FIX) B.fix_list[slot] = (uint32_t)i;
         }
         Sprev = Se;
     }
 }
 
 // walks forward from every flagged element, handing the lagging tooth index to its successors
-__global__ void k_sc_fixup(VecDev V, VcompBuf B, uint32_t *kin, uint32_t *err) {
+__global__ void __launch_bounds__(FR_BLOCK) k_sc_fixup(VecDev V, VcompBuf B, uint32_t *kin, uint32_t *err) {
     CompState *fin = &B.state[FR_MAX_ROUNDS + 1];
     uint32_t nf = fin->n_fix;
     if (nf == 0) return;
-    if (nf > FR_MAX_PART) { atomicOr(err, FR_ERR_BACKLOG); nf = FR_MAX_PART; }
+    if (nf > FR_MAX_FIX) { if (threadIdx.x == 0) atomicOr(err, FR_ERR_BACKLOG); nf = FR_MAX_FIX; }
     const Teeth *th = B.teeth;
     const unsigned n = fin->n_in;
-    for (uint32_t i = 1; i < nf; i++) { uint32_t x = B.fix_list[i]; int j = (int)i - 1; while (j >= 0 && B.fix_list[j] > x) { B.fix_list[j + 1] = B.fix_list[j]; j--; } B.fix_list[j + 1] = x; }
+    fr_sort_fix_list(B.fix_list, nf);
+    if (threadIdx.x != 0) return;
     size_t done_upto = 0;
     for (uint32_t q = 0; q < nf; q++) {
         size_t e = B.fix_list[q];
@@ -316,7 +317,7 @@ void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn) {
         run_seq_from(c, Q2, au, bound, from);
     }
     FR_LAUNCH(c, "k_sc_apply", k_sc_apply, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, kin);
-    FR_LAUNCH(c, "k_sc_fixup", k_sc_fixup, dim3(1), dim3(1), c->vec, B, kin, c->d_err);
+    FR_LAUNCH(c, "k_sc_fixup", k_sc_fixup, dim3(1), dim3(FR_BLOCK), c->vec, B, kin, c->d_err);
     FR_LAUNCH(c, "k_sc_write", k_sc_write, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B, kin);
     if (c->hh_keep0) fr_hh_clear_pos0(c);        // frisys_hh.cpp:356
     fr_vec_delete_flagged(c, &c->vec, B.del, bound);

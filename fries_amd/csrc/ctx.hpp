@@ -193,6 +193,7 @@ struct FriesCtx {
     // driver state (FRIES_bin/frisys_mol.cpp)
     std::mt19937 mt;
     std::vector<uint32_t> proc_scr, vec_scr;
+    std::vector<uint32_t> in_proc_scr;       // --load_dir: the proc scrambler of hash.dat instead of fresh draws (fries_set_proc_scrambler)
     double eps = 0, target_norm = 0, init_thresh = 0, en_shift = 0, last_one_norm = 0;
     uint32_t vec_nonz = 0, mat_nonz = 0;
     bool new_hb = true;

@@ -120,7 +120,8 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     if (p->max_dets == 0 || p->mat_nonz == 0 || p->vec_nonz == 0) throw FriesError("max_dets, mat_nonz and vec_nonz must be positive");
     c->mt.seed(p->seed);
     c->proc_scr.resize(2 * c->n_orb); c->vec_scr.resize(2 * c->n_orb);
-    for (auto &x : c->proc_scr) x = c->mt();        // frisys_mol.cpp:133-135
+    if (c->in_proc_scr.size() == c->proc_scr.size()) c->proc_scr = c->in_proc_scr;     // --load_dir: load_proc_hash (frisys_mol.cpp:128-130), no draws
+    else for (auto &x : c->proc_scr) x = c->mt();   // frisys_mol.cpp:133-135
     for (auto &x : c->vec_scr) x = c->mt();         // :142-144
     // A shard can in principle emit the whole (global) sample budget, so the work arrays are sized for it; the
     // reference sizes them mat_nonz * 4 / n_procs and throws when a shard outgrows that (:109, heat_bathPP.cpp:700-704).
@@ -485,6 +486,13 @@ extern "C" int fries_get_scramblers(fries_ctx *h, uint32_t *proc_scr, uint32_t *
     if (n < c->proc_scr.size()) throw FriesError("scrambler buffer too small");
     if (proc_scr) memcpy(proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size());
     if (vec_scr) memcpy(vec_scr, c->vec_scr.data(), 4 * c->vec_scr.size());
+    FR_API_END
+}
+extern "C" int fries_set_proc_scrambler(fries_ctx *h, const uint32_t *proc_scr, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (c->vec.dets) throw FriesError("fries_set_proc_scrambler must be called before fries_frisys_setup");
+    c->in_proc_scr.assign(proc_scr, proc_scr + n);
     FR_API_END
 }
 extern "C" uint64_t fries_kernel_launches(fries_ctx *h) { return h->c.n_kernel_launch; }

@@ -276,7 +276,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.e_wi = fr_alloc<uint32_t>(cap); W.e_sub = fr_alloc<uint32_t>(cap); W.e_val = fr_alloc<double>(cap);
     W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
     W.teeth = fr_alloc<Teeth>(1);
-    W.fix_list = fr_alloc<uint32_t>(FR_MAX_PART);
+    W.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
     {
         Fks2Work &F = c->F2;
@@ -523,7 +523,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             FR_HIP(hipStreamSynchronize(st));
         }
     }
-    else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(1), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
+    else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     if (n_out_host) {
         FR_HIP(hipMemcpyAsync(n_out_host, &W.state[FR_MAX_ROUNDS + 1].n_out, 4, hipMemcpyDeviceToHost, st));

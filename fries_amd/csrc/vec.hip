@@ -618,18 +618,28 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass) {
     XchSegs G{};
     G.n_src = (uint32_t)P;
     uint64_t n_recv = 0;
+    // Every rank holds the whole P x 2P count matrix, so the limits are checked for ALL (source, destination) pairs on every
+    // rank: either everybody raises here or everybody enters the all-to-all -- a rank-local check would leave the peers
+    // blocked in the collective while one rank unwinds.  (Capacities are equal on all ranks: same parameters.)
+    for (int dst = 0; dst < P; dst++) {
+        uint64_t tot = 0;
+        for (int src = 0; src < P; src++) {
+            const uint32_t n0 = cnt[(size_t)src * nb + 2 * dst], n1 = cnt[(size_t)src * nb + 2 * dst + 1];
+            // Adder::add refuses more than adder_size_ pending elements per destination (vec_utils.hpp:957-971); the reference
+            // then flushes early, which would reorder arrivals.  mat_nonz * 4 / n_ranks (capped at 1e6) per pass is that limit.
+            if (n0 >= c->adder_cap || n1 >= c->adder_cap) throw FriesError("a rank has more pending adds for one destination than the reference's Adder holds (early perform_add flushes are not reproduced)");
+            tot += (uint64_t)n0 + n1;
+        }
+        if (tot > S.cap || tot > cap_recs) throw FriesError("received spawns exceed the spawn buffer on some rank");
+    }
     for (int p = 0; p < P; p++) {
         const uint32_t *mine = &cnt[(size_t)c->rank * nb], *theirs = &cnt[(size_t)p * nb];
         sb[p] = (uint64_t)sizeof(XchRec) * ((uint64_t)mine[2 * p] + mine[2 * p + 1]);
         uint32_t n0 = theirs[2 * c->rank], n1 = theirs[2 * c->rank + 1];
-        // Adder::add refuses more than adder_size_ pending elements per destination (vec_utils.hpp:957-971); the reference
-        // then flushes early, which would reorder arrivals.  mat_nonz * 4 / n_ranks (capped at 1e6) per pass is that limit.
-        if (n0 >= c->adder_cap || n1 >= c->adder_cap) throw FriesError("a rank has more pending adds for one destination than the reference's Adder holds (early perform_add flushes are not reproduced)");
         G.first[p] = (uint32_t)n_recv; G.n0[p] = n0; G.cnt[p] = n0 + n1;
         rb[p] = (uint64_t)sizeof(XchRec) * ((uint64_t)n0 + n1);
         n_recv += (uint64_t)n0 + n1;
     }
-    if (n_recv > S.cap || n_recv > cap_recs) throw FriesError("received spawns exceed the spawn buffer");
     if (c->comm.alltoallv(c->comm.user, sb.data(), rb.data(), (void *)st)) throw FriesError("fries_comm.alltoallv failed");
     c->n_collectives++;
     FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv, one_pass);

@@ -12,6 +12,8 @@
 // the GPU.  --ini_vec / --trial_vec read the reference's text vectors (<prefix>dets, <prefix>vals; load_vec_txt, io_utils.cpp:447-482).
 // --det_space (the semi-stochastic space) is not implemented.  One rank; ranks are driven through fries_set_comm.
 #include "driver_common.hpp"
+#include <sstream>
+#include <random>
 
 struct Args {
     std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir, ini_vec, trial_vec;
@@ -104,17 +106,28 @@ int main(int argc, char **argv) {
         if (!args.trial_vec.empty()) { load_vec_txt(args.trial_vec, tdets, tvals); ck(fries_set_trial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }      // :157-181
         if (args.load_dir.empty() && !args.ini_vec.empty()) { load_vec_txt(args.ini_vec, tdets, tvals); ck(fries_set_initial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }   // :264-274
         if (args.have_ham_shift) ck(fries_set_ham_shift(ctx, args.ham_shift - in.core_en));      // :95-98
+        if (!args.load_dir.empty()) {                       // :128-130 load_proc_hash: the shards of the run that wrote the checkpoint
+            std::ifstream fh(args.load_dir + "hash.dat", std::ios::binary);
+            if (!fh.is_open()) throw std::runtime_error("Error: could not open saved hash scrambler at " + args.load_dir + "hash.dat");
+            std::vector<uint32_t> scr(2 * in.n_orb);
+            fh.read((char *)scr.data(), (std::streamsize)(4 * scr.size()));
+            ck(fries_set_proc_scrambler(ctx, scr.data(), scr.size()));
+        }
         ck(fries_frisys_setup(ctx, &p));
-        double en_shift = 0, last_norm = 0;
-        if (!args.load_dir.empty()) {                       // :257-263, :284-286
+        if (!args.load_dir.empty()) {                       // :257-263
+            double en_shift = 0;
             load_vector(ctx, args.load_dir, in.n_orb);
             load_last_line(args.load_dir + "S.txt", &en_shift);
-            uint32_t n; int32_t nz; uint32_t nf;
-            ck(fries_vec_info(ctx, &n, &nz, &nf));
-            std::vector<uint64_t> d(n ? n : 1); std::vector<double> v(n ? n : 1); size_t m;
-            ck(fries_vec_download(ctx, d.data(), v.data(), d.size(), &m));
-            for (size_t i = 0; i < m; i++) last_norm += fabs(v[i]);
-            ck(fries_frisys_restart(ctx, seed, en_shift, last_norm, 0));
+            // The loaded one-norm goes into `last_norm` (:284-286), which nothing reads: the shift control starts from
+            // last_one_norm = 0 (:337), i.e. the shift stays put until a shift iteration sees the norm above the target.
+            ck(fries_frisys_restart(ctx, seed, en_shift, 0.0, 0));
+            // Generator: seeded, then the 2 n_orb draws of the vec scrambler (:141-144) -- with --load_dir the proc scrambler
+            // takes none -- and the iterations continue that stream.
+            std::mt19937 mt(seed);
+            mt.discard(2 * in.n_orb);
+            std::ostringstream os;
+            os << mt;
+            ck(fries_rng_set_state(ctx, os.str().c_str()));
         }
         const std::string &rd = args.result_dir;
         std::ofstream num_file(rd + "projnum.txt", std::ofstream::app), den_file(rd + "projden.txt", std::ofstream::app),

@@ -25,7 +25,7 @@ EXPORTS = [
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate", "fries_frimulti_setup", "fries_frimulti_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
-    "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
+    "fries_set_proc_scrambler", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
 ]
 
 

@@ -139,6 +139,10 @@ double fries_p_doub(fries_ctx *ctx);
 /* the proc / vec hash scramblers drawn at setup (frisys_mol.cpp:132-145; hash.dat holds the first, io_utils.cpp:589-606).
  * Either pointer may be NULL; n = 2 * n_orb entries each. */
 int fries_get_scramblers(fries_ctx *ctx, uint32_t *proc_scrambler, uint32_t *vec_scrambler, size_t n);
+/* --load_dir: the proc scrambler read from hash.dat (load_proc_hash, io_utils.cpp:608-619; frisys_mol.cpp:128-130) instead of 2 n_orb
+ * fresh draws -- the shards of a restarted run must be the shards of the run that wrote the checkpoint.  Before fries_frisys_setup;
+ * the setup then draws only the vec scrambler, as the reference does. */
+int fries_set_proc_scrambler(fries_ctx *ctx, const uint32_t *proc_scrambler, size_t n);
 uint64_t fries_kernel_launches(fries_ctx *ctx);
 
 /* ---- frifull_mol: FRI with the Hamiltonian applied in full (FRIES_bin/frifull_mol.cpp:258-304): systematic compression of

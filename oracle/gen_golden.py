@@ -206,6 +206,27 @@ def gen_hh_scale(manifest):
                                                gs_energy=gs, vec_nonz=vnz, max_dets=maxd, initiator=ini, target_norm=tgt)
 
 
+# --load_dir through the reference (ref_harness reload): name -> (shape, n1, n2, seed, eps, vec_nonz, mat_nonz, max_dets, initiator, target, distribution)
+RELOAD_RUNS = {
+    "ne_m2000_reload": ("Ne", 60, 30, 20250215, 0.01, 2000, 2000, 20000, 1.0, 150.0, "HB_unnorm"),
+}
+
+
+def gen_reload(manifest):
+    manifest["reload_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (shape, n1, n2, seed, eps, vnz, mnz, maxd, ini, tgt, dist) in RELOAD_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            ck = os.path.join(tmp, name + "_ck") + "/"
+            os.makedirs(ck)
+            subprocess.run([HARNESS, "reload", path, mol.point_group, str(n1), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist,
+                            os.path.join(GOLD, name + ".traj"), str(n2), ck], check=True)
+            manifest["reload_runs"][name] = dict(shape=shape, n1=n1, n2=n2, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini,
+                                                 target_norm=tgt, distribution=dist)
+
+
 def gen_pin(manifest, only=None):
     manifest.setdefault("pin_runs", {})
     with tempfile.TemporaryDirectory() as tmp:
@@ -243,6 +264,13 @@ def gen_hbpiv(manifest):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-reload":
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_reload(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-hh-scale":
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
@@ -402,6 +430,7 @@ def main():
     gen_fp(manifest)
     gen_pin(manifest)
     gen_hh_scale(manifest)
+    gen_reload(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

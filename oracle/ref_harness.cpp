@@ -978,6 +978,45 @@ static int run_pin(int argc, char **argv) {
 }
 
 
+// ref_harness reload <fcidump> <pg> <n1> <seed> <eps> <vnz> <mnz> <max_dets> <ini> <tgt> <dist> <out> <n2> <tmpdir/>
+// --load_dir, pinned: n1 iterations of the reference's loop (n1 a multiple of 10), DistVec::save (vec_utils.hpp:713-746) into
+// tmpdir, then what frisys_mol does when restarted with --load_dir tmpdir and the same seed flag: a fresh vector,
+// DistVec::load (:761-844: entries with |v| <= 1e-9 dropped, the rest compacted into positions 0.., re-hashed), the shift of
+// S.txt's last line, last_one_norm = 0 (frisys_mol.cpp:337: the loaded norm goes into `last_norm`, which nothing reads), the
+// generator seeded and advanced past the 2 n_orb draws of the vec scrambler (:141-144; the proc scrambler comes from hash.dat) --
+// and n2 more iterations.  <out>: a LOADED line (entries kept, digest right after the load), then one row per iteration.
+static int run_reload(int argc, char **argv) {
+    if (argc < 16) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n1 = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10), mnz = strtoul(argv[8], 0, 10);
+    size_t max_dets = strtoull(argv[9], 0, 10); double ini = atof(argv[10]), tgt = atof(argv[11]);
+    int nhb = !strcmp(argv[12], "HB_unnorm");
+    unsigned n2 = atoi(argv[14]);
+    std::string dir = argv[15];
+    RefRun r1;
+    r1.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
+    for (unsigned it = 0; it < n1; it++) r1.iterate();
+    r1.sol->save(dir);
+    RefRun rr;
+    rr.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
+    rr.replace_vector({}, {});                 // a fresh, empty DistVec with the same scramblers
+    rr.sol->load(dir);
+    rr.en_shift = r1.en_shift; rr.last_one_norm = 0; rr.iterat = 0;
+    rr.mt.seed(seed); rr.mt.discard(2 * rr.n_orb);
+    FILE *f = fopen(argv[13], "w");
+    fprintf(f, "# --load_dir through the reference: %u iterations, DistVec::save, DistVec::load into a fresh vector, %u iterations; rows: it numer denom norm shift nkept n_nonz curr_size num_success digest\n", n1, n2);
+    fprintf(f, "# p_doub %a hf_en %a n_htrial %zu hf_proc %u\n", rr.p_doub, rr.hf_en, (size_t)rr.htrial->curr_size(), rr.hf_proc);
+    fprintf(f, "LOADED %zu %d %016" PRIx64 " saved_size %zu shift %a\n", (size_t)rr.sol->curr_size(), rr.sol->n_nonz(), rr.digest(), (size_t)r1.sol->curr_size(), rr.en_shift);
+    for (unsigned it = 0; it < n2; it++) {
+        rr.iterate();
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success, rr.digest());
+    }
+    fclose(f);
+    printf("RELOAD n1=%u n2=%u loaded=%zu of %zu\n", n1, n2, (size_t)rr.sol->curr_size(), (size_t)r1.sol->curr_size());
+    return 0;
+}
+
 // ------------------------------------------------------------------ Hubbard-Holstein: reference frisys_hh loop vs the oracle
 // [mpiexec -n P] ref_harness hh <n_iter> <seed> <n_elec> <n_sites> <eps> <U> <omega> <g> <gs_energy> <vec_nonz> <max_dets> <initiator> <target> <out>
 // One rank: lockstep against fo::FrisysHH + unit checks of the bit-string helpers, writes <out>.  P ranks: every rank writes <out>.r<rank>.
@@ -1884,6 +1923,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "pin")) rc = run_pin(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "reload")) rc = run_reload(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "hh")) rc = run_hh(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "fciqmc")) rc = run_fciqmc(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);

@@ -555,6 +555,60 @@ def test_cli_driver_reproduces_reference_outputs(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("reload_runs", {})))
+def test_cli_load_dir_matches_reference_restart(name, tmp_path):
+    """--load_dir, pinned (tests/golden/*_reload.traj from `ref_harness reload`): the reference runs n1 iterations, DistVec::save,
+    then -- as frisys_mol restarted with --load_dir and the same seed flag does -- DistVec::load into a fresh vector (entries
+    with |v| <= 1e-9 dropped, the rest compacted and re-hashed), the shift of S.txt, last_one_norm = 0 (the shift stays put
+    until a shift iteration sees the norm above the target), the generator continued after the vec scrambler's draws, and n2
+    more iterations crossing shift updates.  frisys_mol_hip does the same through its own checkpoint files."""
+    import subprocess
+    from fries_amd import build
+    r = golden_io.manifest()["reload_runs"][name]
+    rows, loaded = [], None
+    with open(os.path.join(golden_io.GOLD, name + ".traj")) as f:
+        for ln in f:
+            t = ln.split()
+            if ln.startswith("LOADED"):
+                loaded = dict(n=int(t[1]), digest=int(t[3], 16), saved=int(t[5]), shift=float.fromhex(t[7]))
+            elif t and not ln.startswith("#"):
+                rows.append(dict(numer=float.fromhex(t[1]), denom=float.fromhex(t[2]), norm=float.fromhex(t[3]), shift=float.fromhex(t[4]), nkept=int(t[5]),
+                                 n_nonz=int(t[6]), curr_size=int(t[7]), hash=int(t[9], 16)))
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out1, out2 = str(tmp_path / "run1") + "/", str(tmp_path / "run2") + "/"
+    os.makedirs(out1); os.makedirs(out2)
+    base = [build.DRIVER, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--vec_nonz", str(r["vec_nonz"]),
+            "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--initiator", repr(r["initiator"]),
+            "--epsilon", repr(r["epsilon"]), "--seed", str(r["seed"])]
+    res = subprocess.run(base + ["--max_iter", str(r["n1"]), "--result_dir", out1], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    nb = (2 * mol.n_orb + 7) // 8
+    assert os.path.getsize(out1 + "dets0.dat") // nb == loaded["saved"]
+    assert np.loadtxt(out1 + "S.txt").reshape(-1)[-1] == loaded["shift"]
+    res = subprocess.run(base + ["--max_iter", str(r["n2"]), "--result_dir", out2, "--load_dir", out1], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out2 + "projnum.txt"); den = np.loadtxt(out2 + "projden.txt"); nk = np.loadtxt(out2 + "nkept.txt")
+    sh = np.loadtxt(out2 + "S.txt").reshape(-1); nm = np.loadtxt(out2 + "norm.txt").reshape(-1)
+    assert num.size == r["n2"]
+    for i, row in enumerate(rows):
+        assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < ENERGY_TOL, i
+        assert int(nk[i]) == row["nkept"], i
+    for k in range(r["n2"] // 10):
+        assert sh[k] == rows[10 * k + 9]["shift"] and nm[k] == rows[10 * k + 9]["norm"], k
+    assert len(set(sh.tolist())) > 1 and sh[0] == loaded["shift"]       # frozen at first, then it moves: the update was crossed
+    raw = np.fromfile(out2 + "dets0.dat", dtype=np.uint8)
+    n_saved = raw.size // nb
+    assert n_saved == rows[-1]["curr_size"]
+    vals = np.fromfile(out2 + "vals0.dat", dtype=np.float64)
+    dets = np.zeros(n_saved, dtype=np.uint64)
+    for b in range(nb):
+        dets |= raw.reshape(n_saved, nb)[:, b].astype(np.uint64) << np.uint64(8 * b)
+    assert golden_io.vec_hash(dets, vals[:n_saved]) == rows[-1]["hash"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,eps,target,ini,seed,n_it,dist", [("Ne", 0.004, 20000, 3, 5, 300, "NU"), ("N2", 0.006, 50000, 2, 9, 350, "NU"), ("H2O", 0.004, 30000, 0, 11, 250, "NU"),
                                                                  ("N2", 0.006, 50000, 2, 9, 300, "HB"), ("H2O", 0.004, 30000, 0, 11, 250, "HB")])
 def test_fciqmc_matches_oracle_counter_stream(oracle, mols, shape, eps, target, ini, seed, n_it, dist):
