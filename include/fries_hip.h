@@ -73,7 +73,7 @@ typedef struct {
     /* send_bytes[d] bytes of big_send go to rank d, recv_bytes[s] bytes arrive from rank s (host arrays of `size`) */
     int (*alltoallv)(void *user, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *stream);
 } fries_comm;
-/* Native transports that fill a fries_comm (csrc/comm_native.hip) -- the C++ counterpart of MPI_COMM_WORLD in the reference:
+/* Native transports (csrc/comm_native.hip) that fill a fries_comm -- the C++ counterpart of MPI_COMM_WORLD in the reference:
  *   RCCL: one process per MI355X.  Rank 0 makes the 128-byte id (fries_rccl_unique_id) and the launcher hands it to every rank
  *   (a file, MPI_Bcast, a TCP store: the drivers use a rendezvous file); fries_rccl_create joins the communicator on `device`.
  *   The all-gather is ncclAllGather and the all-to-all ncclAllToAllv, both on the engine's stream.
