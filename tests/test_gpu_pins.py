@@ -177,3 +177,72 @@ def test_frisys_hh_budget_1e6_matches_reference():
         assert not fails, fails[:6]
     assert g["rows"][-1]["n_nonz"] > 500000 and max(x["num_success"] for x in g["rows"]) == r["vec_nonz"]
     eng.close()
+
+
+def _read_ckpt(dirname, rank, n_orb):
+    nb = (2 * n_orb + 7) // 8
+    raw = np.fromfile(dirname + f"dets{rank}.dat", dtype=np.uint8)
+    n = raw.size // nb
+    vals = np.fromfile(dirname + f"vals{rank}.dat", dtype=np.float64)
+    dets = np.zeros(n, dtype=np.uint64)
+    for b in range(nb):
+        dets |= raw.reshape(n, nb)[:, b].astype(np.uint64) << np.uint64(8 * b)
+    return dets, vals[:n]
+
+
+def _cli_base(r, fc, mol, out):
+    from fries_amd import build
+    return [build.DRIVER, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--vec_nonz", str(r["vec_nonz"]),
+            "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--initiator", repr(r["initiator"]),
+            "--epsilon", repr(r["epsilon"]), "--seed", str(r["seed"]), "--max_iter", str(r["n_iter"]), "--result_dir", out]
+
+
+@pytest.mark.parametrize("name", ["n2_m10000_unnorm_p2", "h2o_m5000_hb_p3"])
+def test_cpp_driver_thread_ranks_match_mpiexec_goldens(name, tmp_path):
+    """frisys_mol_hip --ranks P (P rank threads of one C++ process over the native local transport, no Python anywhere) against
+    what every rank of the reference logged under mpiexec -n P: the projected energy the HF owner writes, every shift and norm,
+    and every rank's final shard (dets<r>.dat / vals<r>.dat) by digest."""
+    r = golden_io.manifest()["mpi_runs"][name]
+    P = r["n_ranks"]
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "run") + "/"
+    os.makedirs(out)
+    res = subprocess.run(_cli_base(r, fc, mol, out) + ["--ranks", str(P)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-3000:]
+    gs = [golden_io.read_traj(name, rank=k) for k in range(P)]
+    rows = gs[gs[0]["hf_proc"]]["rows"]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nk = np.loadtxt(out + "nkept.txt")
+    sh = np.loadtxt(out + "S.txt").reshape(-1); nm = np.loadtxt(out + "norm.txt").reshape(-1)
+    assert num.size == r["n_iter"]
+    for i, row in enumerate(rows):
+        assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10 and int(nk[i]) == row["nkept"], i
+    for k in range(r["n_iter"] // 10):
+        assert sh[k] == rows[10 * k + 9]["shift"] and nm[k] == rows[10 * k + 9]["norm"], k
+    for k in range(P):
+        d, v = _read_ckpt(out, k, mol.n_orb)
+        assert d.size == gs[k]["rows"][-1]["curr_size"] and golden_io.vec_hash(d, v) == gs[k]["rows"][-1]["hash"], k
+    assert open(out + "dense.txt").read() == ",".join(["0"] * P) + "\n"
+
+
+def test_cpp_driver_rccl_process_rank(tmp_path):
+    """frisys_mol_hip launched as a rank (RANK / WORLD_SIZE in the environment): librccl communicator from the id file in the
+    result directory, every collective of the iteration a real RCCL call from C++; world of one here (one GPU per box)."""
+    name = "n2_m10000_unnorm_ini0"
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "run") + "/"
+    os.makedirs(out)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run(_cli_base(r, fc, mol, out), capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-3000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt")
+    for i, row in enumerate(g["rows"]):
+        assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10, i
+    d, v = _read_ckpt(out, 0, mol.n_orb)
+    assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"]
+    assert not os.path.exists(out + ".rccl_id")
