@@ -274,7 +274,7 @@ def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, 
     return result if rank == 0 else None
 
 
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, json_fd):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh worker processes (one per GPU, RCCL)
     BEFORE this process touches a GPU, relay rank 0's JSON line, return the launcher's exit code."""
     import socket
@@ -291,7 +291,7 @@ def launch_ranks(args, argv):
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, env=env)
+    r = subprocess.run(cmd, env=env, stdout=json_fd)       # the ranks get the real stdout: rank 0 writes the one JSON line there
     return r.returncode
 
 
@@ -305,7 +305,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: sized to ~20 s; 0: skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--backend", default=os.environ.get("FRIES_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--transport", default=os.environ.get("FRIES_BENCH_TRANSPORT", "torch"), choices=["torch", "rccl"],
+    ap.add_argument("--transport", default=os.environ.get("FRIES_BENCH_TRANSPORT", "rccl"), choices=["torch", "rccl"],
                     help="how the engine's collectives travel for N > 1: torch.distributed callbacks, or the native librccl transport (csrc/comm_rccl)")
     ap.add_argument("--config4", type=int, default=-1, help="also time BASELINE config 4 (H2O-shaped, m = 1e7 sharded over the ranks): -1 = only when N == 8")
     args = ap.parse_args()
@@ -313,8 +313,13 @@ def main():
     if args.gpus < 1:
         sys.stderr.write("bench.py: --gpus must be >= 1\n")
         sys.exit(2)
+    # stdout carries ONE JSON line and nothing else: librccl prints a version banner to file descriptor 1 when a communicator
+    # is created, so everything written to fd 1 from here on goes to stderr and the result line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args, sys.argv[1:]))
+        sys.exit(launch_ranks(args, sys.argv[1:], json_fd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -352,8 +357,8 @@ def main():
         if rank == 0:
             result["config4"] = {k: r4[k] for k in ("value", "unit", "ms_per_step", "spawns_per_s", "steps", "warmup", "config", "kernel_launches_per_iter", "collectives_per_iter") if k in r4}
     if rank == 0:
-        print(json.dumps(result))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.destroy_process_group()
 
