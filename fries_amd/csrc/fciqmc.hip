@@ -538,7 +538,8 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     c->eps = p->epsilon; c->target_norm = p->target_walkers; c->en_shift = 0; c->last_one_norm = 0; c->iterat = 0;
     c->mt.seed(p->seed);
     c->proc_scr.resize(2 * c->n_orb); c->vec_scr.resize(2 * c->n_orb);
-    for (auto &x : c->proc_scr) x = c->mt();        // fciqmc_mol.cpp:126-128
+    if (c->in_proc_scr.size() == c->proc_scr.size()) c->proc_scr = c->in_proc_scr;     // --load_dir: load_proc_hash (fciqmc_mol.cpp:122-124)
+    else for (auto &x : c->proc_scr) x = c->mt();   // fciqmc_mol.cpp:126-128
     for (auto &x : c->vec_scr) x = c->mt();         // :134-136
     if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
     uint32_t spawn_length = p->target_walkers * 2;      // what a rank can spawn and receive; the reference's Adder holds

@@ -79,6 +79,59 @@ static Fcidump parse_fcidump(const std::string &path, const std::string &point_g
     return f;
 }
 
+// The legacy HF-output directory (parse_hf_input, FRIES/io_utils.cpp:98-187; still what frifull_mol / frimulti_mol take as --hf_path):
+// sys_params.txt (n_elec, n_frozen, n_orb, eps, hf_energy as keyword / value line pairs), symm.txt (irreps, already in the library's
+// labels, one per orbital incl. the frozen ones), hcore.txt (tot_orb^2 values), eris.txt (tot_orb^4 values, eris[i][j][k][l] =
+// <ij|kl> in physicists' order, FRIES/ndarr.hpp:150-195); values separated by commas and / or line breaks.  The engine works
+// without frozen orbitals (the FCIDUMP drivers hard-code n_frz = 0, frisys_mol.cpp:79): a directory with n_frozen > 0 is refused
+// rather than folded, because the reference sums the frozen orbitals inside every matrix element in its own order.
+static std::vector<double> read_csv_doubles(const std::string &path) {
+    std::ifstream f(path);
+    if (!f.is_open()) throw std::runtime_error("Could not open file " + path);
+    std::vector<double> out;
+    std::string line, tok;
+    while (std::getline(f, line)) {
+        std::stringstream ss(line);
+        while (std::getline(ss, tok, ',')) { std::stringstream num(tok); double v; if (num >> v) out.push_back(v); }
+    }
+    return out;
+}
+struct HfDir { Fcidump mol; double eps = 0, hf_en = 0; unsigned n_frz = 0; };
+static HfDir parse_hf_dir(const std::string &dir) {
+    HfDir r;
+    std::ifstream in(dir + "sys_params.txt");
+    if (!in.is_open()) throw std::runtime_error("Could not open file sys_params.txt");
+    auto kw = [&](const char *name, double *out) {
+        std::string k;
+        if (!std::getline(in, k) || k != name) throw std::runtime_error(std::string("Could not find ") + name + " parameter in sys_params.txt");
+        std::string v;
+        std::getline(in, v);
+        *out = std::stod(v);
+    };
+    double ne, nf, no;
+    kw("n_elec", &ne); kw("n_frozen", &nf); kw("n_orb", &no); kw("eps", &r.eps); kw("hf_energy", &r.hf_en);
+    r.n_frz = (unsigned)nf;
+    if (r.n_frz != 0) throw std::runtime_error("legacy HF directory with frozen orbitals (n_frozen > 0) is not supported: freeze them when writing the integrals");
+    Fcidump &f = r.mol;
+    f.n_orb = (uint32_t)no; f.n_elec = (uint32_t)ne; f.core_en = 0;
+    const size_t n = f.n_orb, np = n * (n + 1) / 2;
+    std::vector<double> sy = read_csv_doubles(dir + "symm.txt");
+    if (sy.size() < n) throw std::runtime_error("Could not read the irreps of all orbitals from symm.txt");
+    f.symm.resize(n);
+    for (size_t i = 0; i < n; i++) f.symm[i] = (uint8_t)sy[i];
+    f.hcore = read_csv_doubles(dir + "hcore.txt");
+    if (f.hcore.size() < n * n) { std::stringstream m; m << "Could not read " << n * n << " elements from " << dir << "hcore.txt"; throw std::runtime_error(m.str()); }
+    f.hcore.resize(n * n);
+    std::vector<double> e4 = read_csv_doubles(dir + "eris.txt");
+    if (e4.size() < n * n * n * n) { std::stringstream m; m << "Could not read " << n * n * n * n << " elements from " << dir << "eris.txt"; throw std::runtime_error(m.str()); }
+    f.eris.assign(np * (np + 1) / 2, 0.0);
+    // (pq|rs) = <pr|qs>; the packed array keeps one representative of the 8 equivalent index orders (SymmERIs, ndarr.hpp:206-244)
+    for (size_t q = 0; q < n; q++) for (size_t p_ = 0; p_ <= q; p_++) for (size_t s_ = 0; s_ < n; s_++) for (size_t r_ = 0; r_ <= s_; r_++) {
+        const size_t p1 = tri(p_, q), p2 = tri(r_, s_);
+        if (p1 <= p2) f.eris[tri(p1, p2)] = e4[((p_ * n + r_) * n + q) * n + s_];
+    }
+    return r;
+}
 
 static std::map<std::string, std::string> parse_kv(int argc, char **argv) {
     std::map<std::string, std::string> kv;

@@ -178,3 +178,25 @@ def write_fcidump(path: str, mol: MolInput) -> None:
                 if mol.h_core[i, j] != 0.0:
                     f.write(f"{float(mol.h_core[i, j])!r} {i + 1} {j + 1} 0 0\n")
         f.write(f"{float(mol.core_en)!r} 0 0 0 0\n")
+
+
+def write_hf_dir(path: str, mol, eps: float = 0.01, hf_energy: float = 0.0) -> None:
+    """The legacy HF-output directory the reference's frifull_mol / frimulti_mol read (parse_hf_input, FRIES/io_utils.cpp:98-187), no
+    frozen orbitals: sys_params.txt, symm.txt (the library's irrep labels), hcore.txt, eris.txt with eris[i][j][k][l] = <ij|kl> =
+    (ik|jl), 17 significant digits so that the text round-trips bit for bit.  `path` ends with a slash."""
+    n = mol.n_orb
+    with open(path + "sys_params.txt", "w") as f:
+        f.write("n_elec\n%d\nn_frozen\n0\nn_orb\n%d\neps\n%r\nhf_energy\n%r\n" % (mol.n_elec, n, float(eps), float(hf_energy)))
+    with open(path + "symm.txt", "w") as f:
+        f.write(",".join(str(int(x)) for x in mol.irreps) + "\n")
+    h = np.asarray(mol.h_core, dtype=np.float64).reshape(n, n)
+    with open(path + "hcore.txt", "w") as f:
+        for i in range(n):
+            f.write(",".join("%.17g" % x for x in h[i]) + "\n")
+    tri = lambda a, b: np.where(a <= b, b * (b + 1) // 2 + a, a * (a + 1) // 2 + b)
+    ii, jj, kk, ll = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    p1, p2 = tri(ii, kk), tri(jj, ll)                    # <ij|kl> = (ik|jl)
+    e4 = np.asarray(mol.eris, dtype=np.float64)[tri(p1, p2)].reshape(n * n * n, n)
+    with open(path + "eris.txt", "w") as f:
+        for row in e4:
+            f.write(",".join("%.17g" % x for x in row) + "\n")

@@ -19,6 +19,7 @@
 #include <FRIES/hh_vec.hpp>
 #include <FRIES/Hamiltonians/hub_holstein.hpp>
 #include <chrono>
+#include <fstream>
 #include <cstdio>
 #include <cstring>
 #include <cinttypes>
@@ -820,6 +821,29 @@ static int run_hbpiv(int argc, char **argv) {
     return n_fail != 0;
 }
 
+// ref_harness hfdir <dir/> <out>: what the reference's parse_hf_input (io_utils.cpp:98-187) reads from a legacy HF directory:
+// header (n_orb, n_elec, n_frz as u32), symm, eps, hf_en, h_core, then the FourDArr <ij|kl> re-packed as chemists' (pq|rs) = <pr|qs>
+static int run_hfdir(const char *dir, const char *out) {
+    hf_input in;
+    parse_hf_input(dir, &in);
+    const unsigned n = in.n_orb + in.n_frz / 2;
+    FILE *f = fopen(out, "wb");
+    uint32_t hdr[3] = {in.n_orb, in.n_elec, in.n_frz};
+    fwrite(hdr, 4, 3, f);
+    fwrite(in.symm - in.n_frz / 2, 1, n, f);
+    fwrite(&in.eps, 8, 1, f); fwrite(&in.hf_en, 8, 1, f);
+    fwrite(in.hcore->data(), 8, (size_t)n * n, f);
+    const size_t np = (size_t)n * (n + 1) / 2;
+    std::vector<double> packed(np * (np + 1) / 2, 0.0);
+    for (unsigned q = 0; q < n; q++) for (unsigned p = 0; p <= q; p++) for (unsigned s2 = 0; s2 < n; s2++) for (unsigned r = 0; r <= s2; r++) {
+        size_t p1 = (size_t)q * (q + 1) / 2 + p, p2 = (size_t)s2 * (s2 + 1) / 2 + r;
+        if (p1 <= p2) packed[p2 * (p2 + 1) / 2 + p1] = (*in.eris)(p, r, q, s2);
+    }
+    fwrite(packed.data(), 8, packed.size(), f);
+    fclose(f);
+    return 0;
+}
+
 static int run_dump_ints(const char *path, const char *pg, const char *out) {
     fcidump_input *in = parse_fcidump(path, pg);
     fo::Integrals oi;
@@ -1542,6 +1566,18 @@ static int run_fciqmc(int argc, char **argv) {
             if (rv != 0 && to_u64(sol_vec.indices()[i], det_size) != fq.sol.dets[i]) bad++;
         }
         CHECK(bad == 0, "fciqmc it %u vector mismatch in %zu slots", iterat, bad);
+        if (getenv("FRIES_SAVE_DIR") && getenv("FRIES_SAVE_AT") && iterat + 1 == (unsigned)atoi(getenv("FRIES_SAVE_AT"))) {
+            // what fciqmc_mol leaves in --result_dir: DistVec<int>::save (vec_utils.hpp:713-746), hash.dat (io_utils.cpp:589-606), S.txt
+            const std::string dir(getenv("FRIES_SAVE_DIR"));
+            sol_vec.save(dir);
+            save_proc_hash(dir, proc_scrambler.data(), 2 * n_orb);
+            std::ofstream sf(dir + "S.txt");
+            sf << en_shift << "\n";
+            double wn = 0; int nz = 0;
+            for (size_t i = 0; i < sol_vec.curr_size(); i++) { wn += abs(sol_vec.values()[i]); nz += sol_vec.values()[i] != 0; }
+            std::ofstream mf(dir + "meta.txt");
+            mf << "iterations " << iterat + 1 << " curr_size " << sol_vec.curr_size() << " nonzero " << nz << " walkers " << (long long)wn << " shift_hex " << std::hexfloat << en_shift << "\n";
+        }
     }
     fclose(f);
     if (n_procs > 1) { if (proc_rank == 0) printf("FCIQMC_MPI ranks=%d iters=%u hf_proc=%u\n", n_procs, n_iter, hf_proc); return 0; }
@@ -1927,6 +1963,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "hh")) rc = run_hh(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "fciqmc")) rc = run_fciqmc(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);
+    else if (argc >= 4 && !strcmp(argv[1], "hfdir")) rc = run_hfdir(argv[2], argv[3]);
     else fprintf(stderr, "unknown command\n");
     MPI_Finalize();
     return rc;

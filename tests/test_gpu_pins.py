@@ -246,3 +246,60 @@ def test_cpp_driver_rccl_process_rank(tmp_path):
     d, v = _read_ckpt(out, 0, mol.n_orb)
     assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"]
     assert not os.path.exists(out + ".rccl_id")
+
+
+def test_fciqmc_cli_reads_the_references_checkpoint_and_its_own(tmp_path):
+    """f-3: fciqmc_mol_hip --load_dir on a checkpoint the REFERENCE wrote (tests/golden/fciqmc_ne_ck: DistVec<int>::save + hash.dat +
+    S.txt after 120 iterations of its loop) -- the walkers, the non-zero determinants and the shift must come back -- and on its own
+    checkpoint: the restarted run starts from the walker number the first run ended with."""
+    from fries_amd import build
+    mol = fcidump.synthetic("Ne")
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    ck = os.path.join(golden_io.GOLD, "fciqmc_ne_ck") + "/"
+    meta = open(ck + "meta.txt").read().split()
+    ref_nonzero, ref_walkers = int(meta[meta.index("nonzero") + 1]), int(meta[meta.index("walkers") + 1])
+    exe = build.DRIVERS["fciqmc_mol_hip"]
+    base = [exe, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", "NU", "--target", "5000", "--max_dets", "20000", "--epsilon", "0.002",
+            "--initiator", "3", "--seed", "5"]
+    out1 = str(tmp_path / "r1") + "/"
+    os.makedirs(out1)
+    res = subprocess.run(base + ["--max_iter", "1", "--result_dir", out1, "--load_dir", ck], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    assert f"loaded {ref_walkers} walkers" in res.stdout, res.stdout[-500:]
+    assert np.array_equal(np.fromfile(out1 + "hash.dat", dtype=np.uint32), np.fromfile(ck + "hash.dat", dtype=np.uint32)[:2 * mol.n_orb])
+    # own checkpoint round trip
+    out2, out3 = str(tmp_path / "r2") + "/", str(tmp_path / "r3") + "/"
+    os.makedirs(out2); os.makedirs(out3)
+    res = subprocess.run(base + ["--max_iter", "150", "--result_dir", out2], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    nb = (2 * mol.n_orb + 7) // 8
+    n = os.path.getsize(out2 + "dets0.dat") // nb
+    iv = np.fromfile(out2 + "vals0.dat", dtype=np.int32)
+    assert iv.size == n and np.abs(iv).sum() > 100
+    res = subprocess.run(base + ["--max_iter", "10", "--result_dir", out3, "--load_dir", out2], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    assert f"loaded {int(np.abs(iv).sum())} walkers" in res.stdout
+    assert int(np.loadtxt(out3 + "nnonz.txt").reshape(-1)[0]) > 0
+
+
+def test_frifull_cli_from_legacy_hf_directory(tmp_path):
+    """f-3: frifull_mol_hip --hf_path (the legacy HF-output directory the reference's frifull_mol takes) reproduces the reference's
+    frifull_mol trajectory of tests/golden/full_ne_m300.traj, like the FCIDUMP route."""
+    from fries_amd import build
+    name = "full_ne_m300"
+    r = golden_io.manifest()["full_runs"][name]
+    g = golden_io.read_traj(name)
+    mol = fcidump.synthetic(r["shape"])
+    hf = str(tmp_path / "hf") + "/"
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(hf); os.makedirs(out)
+    fcidump.write_hf_dir(hf, mol, eps=r["epsilon"])
+    cmd = [build.DRIVERS["frifull_mol_hip"], "--hf_path", hf, "--vec_nonz", str(r["vec_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]),
+           "--seed", str(r["seed"]), "--max_iter", str(r["n_iter"]), "--result_dir", out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nk = np.loadtxt(out + "nkept.txt")
+    assert num.size == r["n_iter"]
+    for i, row in enumerate(g["rows"]):
+        assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10 and den[i] == row["denom"] and int(nk[i]) == row["nkept"], i
