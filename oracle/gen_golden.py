@@ -379,13 +379,7 @@ def main():
             mol = fcidump.synthetic(shape)
             path = os.path.join(tmp, shape + ".FCIDUMP")
             out = os.path.join(GOLD, name + ".traj")
-            for attempt in range(3):      # the function-level hb_doub_multi comparison on random determinants is intermittent
-                rc = subprocess.run([HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist]).returncode
-                if rc == 0:
-                    break
-                print(f"gen_golden: harness fciqmc {name} reported mismatches (attempt {attempt + 1}), retrying", file=sys.stderr)
-            else:
-                raise RuntimeError(f"harness fciqmc {name} failed three times")
+            subprocess.run([HARNESS, "fciqmc", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
             manifest["fciqmc_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist)
         # fciqmc_mol with --trial_vec / --ini_vec: the N2 trial fixture above and an integer start vector over its first 12 determinants
         with open(os.path.join(GOLD, "n2_fq_ini_dets"), "w") as f:

@@ -1438,7 +1438,13 @@ static int run_fciqmc(int argc, char **argv) {
     if (lockstep) {
         std::mt19937 ga(777 + seed), gb(777 + seed);
         fo::Rng rb; rb.mt = &gb;
+        // The reference's calc_u1_probs reads occ_orbs[n_elec] -- one entry past the list -- when the first occupied orbital is the last
+        // electron (heat_bathPP.cpp:300-301: `occ_idx++; curr_occ = occ_orbs[occ_idx];`).  Inside a DistVec that byte is the next row's
+        // first (alpha) orbital, which can never equal the beta index it is compared with, so the overrun is harmless there; a stack array
+        // with an unwritten tail made this comparison depend on whatever the stack held (the "intermittent" mismatches of round 1).  The
+        // tail is therefore filled with a value no orbital index takes, which is also what the restatement assumes (fo::calc_u1_probs).
         uint8_t occ[64];
+        memset(occ, 0xff, sizeof occ);
         for (int trial = 0; trial < 4000; trial++) {
             fo::det_t d = 0;
             std::mt19937 &rg = ga;
@@ -1469,6 +1475,14 @@ static int run_fciqmc(int argc, char **argv) {
                 unsigned cr2 = hb_doub_multi(db, occ, n_elec, &symm_basis, hb_probs, nh, ga, hr, hp);
                 uint8_t ho[64 * 4]; double hq[64]; uint32_t hatt[64];
                 unsigned co2 = fo::hb_doub_multi(d, occ, n_elec, fq.sys.symm, fq.sys.hb, nh, rb, 0, ho, hq, hatt);
+                if (getenv("FRIES_HB_DEBUG") && cr2 != co2) {
+                    static int once = 0;
+                    if (!once++) {
+                        fprintf(stderr, "HBDBG trial %d det %016llx nh %u ref %u oracle %u\n", trial, (unsigned long long)d, nh, cr2, co2);
+                        for (unsigned i = 0; i < cr2; i++) fprintf(stderr, "  ref %u: %u %u %u %u p %a\n", i, hr[i][0], hr[i][1], hr[i][2], hr[i][3], hp[i]);
+                        for (unsigned i = 0; i < co2; i++) fprintf(stderr, "  orc %u: %u %u %u %u p %a att %x\n", i, ho[4 * i], ho[4 * i + 1], ho[4 * i + 2], ho[4 * i + 3], hq[i], hatt[i]);
+                    }
+                }
                 CHECK(cr2 == co2, "hb_doub_multi count %u %u", cr2, co2);
                 for (unsigned i = 0; i < std::min(cr2, co2); i++) CHECK(!memcmp(hr[i], &ho[4 * i], 4) && same_bits(hp[i], hq[i]), "hb_doub_multi sample %u", i);
             }
