@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_reduce(VcompBuf B, int round, F
     if (threadIdx.x == 0) { msg->G = G; msg->kept = k; msg->pad = 0; }
 }
 
-__global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int round, const FpMsg *all, int n_ranks) {
+__global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int round, const FpMsg *all, int n_ranks, uint32_t *tie) {
     __shared__ double shd[12];
     __shared__ uint32_t shu[4];
     const CompState prev = B.state[round - 1];
@@ -108,14 +108,20 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fp_round(VecDev V, VcompBuf B, int
     size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     double sum = 0;
     uint32_t kept = 0;
+    float mrel = INFINITY;       // tie statistics (optional): distance of the closest |v| >= norm / budget comparison from flipping, relative
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t i = base + (size_t)it * FR_BLOCK;
         if (i >= n) break;
         double a = fabs(V.v0[i]);
         if (!B.keep[i] && a != 0) {
+            if (tie) { const float m = (float)fabs(a - thr) / (float)(a > thr ? a : thr); mrel = m < mrel ? m : mrel; }
             if (a >= thr) { B.keep[i] = 1; kept++; }
             else sum += a;
         }
+    }
+    if (tie) {
+        for (int off = 32; off > 0; off >>= 1) { const float t = __shfl_xor(mrel, off); mrel = t < mrel ? t : mrel; }
+        if (fr_lane() == 0 && mrel < INFINITY) atomicMin(&tie[1], __float_as_uint(mrel));
     }
     double bs;
     fr_block_excl_f64(sum, shd, &bs);
@@ -180,7 +186,7 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
             // one workgroup reduces the previous round's partials (every workgroup of the round would otherwise redo it)
             FR_LAUNCH(c, "k_fp_reduce", k_fp_reduce, dim3(1), dim3(FR_BLOCK), B, r, (FpMsg *)c->comm.small_send);
             const FpMsg *all = (const FpMsg *)fr_allgather(c, sizeof(FpMsg));
-            FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r, all, P);
+            FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r, all, P, c->d_tie);
         }
         FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
         FR_HIP(hipMemcpyAsync(glob_norm, B.gnorm, 8, hipMemcpyDeviceToHost, st));

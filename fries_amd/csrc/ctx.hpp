@@ -183,6 +183,7 @@ struct FriesCtx {
     bool full_mode = false;
     uint32_t full_cap = 0, *full_cnt = nullptr, *full_nz = nullptr, *full_off = nullptr, *full_list = nullptr;
     uint32_t *d_err = nullptr;
+    uint32_t *d_tie = nullptr;               // [2] tie statistics when enabled (fries_tie_margins): float bits of the smallest relative margin in find_keep_sub / find_preserve
     // optional driver inputs, set before fries_frisys_setup: --trial_vec, --ini_vec, --ham_shift (frisys_mol.cpp:95-98, 157-181, 264-274)
     std::vector<det_t> in_trial_det, in_ini_det; std::vector<double> in_trial_val, in_ini_val;
     bool ham_shift_set = false; double ham_shift_hf_en = 0;

@@ -488,6 +488,26 @@ extern "C" int fries_get_scramblers(fries_ctx *h, uint32_t *proc_scr, uint32_t *
     if (vec_scr) memcpy(vec_scr, c->vec_scr.data(), 4 * c->vec_scr.size());
     FR_API_END
 }
+extern "C" int fries_tie_margins(fries_ctx *h, int enable, double *fks_min_rel, double *fp_min_rel) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    const uint32_t inf2[2] = {0x7F800000u, 0x7F800000u};
+    if (c->d_tie) {
+        uint32_t v[2];
+        FR_HIP(hipMemcpyAsync(v, c->d_tie, 8, hipMemcpyDeviceToHost, c->stream));
+        FR_HIP(hipStreamSynchronize(c->stream));
+        float f0, f1; memcpy(&f0, &v[0], 4); memcpy(&f1, &v[1], 4);
+        if (fks_min_rel) *fks_min_rel = f0;
+        if (fp_min_rel) *fp_min_rel = f1;
+        FR_HIP(hipMemcpyAsync(c->d_tie, inf2, 8, hipMemcpyHostToDevice, c->stream));       // the statistics restart
+        FR_HIP(hipStreamSynchronize(c->stream));
+    }
+    else { if (fks_min_rel) *fks_min_rel = INFINITY; if (fp_min_rel) *fp_min_rel = INFINITY; }
+    if (enable && !c->d_tie) { c->d_tie = fr_alloc<uint32_t>(2); FR_HIP(hipMemcpy(c->d_tie, inf2, 8, hipMemcpyHostToDevice)); }
+    if (!enable && c->d_tie) { FR_HIP(hipFree(c->d_tie)); c->d_tie = nullptr; }
+    FR_API_END
+}
 extern "C" int fries_set_proc_scrambler(fries_ctx *h, const uint32_t *proc_scr, size_t n) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;

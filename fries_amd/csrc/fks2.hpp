@@ -585,6 +585,19 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
     }
 }
 
+// tie statistics (optional): the smallest relative margin any comparison of the settled stage has (the tiles' records of their last evaluation)
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_t *tie) {
+    const FksScal *S = F.scal;
+    const unsigned nb8 = S->n_in / 8 + 1;
+    const unsigned ntile = (unsigned)(((size_t)nb8 * 8 + FR_BLOCK - 1) / FR_BLOCK);
+    const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
+    float m = INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)ntile * FR_FKS_PMAX; i += (size_t)gridDim.x * blockDim.x)
+        if ((int)(i % FR_FKS_PMAX) < n_pass) { const float r = F.tR[i]; m = r < m ? r : m; }
+    for (int off = 32; off > 0; off >>= 1) { const float t = __shfl_xor(m, off); m = t < m ? t : m; }
+    if (fr_lane() == 0 && m < INFINITY) atomicMin(&tie[0], __float_as_uint(m));
+}
+
 // records the settled replay for the next iteration's warm start (one workgroup)
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
     const FksScal *S = F.scal;

@@ -473,6 +473,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
     if (!sequential) {
+        if (c->d_tie) FR_LAUNCH(c, "k_fks_tie", k_fks_tie, dim3(64), dim3(FR_BLOCK), F, c->d_tie);
         FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
         if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_PMAX), dim3(FR_BLOCK), F);
         // settled: recompute every wt_remain with the budget of its last flagged sweep

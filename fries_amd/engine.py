@@ -25,7 +25,7 @@ EXPORTS = [
     "fries_set_comm", "fries_stream", "fries_idx_to_proc", "fries_hh_setup", "fries_hh_iterate", "fries_get_scramblers", "fries_fciqmc_setup", "fries_fciqmc_iterate", "fries_frimulti_setup", "fries_frimulti_iterate",
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
-    "fries_set_proc_scrambler", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
+    "fries_set_proc_scrambler", "fries_tie_margins", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
 ]
 
 
@@ -136,6 +136,7 @@ def load_library() -> C.CDLL:
     lib.fries_hh_setup.argtypes = [C.c_void_p, C.POINTER(HHParams)]
     lib.fries_hh_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.fries_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fries_tie_margins.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fries_rccl_unique_id.argtypes = [C.c_void_p]
     lib.fries_rccl_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
     lib.fries_local_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]
@@ -435,6 +436,12 @@ class FriEngine:
 
     def restart(self, seed: int, en_shift: float = 0.0, last_one_norm: float = 0.0, iterat: int = 0):
         self._ck(self.lib.fries_frisys_restart(self.h, seed, en_shift, last_one_norm, iterat))
+
+    def tie_margins(self, enable: bool = True):
+        """(smallest relative margin of a find_keep_sub comparison, of a find_preserve comparison) since the last call."""
+        a, b = C.c_double(), C.c_double()
+        self._ck(self.lib.fries_tie_margins(self.h, int(enable), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def prof_enable(self, on: bool = True):
         self._ck(self.lib.fries_prof_enable(self.h, int(on)))

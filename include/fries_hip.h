@@ -278,6 +278,13 @@ int fries_frisys_restart(fries_ctx *ctx, uint32_t seed, double en_shift, double 
  * find_keep_sub replays, elements emitted by the five HB-PP stages */
 int fries_counters(fries_ctx *ctx, uint64_t *iters, uint64_t *spawns, uint64_t *launches, uint64_t *fks_replays, uint64_t *stage_elems);
 
+/* Tie statistics: how close the run came to a comparison whose outcome floating-point reassociation could change.  While enabled,
+ * every find_keep_sub stage (its threshold tests v * w * budget >= norm, compress_utils.cpp:172-241) and every find_preserve round
+ * (|v| >= norm / budget, :57-63) records the smallest |a - b| / max(a, b) over all its comparisons; the call returns the minima since
+ * the last call (infinity when nothing was recorded) and restarts them.  The device forms those norms as prefix sums, the reference as
+ * running sums: a margin far above ~1e-13 means the kept sets are provably the same.  enable: 1 start / keep recording, 0 stop. */
+int fries_tie_margins(fries_ctx *ctx, int enable, double *fks_min_rel, double *fp_min_rel);
+
 /* device-to-device copy bandwidth of the context's GPU in GB/s (read + write), `reps` copies of `bytes` on the engine's stream */
 int fries_measure_copy_bandwidth(fries_ctx *ctx, size_t bytes, int reps, double *gb_per_s);
 /* Per-kernel timing with HIP events recorded on the engine's own stream (off by default). */

@@ -1,0 +1,54 @@
+"""Tie margins of the fixtures: for every golden run, the smallest relative distance |a - b| / max(a, b) of any
+find_keep_sub comparison (sub-weight x budget >= running norm) and of any find_preserve comparison (|v| >= norm / budget) from
+flipping, over the whole run.  The device forms the norms as prefix sums where the reference keeps running sums (relative difference
+~1e-16 x norm entering the stage / norm at the comparison); a stage whose norm collapses by > 1e3 is redone in the reference's own
+order (fks_seq.hpp) and has no margin to report.  Usage: python tests/gpu_tie_margins.py > profiles/r02_tie_margins.txt"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+
+import golden_io
+from fries_amd import fcidump
+from fries_amd.engine import FriEngine
+
+man = golden_io.manifest()
+print("%-28s %10s %6s %14s %14s %s" % ("fixture", "m", "iters", "fks min margin", "fp min margin", "first iteration with sampling"))
+for name, r in sorted(man["runs"].items()):
+    eng = FriEngine(fcidump.synthetic(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], initiator=r["initiator"],
+              seed=r["seed"], distribution=r["distribution"])
+    eng.tie_margins(True)
+    mf, mp, first = np.inf, np.inf, None
+    for it in range(r["n_iter"]):
+        lg = eng.iterate(1)[0]
+        a, b = eng.tie_margins(True)
+        mf, mp = min(mf, a), min(mp, b)
+        if first is None and lg["nkept"] < r["vec_nonz"]:
+            first = it
+    print("%-28s %10d %6d %14.3e %14.3e %s" % (name, r["vec_nonz"], r["n_iter"], mf, mp, first))
+    eng.close()
+# BASELINE config 2: the pinned N2 run at m = 1e6 (filler + restart + 100 iterations), margins of the measured part
+r = man["pin_runs"]["pin_n2_m1e6"]
+import bench
+mol = fcidump.synthetic("N2")
+dets, vals = bench.build_state(mol, r["m"], r["max_dets"], r["seed"], 0, None, None)
+eng = FriEngine(mol)
+eng.setup(epsilon=r["epsilon"], vec_nonz=r["m"], mat_nonz=r["m"], max_dets=r["max_dets"], target_norm=float(r["m"]), initiator=1.0, seed=r["seed"], distribution=r["distribution"])
+eng.vec_load(dets, vals); eng.restart(r["run_seed"], 0.0, 0.0, 0)
+eng.tie_margins(True)
+mf, mp = np.inf, np.inf
+per = []
+for it in range(100):
+    eng.iterate(1)
+    a, b = eng.tie_margins(True)
+    per.append((a, b))
+    mf, mp = min(mf, a), min(mp, b)
+print("%-28s %10d %6d %14.3e %14.3e %s" % ("pin_n2_m1e6 (restart part)", r["m"], 100, mf, mp, 0))
+pa = np.array(per)
+print("  per-iteration minima at m = 1e6: fks median %.2e, 10th percentile %.2e; find_preserve median %.2e, 10th percentile %.2e" %
+      (np.median(pa[:, 0]), np.percentile(pa[:, 0], 10), np.median(pa[:, 1]), np.percentile(pa[:, 1], 10)))
+print("  comparisons per iteration at m = 1e6: ~3e7 in find_keep_sub (5 stages x ~6 sweeps x 1e6 elements), ~5e6 in find_preserve")
+eng.close()
