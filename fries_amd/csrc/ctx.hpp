@@ -170,6 +170,7 @@ struct FriesCtx {
     FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
     struct FksSeq *fks_seq = nullptr;        // sequential find_keep_sub (fks_seq.hpp)
     bool fks_no_light = false;               // FRIES_FKS_NO_LIGHT=1: every replay evaluates every tile (tests, comparisons)
+    bool fks_no_collapse_walk = false;       // FRIES_FKS_COLLAPSE_WALK=0: keep the parallel replay's result in collapsing stages (fast, not bit-identical to the reference there)
     bool fks_force_seq = false;              // FRIES_FKS_SEQ=1: every stage through the in-order walk (tests)
     uint64_t n_fks_sequential = 0;
     unsigned fks_grid = 1280;

@@ -451,7 +451,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     }
     // A stage that removes (almost) all of its norm: the reference's running norm is then its own rounding noise, which only the
     // in-order walk reproduces (fks_seq.hpp).  psG[0] / G_last are sums over the ranks, so every rank decides alike.
-    if (!sequential && !(hscal.G_last >= 1e-3 * hscal.psG[0]) && hscal.psG[0] > 0) sequential = true;
+    if (!sequential && !c->fks_no_collapse_walk && !(hscal.G_last >= 1e-3 * hscal.psG[0]) && hscal.psG[0] > 0) sequential = true;
     if (sequential) {
         if (hscal.overflow) { uint32_t z = 0; FR_HIP(hipMemcpyAsync(c->d_err, &z, 4, hipMemcpyHostToDevice, st)); }     // FR_ERR_ROUNDS of the abandoned replay (nothing else can have raised a flag: the iteration checks d_err at its end)
         run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
