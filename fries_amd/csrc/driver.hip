@@ -637,6 +637,118 @@ extern "C" int fries_vec_download(fries_ctx *h, uint64_t *dets, double *vals, si
     FR_API_END
 }
 
+// ---- column mirrors for hosts that keep DistVec::values() / operator[] / matr_el_at_pos pointer semantics (include/FRIES/vec_utils.hpp)
+extern "C" int fries_vec_column_download(fries_ctx *h, int column, double *out, size_t cap, size_t *n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (column != 0 && column != 1) throw FriesError("column must be 0 or 1");
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    size_t m = c->h_vst.curr_size;
+    if (n) *n = m;
+    if (cap < m) throw FriesError("output buffer too small");
+    if (out && m) FR_HIP(hipMemcpy(out, column ? c->vec.v1 : c->vec.v0, 8 * m, hipMemcpyDeviceToHost));
+    FR_API_END
+}
+extern "C" int fries_vec_column_upload(fries_ctx *h, int column, const double *in, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (column != 0 && column != 1) throw FriesError("column must be 0 or 1");
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    if (n > c->h_vst.curr_size) throw FriesError("more values than stored positions");
+    if (n) FR_HIP(hipMemcpy(column ? c->vec.v1 : c->vec.v0, in, 8 * n, hipMemcpyHostToDevice));
+    FR_API_END
+}
+extern "C" int fries_vec_column_zero(fries_ctx *h, int column) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (column != 0 && column != 1) throw FriesError("column must be 0 or 1");
+    FR_HIP(hipMemsetAsync(column ? c->vec.v1 : c->vec.v0, 0, 8 * (size_t)c->vec.cap, c->stream));      // DistVec::zero_vec: the whole row (vec_utils.hpp:577-579)
+    FR_API_END
+}
+// DistVec::add_vecs(idx1, idx2, c) (vec_utils.hpp:553-557): v[idx1][i] += v[idx2][i] * c over the stored positions
+__global__ void __launch_bounds__(FR_BLOCK) k_add_vecs(VecDev V, int idx1, int idx2, double cf) {
+    const uint32_t n = V.st->curr_size;
+    double *a = idx1 ? V.v1 : V.v0; const double *b = idx2 ? V.v1 : V.v0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i] * cf;
+}
+extern "C" int fries_vec_add_vecs(fries_ctx *h, int idx1, int idx2, double cf) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if ((idx1 != 0 && idx1 != 1) || (idx2 != 0 && idx2 != 1)) throw FriesError("column must be 0 or 1");
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    const uint32_t m = c->h_vst.curr_size;
+    if (m) FR_LAUNCH(c, "k_add_vecs", k_add_vecs, dim3(fr_blocks(m, FR_BLOCK) > 2048 ? 2048 : fr_blocks(m, FR_BLOCK)), dim3(FR_BLOCK), c->vec, idx1, idx2, cf);
+    FR_API_END
+}
+// DistVec::matr_el_at_pos for every stored position (vec_utils.hpp:672-677): the cached diagonal element - hf_en, computed where missing
+__global__ void __launch_bounds__(FR_BLOCK) k_fill_diag(VecDev V, SysDev S) {
+    const uint32_t n = V.st->curr_size;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (!V.active[i]) continue;
+        double d = V.diag[i];
+        if (d != d) V.diag[i] = fr_diag_matrel(V.dets[i], S.h_core, S.eris, S.n_orb) - S.hf_en;
+    }
+}
+extern "C" int fries_vec_diag_download(fries_ctx *h, double *out, size_t cap, size_t *n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    size_t m = c->h_vst.curr_size;
+    if (n) *n = m;
+    if (cap < m) throw FriesError("output buffer too small");
+    if (m) {
+        SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+        FR_LAUNCH(c, "k_fill_diag", k_fill_diag, dim3(fr_blocks(m, FR_BLOCK) > 2048 ? 2048 : fr_blocks(m, FR_BLOCK)), dim3(FR_BLOCK), c->vec, S);
+        FR_HIP(hipStreamSynchronize(c->stream));
+        FR_HIP(hipMemcpy(out, c->vec.diag, 8 * m, hipMemcpyDeviceToHost));
+    }
+    FR_API_END
+}
+// DistVec::dot(idx2, vals2, num2, hashes2) (vec_utils.hpp:228-238): sum over the list IN LIST ORDER of vals2[i] * v[column][pos(idx2[i])],
+// absent determinants skipped -- bit-identical to the reference's loop (products in parallel, the additions by one lane in order)
+__global__ void __launch_bounds__(FR_BLOCK) k_dot_list(VecDev V, int column, const det_t *dets, const double *w, uint32_t n, double *out) {
+    __shared__ double prod[FR_BLOCK];
+    const double *col = column ? V.v1 : V.v0;
+    double acc = 0;
+    for (uint32_t base = 0; base < n; base += FR_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        double p = 0;
+        if (i < n) {
+            uint32_t s = fr_hash_find(V, dets[i]);
+            if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) p = w[i] * col[pos]; }
+        }
+        prod[threadIdx.x] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t m = n - base < FR_BLOCK ? n - base : FR_BLOCK; for (uint32_t j = 0; j < m; j++) acc += prod[j]; }   // + (+-0) leaves acc as it is
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = acc;
+}
+extern "C" int fries_vec_dot_list(fries_ctx *h, int column, const uint64_t *dets, const double *vals, size_t n, double *out) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (column != 0 && column != 1) throw FriesError("column must be 0 or 1");
+    if (n > 0xffffffffull) throw FriesError("list too long");
+    double r = 0;
+    if (n) {
+        det_t *dd = fr_alloc<det_t>(n); double *dw = fr_alloc<double>(n + 1);
+        FR_HIP(hipMemcpy(dd, dets, 8 * n, hipMemcpyHostToDevice));
+        FR_HIP(hipMemcpy(dw, vals, 8 * n, hipMemcpyHostToDevice));
+        FR_LAUNCH(c, "k_dot_list", k_dot_list, dim3(1), dim3(FR_BLOCK), c->vec, column, dd, dw, (uint32_t)n, dw + n);
+        FR_HIP(hipStreamSynchronize(c->stream));
+        FR_HIP(hipMemcpy(&r, dw + n, 8, hipMemcpyDeviceToHost));
+        hipFree(dd); hipFree(dw);
+    }
+    if (out) *out = r;
+    FR_API_END
+}
+
 extern "C" int fries_htrial_download(fries_ctx *h, uint64_t *dets, double *vals, size_t cap, size_t *n) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;

@@ -26,6 +26,7 @@ EXPORTS = [
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
     "fries_set_proc_scrambler", "fries_tie_margins", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
+    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs",
 ]
 
 
@@ -102,6 +103,12 @@ def load_library() -> C.CDLL:
     lib.fries_vec_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fries_htrial_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fries_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fries_vec_column_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fries_vec_column_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.fries_vec_column_zero.argtypes = [C.c_void_p, C.c_int]
+    lib.fries_vec_add_vecs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    lib.fries_vec_diag_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fries_vec_dot_list.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
     lib.fries_vec_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.fries_rng_set_state.argtypes = [C.c_void_p, C.c_char_p]
     lib.fries_rng_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

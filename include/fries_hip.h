@@ -235,6 +235,16 @@ int fries_find_preserve(fries_ctx *ctx, uint32_t *n_samp, double *glob_norm);
 int fries_sys_comp(fries_ctx *ctx, uint32_t n_samp, double rn);
 /* replaces the stored vector: determinants land in positions 0..n-1 (DistVec::load, vec_utils.hpp:761-844) */
 int fries_vec_load(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n);
+/* Column mirrors for hosts that keep the reference's pointer semantics (DistVec::values(), operator[], zero_vec, matr_el_at_pos,
+ * dot: vec_utils.hpp:506-508, 647-649, 577-579, 672-677, 228-238) -- what include/FRIES/vec_utils.hpp is built on.
+ * fries_vec_dot_list sums in list order, bit-identical to the reference's loop. */
+int fries_vec_column_download(fries_ctx *ctx, int column, double *out, size_t cap, size_t *n);
+int fries_vec_column_upload(fries_ctx *ctx, int column, const double *in, size_t n);
+int fries_vec_column_zero(fries_ctx *ctx, int column);
+/* DistVec::add_vecs(idx1, idx2, c) (vec_utils.hpp:553-557) */
+int fries_vec_add_vecs(fries_ctx *ctx, int idx1, int idx2, double c);
+int fries_vec_diag_download(fries_ctx *ctx, double *out, size_t cap, size_t *n);
+int fries_vec_dot_list(fries_ctx *ctx, int column, const uint64_t *dets, const double *vals, size_t n, double *out);
 int fries_htrial_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
 
 /* The hot-path operators one by one, on the context's solution vector. */
