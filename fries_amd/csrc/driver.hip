@@ -362,6 +362,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     fries_ctx *h = new fries_ctx();
     h->c.device = device;
     if (getenv("FRIES_DBG")) h->c.dbg = atoi(getenv("FRIES_DBG"));
+    if (getenv("FRIES_FKS_REC_AT")) h->c.fks_rec_at = atoi(getenv("FRIES_FKS_REC_AT"));
     if (getenv("FRIES_FKS_NO_LIGHT")) h->c.fks_no_light = atoi(getenv("FRIES_FKS_NO_LIGHT")) != 0;
     if (getenv("FRIES_FKS_COLLAPSE_WALK")) h->c.fks_no_collapse_walk = atoi(getenv("FRIES_FKS_COLLAPSE_WALK")) == 0;
     if (getenv("FRIES_FKS_SEQ")) h->c.fks_force_seq = atoi(getenv("FRIES_FKS_SEQ")) != 0;

@@ -35,6 +35,7 @@ struct FksScal {
     int valid_upto;                 // sweeps 0..valid_upto have prefixes / chunk totals from the previous replay
     uint32_t warm;                  // replay 0 starts from the previous iteration's sweep structure (FksSaved)
     double warm_scale;              // this stage's norm / the saved stage's norm
+    double G_neg;                   // the negative norm that ended the sweeps (compress_utils.cpp:155-157), else +inf
 };
 
 // What the settled replay of this stage looked like in the previous FRI iteration: the sweep scalars and, per sweep,
@@ -51,12 +52,12 @@ struct FksSaved {
 struct Fks2Work {
     uint32_t nb8_cap;
     uint32_t *dk8; double *dg8, *ws8;       // [FR_FKS_PMAX][nb8_cap] group deltas of the latest evaluation of every group
-    // Per (tile of FR_BLOCK elements, sweep): the inputs the tile was last evaluated with -- running norm and remaining budget at its
-    // first group -- and the smallest distance of any of its comparisons from flipping (in units of the norm).  A later replay whose
-    // inputs for the tile differ by less (same integers) cannot change any decision of the tile and skips it ("light" replays).
-    double *tG; float *tR, *tGm; uint32_t *tK; uint32_t *tNp;     // [ntile_cap][FR_FKS_PMAX] x4, [ntile_cap]: tR = tightest relative margin, tGm = smallest norm compared against
+    // Per (group of 8 elements, sweep): the start state the group was last evaluated with -- running norm and remaining budget at its
+    // first element -- and the smallest relative distance of any of its comparisons from flipping.  A later replay whose start state
+    // for the group differs by less cannot change any decision of the group and skips it ("light" replays).
+    // gG / gK: start state; gR = tightest relative margin; gM = smallest norm compared against: [FR_FKS_PMAX][nb8_cap]; gNp[nb8_cap] = sweeps the group last ran
+    double *gG; float *gR, *gM; uint32_t *gK; uint32_t *gNp;
     uint32_t *cdirty;                       // [FR_FKS_MAXCHUNK] it + 1 of the last replay that changed a delta inside the chunk
-    uint32_t ntile_cap;
     uint32_t *xk8; double *xg8;             // exclusive prefixes over the groups of a chunk, same shape
     uint32_t *ck; double *cg, *cw;          // [FR_FKS_PMAX][FR_FKS_MAXCHUNK] totals per chunk of 2048 groups
     uint32_t *ckx; double *cgx;             // exclusive prefixes of (ck, cg) over the chunks
@@ -89,11 +90,12 @@ __device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, i
     if (hist_it) *hist_it = ch;
     uint32_t n = S->n0;
     int last_pass = 0, p = 0;
+    S->G_neg = INFINITY;
     for (; p < FR_FKS_PMAX; p++) {
         double G = 0;
         for (int r = 0; r < n_ranks; r++) G += L[r];
         S->psG[p] = G; S->psN[p] = n;
-        if (G < 0) break;
+        if (G < 0) { S->G_neg = G; break; }
         uint32_t K = 0;
         for (int r = 0; r < n_ranks; r++) K += msgs[r].totK[p];
         n -= K;
@@ -210,15 +212,12 @@ __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32
 //         with `light` a tile whose inputs moved by less than its tightest comparison tolerates is skipped.
 // MODE 2: final pass -- wt_remain with the budget of the last sweep that flagged the element.
 #define FR_FKS_TILE_MAXK 8192u      // a tile of FR_BLOCK elements preserves at most 32 sub-weights per element
+#define FR_FKS_GRP_MAXK 256u        // a group of 8 elements likewise
 
 template <int STAGE, bool NEW_HB, int MODE>
 __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
     __shared__ HbTables T;
     __shared__ FksScal S;
-    __shared__ uint32_t sm_r[FR_FKS_PMAX + 1];      // per sweep: smallest relative margin of the tile's comparisons, smallest norm compared against (float bits)
-    __shared__ uint32_t sm_gm[FR_FKS_PMAX + 1];
-    __shared__ double sm_G[FR_FKS_PMAX + 1];
-    __shared__ uint32_t sm_K[FR_FKS_PMAX + 1];
     {
         const uint32_t *src = (const uint32_t *)F.scal;
         uint32_t *dst = (uint32_t *)&S;
@@ -232,7 +231,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     const StageElems E = W.el[cur];
     const int n_pass = S.n_pass;
     const bool zp = S.zero_prefix != 0;
-    const bool warm0 = MODE == 0 && zp && S.warm;            // replay 0 of a warm start: prefixes from the saved chunk totals
+    const bool warm0 = MODE != 2 && zp && S.warm;            // replay 0 of a warm start: prefixes from the saved chunk totals
     const int vup = S.valid_upto;
     const unsigned n_chunk_saved = warm0 ? F.saved->nchunk : 0u;
     const unsigned saved_nb8 = warm0 ? F.saved->nb8 : 0u;
@@ -249,42 +248,56 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         const bool in_grp = b < nb8;
         const bool live = e < n_in;
         const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
+        bool act = true;            // MODE 1: my group decides in this replay
+        int gstart = 0;             // ... from this sweep on (> 0: the sweeps before it stand)
         if (MODE == 1) {
-            // Light replay: has anything this tile's decisions depend on moved by more than its tightest comparison tolerates?
-            // Every comparison of the tile has the form  c * (budget - k) >= norm - g  with (k, g) = what the tile itself used up
-            // before that point.  If no decision of the tile changes, (k, g) stay as they were, so a change of the tile's inputs
-            // (budget: integer, norm) moves the left side by a factor within 1 +- eps1 and the right side within 1 +- eps2, and no
-            // comparison whose two sides differ by more than (eps1 + eps2) x the larger side can flip.
-            int ok = 1;
-            if (MODE == 1 && light) {
-                const int p = threadIdx.x;
-                const size_t b0 = (size_t)tile * (FR_BLOCK / 8);
-                if (p < n_pass) {
-                    double xg = 0.0; uint32_t xk = 0u;
-                    if (p <= vup) {
-                        const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
-                        xg = F.cgx[cx] + F.xg8[(size_t)p * stride + b0]; xk = F.ckx[cx] + F.xk8[(size_t)p * stride + b0];
+            // Light replay: has anything this GROUP's decisions depend on moved by more than its tightest comparison tolerates?
+            // A group of 8 elements is evaluated exactly in the reference's order from its start state (running norm and remaining
+            // budget at its first element), so its decisions are a function of that start state alone.  Every comparison has the form
+            //   c * (budget - k) >= norm - g   with (k, g) = what the group itself used up before that point;
+            // if no decision changes, (k, g) stay as they were, so a change of the start state moves the left side by a factor within
+            // 1 +- eps1 and the right side within 1 +- eps2, and no comparison whose two sides differ by more than (eps1 + eps2) x the
+            // larger side can flip.  Lane f of the group checks sweeps f, f + 8, ...
+            if (light) {
+                int ok = 1;
+                if (in_grp) {
+                    const uint32_t np_old = F.gNp[b];
+                    if (np_old > (uint32_t)n_pass) ok = 0;          // fewer sweeps than the group ran: its state is past the end
+                    else for (int p = f; p < (int)np_old; p += 8) {
+                        double xg = 0.0; uint32_t xk = 0u;
+                        if (p <= vup) {
+                            const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
+                            xg = F.cgx[cx] + F.xg8[(size_t)p * stride + b]; xk = F.ckx[cx] + F.xk8[(size_t)p * stride + b];
+                        }
+                        const double G_in = S.psG[p] - xg; const uint32_t K_in = S.psN[p] - xk;
+                        const size_t gx = (size_t)p * stride + b;
+                        const uint32_t K_old = F.gK[gx]; const double G_old = F.gG[gx];
+                        const double gmin = (double)F.gM[gx], rmar = (double)F.gR[gx];
+                        const uint32_t k_lo = K_in < K_old ? K_in : K_old, dk = K_in < K_old ? K_old - K_in : K_in - K_old;
+                        int okp = 0;
+                        if (rmar == INFINITY) okp = 1;                  // the group compared nothing in this sweep
+                        else if (k_lo > 2u * FR_FKS_GRP_MAXK && gmin > 0) {
+                            const double eps1 = (double)dk / (double)(k_lo - FR_FKS_GRP_MAXK);
+                            const double eps2 = (fabs(G_in - G_old) + 1e-12 * S.psG[0]) / gmin;     // prefix sums carry ~1e-16 of the stage's norm
+                            okp = (eps1 + eps2) * 1.0001 < rmar;
+                        }
+                        if (dk == 0u && G_in == G_old) okp = 1;         // nothing moved at all
+                        ok &= okp;
                     }
-                    const double G_in = S.psG[p] - xg; const uint32_t K_in = S.psN[p] - xk;
-                    const size_t tx = (size_t)tile * FR_FKS_PMAX + p;
-                    const uint32_t K_old = F.tK[tx]; const double G_old = F.tG[tx];
-                    const double gmin = (double)F.tGm[tx], rmar = (double)F.tR[tx];
-                    const uint32_t k_lo = K_in < K_old ? K_in : K_old, dk = K_in < K_old ? K_old - K_in : K_in - K_old;
-                    ok = 0;
-                    if (k_lo > 2u * FR_FKS_TILE_MAXK && gmin > 0) {
-                        const double eps1 = (double)dk / (double)(k_lo - FR_FKS_TILE_MAXK);
-                        const double eps2 = (fabs(G_in - G_old) + 1e-12 * S.psG[0]) / gmin;     // prefix sums carry ~1e-16 of the stage's norm
-                        ok = (eps1 + eps2) * 1.0001 < rmar;
-                    }
-                    if (dk == 0u && G_in == G_old) ok = 1;          // nothing moved at all
                 }
-                else if (p == FR_FKS_PMAX) ok = (F.tNp[tile] == (uint32_t)n_pass);
+                uint32_t u = (uint32_t)ok, t;
+                t = fr_dpp_u32<FR_DPP_HMIRROR>(u); u &= t; t = fr_dpp_u32<FR_DPP_XOR1>(u); u &= t; t = fr_dpp_u32<FR_DPP_XOR2>(u); u &= t;
+                act = in_grp && u == 0u;
+                // every sweep the group ran stands, but the stage now has more sweeps: the group only adds those, from its stored state
+                if (in_grp && !act && F.gNp[b] < (uint32_t)n_pass) { act = true; gstart = (int)F.gNp[b]; }
             }
-            if (threadIdx.x <= FR_FKS_PMAX) { sm_r[threadIdx.x] = 0x7F800000u; sm_gm[threadIdx.x] = 0x7F800000u; }
-            ok = __syncthreads_and(ok);
-            if (dbg == 3 && threadIdx.x == 0 && it < FR_MAX_ROUNDS) { atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u); if (!(MODE == 1 && light && ok)) atomicAdd(&F.dbg_cnt[it * 4], 1u); }
-            if (MODE == 1 && light && ok) continue;
+            if (dbg == 3 && it < FR_MAX_ROUNDS) {
+                if (f == 0 && in_grp) { atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u); if (act) atomicAdd(&F.dbg_cnt[it * 4], 1u); }
+                if (lane == 0) { atomicAdd(&F.dbg_cnt[it * 4 + 3], 1u); if (__any(act)) atomicAdd(&F.dbg_cnt[it * 4 + 2], 1u); }
+            }
+            if (light && !__any(act)) continue;         // nothing to decide in this wave
         }
+        const bool lv = live && act, ig = in_grp && act;      // (MODE 1: lanes of groups that stand are passive from here on)
         const double chunk_frac = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
         // group start state of sweep p: what the groups before mine removed (norm) and used (samples) in that sweep
         // The loads are issued one sweep ahead and only added up when the sweep starts: any arithmetic on them here would make the
@@ -292,7 +305,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         struct Pfx { double a, b; uint32_t c, d; };
         auto prefix_issue = [&](int p, Pfx *o) {
             o->a = 0.0; o->b = 0.0; o->c = 0u; o->d = 0u;
-            if (MODE == 0 && warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
+            if (MODE != 2 && warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
                 double xg = 0.0; uint32_t xk = 0u;
                 if (F.sxk8 && b < saved_nb8 && my_chunk < n_chunk_saved) {       // stage 1: the same elements sat in this group last time
                     const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
@@ -311,19 +324,20 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 if (xk >= S.psN[p]) xk = S.psN[p] - 1;
                 o->a = xg; o->c = xk;
             }
-            else if (!zp && in_grp && p <= vup) {
+            else if (!zp && ig && p <= vup) {
                 const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
                 o->a = F.cgx[cx]; o->b = F.xg8[(size_t)p * stride + b];
                 o->c = F.ckx[cx]; o->d = F.xk8[(size_t)p * stride + b];
             }
         };
         // my element
-        double v = live ? E.val[e] : 0.0;
-        uint32_t nd = live ? E.ndiv[e] : 1u;
+        double v = lv ? E.val[e] : 0.0;
+        uint32_t nd = lv ? E.ndiv[e] : 1u;
         double wr = v;
-        uint32_t kp = (MODE == 2 && live) ? W.keep[e] : 0u;
+        uint32_t kp = (MODE == 2 && lv) ? W.keep[e] : 0u;
+        if (MODE == 1 && gstart > 0 && lv) { kp = W.keep[e]; wr = W.wt_remain[e]; }
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
-        if (STAGE != 1 && live && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
+        if (STAGE != 1 && lv && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
         if (MODE == 2) {
             double lastwf = 0;
             Pfx nx;
@@ -358,16 +372,15 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         Pfx nx;
         double xg_n = 0.0; uint32_t xk_n = 0u;
         if (n_pass > 0) { prefix_issue(0, &nx); xg_n = nx.a + nx.b; xk_n = nx.c + nx.d; }
-        double gw_last = fr_grp8_sum(live ? wr : 0.0);      // the group's remaining weight as of the last sweep that touched this wave
+        double gw_last = fr_grp8_sum(lv ? wr : 0.0);        // the group's remaining weight as of the last sweep that touched this wave
         for (int p = 0; p < n_pass; p++) {
             const double xg = xg_n; const uint32_t xk = xk_n;
             if (p + 1 < n_pass) { prefix_issue(p + 1, &nx); xg_n = nx.a + nx.b; xk_n = nx.c + nx.d; }
             const double glob0 = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
-            if (MODE == 1 && threadIdx.x == 0) { sm_G[p] = glob0; sm_K[p] = S.psN[p] - xk; }       // the tile's inputs for this sweep
             // flags are taken against the group's start norm (compress_utils.cpp:172-180)
             double cw = v * wf;
             if (nd > 0) cw /= nd;
-            const bool cmp = live && wr > 0;
+            const bool cmp = lv && wr > 0 && (MODE != 1 || p >= gstart);
             const bool flagged = cmp && cw >= glob0;
             // distance of my comparisons from flipping, relative to their larger side (float is plenty; rounded down)
             float mr = INFINITY;
@@ -439,17 +452,18 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 uint32_t ur = __float_as_uint(mr * 0.9999f), ug = __float_as_uint(gm), t;
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR1>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR2>(ur); ur = t < ur ? t : ur;
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR1>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR2>(ug); ug = t < ug ? t : ug;
-                if (f == 0 && ur != 0x7F800000u) { atomicMin(&sm_r[p], ur); atomicMin(&sm_gm[p], ug); }
+                // what this evaluation of the group was based on and how close its tightest comparison came, for the light replays
+                if (f == 0 && ig && p >= gstart) { const size_t gx = (size_t)p * stride + b; F.gG[gx] = glob0; F.gK[gx] = S.psN[p] - xk; F.gR[gx] = __uint_as_float(ur); F.gM[gx] = __uint_as_float(ug); }
             }
             // group totals (a wave without a flagged lane, the usual case from the third sweep on, has nothing new to add up)
             uint32_t gk = 0; double gg = 0.0, gw = gw_last;
             if (any_flagged) {
                 gk = fr_grp8_sum_u32(add);
                 gg = fr_grp8_sum(change);
-                gw = fr_grp8_sum(live ? wr : 0.0);
+                gw = fr_grp8_sum(lv ? wr : 0.0);
                 gw_last = gw;
             }
-            if (f == 0 && in_grp) {
+            if (f == 0 && ig && (MODE != 1 || p >= gstart)) {
                 size_t ix = (size_t)p * stride + b;
                 if (MODE == 1) {
                     if (dk8[ix] != gk || __double_as_longlong(dg8[ix]) != __double_as_longlong(gg) || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
@@ -462,7 +476,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         // one sweep beyond: keeps nothing, but its wt_remain sum is what a re-summed norm would be
         if (n_pass < FR_FKS_PMAX) {
             const double gw = gw_last;
-            if (f == 0 && in_grp) {
+            if (f == 0 && ig) {
                 size_t ix = (size_t)n_pass * stride + b;
                 if (MODE == 1) {
                     if (dk8[ix] != 0u || __double_as_longlong(dg8[ix]) != 0ll || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
@@ -476,16 +490,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             if (F.hist[it] == 0) atomicOr(&F.hist[it], 1u);
             F.cdirty[my_chunk] = (uint32_t)it + 1u;
         }
-        if (live) { W.keep[e] = kp; W.wt_remain[e] = wr; }
-        // what this evaluation was based on, for the light replays that follow
-        if (MODE != 1) continue;
-        __syncthreads();
-        if ((int)threadIdx.x < n_pass) {
-            const size_t tx = (size_t)tile * FR_FKS_PMAX + threadIdx.x;
-            F.tG[tx] = sm_G[threadIdx.x]; F.tK[tx] = sm_K[threadIdx.x];
-            F.tR[tx] = __uint_as_float(sm_r[threadIdx.x]); F.tGm[tx] = __uint_as_float(sm_gm[threadIdx.x]);
-        }
-        else if (threadIdx.x == FR_FKS_PMAX) F.tNp[tile] = (uint32_t)n_pass;
+        if (lv) { W.keep[e] = kp; W.wt_remain[e] = wr; }
+        if (MODE == 1 && f == 0 && ig) F.gNp[b] = (uint32_t)n_pass;
     }
 }
 
@@ -589,11 +595,11 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_t *tie) {
     const FksScal *S = F.scal;
     const unsigned nb8 = S->n_in / 8 + 1;
-    const unsigned ntile = (unsigned)(((size_t)nb8 * 8 + FR_BLOCK - 1) / FR_BLOCK);
     const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
+    const size_t stride = F.nb8_cap;
     float m = INFINITY;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)ntile * FR_FKS_PMAX; i += (size_t)gridDim.x * blockDim.x)
-        if ((int)(i % FR_FKS_PMAX) < n_pass) { const float r = F.tR[i]; m = r < m ? r : m; }
+    for (int p = 0; p < n_pass; p++)
+        for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb8; b += (size_t)gridDim.x * blockDim.x) { const float r = F.gR[(size_t)p * stride + b]; m = r < m ? r : m; }
     for (int off = 32; off > 0; off >>= 1) { const float t = __shfl_xor(m, off); m = t < m ? t : m; }
     if (fr_lane() == 0 && m < INFINITY) atomicMin(&tie[0], __float_as_uint(m));
 }

@@ -283,11 +283,9 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         F.nb8_cap = (uint32_t)(((size_t)cap / 8 + 2 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK * FR_FKS_CHUNK);     // whole chunks: k_fks_scan uses unguarded vector loads
         size_t n8 = (size_t)FR_FKS_PMAX * F.nb8_cap;
         F.dk8 = fr_alloc<uint32_t>(n8); F.dg8 = fr_alloc<double>(n8); F.ws8 = fr_alloc<double>(n8);
-        F.ntile_cap = (uint32_t)(((size_t)F.nb8_cap * 8 + FR_BLOCK - 1) / FR_BLOCK + 1);
-        F.tG = fr_alloc<double>((size_t)F.ntile_cap * FR_FKS_PMAX); F.tR = fr_alloc<float>((size_t)F.ntile_cap * FR_FKS_PMAX); F.tGm = fr_alloc<float>((size_t)F.ntile_cap * FR_FKS_PMAX);
-        F.tK = fr_alloc<uint32_t>((size_t)F.ntile_cap * FR_FKS_PMAX); F.tNp = fr_alloc<uint32_t>(F.ntile_cap);
         F.cdirty = fr_alloc<uint32_t>(FR_FKS_MAXCHUNK);
-        FR_HIP(hipMemset(F.tNp, 0xff, 4 * (size_t)F.ntile_cap));
+        F.gG = fr_alloc<double>(n8); F.gR = fr_alloc<float>(n8); F.gM = fr_alloc<float>(n8); F.gK = fr_alloc<uint32_t>(n8); F.gNp = fr_alloc<uint32_t>(F.nb8_cap);
+        FR_HIP(hipMemset(F.gNp, 0xff, 4 * (size_t)F.nb8_cap));
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
         F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
         F.ck = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cg = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cw = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
@@ -430,7 +428,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             // The replay needs about as many rounds as the reference runs sweeps (a sweep's start state is only right once the sweep
             // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
             // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
-            const int rec_at = c->fks_no_light ? 1 : (c->rounds_hint[STAGE] > 3 ? c->rounds_hint[STAGE] - 2 : 1);
+            const int rec_at = c->fks_no_light ? 1 : c->fks_rec_at >= 0 ? c->fks_rec_at : (c->rounds_hint[STAGE] > 3 ? c->rounds_hint[STAGE] - 2 : 1);
             const int light = (it > rec_at && !c->fks_no_light) ? 1 : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
             if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             else FR_LAUNCH(c, light ? "k_fks_sweep_light" : "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
@@ -451,7 +449,8 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     }
     // A stage that removes (almost) all of its norm: the reference's running norm is then its own rounding noise, which only the
     // in-order walk reproduces (fks_seq.hpp).  psG[0] / G_last are sums over the ranks, so every rank decides alike.
-    if (!sequential && !c->fks_no_collapse_walk && !(hscal.G_last >= 1e-3 * hscal.psG[0]) && hscal.psG[0] > 0) sequential = true;
+    // (a norm that went negative did so by rounding noise of the same kind)
+    if (!sequential && !c->fks_no_collapse_walk && (!(hscal.G_last >= 1e-3 * hscal.psG[0]) || hscal.G_neg < 0) && hscal.psG[0] > 0) sequential = true;
     if (sequential) {
         if (hscal.overflow) { uint32_t z = 0; FR_HIP(hipMemcpyAsync(c->d_err, &z, 4, hipMemcpyHostToDevice, st)); }     // FR_ERR_ROUNDS of the abandoned replay (nothing else can have raised a flag: the iteration checks d_err at its end)
         run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
@@ -465,10 +464,10 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         fprintf(stderr, "[fks] stage %d n_in %u replays %d needed %d n_pass %d lane_evals %u wave_eval_rounds %u (per replay %.0f / %.0f) psN:", STAGE, hs.n_in, it, needed, hs.n_pass,
                 hh[FR_MAX_ROUNDS], hh[FR_MAX_ROUNDS + 1], hh[FR_MAX_ROUNDS] / (double)it, hh[FR_MAX_ROUNDS + 1] / (double)it);
         for (int p = 0; p < hs.n_pass; p++) fprintf(stderr, " %u", hs.psN[p]);
-        fprintf(stderr, "\n   tiles evaluated / tiles | - | - per replay:");
+        fprintf(stderr, "\n   groups deciding (waves with such a group) / groups per replay:");
         std::vector<uint32_t> dc((size_t)FR_MAX_ROUNDS * 4);
         FR_HIP(hipMemcpy(dc.data(), F.dbg_cnt, dc.size() * 4, hipMemcpyDeviceToHost));
-        for (int k = 0; k < it; k++) fprintf(stderr, "  [%d] %u/%u chg %u", k, dc[k * 4], dc[k * 4 + 1], hh[k]);
+        for (int k = 0; k < it; k++) fprintf(stderr, "  [%d] %u(%u)/%u chg %u", k, dc[k * 4], dc[k * 4 + 2], dc[k * 4 + 1], hh[k]);
         fprintf(stderr, "\n");
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
