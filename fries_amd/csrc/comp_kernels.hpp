@@ -84,6 +84,7 @@ struct CompWork {
     uint32_t *kin, *cnt;
     uint32_t *kend;               // tooth index after each element (propagation repair, see k_sys_prop)
     uint32_t *act[2], *act_n;     // active lists of the propagation repair, and their lengths [2]
+    uint32_t *kstart;             // tag of the repair round in which the element heads a chain (k_sys_walk)
     uint32_t prop;                // 1: repair by parallel propagation (many repairs expected), 0: short sequential fix-up
     uint32_t *e_wi, *e_sub;       // emissions: source element, sub index
     double *e_val;
@@ -384,6 +385,47 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_prop(CompWork W, VecDev V, con
         if (k != W.kend[e]) {
             W.kend[e] = k;
             if (e + 1 < n_in) W.act[in ^ 1][atomicAdd(&W.act_n[in ^ 1], 1u)] = e + 1;
+        }
+    }
+}
+
+// The same repair with every chain followed by ONE lane: a lane takes an element of the list and keeps walking forward while the
+// comb pointer it hands on keeps changing, instead of handing each step to the next round (a chain of 300 elements then costs one
+// launch, not 300).  Segments stay disjoint: every list element carries this round's tag in W.kstart, and a walker that reaches a
+// tagged element stops there and queues it for the next round (its owner may have started from the pointer that has just moved).
+// The number of rounds is the number of times chains run into one another, not their length.
+static __global__ void __launch_bounds__(FR_BLOCK) k_sys_mark(CompWork W, int in, uint32_t tag) {
+    const uint32_t n_act = W.act_n[in];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) W.kstart[W.act[in][i]] = tag;
+}
+template <int STAGE, bool NEW_HB>
+__global__ void __launch_bounds__(FR_BLOCK) k_sys_walk(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, int in, uint32_t tag) {
+    __shared__ HbTables T;
+    __shared__ Teeth Tsh;
+    const uint32_t n_act = W.act_n[in];
+    if (blockIdx.x * blockDim.x >= n_act) return;
+    if (STAGE != 1) fr_stage_tables(&T, Tg);
+    fr_stage_teeth(&Tsh, W.teeth);
+    CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
+    const unsigned n_in = fin->n_in;
+    const double unit = fin->unit;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_act; i += gridDim.x * blockDim.x) {
+        uint32_t e = W.act[in][i];
+        while (true) {
+            const uint32_t kin_new = W.kend[e - 1];
+            if (kin_new == W.kin[e]) break;
+            ElemIn x1[1];
+            fr_load_elems<STAGE, 1>(W, V, cur, e, n_in, x1);
+            uint32_t k = kin_new;
+            const uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, &Tsh, x1[0], e, W.S[e], &k, unit, p_doub, 0);
+            const uint32_t old = W.cnt[e];
+            W.kin[e] = kin_new; W.cnt[e] = c;
+            if (c != old) atomicAdd(&W.pcnt[1][e / FR_TILE], c - old);
+            if (k == W.kend[e]) break;              // the comb leaves this element where it did before: the chain ends
+            W.kend[e] = k;
+            e++;
+            if (e >= n_in) break;
+            if (W.kstart[e] == tag) { W.act[in ^ 1][atomicAdd(&W.act_n[in ^ 1], 1u)] = e; break; }     // somebody else's start: next round
         }
     }
 }

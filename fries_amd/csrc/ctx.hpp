@@ -169,6 +169,7 @@ struct FriesCtx {
     uint32_t *fks_sxk8 = nullptr; double *fks_sxg8 = nullptr;
     FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
     struct FksSeq *fks_seq = nullptr;        // sequential find_keep_sub (fks_seq.hpp)
+    uint32_t prop_tag = 0;                   // last tag handed to a comb-repair round (k_sys_walk)
     int fks_rec_at = -1;                     // FRIES_FKS_REC_AT=k: the replay that records the tiles' margins (default: rounds hint - 2)
     bool fks_no_light = false;               // FRIES_FKS_NO_LIGHT=1: every replay evaluates every tile (tests, comparisons)
     bool fks_no_collapse_walk = false;       // FRIES_FKS_COLLAPSE_WALK=0: keep the parallel replay's result in collapsing stages (fast, not bit-identical to the reference there)

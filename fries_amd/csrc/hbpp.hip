@@ -272,7 +272,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     }
     W.wt_remain = fr_alloc<double>(cap); W.keep = fr_alloc<uint32_t>(cap); W.S = fr_alloc<double>(cap);
     W.kin = fr_alloc<uint32_t>(cap); W.cnt = fr_alloc<uint32_t>(cap);
-    W.kend = nullptr; W.act[0] = W.act[1] = nullptr; W.act_n = nullptr; W.prop = 0;
+    W.kend = nullptr; W.act[0] = W.act[1] = nullptr; W.act_n = nullptr; W.kstart = nullptr; W.prop = 0;
     W.e_wi = fr_alloc<uint32_t>(cap); W.e_sub = fr_alloc<uint32_t>(cap); W.e_val = fr_alloc<double>(cap);
     W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
     W.teeth = fr_alloc<Teeth>(1);
@@ -502,9 +502,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
     if (W.prop) {
-        // rounds of parallel propagation until no element's entry pointer changes: enqueued in batches of 8 (a round that finds
-        // an empty list returns at once), one host look at the list length per batch.  This is the frisys_hh path, where one
-        // stage needs ~1e4 repairs; the molecular path keeps the short sequential fix-up below.
+        // chains of repairs, each walked by one lane (k_sys_walk); a round ends where chains ran into one another, and those are walked
+        // on in the next round.  This is the frisys_hh path, where one stage needs ~1e4 repairs in chains of up to a few hundred
+        // elements; the molecular path keeps the short sequential fix-up below.  Two rounds per host look at the list length.
         int in = 0;
         uint32_t na = 0;
         FR_HIP(hipMemcpyAsync(&na, &W.act_n[0], 4, hipMemcpyDeviceToHost, st));
@@ -514,9 +514,12 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             if (round > 100000) throw FriesError("comb repair did not settle");
             unsigned gp = fr_blocks(na, FR_BLOCK);
             if (gp > 1024) gp = 1024;
-            for (int k = 0; k < 8; k++, round++) {      // the list can only grow by the elements it names: later rounds are never longer
+            for (int k = 0; k < 2; k++, round++) {      // the next list is never longer than this one
+                const uint32_t tag = ++c->prop_tag;
+                if (tag == 0) throw FriesError("repair tags exhausted");
                 FR_HIP(hipMemsetAsync(&W.act_n[in ^ 1], 0, 4, st));
-                FR_LAUNCH(c, "k_sys_prop", (k_sys_prop<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in);
+                FR_LAUNCH(c, "k_sys_mark", k_sys_mark, dim3(gp), dim3(FR_BLOCK), W, in, tag);
+                FR_LAUNCH(c, "k_sys_walk", (k_sys_walk<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in, tag);
                 in ^= 1;
             }
             FR_HIP(hipMemcpyAsync(&na, &W.act_n[in], 4, hipMemcpyDeviceToHost, st));

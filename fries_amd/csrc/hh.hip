@@ -216,14 +216,16 @@ __global__ void __launch_bounds__(FR_BLOCK) k_hh_death_clone(VecDev V, VcompBuf 
 // calc_ref_ovlp (hub_holstein.hpp:93-186) of this shard: sum over the stored states of their off-diagonal coupling (over t) to
 // the Neel state.  Two byte-level details of the reference are behaviour and are kept: the orbital to the right of bit 7 of every byte
 // counts as empty (integer promotion of ~byte >> 1, :150), and the open-boundary mask lands in byte ceil(L / 8) (:165-167).
-__global__ void __launch_bounds__(FR_BLOCK) k_hh_ref_ovlp(VecDev V, det_t ref, double g_over_t, double *out) {
+#define FR_HH_OVLP_BLOCKS 256
+// (fixed grid, one partial per workgroup, added up in workgroup order by k_hh_ref_ovlp_sum: the same bits whatever the device does)
+__global__ void __launch_bounds__(FR_BLOCK) k_hh_ref_ovlp(VecDev V, det_t ref, double g_over_t, double *part) {
     __shared__ double shd[4];
     const uint32_t n = V.st->curr_size;
     const unsigned L = V.hh_sites, n_elec = V.hh_nelec;
     const unsigned nbytes = (2 * L + 7) / 8;
     const det_t emask = (1ull << (2 * L)) - 1ull, byte_mask = (1ull << (8 * nbytes)) - 1ull;
     double acc = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double val = V.v0[i];
         if (val == 0) continue;
         const det_t cur = V.dets[i];
@@ -260,7 +262,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_hh_ref_ovlp(VecDev V, det_t ref, d
         }
     }
     double r = fr_block_sum(acc, shd);
-    if (threadIdx.x == 0) { out[0] = r; out[1] = V.v0[0]; out[2] = (double)fr_hub_diag(V.dets[0], L); }
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(64) k_hh_ref_ovlp_sum(VecDev V, const double *part, double *out) {
+    if (threadIdx.x != 0) return;
+    double r = 0;
+    for (int k = 0; k < FR_HH_OVLP_BLOCKS; k++) r += part[k];
+    out[0] = r; out[1] = V.v0[0]; out[2] = (double)fr_hub_diag(V.dets[0], V.hh_sites);
 }
 
 // sys_comp zeroes elements and flags them for deletion; frisys_hh never deletes position 0 of rank 0 (:356)
@@ -295,6 +303,7 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     fr_hbpp_alloc(c, wcap);
     // un-normalised stage-1 rows make comb repairs the rule rather than the exception (comp_kernels.hpp: k_sys_prop)
     c->W.prop = 1; c->W.kend = fr_alloc<uint32_t>(wcap); c->W.act[0] = fr_alloc<uint32_t>(wcap + 1); c->W.act[1] = fr_alloc<uint32_t>(wcap + 1); c->W.act_n = fr_alloc<uint32_t>(2);
+    c->W.kstart = fr_alloc<uint32_t>(wcap + 1); FR_HIP(hipMemset(c->W.kstart, 0, 4 * ((size_t)wcap + 1)));
     // frifull_hh: at most 4 n_elec adds per stored state (2 hops and 2 phonon moves per electron), vec_nonz states after a compression
     const uint64_t sp_need = p->full ? (uint64_t)4 * p->n_elec * ((uint64_t)p->vec_nonz + 64) + 4096 : (uint64_t)p->vec_nonz + 4096;
     if (sp_need > 0x7fffffffull) throw FriesError("vec_nonz too large for the spawn list");
@@ -303,7 +312,7 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     if (p->full) c->hhf_cnt = fr_alloc<unsigned long long>(2);
     fr_vcomp_alloc(c, p->max_dets);
     c->hh_fdet = fr_alloc<det_t>(wcap);
-    c->hh_ovlp = fr_alloc<double>(4);
+    c->hh_ovlp = fr_alloc<double>(4 + FR_HH_OVLP_BLOCKS);
     c->W.row1[0] = 1.0; c->W.row1[1] = p->g;        // {hub_t, elec_ph}, :191-192
     // Neel state: alpha electrons on the even sites, beta on the odd ones (hub_holstein.cpp:139-171)
     det_t neel = 0;
@@ -389,7 +398,8 @@ void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg) {
         if (c->last_one_norm == 0 && glob_norm > c->target_norm) c->last_one_norm = glob_norm;
     }
     // energy estimate (:336-349): every shard's overlap with the Neel state, gathered to the rank that owns it
-    FR_LAUNCH(c, "k_hh_ref_ovlp", k_hh_ref_ovlp, dim3(1), dim3(FR_BLOCK), c->vec, c->hf_det, P.g / 1.0, c->hh_ovlp);
+    FR_LAUNCH(c, "k_hh_ref_ovlp", k_hh_ref_ovlp, dim3(FR_HH_OVLP_BLOCKS), dim3(FR_BLOCK), c->vec, c->hf_det, P.g / 1.0, c->hh_ovlp + 4);
+    FR_LAUNCH(c, "k_hh_ref_ovlp_sum", k_hh_ref_ovlp_sum, dim3(1), dim3(64), c->vec, c->hh_ovlp + 4, c->hh_ovlp);
     {
         const int R = c->n_ranks;
         double h[3 * FR_MAX_RANKS];
