@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     const StageElems E = W.el[cur];
     const int n_pass = S.n_pass;
     const bool zp = S.zero_prefix != 0;
-    const bool warm0 = MODE != 2 && zp && S.warm;            // replay 0 of a warm start: prefixes from the saved chunk totals
+    const bool warm0 = MODE == 0 && zp && S.warm;            // replay 0 of a warm start: prefixes from the saved chunk totals
     const int vup = S.valid_upto;
     const unsigned n_chunk_saved = warm0 ? F.saved->nchunk : 0u;
     const unsigned saved_nb8 = warm0 ? F.saved->nb8 : 0u;
@@ -249,7 +249,6 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         const bool live = e < n_in;
         const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
         bool act = true;            // MODE 1: my group decides in this replay
-        int gstart = 0;             // ... from this sweep on (> 0: the sweeps before it stand)
         if (MODE == 1) {
             // Light replay: has anything this GROUP's decisions depend on moved by more than its tightest comparison tolerates?
             // A group of 8 elements is evaluated exactly in the reference's order from its start state (running norm and remaining
@@ -261,9 +260,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             if (light) {
                 int ok = 1;
                 if (in_grp) {
-                    const uint32_t np_old = F.gNp[b];
-                    if (np_old > (uint32_t)n_pass) ok = 0;          // fewer sweeps than the group ran: its state is past the end
-                    else for (int p = f; p < (int)np_old; p += 8) {
+                    if (F.gNp[b] != (uint32_t)n_pass) ok = 0;         // the stage has a different number of sweeps than the group ran
+                    else for (int p = f; p < n_pass; p += 8) {
                         double xg = 0.0; uint32_t xk = 0u;
                         if (p <= vup) {
                             const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
@@ -288,8 +286,6 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 uint32_t u = (uint32_t)ok, t;
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(u); u &= t; t = fr_dpp_u32<FR_DPP_XOR1>(u); u &= t; t = fr_dpp_u32<FR_DPP_XOR2>(u); u &= t;
                 act = in_grp && u == 0u;
-                // every sweep the group ran stands, but the stage now has more sweeps: the group only adds those, from its stored state
-                if (in_grp && !act && F.gNp[b] < (uint32_t)n_pass) { act = true; gstart = (int)F.gNp[b]; }
             }
             if (dbg == 3 && it < FR_MAX_ROUNDS) {
                 if (f == 0 && in_grp) { atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u); if (act) atomicAdd(&F.dbg_cnt[it * 4], 1u); }
@@ -305,7 +301,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         struct Pfx { double a, b; uint32_t c, d; };
         auto prefix_issue = [&](int p, Pfx *o) {
             o->a = 0.0; o->b = 0.0; o->c = 0u; o->d = 0u;
-            if (MODE != 2 && warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
+            if (MODE == 0 && warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
                 double xg = 0.0; uint32_t xk = 0u;
                 if (F.sxk8 && b < saved_nb8 && my_chunk < n_chunk_saved) {       // stage 1: the same elements sat in this group last time
                     const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
@@ -335,7 +331,6 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
         uint32_t nd = lv ? E.ndiv[e] : 1u;
         double wr = v;
         uint32_t kp = (MODE == 2 && lv) ? W.keep[e] : 0u;
-        if (MODE == 1 && gstart > 0 && lv) { kp = W.keep[e]; wr = W.wt_remain[e]; }
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
         if (STAGE != 1 && lv && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
         if (MODE == 2) {
@@ -380,7 +375,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             // flags are taken against the group's start norm (compress_utils.cpp:172-180)
             double cw = v * wf;
             if (nd > 0) cw /= nd;
-            const bool cmp = lv && wr > 0 && (MODE != 1 || p >= gstart);
+            const bool cmp = lv && wr > 0;
             const bool flagged = cmp && cw >= glob0;
             // distance of my comparisons from flipping, relative to their larger side (float is plenty; rounded down)
             float mr = INFINITY;
@@ -453,7 +448,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR1>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR2>(ur); ur = t < ur ? t : ur;
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR1>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR2>(ug); ug = t < ug ? t : ug;
                 // what this evaluation of the group was based on and how close its tightest comparison came, for the light replays
-                if (f == 0 && ig && p >= gstart) { const size_t gx = (size_t)p * stride + b; F.gG[gx] = glob0; F.gK[gx] = S.psN[p] - xk; F.gR[gx] = __uint_as_float(ur); F.gM[gx] = __uint_as_float(ug); }
+                if (f == 0 && ig) { const size_t gx = (size_t)p * stride + b; F.gG[gx] = glob0; F.gK[gx] = S.psN[p] - xk; F.gR[gx] = __uint_as_float(ur); F.gM[gx] = __uint_as_float(ug); }
             }
             // group totals (a wave without a flagged lane, the usual case from the third sweep on, has nothing new to add up)
             uint32_t gk = 0; double gg = 0.0, gw = gw_last;
@@ -463,7 +458,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 gw = fr_grp8_sum(lv ? wr : 0.0);
                 gw_last = gw;
             }
-            if (f == 0 && ig && (MODE != 1 || p >= gstart)) {
+            if (f == 0 && ig) {
                 size_t ix = (size_t)p * stride + b;
                 if (MODE == 1) {
                     if (dk8[ix] != gk || __double_as_longlong(dg8[ix]) != __double_as_longlong(gg) || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
@@ -495,21 +490,61 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     }
 }
 
-// Exclusive prefixes over the 8-blocks inside chunks of 2048 groups (grid: chunks x sweeps); chunk totals go to
-// (ck, cg, cw).  Also compares this replay's deltas with the previous replay's and raises hist[it] on any difference.
+// Exclusive prefixes over the chunks and sweep totals (one wave per sweep) into this rank's FksMsg; with one rank, also the sweep
+// scalars of the next replay.
+__device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it, FksMsg *sm) {
+    FksScal *S = F.scal;
+    const unsigned nb8 = S->n_in / 8 + 1;
+    const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
+    const int n_pass = S->n_pass;
+    const int lane = fr_lane(), wv = threadIdx.x >> 6;
+    for (int q = wv; q < FR_FKS_PMAX; q += 4) {
+        uint32_t rk = 0; double rg = 0, rw = 0;
+        if (q <= n_pass) {
+            for (unsigned c0 = 0; c0 < nchunk; c0 += 64) {
+                unsigned c = c0 + lane;
+                size_t ix = (size_t)q * FR_FKS_MAXCHUNK + c;
+                uint32_t k = c < nchunk ? F.ck[ix] : 0u;
+                double g = c < nchunk ? F.cg[ix] : 0.0, w = c < nchunk ? F.cw[ix] : 0.0;
+                uint32_t tk; double tg, tw;
+                uint32_t ek = fr_wave_excl_u32(k, &tk);
+                double eg = fr_wave_excl_f64(g, &tg);
+                fr_wave_excl_f64(w, &tw);
+                if (c < nchunk) { F.ckx[ix] = rk + ek; F.cgx[ix] = rg + eg; }
+                rk += tk; rg += tg; rw += tw;
+            }
+        }
+        if (lane == 0) { msg->totK[q] = rk; msg->totG[q] = rg; msg->totW[q] = rw; sm->totK[q] = rk; sm->totG[q] = rg; sm->totW[q] = rw; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->zero_prefix = 0;
+        S->valid_upto = n_pass;         // the scan covered sweeps 0..n_pass of the replay that just ran
+        const double L0 = S->G0; const uint32_t ch = F.hist[it];
+        msg->L0 = L0; msg->changed = ch; msg->pad = 0;
+        sm->L0 = L0; sm->changed = ch;
+        if (inline_passes) {
+            fr_fks2_passes(S, sm, 1, nullptr);
+            if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
+        }
+    }
+}
+
+// Exclusive prefixes over the 8-blocks inside chunks of 2048 groups (grid: chunks x a few sweep lanes, each looping over the
+// sweeps); chunk totals go to (ck, cg, cw).
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it, int light) {
     __shared__ double shd[12];
     __shared__ uint32_t shu[4];
     const FksScal *S = F.scal;
-    const int p = blockIdx.y;
     const unsigned c = blockIdx.x;
     const unsigned nb8 = S->n_in / 8 + 1;
     const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
     const int n_pass = S->n_pass;
     const size_t stride = F.nb8_cap;            // a multiple of FR_FKS_CHUNK: every chunk of a sweep's row is fully addressable
     // no delta of this chunk moved in this replay (and the sweeps are the same as before): its prefixes and totals stand
-    if (light && n_pass == S->valid_upto && F.cdirty[c] != (uint32_t)it + 1u) return;
-    if (c < nchunk && p <= n_pass && p < FR_FKS_PMAX) {
+    const bool stands = light && n_pass == S->valid_upto && F.cdirty[c] != (uint32_t)it + 1u;
+    if (!stands && c < nchunk)
+    for (int p = blockIdx.y; p <= n_pass && p < FR_FKS_PMAX; p += gridDim.y) {
         // thread t owns groups [8t, 8t + 8) of the chunk: 32 / 64 contiguous bytes per array, fetched as 16-byte vectors
         const size_t base = (size_t)p * stride + (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8;
         const unsigned left = (size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8 < nb8 ? (unsigned)(nb8 - ((size_t)c * FR_FKS_CHUNK + (size_t)threadIdx.x * 8)) : 0u;   // valid groups of mine
@@ -547,48 +582,15 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
         if (threadIdx.x == 0) {
             F.ck[(size_t)p * FR_FKS_MAXCHUNK + c] = totk; F.cg[(size_t)p * FR_FKS_MAXCHUNK + c] = totg; F.cw[(size_t)p * FR_FKS_MAXCHUNK + c] = totw;
         }
+        __syncthreads();        // shd / shu are reused by the next sweep
     }
 }
 
-// Exclusive prefixes over the chunks and sweep totals (one wave per sweep) into this rank's FksMsg; with one rank,
-// also the sweep scalars of the next replay
+// (a separate launch: folding it into the last workgroup of k_fks_scan needs a device-scope fence in every workgroup, which on this part
+// writes the L2 back each time -- measured 68 us per replay instead of 9 + 9)
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
-    __shared__ FksMsg sm;        // the bookkeeping below is one thread chasing ~20 values per sweep: keep them in LDS
-    FksScal *S = F.scal;
-    const unsigned nb8 = S->n_in / 8 + 1;
-    const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
-    const int n_pass = S->n_pass;
-    const int lane = fr_lane(), wv = threadIdx.x >> 6;
-    for (int q = wv; q < FR_FKS_PMAX; q += 4) {
-        uint32_t rk = 0; double rg = 0, rw = 0;
-        if (q <= n_pass) {
-            for (unsigned c0 = 0; c0 < nchunk; c0 += 64) {
-                unsigned c = c0 + lane;
-                size_t ix = (size_t)q * FR_FKS_MAXCHUNK + c;
-                uint32_t k = c < nchunk ? F.ck[ix] : 0u;
-                double g = c < nchunk ? F.cg[ix] : 0.0, w = c < nchunk ? F.cw[ix] : 0.0;
-                uint32_t tk; double tg, tw;
-                uint32_t ek = fr_wave_excl_u32(k, &tk);
-                double eg = fr_wave_excl_f64(g, &tg);
-                fr_wave_excl_f64(w, &tw);
-                if (c < nchunk) { F.ckx[ix] = rk + ek; F.cgx[ix] = rg + eg; }
-                rk += tk; rg += tg; rw += tw;
-            }
-        }
-        if (lane == 0) { msg->totK[q] = rk; msg->totG[q] = rg; msg->totW[q] = rw; sm.totK[q] = rk; sm.totG[q] = rg; sm.totW[q] = rw; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        S->zero_prefix = 0;
-        S->valid_upto = n_pass;         // k_fks_scan covered sweeps 0..n_pass of the replay that just ran
-        const double L0 = S->G0; const uint32_t ch = F.hist[it];
-        msg->L0 = L0; msg->changed = ch; msg->pad = 0;
-        sm.L0 = L0; sm.changed = ch;
-        if (inline_passes) {
-            fr_fks2_passes(S, &sm, 1, nullptr);
-            if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
-        }
-    }
+    __shared__ FksMsg sm;        // the bookkeeping is one thread chasing ~20 values per sweep: keep them in LDS
+    fr_fks_totals(F, err, msg, inline_passes, it, &sm);
 }
 
 // tie statistics (optional): the smallest relative margin any comparison of the settled stage has (the tiles' records of their last evaluation)

@@ -428,11 +428,11 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             // The replay needs about as many rounds as the reference runs sweeps (a sweep's start state is only right once the sweep
             // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
             // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
-            const int rec_at = c->fks_no_light ? 1 : c->fks_rec_at >= 0 ? c->fks_rec_at : (c->rounds_hint[STAGE] > 3 ? c->rounds_hint[STAGE] - 2 : 1);
+            const int rec_at = c->fks_no_light ? 1 : c->fks_rec_at >= 1 ? c->fks_rec_at : (c->rounds_hint[STAGE] > 3 ? c->rounds_hint[STAGE] - 2 : 1);
             const int light = (it > rec_at && !c->fks_no_light) ? 1 : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
             if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             else FR_LAUNCH(c, light ? "k_fks_sweep_light" : "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
-            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, FR_FKS_PMAX), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0);
+            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0);
             FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
             if (xr) {
                 const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
