@@ -399,19 +399,27 @@ void fr_multi_walks(FriesCtx *c, double rn, double prev_glob_norm, uint32_t n_te
     FR_LAUNCH(c, "k_mc_walk", k_mc_walk, dim3(fr_blocks(bound, FR_TILE)), dim3(FR_BLOCK), c->vec, B, n_walk, c->d_err);
 }
 
-// block 0: <H trial | v>, block 1: <trial | v>
+// block 0: <H trial | v>, block 1: <trial | v>.  The products are formed in parallel, the additions by one lane IN LIST ORDER, absent
+// determinants contributing +0: the doubles of the reference's loop (vec_utils.hpp:228-238), not a tree sum of them.
 __global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, const double *hv, uint32_t nh, const det_t *td, const double *tv, uint32_t nt, double *out) {
-    __shared__ double shd[4];
+    __shared__ double prod[FR_BLOCK];
     const det_t *d = blockIdx.x == 0 ? hd : td;
     const double *w = blockIdx.x == 0 ? hv : tv;
-    uint32_t n = blockIdx.x == 0 ? nh : nt;
+    const uint32_t n = blockIdx.x == 0 ? nh : nt;
     double acc = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        uint32_t s = fr_hash_find(V, d[i]);
-        if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) acc += w[i] * V.v0[pos]; }
+    for (uint32_t base = 0; base < n; base += FR_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        double p = 0;
+        if (i < n) {
+            uint32_t s = fr_hash_find(V, d[i]);
+            if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) p = w[i] * V.v0[pos]; }
+        }
+        prod[threadIdx.x] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t m = n - base < FR_BLOCK ? n - base : FR_BLOCK; for (uint32_t j = 0; j < m; j++) acc += prod[j]; }
+        __syncthreads();
     }
-    double r = fr_block_sum(acc, shd);
-    if (threadIdx.x == 0) out[blockIdx.x] = r;
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
 void fr_dots(FriesCtx *c, double *numer, double *denom) {

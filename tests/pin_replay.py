@@ -3,7 +3,7 @@ restart (non-zero entries compacted, scaled to one-norm m, initiator 1, generato
 bench.py's workload, iteration by iteration, against what the REAL reference logged at the BASELINE sizes.
 
 Bar per iteration: counts (nkept, n_nonz, curr_size, num_success) equal, one-norm and shift bit-identical, projected-energy
-numerator / denominator within 1e-10 relative (block-parallel dot products on the device), the shard's digest (position,
+numerator / denominator identical with one rank (the device adds the products in list order), within 1e-10 relative with ranks, the shard's digest (position,
 determinant, value bits of every non-zero entry) equal on sampled iterations and on the last one.
 
 Ranks are threads of this process talking through the native "local" transport (csrc/comm_native.hip), so 8 ranks can share
@@ -18,7 +18,7 @@ from fries_amd import fcidump
 REL_TOL = 1e-10
 
 
-def _check_row(lg, row, fails, phase):
+def _check_row(lg, row, fails, phase, exact=False):
     for f in ("nkept", "n_nonz", "curr_size", "num_success"):
         if int(lg[f]) != row[f]:
             fails.append((phase, row["it"], f, int(lg[f]), row[f]))
@@ -26,7 +26,9 @@ def _check_row(lg, row, fails, phase):
         if float(lg[f]) != row[f]:
             fails.append((phase, row["it"], f, float(lg[f]).hex(), row[f].hex()))
     for f in ("numer", "denom"):
-        if abs(float(lg[f]) - row[f]) > REL_TOL * max(1.0, abs(row[f])):
+        # one rank: the device adds the products in list order like the reference's loop -> the same doubles; with ranks the reference's
+        # gathered H * trial list is ordered by rank, ours by enumeration, so the partial sums round differently
+        if (float(lg[f]) != row[f]) if exact else (abs(float(lg[f]) - row[f]) > REL_TOL * max(1.0, abs(row[f]))):
             fails.append((phase, row["it"], f, float(lg[f]), row[f]))
     if int(lg["err"]):
         fails.append((phase, row["it"], "err", int(lg["err"])))
@@ -53,7 +55,7 @@ def replay_rank(name, r, rank, comm, device, shared, digest_every=10, max_run_it
         fails.append(("setup", eng.p_doub, g["p_doub"], eng.hf_energy, g["hf_en"]))
     for row in g["fill"]:
         lg = eng.iterate(1)[0]
-        _check_row(lg, row, fails, "F")
+        _check_row(lg, row, fails, "F", exact=(P == 1))
         if row["it"] % digest_every == digest_every - 1 or row is g["fill"][-1]:
             d, v = eng.vector()
             if golden_io.vec_hash(d, v) != row["hash"]:
@@ -83,7 +85,7 @@ def replay_rank(name, r, rank, comm, device, shared, digest_every=10, max_run_it
     c0 = eng.counters()
     for row in rows:
         lg = eng.iterate(1)[0]
-        _check_row(lg, row, fails, "R")
+        _check_row(lg, row, fails, "R", exact=(P == 1))
         if row["it"] % digest_every == digest_every - 1 or row is rows[-1]:
             dd, vv = eng.vector()
             if golden_io.vec_hash(dd, vv) != row["hash"]:

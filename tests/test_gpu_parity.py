@@ -1,7 +1,7 @@
 """GPU suite (-m gpu): the hand-written HIP path, called through the C ABI, against the CPU oracle
 on the same seeded inputs and against the golden vectors the real reference produced.
 Bar: integers (positions, determinants, counts) and stored doubles bit-exact; projected energy
-numer/denom within 1e-10 (their mixed-sign dot products are summed in a tree on the GPU)."""
+numer/denom identical on one rank (the products are added in list order), within 1e-10 with ranks and for the drivers that gather partial sums."""
 import os
 
 import numpy as np
@@ -207,7 +207,8 @@ def test_frisys_trajectory_matches_reference_golden(Engine, mols, name):
         for f in ("nkept", "n_nonz", "curr_size", "num_success"):
             assert int(lg[f]) == row[f], (row["it"], f)
         assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"]
-        assert abs(lg["numer"] / lg["denom"] - row["numer"] / row["denom"]) < ENERGY_TOL
+        # one rank: the products of the dot are added in list order on the device -> the reference's doubles, not merely close ones
+        assert float(lg["numer"]) == row["numer"] and float(lg["denom"]) == row["denom"], (row["it"], float(lg["numer"]).hex(), row["numer"].hex())
         if row["it"] % 10 == 9:
             d, v = eng.vector()
             assert golden_io.vec_hash(d, v) == row["hash"], row["it"]
@@ -236,8 +237,7 @@ def test_frisys_driver_options_match_reference_golden(Engine, mols, name):
         for f in ("nkept", "n_nonz", "curr_size", "num_success"):
             assert int(lg[f]) == row[f], (row["it"], f)
         assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"]
-        assert abs(lg["numer"] / lg["denom"] - row["numer"] / row["denom"]) < ENERGY_TOL
-        assert abs(lg["denom"] - row["denom"]) <= 1e-12 * abs(row["denom"])
+        assert float(lg["numer"]) == row["numer"] and float(lg["denom"]) == row["denom"], (row["it"], float(lg["numer"]).hex(), row["numer"].hex())
     d, v = eng.vector()
     assert golden_io.vec_hash(d, v) == g["rows"][-1]["hash"]
     eng.close()
