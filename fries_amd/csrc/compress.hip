@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
             v *= 1 - eps * (d - shift);
         }
         if (add_col1) { v += V.v1[i] * 1.0; V.v0[i] = v; V.v1[i] = 0; }
-        sum += fabs(v);
+        if (i >= V.n_dense) sum += fabs(v);     // the dense space is not part of the array find_preserve is given
     }
     double bs;
     fr_block_excl_f64(sum, shd, &bs);
@@ -166,7 +166,10 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
     uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
     unsigned grid = fr_blocks(bound, FR_TILE);
     // *global_norm: exact in-order sum of |v| (compress_utils.cpp:34-35, :50)
-    AccAbs aa{c->vec.v0, c->vec.st};
+    // the dense space keeps its values whatever the compression does: marked as already preserved (no share of the norm, no samples, no
+    // deletion; sys_comp clears the marks again)
+    if (c->vec.n_dense) FR_HIP(hipMemsetAsync(B.keep, 1, c->vec.n_dense, st));
+    AccAbs aa{c->vec.v0, c->vec.st, c->vec.n_dense};
     SeqWork Qg = B.seq; Qg.total = B.gnorm;
     run_seq(c, Qg, aa, bound);
     const int P = c->n_ranks;

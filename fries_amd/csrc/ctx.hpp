@@ -65,10 +65,10 @@ struct VcompBuf {
 };
 
 // addend sequences of the vector's in-order sums
-struct AccAbs {             // compress_utils.cpp:34-35
-    const double *v; const VecState *st;
+struct AccAbs {             // compress_utils.cpp:34-35 (the dense space in front is not part of the array find_preserve is given)
+    const double *v; const VecState *st; uint32_t n_dense = 0;
     __device__ unsigned count() const { return st->curr_size; }
-    __device__ double get(size_t i) const { return fabs(v[i]); }
+    __device__ double get(size_t i) const { return i < n_dense ? 0.0 : fabs(v[i]); }
 };
 struct AccUnkept {          // compress_utils.cpp:98-101 and the lbound of sys_comp (:313-314)
     const double *v; const uint8_t *keep; const VecState *st;
@@ -189,6 +189,11 @@ struct FriesCtx {
     uint32_t *d_tie = nullptr;               // [2] tie statistics when enabled (fries_tie_margins): float bits of the smallest relative margin in find_keep_sub / find_preserve
     // optional driver inputs, set before fries_frisys_setup: --trial_vec, --ini_vec, --ham_shift (frisys_mol.cpp:95-98, 157-181, 264-274)
     std::vector<det_t> in_trial_det, in_ini_det; std::vector<double> in_trial_val, in_ini_val;
+    // --det_space (semi-stochastic, one rank): the dense determinants (positions 0 .. n-1 of the vector) and H inside that space
+    // times -eps, per determinant its singles then its doubles (frisys_mol.cpp:236-239, 347-401)
+    std::vector<det_t> in_det_space;
+    uint32_t n_dense_h = 0, n_dense_h_nz = 0;       // symmetry-allowed excitations (what the sample budget is reduced by) / those with a non-zero element
+    uint32_t *d_dh_from = nullptr; det_t *d_dh_to = nullptr; double *d_dh_el = nullptr, *d_dense_norm = nullptr;
     bool ham_shift_set = false; double ham_shift_hf_en = 0;
     // trial vectors (replicated, small)
     uint32_t n_trial = 0, n_htrial = 0;
@@ -259,6 +264,7 @@ void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]);
 void fr_hh_clear_pos0(FriesCtx *c);
 int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 // system.hip
+void fr_dense_h_setup(FriesCtx *c);      // system.hip
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);
 void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac);

@@ -139,6 +139,24 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     fr_vcomp_alloc(c, p->max_dets);
     if (c->ham_shift_set) c->hf_en = c->ham_shift_hf_en;        // --ham_shift (:95-98)
     fr_h_trial_setup(c);        // replicated: every rank enumerates H * trial (the reference gathers the shards, vec_utils.hpp:920-952)
+    if (!c->in_det_space.empty()) {
+        // --det_space (frisys_mol.cpp:236-239): DistVec::init_dense adds every determinant of the file with value 1 (they take positions
+        // 0 .. n - 1 of the empty vector), then zeroes the values; the entries stay
+        if (c->n_ranks > 1) throw FriesError("the dense (semi-stochastic) space runs on one rank in this version");
+        const uint32_t m = (uint32_t)c->in_det_space.size();
+        if (m > c->sp.cap || m > p->max_dets) throw FriesError("dense space larger than the vector / spawn buffer");
+        std::vector<double> v(m, 1.0); std::vector<uint8_t> f(m, 1);
+        FR_HIP(hipMemcpyAsync(c->sp.det, c->in_det_space.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
+        fr_vec_merge(c, &c->vec, m, true);
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+        c->vec.n_dense = c->h_vst.curr_size;          // (a determinant listed twice takes one position)
+        FR_HIP(hipMemsetAsync(c->vec.v0, 0, 8 * (size_t)c->vec.n_dense, c->stream));
+        fr_dense_h_setup(c);
+        if (c->n_dense_h >= p->mat_nonz) throw FriesError("mat_nonz must exceed the number of matrix elements inside the dense space (the compression gets mat_nonz minus that many samples)");
+    }
     if (!c->in_ini_det.empty()) {
         // --ini_vec (:264-274): rank 0 add()s every entry in file order; each rank receives the ones it owns in that order
         std::vector<det_t> d; std::vector<double> v;
@@ -171,6 +189,29 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
 
 static inline double uni(std::mt19937 &mt) { return mt() / (1. + UINT32_MAX); }
 
+// the non-zero products of the dense block of H with column 0, in the stored order (one workgroup: ordered compaction)
+static __global__ void __launch_bounds__(FR_BLOCK) k_dense_spawn(VecDev V, SpawnBuf P, const uint32_t *from, const det_t *to, const double *el, uint32_t n) {
+    __shared__ uint32_t shu[4];
+    uint32_t written = 0;
+    for (uint32_t base = 0; base < n; base += FR_BLOCK) {
+        const uint32_t k = base + threadIdx.x;
+        double mv = 0;
+        if (k < n) mv = V.v0[from[k]] * el[k];
+        const uint32_t f = mv != 0 ? 1u : 0u;       // DistVec::add drops zero values (vec_utils.hpp:418-423)
+        uint32_t tot;
+        const uint32_t incl = fr_block_scan_u32(f, shu, &tot);
+        if (f) { const uint32_t o = written + incl - 1; P.det[o] = to[k]; P.val[o] = mv; P.ini[o] = 1; }
+        written += tot;
+    }
+    if (threadIdx.x == 0) *P.n_spawn = written;
+}
+// DistVec::dense_norm (vec_utils.hpp:903-918): the magnitudes of the dense space added up in position order
+static __global__ void k_dense_norm(VecDev V, double *out) {
+    double r = 0;
+    for (uint32_t i = 0; i < V.n_dense; i++) { const double e = V.v0[i]; r += e >= 0 ? e : -e; }
+    *out = r;
+}
+
 static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     hipStream_t st = c->stream;
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
@@ -178,7 +219,7 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     // systematic matrix compression (:414-422)
     double rn[5];
     for (int k = 0; k < 5; k++) rn[k] = uni(c->mt);
-    fr_hbpp_apply(c, c->mat_nonz, rn);
+    fr_hbpp_apply(c, c->mat_nonz - c->n_dense_h, rn);      // :421 matr_samp - tot_dense_h
     uint32_t vec_size = c->h_vst.curr_size;
     // spawning + annihilation (:429-471)
     if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
@@ -186,6 +227,15 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     uint32_t n_merge = c->num_success;
     if (c->use_comm) n_merge = fr_spawn_exchange(c, c->num_success);      // every rank takes part, also with nothing to send
     if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false);
+    if (c->n_dense_h_nz) {
+        // the dense block of H applied exactly (:480-485): value at the origin x stored element, added as initiator contributions in
+        // the stored order, as a perform_add of its own
+        FR_LAUNCH(c, "k_dense_spawn", k_dense_spawn, dim3(1), dim3(FR_BLOCK), c->vec, c->sp, c->d_dh_from, c->d_dh_to, c->d_dh_el, c->n_dense_h_nz);
+        uint32_t m = 0;
+        FR_HIP(hipMemcpyAsync(&m, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        if (m) fr_vec_merge(c, &c->vec, m, false);
+    }
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     if (c->h_vst.err) check_dev_err(c);
     // death / cloning, column add (:487-499)
@@ -194,6 +244,13 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     uint32_t n_samp = c->vec_nonz;
     double glob_norm = 0;
     fr_find_preserve(c, &n_samp, &glob_norm);
+    if (c->vec.n_dense) {       // glob_norm += sol_vec.dense_norm() (:503, vec_utils.hpp:903-918)
+        double dn = 0;
+        FR_LAUNCH(c, "k_dense_norm", k_dense_norm, dim3(1), dim3(1), c->vec, c->d_dense_norm);
+        FR_HIP(hipMemcpyAsync(&dn, c->d_dense_norm, 8, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        glob_norm += dn;
+    }
     c->glob_norm = glob_norm;
     c->nkept = c->vec_nonz - n_samp;
     const unsigned shift_interval = 10;
@@ -318,6 +375,12 @@ extern "C" int fries_set_initial_vector(fries_ctx *h, const uint64_t *dets, cons
     FR_API_BEGIN
     if (h->c.vec.dets) throw FriesError("fries_set_initial_vector must be called before the driver's setup");
     h->c.in_ini_det.assign(dets, dets + n); h->c.in_ini_val.assign(vals, vals + n);
+    FR_API_END
+}
+extern "C" int fries_set_det_space(fries_ctx *h, const uint64_t *dets, size_t n) {
+    FR_API_BEGIN
+    if (h->c.vec.dets) throw FriesError("fries_set_det_space must come before fries_frisys_setup");
+    h->c.in_det_space.assign(dets, dets + n);
     FR_API_END
 }
 extern "C" int fries_set_ham_shift(fries_ctx *h, double hf_en) {

@@ -69,6 +69,7 @@ struct VecDev {
     // Hubbard-Holstein indices (hh_vec.hpp): electrons in the low 2 * hh_sites bits, 3 bits per phonon above them
     uint32_t hh_sites, hh_nelec, hh_buckets;
     const uint32_t *hh_scr;     // the reference's vec_hash_ scrambler (device)
+    uint32_t n_dense;           // positions [0, n_dense) hold the semi-stochastic dense space: never compressed, never deleted (DistVec::init_dense)
 };
 #define FR_HH_PH_BITS 3
 

@@ -9,7 +9,8 @@
 // Stage 1 elements are the stored vector elements (frisys_mol.cpp:414-420, heat_bathPP.cpp:714-727).
 __global__ void __launch_bounds__(FR_BLOCK) k_prep1(CompWork W, VecDev V, int cur, uint32_t n_samp) {
     __shared__ double shd[12];
-    const unsigned n_in = V.st->curr_size;
+    const unsigned nd = V.n_dense;                      // the dense space in front is multiplied exactly, not compressed (frisys_mol.cpp:414-420)
+    const unsigned n_in = V.st->curr_size - nd;
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CompState s{};
@@ -23,8 +24,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep1(CompWork W, VecDev V, int cu
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + (size_t)it * FR_BLOCK;
         if (e >= n_in) break;
-        double w = fabs(V.v0[e]);
-        E.val[e] = w; E.pos[e] = (uint32_t)e; E.code[e] = 0; E.ndiv[e] = (w > 0) ? 0u : 1u; E.nsub[e] = 2; E.rinv[e] = 1.0; E.raux[e] = 0;
+        double w = fabs(V.v0[e + nd]);
+        E.val[e] = w; E.pos[e] = (uint32_t)(e + nd); E.code[e] = 0; E.ndiv[e] = (w > 0) ? 0u : 1u; E.nsub[e] = 2; E.rinv[e] = 1.0; E.raux[e] = 0;
         W.wt_remain[e] = w; W.keep[e] = 0;
         sum += w;
     }
@@ -543,7 +544,7 @@ template <bool NEW_HB>
 static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int unit_matrel) {
     CompWork &W = c->W;
     hipStream_t st = c->stream;
-    uint32_t bound1 = c->h_vst.curr_size;
+    uint32_t bound1 = c->h_vst.curr_size - c->vec.n_dense;
     uint32_t bound = n_samp + 64 < W.cap ? n_samp + 64 : W.cap;     // a stage never emits more than n_samp entries
     if (bound1 > W.cap) throw FriesError("vector larger than HB-PP work capacity");
     // with ranks, n_samp is the global budget and a shard usually emits ~1/n_ranks of it: size the next stage's

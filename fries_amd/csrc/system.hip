@@ -175,6 +175,46 @@ __global__ void __launch_bounds__(FR_BLOCK) k_enum(const det_t *src, const doubl
     if (!pass && threadIdx.x == 0) { counts[2 * d + mode] = n_allowed; nz[2 * d + mode] = n_written; }
 }
 
+// H restricted to the dense space, times -eps (frisys_mol.cpp:347-397): for every dense determinant, in position order, its
+// symmetry-allowed singles and then its doubles as (from position, to determinant, <to|H|from> * parity * -eps).  Excitations whose
+// element is zero are counted (they are part of tot_dense_h, which the matrix sample budget is reduced by, :421) but not stored:
+// the reference's add() drops a zero value.
+void fr_dense_h_setup(FriesCtx *c) {
+    hipStream_t st = c->stream;
+    const uint32_t ns = c->vec.n_dense;
+    c->n_dense_h = c->n_dense_h_nz = 0;
+    if (!ns) return;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    std::vector<double> ones(ns, 1.0);
+    double *d_val = fr_alloc<double>(ns);
+    uint32_t *d_cnt = fr_alloc<uint32_t>(2 * ns), *d_nz = fr_alloc<uint32_t>(2 * ns), *d_off = fr_alloc<uint32_t>(2 * ns);
+    FR_HIP(hipMemcpyAsync(d_val, ones.data(), 8 * (size_t)ns, hipMemcpyHostToDevice, st));
+    EnumOut eo{nullptr, nullptr, nullptr};
+    for (int mode = 0; mode < 2; mode++)
+        FR_LAUNCH(c, "k_enum", k_enum, dim3(ns), dim3(FR_BLOCK), c->vec.dets, d_val, ns, S, mode, 0, d_cnt, d_nz, d_off, eo, -c->eps);
+    std::vector<uint32_t> cnt(2 * ns), nz(2 * ns), off(2 * ns);
+    FR_HIP(hipMemcpyAsync(cnt.data(), d_cnt, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipMemcpyAsync(nz.data(), d_nz, 8 * (size_t)ns, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    uint64_t tot = 0; uint32_t o = 0;
+    std::vector<uint32_t> from;
+    for (uint32_t d = 0; d < ns; d++)
+        for (int mode = 0; mode < 2; mode++) { tot += cnt[2 * d + mode]; off[2 * d + mode] = o; o += nz[2 * d + mode]; from.insert(from.end(), nz[2 * d + mode], d); }
+    if (tot > 0xffffffffull) throw FriesError("dense block of H too large");
+    c->n_dense_h = (uint32_t)tot; c->n_dense_h_nz = o;
+    c->d_dh_from = fr_alloc<uint32_t>(o ? o : 1); c->d_dh_to = fr_alloc<det_t>(o ? o : 1); c->d_dh_el = fr_alloc<double>(o ? o : 1);
+    c->d_dense_norm = fr_alloc<double>(1);
+    if (o) {
+        FR_HIP(hipMemcpyAsync(d_off, off.data(), 8 * (size_t)ns, hipMemcpyHostToDevice, st));
+        FR_HIP(hipMemcpyAsync(c->d_dh_from, from.data(), 4 * (size_t)o, hipMemcpyHostToDevice, st));
+        EnumOut wo{c->d_dh_to, c->d_dh_el, nullptr};
+        for (int mode = 0; mode < 2; mode++)
+            FR_LAUNCH(c, "k_enum", k_enum, dim3(ns), dim3(FR_BLOCK), c->vec.dets, d_val, ns, S, mode, 1, d_cnt, d_nz, d_off, wo, -c->eps);
+    }
+    FR_HIP(hipStreamSynchronize(st));
+    FR_HIP(hipFree(d_val)); FR_HIP(hipFree(d_cnt)); FR_HIP(hipFree(d_nz)); FR_HIP(hipFree(d_off));
+}
+
 // H * trial with trial = the list (src, src_val): returns on the host the merged (det, value)
 // list in the reference's storage order, i.e. what htrial_vec holds after
 // h_op_offdiag / h_op_diag / add_vecs (frisys_mol.cpp:205-210).

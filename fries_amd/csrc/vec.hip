@@ -12,7 +12,7 @@
 
 // ------------------------------------------------------------------ allocation / state
 void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
-    v->cap = cap;
+    v->cap = cap; v->n_dense = 0;
     uint32_t h = 1024;
     while (h < 2u * cap + 1024u) h <<= 1;
     v->hcap_max = h;

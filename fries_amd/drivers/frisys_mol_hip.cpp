@@ -3,14 +3,14 @@
 //
 //   frisys_mol_hip --fcidump_path F --point_group D2h --distribution HB_unnorm --vec_nonz N --mat_nonz N --max_dets N
 //                  [--target T] [--initiator I] [--epsilon E] [--max_iter K] [--result_dir DIR/] [--load_dir DIR/]
-//                  [--ini_vec PREFIX] [--trial_vec PREFIX] [--ham_shift E] [--seed S] [--device D]
+//                  [--ini_vec PREFIX] [--trial_vec PREFIX] [--det_space FILE] [--ham_shift E] [--seed S] [--device D]
 //
 // Host side only: option parsing (argparse there, a loop here), the FCIDUMP reader (parse_fcidump / convert_symm,
 // FRIES/io_utils.cpp:189-318), the text outputs projnum.txt / projden.txt / S.txt / norm.txt / nkept.txt / params.txt
 // (frisys_mol.cpp:288-345, 505-531) and the binary checkpoint dets0.dat / vals0.dat / dense.txt / hash.dat
 // (DistVec::save / load, FRIES/vec_utils.hpp:703-844; save_proc_hash, io_utils.cpp:589-606).  Everything numeric runs on
 // the GPU.  --ini_vec / --trial_vec read the reference's text vectors (<prefix>dets, <prefix>vals; load_vec_txt, io_utils.cpp:447-482).
-// --det_space (the semi-stochastic space) is not implemented.
+// --det_space FILE: the semi-stochastic dense space (one rank; with --load_dir the checkpoint must not hold one).
 //
 // Ranks (the reference under mpiexec -n P: hash-sharded vector, MPI_Alltoallv of the adds, rank-ordered sums):
 //   * one process per MI355X over librccl: start P copies with RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun's names;
@@ -27,7 +27,7 @@
 #include <unistd.h>
 
 struct Args {
-    std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir, ini_vec, trial_vec;
+    std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir, ini_vec, trial_vec, det_space;
     bool have_ham_shift = false; double ham_shift = 0;
     double target = 0, initiator = 0, epsilon = 0.01;
     uint32_t max_iter = 1000000, vec_nonz = 0, mat_nonz = 0, max_dets = 0, seed = 0, device = 0;
@@ -48,8 +48,8 @@ static Args parse_args(int argc, char **argv) {
     if (kv.count("load_dir")) r.load_dir = kv["load_dir"];
     if (kv.count("ini_vec")) r.ini_vec = kv["ini_vec"];
     if (kv.count("trial_vec")) r.trial_vec = kv["trial_vec"];
+    if (kv.count("det_space")) r.det_space = kv["det_space"];
     if (kv.count("ham_shift")) { r.ham_shift = std::stod(kv["ham_shift"]); r.have_ham_shift = true; }
-    if (kv.count("det_space")) throw std::runtime_error("--det_space (semi-stochastic space) is not implemented in frisys_mol_hip");
     if (kv.count("target")) r.target = std::stod(kv["target"]);
     if (kv.count("initiator")) r.initiator = std::stod(kv["initiator"]);
     if (kv.count("epsilon")) r.epsilon = std::stod(kv["epsilon"]);
@@ -124,6 +124,15 @@ static void run_rank(const Args &args, const Fcidump &in, uint32_t seed, int ran
     if (!args.trial_vec.empty()) { load_vec_txt(args.trial_vec, tdets, tvals); ck(fries_set_trial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }      // :157-181
     if (args.load_dir.empty() && !args.ini_vec.empty()) { load_vec_txt(args.ini_vec, tdets, tvals); ck(fries_set_initial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }   // :264-274
     if (args.have_ham_shift) ck(fries_set_ham_shift(ctx, args.ham_shift - in.core_en));      // :95-98
+    if (args.load_dir.empty() && !args.det_space.empty()) {     // --det_space (:236-239): the integers read_dets reads (io_utils.cpp:565-586)
+        if (n_ranks > 1) throw std::runtime_error("--det_space runs on one rank in this version");
+        std::ifstream f(args.det_space);
+        if (!f.is_open()) throw std::runtime_error("Could not open file: " + args.det_space);
+        std::vector<uint64_t> space;
+        long long d;
+        while (f >> d) space.push_back((uint64_t)d);
+        ck(fries_set_det_space(ctx, space.data(), space.size()));
+    }
     if (!args.load_dir.empty()) {                       // :128-130 load_proc_hash: the shards of the run that wrote the checkpoint
         std::ifstream fh(args.load_dir + "hash.dat", std::ios::binary);
         if (!fh.is_open()) throw std::runtime_error("Error: could not open saved hash scrambler at " + args.load_dir + "hash.dat");

@@ -26,7 +26,7 @@ EXPORTS = [
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
     "fries_set_proc_scrambler", "fries_tie_margins", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
-    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs",
+    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs", "fries_set_det_space",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
     lib.fries_vec_column_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.fries_vec_column_zero.argtypes = [C.c_void_p, C.c_int]
     lib.fries_vec_add_vecs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    lib.fries_set_det_space.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.fries_vec_diag_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fries_vec_dot_list.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
     lib.fries_vec_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -237,9 +238,9 @@ class FriEngine:
 
     # ---- frisys_mol
     def setup(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm",
-              trial=None, ini=None, ham_shift=None):
+              trial=None, ini=None, ham_shift=None, det_space=None):
         """frisys_mol setup.  trial / ini: (dets, vals) of --trial_vec / --ini_vec; ham_shift: the diagonal offset that replaces
-        the HF energy (--ham_shift minus the core energy)."""
+        the HF energy (--ham_shift minus the core energy); det_space: the determinants of --det_space (semi-stochastic dense space)."""
         if distribution not in ("HB", "HB_unnorm"):
             raise RuntimeError('"dist_str" argument must be either "HB" or "HB_unnorm"')
         for pair, fn in ((trial, self.lib.fries_set_trial_vector), (ini, self.lib.fries_set_initial_vector)):
@@ -249,6 +250,9 @@ class FriEngine:
                 self._ck(fn(self.h, _ptr(d), _ptr(v), min(d.size, v.size)))
         if ham_shift is not None:
             self._ck(self.lib.fries_set_ham_shift(self.h, float(ham_shift)))
+        if det_space is not None:
+            d = np.ascontiguousarray(det_space, dtype=np.uint64)
+            self._ck(self.lib.fries_set_det_space(self.h, _ptr(d), d.size))
         if self.comm is not None and self.comm.big_bytes < 16 * (mat_nonz + 4096):
             raise RuntimeError("TorchComm was sized for a smaller mat_nonz")
         p = FrisysParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)

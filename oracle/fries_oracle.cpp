@@ -1810,12 +1810,41 @@ void Frisys::setup() {
         p_doub = (double)n_doub / (n_sing2 + n_doub);
     }
     }
+    n_determ = 0; determ_from.clear(); determ_to.clear(); determ_el.clear();
+    if (!det_space.empty()) {
+        // init_dense (vec_utils.hpp:858-873): add every determinant with value 1, then zero the values; they stay stored
+        if (cm.size != 1) throw std::runtime_error("the dense subspace of the restatement is one rank");
+        for (det_t d : det_space) sol.add(d, 1, 1);
+        sol.perform_add(0);
+        n_determ = sol.curr_size;
+        for (auto &col : sol.vals) std::fill(col.begin(), col.begin() + n_determ, 0.0);
+    }
     if (!ini_det.empty()) { if (cm.rank == 0) for (size_t i = 0; i < ini_det.size(); i++) sol.add(ini_det[i], ini_val[i], 1); }      // :264-274
     else if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);       // :277-279
     sol.perform_add(0);
     sys.hb.set_up(sys.ints);
     srt.assign(sol.max_size, 0); keep.assign(sol.max_size, 0);
     en_shift = 0; last_one_norm = 0; iterat = 0;
+    // H inside the dense space, times -eps (frisys_mol.cpp:347-397): per determinant its singles, then its doubles
+    std::vector<uint8_t> ex;
+    for (size_t di = 0; di < n_determ; di++) {
+        const det_t cur = sol.dets[di];
+        const uint8_t *occ = sol.orbs_at(di);
+        size_t n_sing = sing_ex_symm(cur, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
+        for (size_t e = 0; e < n_sing; e++) {
+            double m = sing_matrel_nosgn(&ex[2 * e], occ, sys.ints, n_elec);
+            det_t nd = cur;
+            m *= sing_det_parity(&nd, &ex[2 * e]) * -par.eps;
+            determ_from.push_back(di); determ_to.push_back(nd); determ_el.push_back(m);
+        }
+        size_t n_doub = doub_ex_symm(cur, occ, n_elec, n_orb, ex, sys.symm.irrep.data());
+        for (size_t e = 0; e < n_doub; e++) {
+            double m = doub_matrel_nosgn(&ex[4 * e], sys.ints);
+            det_t nd = cur;
+            m *= doub_det_parity(&nd, &ex[4 * e]) * -par.eps;
+            determ_from.push_back(di); determ_to.push_back(nd); determ_el.push_back(m);
+        }
+    }
 }
 
 void Frisys::iterate(unsigned n_iter) {
@@ -1825,13 +1854,13 @@ void Frisys::iterate(unsigned n_iter) {
     for (unsigned it = 0; it < n_iter; it++, iterat++) {
         IterLog lg{};
         // :414-421
-        std::copy(sol.vals[0].begin(), sol.vals[0].begin() + sol.curr_size, sc.vec1.begin());
-        for (size_t i = 0; i < sol.curr_size; i++) sc.det_idx1[i] = i;
-        sc.vec_len = sol.curr_size;
+        std::copy(sol.vals[0].begin() + n_determ, sol.vals[0].begin() + sol.curr_size, sc.vec1.begin());
+        for (size_t i = n_determ; i < sol.curr_size; i++) sc.det_idx1[i - n_determ] = i;
+        sc.vec_len = sol.curr_size - n_determ;
         double rn[5];
         for (int k = 0; k < 5; k++) rn[k] = uni(mt);     // comp_sub broadcasts rank 0's draw (compress_utils.cpp:806);
                                                            // all ranks seed alike here, so the streams agree
-        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz, false, cm);
+        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz - (uint32_t)determ_el.size(), false, cm);      // :421 matr_samp - tot_dense_h
         size_t comp_len = sc.vec_len;
         lg.num_success = comp_len;
         for (int k = 0; k < 5; k++) lg.comp_len[k] = sc.stage_len[k];
@@ -1865,6 +1894,10 @@ void Frisys::iterate(unsigned n_iter) {
             }
         }
         if (sol.max_size > srt.size()) { srt.resize(sol.max_size); keep.resize(sol.max_size, 0); }
+        // the dense block of H, exactly (:480-485; the reference's loop bound is the allocated size -- the entries beyond the filled
+        // ones are zero pages of a fresh allocation and add nothing)
+        for (size_t k = 0; k < determ_el.size(); k++) sol.add(determ_to[k], before[determ_from[k]] * determ_el[k], 1);
+        sol.perform_add(0);
         // death / cloning :488-499
         sol.cur = 0;
         for (size_t i = 0; i < vec_size; i++) {
@@ -1880,7 +1913,12 @@ void Frisys::iterate(unsigned n_iter) {
         unsigned n_samp = par.vec_nonz;
         double glob_norm;
         std::vector<double> loc_norms(cm.size);
-        double mine = find_preserve(sol.vals[0].data(), srt, keep, sol.curr_size, &n_samp, &glob_norm, cm);
+        double mine = find_preserve(sol.vals[0].data() + n_determ, srt, keep, sol.curr_size - n_determ, &n_samp, &glob_norm, cm);
+        {   // dense_norm (vec_utils.hpp:903-918)
+            double dn = 0;
+            for (size_t i = 0; i < n_determ; i++) { double e = sol.vals[0][i]; dn += e >= 0 ? e : -e; }
+            glob_norm += cm.sum(dn);
+        }
         lg.nkept = par.vec_nonz - n_samp;
         if ((iterat + 1) % shift_interval == 0)
             adjust_shift(&en_shift, glob_norm, &last_one_norm, par.target_norm, shift_damping / shift_interval / eps);
@@ -1889,9 +1927,9 @@ void Frisys::iterate(unsigned n_iter) {
         lg.shift = en_shift; lg.norm = glob_norm;
         double rn_sys = uni(mt);    // the reference draws on rank 0 only and broadcasts (:528, compress_utils.cpp:291)
         cm.allgather(&mine, loc_norms.data(), sizeof(double));
-        sys_comp(sol.vals[0].data(), sol.curr_size, loc_norms.data(), n_samp, keep, rn_sys, cm);
-        for (size_t i = 0; i < sol.curr_size; i++) {
-            if (keep[i]) { sol.del_at_pos(i); keep[i] = 0; }
+        sys_comp(sol.vals[0].data() + n_determ, sol.curr_size - n_determ, loc_norms.data(), n_samp, keep, rn_sys, cm);
+        for (size_t i = 0; i < sol.curr_size - n_determ; i++) {
+            if (keep[i]) { sol.del_at_pos(i + n_determ); keep[i] = 0; }
         }
         lg.n_nonz = sol.n_nonz; lg.curr_size = sol.curr_size;
         log.push_back(lg);

@@ -212,6 +212,36 @@ RELOAD_RUNS = {
 }
 
 
+# --det_space (semi-stochastic): name -> ((shape, n_iter, seed, eps, vec_nonz, mat_nonz, max_dets, initiator, target, dist), n_dense): the dense space is the
+# first n_dense determinants of H|HF> (HF first), written as the integers DistVec::init_dense reads
+DENSE_RUNS = {
+    # (mat_nonz is the budget INCLUDING the dense block of H: frisys_mol.cpp:421 hands mat_nonz - tot_dense_h to the compression)
+    "ne_m2000_dense": (("Ne", 60, 33, 0.01, 2000, 20000, 20000, 1.0, 1000.0, "HB_unnorm"), 12),
+    "n2_m10000_dense_hb": (("N2", 40, 5, 0.01, 10000, 120000, 80000, 2.0, 5000.0, "HB"), 40),
+}
+
+
+def gen_dense(manifest):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    manifest["dense_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, ((shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt, dist), n_dense) in DENSE_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            orc = oracle_lib.OracleFrisys(mol, epsilon=0.01, vec_nonz=10, mat_nonz=10, max_dets=100, seed=1)
+            hd, _ = orc.htrial()
+            space = name + "_space.txt"
+            with open(os.path.join(GOLD, space), "w") as f:
+                f.write("".join("%d\n" % int(d) for d in hd[:n_dense]))
+            env = dict(os.environ, FRIES_DETSPACE=os.path.join(GOLD, space), FRIES_DETSPACE_DIR=tmp + "/")
+            subprocess.run([HARNESS, "frisys", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist,
+                            os.path.join(GOLD, name + ".traj")], check=True, env=env)
+            manifest["dense_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini,
+                                                target_norm=tgt, distribution=dist, det_space=space, n_dense=n_dense)
+
+
 def gen_reload(manifest):
     manifest["reload_runs"] = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -268,6 +298,13 @@ def main():
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
         gen_reload(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-dense":
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_dense(manifest)
         with open(os.path.join(GOLD, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return

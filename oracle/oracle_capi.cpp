@@ -39,11 +39,24 @@ void *fo_frisys_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, c
     return f;
 }
 // the same with the driver's optional inputs (--trial_vec, --ini_vec, --ham_shift); n == 0 / has_shift == 0 leave the defaults
+void *fo_frisys_create_ex2(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                           double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm,
+                           const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const double *in_val, size_t n_in,
+                           int has_shift, double ham_shift_hf_en, const uint64_t *space, size_t n_space);
 void *fo_frisys_create_ex(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                           double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm,
                           const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const double *in_val, size_t n_in,
                           int has_shift, double ham_shift_hf_en) {
+    return fo_frisys_create_ex2(n_orb, n_elec, irreps, h, eris, eps, target, init, vec_nonz, mat_nonz, max_dets, seed, hb_unnorm, tr_det, tr_val, n_tr, in_det, in_val, n_in,
+                                has_shift, ham_shift_hf_en, nullptr, 0);
+}
+/* ... and --det_space: the determinants of the dense (semi-stochastic) space */
+void *fo_frisys_create_ex2(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                           double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm,
+                           const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const double *in_val, size_t n_in,
+                           int has_shift, double ham_shift_hf_en, const uint64_t *space, size_t n_space) {
     Frisys *f = new Frisys();
+    if (n_space) f->det_space.assign(space, space + n_space);
     f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
     f->sys.ints.n_orb = n_orb;
     f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);

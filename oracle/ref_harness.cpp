@@ -354,6 +354,11 @@ struct RefRun {
     std::vector<fo::det_t> trial_in_det, ini_in_det; std::vector<double> trial_in_val, ini_in_val;      // what the text files held
     size_t max_dets_ = 0, adder_size_ = 0;
     std::function<double(const uint8_t *)> diag_sc_;
+    // --det_space (frisys_mol.cpp:236-239, 347-401): the dense subspace through the reference's own init_dense, and H inside it
+    size_t n_determ = 0, determ_h_size = 0;
+    unsigned n_determ_h = 0, tot_dense_h = 0;
+    size_t *determ_from = nullptr; Matrix<uint8_t> *determ_to = nullptr; double *determ_matr_el = nullptr;
+    std::vector<fo::det_t> det_space_in;
     // per-iteration record
     double numer, denom, glob_norm; unsigned nkept; size_t num_success;
 
@@ -419,6 +424,11 @@ struct RefRun {
         size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec, n_orb, (uint8_t (*)[4])scratch.data(), in->symm);
         size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec, basis_symm);
         p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
+        if (getenv("FRIES_DETSPACE")) {  // --det_space (:236-239)
+            std::string dir = getenv("FRIES_DETSPACE_DIR") ? getenv("FRIES_DETSPACE_DIR") : "/tmp/";
+            n_determ = sol->init_dense(std::string(getenv("FRIES_DETSPACE")), dir);
+            for (size_t i = 0; i < n_determ; i++) det_space_in.push_back(to_u64(sol->indices()[i], det_size));
+        }
         if (getenv("FRIES_INI")) {       // --ini_vec (:264-274)
             Matrix<uint8_t> ini_dets(sol->max_size(), det_size);
             double *lv = sol->values();
@@ -433,6 +443,37 @@ struct RefRun {
         sol->perform_add(0);
         hb = set_up(n_orb, n_orb, *eris);
         srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
+        // H inside the dense space (:347-401), with the reference's allocation sizes and its scratch use of orb_indices1
+        determ_h_size = n_determ * n_elec * n_elec * (n_orb - n_elec / 2) * (n_orb - n_elec / 2);
+        n_determ_h = 0;
+        determ_from = (size_t *)malloc(determ_h_size * sizeof(size_t));
+        determ_to = new Matrix<uint8_t>(determ_h_size, det_size);
+        determ_matr_el = (double *)malloc(determ_h_size * sizeof(double));
+        for (size_t det_idx = 0; det_idx < n_determ; det_idx++) {
+            uint8_t *curr_det = sol->indices()[det_idx];
+            uint8_t *occ_orbs = sol->orbs_at_pos(det_idx);
+            uint8_t (*sing_ex)[2] = (uint8_t (*)[2])comp->orb_indices1;
+            size_t n_sing = sing_ex_symm(curr_det, occ_orbs, n_elec, n_orb, sing_ex, in->symm);
+            if (n_sing + n_determ_h > determ_h_size) { fprintf(stderr, "dense H larger than its allocation\n"); exit(3); }
+            for (size_t e = 0; e < n_sing; e++) {
+                double m = sing_matr_el_nosgn(sing_ex[e], occ_orbs, n_orb, *eris, *h_core, 0, n_elec);
+                uint8_t *new_det = (*determ_to)[n_determ_h];
+                memcpy(new_det, curr_det, det_size);
+                m *= sing_det_parity(new_det, sing_ex[e]) * -eps;
+                determ_from[n_determ_h] = det_idx; determ_matr_el[n_determ_h] = m; n_determ_h++;
+            }
+            uint8_t (*doub_ex)[4] = (uint8_t (*)[4])comp->orb_indices1;
+            size_t n_doub = doub_ex_symm(curr_det, occ_orbs, n_elec, n_orb, doub_ex, in->symm);
+            if (n_doub + n_determ_h > determ_h_size) { fprintf(stderr, "dense H larger than its allocation\n"); exit(3); }
+            for (size_t e = 0; e < n_doub; e++) {
+                double m = doub_matr_el_nosgn(doub_ex[e], n_orb, *eris, 0);
+                uint8_t *new_det = (*determ_to)[n_determ_h];
+                memcpy(new_det, curr_det, det_size);
+                m *= doub_det_parity(new_det, doub_ex[e]) * -eps;
+                determ_from[n_determ_h] = det_idx; determ_matr_el[n_determ_h] = m; n_determ_h++;
+            }
+        }
+        tot_dense_h = sum_mpi((int)n_determ_h, proc_rank, n_procs);
     }
 
     // A fresh solution vector holding (dets, vals) in positions 0..n-1 -- what DistVec::load / fries_vec_load leave behind
@@ -464,10 +505,10 @@ struct RefRun {
     void iterate() {
         DistVec<double> &sol_vec = *sol;
         HBCompressSys &cv = *comp;
-        std::copy(sol_vec.values(), sol_vec.values() + sol_vec.curr_size(), cv.vec1.begin());
-        for (size_t i = 0; i < sol_vec.curr_size(); i++) cv.det_indices1[i] = i;
-        cv.vec_len = sol_vec.curr_size();
-        apply_HBPP_sys(sol_vec.occ_orbs(), sol_vec.indices(), &cv, hb, basis_symm, p_doub, new_hb, mt, mat_nonz, sing_sc, doub_sc);
+        std::copy(sol_vec.values() + n_determ, sol_vec.values() + sol_vec.curr_size(), cv.vec1.begin());
+        for (size_t i = n_determ; i < sol_vec.curr_size(); i++) cv.det_indices1[i - n_determ] = i;
+        cv.vec_len = sol_vec.curr_size() - n_determ;
+        apply_HBPP_sys(sol_vec.occ_orbs(), sol_vec.indices(), &cv, hb, basis_symm, p_doub, new_hb, mt, mat_nonz - tot_dense_h, sing_sc, doub_sc);
         size_t comp_len = cv.vec_len;
         num_success = comp_len;
         double *before = sol_vec.values();
@@ -501,6 +542,14 @@ struct RefRun {
             }
         }
         if (sol_vec.max_size() > srt.size()) { srt.resize(sol_vec.max_size()); keep.resize(sol_vec.max_size(), false); }
+        // the dense block of H (:480-485), with the reference's loop bound: the ALLOCATED size.  The entries beyond the n_determ_h
+        // filled ones are whatever malloc returned -- zero pages for an allocation of this size -- and add() drops zero values.
+        for (size_t k = 0; k < determ_h_size; k++) {
+            size_t d = determ_from[k];
+            double mat_vec = before[d] * determ_matr_el[k];
+            sol_vec.add((*determ_to)[k], mat_vec, 1);
+        }
+        sol_vec.perform_add(0);
         sol_vec.set_curr_vec_idx(0);
         for (size_t i = 0; i < vec_size; i++) {
             double *c = sol_vec[i];
@@ -510,7 +559,7 @@ struct RefRun {
         sol_vec.set_curr_vec_idx(1); sol_vec.zero_vec(); sol_vec.set_curr_vec_idx(0);
         unsigned n_samp = vec_nonz;
         double loc_norms[64];
-        loc_norms[proc_rank] = find_preserve(sol_vec.values(), srt, keep, sol_vec.curr_size(), &n_samp, &glob_norm);
+        loc_norms[proc_rank] = find_preserve(&(sol_vec.values()[n_determ]), srt, keep, sol_vec.curr_size() - n_determ, &n_samp, &glob_norm);
         glob_norm += sol_vec.dense_norm();
         nkept = vec_nonz - n_samp;
         if ((iterat + 1) % 10 == 0) adjust_shift(&en_shift, glob_norm, &last_one_norm, target, 0.05 / 10 / eps);
@@ -521,8 +570,8 @@ struct RefRun {
         double rn_sys = 0;
         if (proc_rank == 0) rn_sys = mt() / (1. + UINT32_MAX);
         MPI_Allgather(MPI_IN_PLACE, 0, MPI_DOUBLE, loc_norms, 1, MPI_DOUBLE, MPI_COMM_WORLD);
-        sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, keep, rn_sys);
-        for (size_t i = 0; i < sol_vec.curr_size(); i++) if (keep[i]) { sol_vec.del_at_pos(i); keep[i] = 0; }
+        sys_comp(&(sol_vec.values()[n_determ]), sol_vec.curr_size() - n_determ, loc_norms, n_samp, keep, rn_sys);
+        for (size_t i = 0; i < sol_vec.curr_size() - n_determ; i++) if (keep[i]) { sol_vec.del_at_pos(i + n_determ); keep[i] = 0; }
         iterat++;
     }
 };
@@ -616,6 +665,7 @@ static void setup_oracle_from_ref(fo::Frisys &fr, RefRun &rr, uint32_t seed, siz
     fr.trial_in_det = rr.trial_in_det; fr.trial_in_val = rr.trial_in_val;
     fr.ini_det = rr.ini_in_det; fr.ini_val = rr.ini_in_val;
     if (getenv("FRIES_HAM_SHIFT")) { fr.has_ham_shift = true; fr.ham_shift = rr.hf_en; }
+    fr.det_space = rr.det_space_in;
     fr.setup();
 }
 

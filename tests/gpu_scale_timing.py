@@ -32,6 +32,10 @@ else:
     eng = FriEngine(mol)
     eng.setup(epsilon=0.01, vec_nonz=m, mat_nonz=m, max_dets=4 * m, target_norm=float(m), initiator=1.0, seed=20250215, distribution="HB_unnorm")
     eng.vec_load(dets, vals); eng.restart(777, 0.0, 0.0, 0)
-    for k in range(3):
+    for k in range(10):
+        if k == 9: eng.prof_enable(True)
         t0 = time.perf_counter(); out = eng.apply_hbpp_piv(m); dt = time.perf_counter() - t0
         print("apply_HBPP_piv n_samp=1e6 call", k, "%.1f ms" % (1e3 * dt), "emitted", len(out[0]) if isinstance(out, tuple) else out, "piv_stats", eng.piv_stats() if hasattr(eng, "piv_stats") else None, flush=True)
+    rep = eng.prof_report()
+    print("kernels of the last call: %.1f ms" % sum(v[0] for v in rep.values()))
+    for name, (ms, calls) in sorted(rep.items(), key=lambda x: -x[1][0])[:18]: print("  %-28s %9.2f ms %7d calls  %.1f us/call" % (name, ms, calls, 1e3 * ms / max(1, calls)))

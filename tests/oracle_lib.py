@@ -67,6 +67,8 @@ def load():
         lib.fo_fqranks_hf_proc.argtypes = [C.c_void_p]
         lib.fo_frisys_create_ex.restype = C.c_void_p
         lib.fo_frisys_create_ex.argtypes = lib.fo_frisys_create.argtypes + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double]
+        lib.fo_frisys_create_ex2.restype = C.c_void_p
+        lib.fo_frisys_create_ex2.argtypes = lib.fo_frisys_create_ex.argtypes + [C.c_void_p, C.c_size_t]
         lib.fo_frifull_create.restype = C.c_void_p
         lib.fo_frifull_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.fo_frifull_destroy.argtypes = [C.c_void_p]
@@ -129,22 +131,24 @@ class OracleFrisys:
     """fo::Frisys -- the sequential CPU restatement of frisys_mol (one rank)."""
 
     def __init__(self, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm",
-                 trial=None, ini=None, ham_shift=None):
+                 trial=None, ini=None, ham_shift=None, det_space=None):
         self.lib = load()
         self.mol = mol
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
-        if trial is None and ini is None and ham_shift is None:
+        if trial is None and ini is None and ham_shift is None and det_space is None:
             self.h = self.lib.fo_frisys_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, initiator,
                                                vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
         else:
             td, tv = (np.ascontiguousarray(trial[0], dtype=np.uint64), np.ascontiguousarray(trial[1], dtype=np.float64)) if trial is not None else (np.zeros(1, np.uint64), np.zeros(1))
             idd, iv = (np.ascontiguousarray(ini[0], dtype=np.uint64), np.ascontiguousarray(ini[1], dtype=np.float64)) if ini is not None else (np.zeros(1, np.uint64), np.zeros(1))
-            self.h = self.lib.fo_frisys_create_ex(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, initiator,
-                                                  vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0,
-                                                  _p(td), _p(tv), td.size if trial is not None else 0, _p(idd), _p(iv), idd.size if ini is not None else 0,
-                                                  0 if ham_shift is None else 1, 0.0 if ham_shift is None else float(ham_shift))
+            sp = np.ascontiguousarray(det_space, dtype=np.uint64) if det_space is not None else np.zeros(1, np.uint64)
+            self.h = self.lib.fo_frisys_create_ex2(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, initiator,
+                                                   vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0,
+                                                   _p(td), _p(tv), td.size if trial is not None else 0, _p(idd), _p(iv), idd.size if ini is not None else 0,
+                                                   0 if ham_shift is None else 1, 0.0 if ham_shift is None else float(ham_shift),
+                                                   _p(sp), sp.size if det_space is not None else 0)
         self.max_dets = max_dets
 
     def __del__(self):

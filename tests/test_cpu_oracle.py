@@ -563,3 +563,27 @@ def test_legacy_hf_directory_reader_matches_reference(tmp_path):
         b = np.frombuffer(blob[12 + n:], dtype=np.float64)
         assert b[0] == 0.0125 and b[1] == -1.5
         assert np.array_equal(b[2:2 + n * n], np.asarray(mol.h_core).reshape(-1)) and np.array_equal(b[2 + n * n:], np.asarray(mol.eris))
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("dense_runs", {})))
+def test_oracle_dense_space_matches_reference_golden(name):
+    """--det_space (semi-stochastic): the restatement with a dense space -- init_dense, H inside the space applied exactly, the
+    compressions restricted to the rest, dense_norm -- against what the real reference logged (`ref_harness frisys` with FRIES_DETSPACE:
+    DistVec::init_dense and the driver's own loop bound over the allocated dense-H arrays)."""
+    import oracle_lib
+    r = golden_io.manifest()["dense_runs"][name]
+    g = golden_io.read_traj(name)
+    space = np.array([int(x) for x in open(os.path.join(golden_io.GOLD, r["det_space"])).read().split()], dtype=np.uint64)
+    assert space.size == r["n_dense"]
+    orc = oracle_lib.OracleFrisys(fcidump.synthetic(r["shape"]), epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"],
+                                  target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"], det_space=space)
+    n_it = min(r["n_iter"], 30)
+    lo = orc.iterate(n_it)
+    for i in range(n_it):
+        row = g["rows"][i]
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lo[f][i]) == row[f], (i, f)
+        assert float(lo["norm"][i]) == row["norm"] and float(lo["shift"][i]) == row["shift"] and float(lo["numer"][i]) == row["numer"] and float(lo["denom"][i]) == row["denom"], i
+    d, v = orc.vector()
+    assert golden_io.vec_hash(d, v) == g["rows"][n_it - 1]["hash"]
+    assert np.array_equal(d[:space.size], space)         # the dense space sits in front, in file order, whatever its values

@@ -899,3 +899,56 @@ def test_fciqmc_trial_and_initial_vectors(oracle, mols, tmp_path):
     assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
     den = np.loadtxt(out + "projden.txt"); num = np.loadtxt(out + "projnum.txt")
     assert np.all(np.abs(den - lo["denom"][:60]) <= 1e-12 * np.abs(lo["denom"][:60])) and np.all(np.abs(num - lo["numer"][:60]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"][:60])))
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("dense_runs", {})))
+def test_frisys_dense_space_matches_reference_golden(Engine, mols, name):
+    """--det_space on the device (fries_set_det_space): the dense determinants in front of the vector, H inside the space applied exactly
+    as a perform_add of its own, the H compression and find_preserve / sys_comp restricted to the rest with mat_nonz - tot_dense_h
+    samples, dense_norm added to the one-norm -- every count, norm, shift, projected-energy numerator / denominator and the stored
+    vector against the reference's trajectory."""
+    r = golden_io.manifest()["dense_runs"][name]
+    g = golden_io.read_traj(name)
+    space = np.array([int(x) for x in open(os.path.join(golden_io.GOLD, r["det_space"])).read().split()], dtype=np.uint64)
+    eng = Engine(mols(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"], det_space=space)
+    for row in g["rows"]:
+        lg = eng.iterate(1)[0]
+        assert int(lg["err"]) == 0
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (row["it"], f, int(lg[f]), row[f])
+        assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"], row["it"]
+        assert float(lg["numer"]) == row["numer"] and float(lg["denom"]) == row["denom"], row["it"]
+        if row["it"] % 10 == 9 or row is g["rows"][-1]:
+            d, v = eng.vector()
+            assert golden_io.vec_hash(d, v) == row["hash"], row["it"]
+            assert np.array_equal(d[:space.size], space)
+    eng.close()
+
+
+def test_cli_det_space(tmp_path):
+    """frisys_mol_hip --det_space FILE (the integers DistVec::init_dense reads) against the reference's dense-space trajectory."""
+    import subprocess
+    from fries_amd import build
+    name = "ne_m2000_dense"
+    r = golden_io.manifest()["dense_runs"][name]
+    g = golden_io.read_traj(name)
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "run") + "/"
+    os.makedirs(out)
+    n_it = 30
+    cmd = [build.DRIVER, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--vec_nonz", str(r["vec_nonz"]),
+           "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--initiator", repr(r["initiator"]),
+           "--epsilon", repr(r["epsilon"]), "--max_iter", str(n_it), "--result_dir", out, "--seed", str(r["seed"]), "--det_space", os.path.join(golden_io.GOLD, r["det_space"])]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nk = np.loadtxt(out + "nkept.txt")
+    sh = np.loadtxt(out + "S.txt").reshape(-1); nm = np.loadtxt(out + "norm.txt").reshape(-1)
+    for i in range(n_it):
+        row = g["rows"][i]
+        assert num[i] == row["numer"] and den[i] == row["denom"] and int(nk[i]) == row["nkept"], i
+    for k in range(n_it // 10):
+        assert sh[k] == g["rows"][10 * k + 9]["shift"] and nm[k] == g["rows"][10 * k + 9]["norm"], k
