@@ -108,3 +108,38 @@ def test_reference_driver_source_runs_on_the_engine(name, tmp_path):
     assert dets.size == g["rows"][n_it - 1]["curr_size"]
     assert golden_io.vec_hash(dets, vals) == g["rows"][n_it - 1]["hash"]
     assert np.fromfile(out + "hash.dat", dtype=np.uint32).size == 2 * mol.n_orb
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["extra_runs"]))
+def test_reference_driver_source_options_on_the_engine(name, tmp_path):
+    """The unmodified reference driver with --trial_vec / --ini_vec (load_vec_txt, a 25-determinant trial vector through the host
+    h_op_offdiag / h_op_diag of include/FRIES/Hamiltonians/molecule.hpp) and --ham_shift (the diagonal offset recovered from the
+    driver's diag_shortcut lambda when the vector moves to the device), against the reference's trajectories."""
+    if not os.path.exists(REFSRC):
+        pytest.skip("oracle/_ref/frisys_mol_refsrc_on_hip is built from /root/reference by __graft_entry__.build() in the container")
+    r = golden_io.manifest()["extra_runs"][name]
+    g = golden_io.read_traj(name)
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "run") + "/"
+    os.makedirs(out)
+    n_it = r["n_iter"]
+    cmd = _cmd(REFSRC, fc, mol, r, n_it, out)
+    if "trial" in r:
+        cmd += ["--trial_vec", os.path.join(golden_io.GOLD, r["trial"])]
+    if "ini" in r:
+        cmd += ["--ini_vec", os.path.join(golden_io.GOLD, r["ini"])]
+    if "ham_shift" in r:
+        cmd += ["--ham_shift", repr(r["ham_shift"])]
+    env = dict(os.environ, LD_PRELOAD=SHIM, FRIES_FIXED_CLOCK_NS=str(r["seed"]))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nk = np.loadtxt(out + "nkept.txt")
+    six = lambda x: float("%.6g" % x)
+    for i in range(n_it):
+        row = g["rows"][i]
+        assert int(nk[i]) == row["nkept"], i
+        assert num[i] == six(row["numer"]) and den[i] == six(row["denom"]), (i, num[i], row["numer"], den[i], row["denom"])
+    dets, vals = _saved_vector(out, mol)
+    assert golden_io.vec_hash(dets, vals) == g["rows"][n_it - 1]["hash"]
