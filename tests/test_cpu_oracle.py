@@ -587,3 +587,25 @@ def test_oracle_dense_space_matches_reference_golden(name):
     d, v = orc.vector()
     assert golden_io.vec_hash(d, v) == g["rows"][n_it - 1]["hash"]
     assert np.array_equal(d[:space.size], space)         # the dense space sits in front, in file order, whatever its values
+
+
+def test_fries_headers_host_logic(tmp_path):
+    """include/FRIES (the reference's headers of this build): everything that runs on the HOST -- bit strings, fermionic signs, excitation
+    lists in the reference's order, SymmInfo, the rank / vector hash, the host DistVec + Adder (positions, LIFO re-use of freed
+    positions, initiator rule, order of additions, dot, local_norm), Matrix / Matrix<bool> / SymmERIs, adjust_shift and the
+    command-line parser -- against the oracle's restatement on random inputs (tests/cpp/test_fries_headers.cpp).  No device call."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import oracle_lib
+    oracle_lib.load()                   # builds oracle/_build/libfries_oracle.so if needed
+    from fries_amd import build
+    assert os.path.exists(build.LIB), "libfries_hip.so has not been built (the headers reference the C ABI)"
+    exe = str(tmp_path / "test_fries_headers")
+    cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "include", "FRIES", "compat"),
+           "-I" + os.path.join(root, "oracle"), os.path.join(root, "tests", "cpp", "test_fries_headers.cpp"), "-o", exe,
+           os.path.join(root, "oracle", "_build", "libfries_oracle.so"), "-L" + os.path.dirname(build.LIB), "-lfries_hip",
+           "-Wl,-rpath," + os.path.join(root, "oracle", "_build"), "-Wl,-rpath," + os.path.dirname(build.LIB), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fails=0" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
