@@ -3,6 +3,7 @@
 // resampling in storage order (sys_comp, :283-327) and the projected-energy dot products
 // (DistVec::dot, FRIES/vec_utils.hpp:228-238).
 #include "ctx.hpp"
+#include <cstring>
 
 void fr_vcomp_alloc(FriesCtx *c, uint32_t cap) {
     VcompBuf &B = c->vc;
@@ -191,9 +192,10 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
             const FpMsg *all = (const FpMsg *)fr_allgather(c, sizeof(FpMsg));
             FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r, all, P, c->d_tie);
         }
-        FR_HIP(hipMemcpyAsync(&hs, &B.state[r], sizeof(CompState), hipMemcpyDeviceToHost, st));
-        FR_HIP(hipMemcpyAsync(glob_norm, B.gnorm, 8, hipMemcpyDeviceToHost, st));
+        const void *h_cs = fr_readback(c, &B.state[r], sizeof(CompState));
+        const void *h_gn = fr_readback(c, B.gnorm, 8);
         FR_HIP(hipStreamSynchronize(st));
+        memcpy(&hs, h_cs, sizeof(CompState)); memcpy(glob_norm, h_gn, 8);
         batch = 2;
     }
     c->rounds_hint[6] = hs.n_pass > 3 ? (int)hs.n_pass - 1 : 2;     // next iteration's first batch = the rounds this one needed
@@ -425,6 +427,25 @@ __global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, co
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
+// the two halves of fr_dots for a caller that synchronises the stream anyway in between (frisys_iterate: find_preserve's rounds)
+const void *fr_dots_enqueue(FriesCtx *c) {
+    FR_LAUNCH(c, "k_dots", k_dots, dim3(2), dim3(FR_BLOCK), c->vec, c->htr_det, c->htr_val, c->n_htrial, c->tr_det, c->tr_val, c->n_trial, c->vc.dots);
+    const double *src = c->vc.dots;
+    if (c->use_comm) {
+        FR_HIP(hipMemcpyAsync(c->comm.small_send, c->vc.dots, 16, hipMemcpyDeviceToDevice, c->stream));
+        src = (const double *)fr_allgather(c, 16);
+    }
+    return fr_readback(c, src, 16 * (size_t)c->n_ranks);
+}
+void fr_dots_collect(FriesCtx *c, const void *h_d, double *numer, double *denom) {
+    const int P = c->n_ranks;
+    double h[2 * FR_MAX_RANKS];
+    memcpy(h, h_d, 16 * (size_t)P);
+    double nu = 0, de = 0;          // sum_mpi in rank order (frisys_mol.cpp:512-517)
+    if (c->dots_slot0_from_hf && P > 1) { h[0] = h[2 * c->hf_proc]; h[1] = h[2 * c->hf_proc + 1]; }
+    for (int p = 0; p < P; p++) { nu += h[2 * p]; de += h[2 * p + 1]; }
+    *numer = nu; *denom = de;
+}
 void fr_dots(FriesCtx *c, double *numer, double *denom) {
     FR_LAUNCH(c, "k_dots", k_dots, dim3(2), dim3(FR_BLOCK), c->vec, c->htr_det, c->htr_val, c->n_htrial, c->tr_det, c->tr_val, c->n_trial, c->vc.dots);
     const int P = c->n_ranks;
@@ -434,8 +455,9 @@ void fr_dots(FriesCtx *c, double *numer, double *denom) {
         FR_HIP(hipMemcpyAsync(c->comm.small_send, c->vc.dots, 16, hipMemcpyDeviceToDevice, c->stream));
         src = (const double *)fr_allgather(c, 16);
     }
-    FR_HIP(hipMemcpyAsync(h, src, 16 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
+    const void *h_d = fr_readback(c, src, 16 * (size_t)P);
     FR_HIP(hipStreamSynchronize(c->stream));
+    memcpy(h, h_d, 16 * (size_t)P);
     double nu = 0, de = 0;          // sum_mpi in rank order (frisys_mol.cpp:512-517)
     if (c->dots_slot0_from_hf && P > 1) { h[0] = h[2 * c->hf_proc]; h[1] = h[2 * c->hf_proc + 1]; }      // fciqmc_fp_mol.cpp:461-462: slot 0 overwritten by the gathering rank
     for (int p = 0; p < P; p++) { nu += h[2 * p]; de += h[2 * p + 1]; }

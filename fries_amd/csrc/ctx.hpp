@@ -169,6 +169,12 @@ struct FriesCtx {
     uint32_t *fks_sxk8 = nullptr; double *fks_sxg8 = nullptr;
     FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
     struct FksSeq *fks_seq = nullptr;        // sequential find_keep_sub (fks_seq.hpp)
+    FksHost *h_fks = nullptr;                // host side of Fks2Work::hm
+    // small device-to-host readbacks (state structs, counters, norms): a one-wave kernel copies them into a pinned, host-coherent block
+    // mapped into the device's address space; the host reads it after the stream synchronisation it needs anyway.  (hipMemcpy of a few
+    // bytes into pageable memory costs a blit kernel, a staging buffer and a host copy per call.)
+    uint8_t *h_rb = nullptr, *d_rb = nullptr; size_t rb_used = 0;
+    static constexpr size_t RB_BYTES = 8192;
     uint32_t prop_tag = 0;                   // last tag handed to a comb-repair round (k_sys_walk)
     int fks_rec_at = -1;                     // FRIES_FKS_REC_AT=k: the replay that records the tiles' margins (default: rounds hint - 2)
     bool fks_no_light = false;               // FRIES_FKS_NO_LIGHT=1: every replay evaluates every tile (tests, comparisons)
@@ -242,6 +248,8 @@ void fr_abs_sums(FriesCtx *c);
 void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm);
 void fr_sys_comp(FriesCtx *c, uint32_t n_samp, double rn);
 void fr_dots(FriesCtx *c, double *numer, double *denom);
+const void *fr_dots_enqueue(FriesCtx *c);
+void fr_dots_collect(FriesCtx *c, const void *h_d, double *numer, double *denom);
 void fr_unkept_norm(FriesCtx *c, uint32_t bound);
 // pivotal.hip
 void fr_piv_flat_reserve(FriesCtx *c, uint32_t cap);
@@ -265,6 +273,9 @@ void fr_hh_clear_pos0(FriesCtx *c);
 int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 // system.hip
 void fr_dense_h_setup(FriesCtx *c);      // system.hip
+// enqueue a copy of `bytes` (a multiple of 4, <= 2 KB) at device address src into the readback block; -> host address to read AFTER the next
+// synchronisation of the stream.  The block is a ring: a slot stays valid until ~RB_BYTES more have been asked for.  (vec.hip)
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes);
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);
 void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac);

@@ -236,14 +236,22 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
         FR_HIP(hipStreamSynchronize(st));
         if (m) fr_vec_merge(c, &c->vec, m, false);
     }
-    fr_vec_sync_state(c, &c->vec, &c->h_vst);
-    if (c->h_vst.err) check_dev_err(c);
+    // no host look at the vector's state here: the kernels read the stored size themselves, the launches only need an upper bound of it
+    // (every merged spawn may have taken a new position); an overflow raised by the merge is reported at the end of the iteration
+    {
+        const uint64_t ub = (uint64_t)c->h_vst.curr_size + n_merge + c->n_dense_h_nz;
+        c->h_vst.curr_size = ub < c->vec.cap ? (uint32_t)ub : c->vec.cap;
+    }
     // death / cloning, column add (:487-499)
     fr_death_clone(c, vec_size);
+    // the projected-energy dot products are taken here -- find_preserve does not touch the values -- so that their readback rides on
+    // the synchronisation find_preserve needs anyway (the reference forms them after it, frisys_mol.cpp:511-517)
+    const void *h_dots = fr_dots_enqueue(c);
     // vector compression (:501-539)
     uint32_t n_samp = c->vec_nonz;
     double glob_norm = 0;
     fr_find_preserve(c, &n_samp, &glob_norm);
+    fr_dots_collect(c, h_dots, &c->numer, &c->denom);
     if (c->vec.n_dense) {       // glob_norm += sol_vec.dense_norm() (:503, vec_utils.hpp:903-918)
         double dn = 0;
         FR_LAUNCH(c, "k_dense_norm", k_dense_norm, dim3(1), dim3(1), c->vec, c->d_dense_norm);
@@ -260,7 +268,6 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
         if (c->last_one_norm) { c->en_shift -= damp * log(glob_norm / c->last_one_norm); c->last_one_norm = glob_norm; }
         if (c->last_one_norm == 0 && glob_norm > c->target_norm) c->last_one_norm = glob_norm;
     }
-    fr_dots(c, &c->numer, &c->denom);
     double rn_sys = uni(c->mt);
     fr_sys_comp(c, n_samp, rn_sys);
     c->iterat++;
@@ -471,6 +478,8 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     if (h->c.pv_goff) hipFree(h->c.pv_goff);
     if (h->c.hh_fdet) hipFree(h->c.hh_fdet);
     if (h->c.hh_ovlp) hipFree(h->c.hh_ovlp);
+    if (h->c.h_fks) hipHostFree(h->c.h_fks);
+    if (h->c.h_rb) hipHostFree(h->c.h_rb);
     if (h->c.hhf_cnt) hipFree(h->c.hhf_cnt);
     hipFree(h->c.tr_det); hipFree(h->c.tr_val); hipFree(h->c.htr_det); hipFree(h->c.htr_val);
     if (h->c.stream) hipStreamDestroy(h->c.stream);

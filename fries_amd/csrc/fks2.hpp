@@ -49,7 +49,17 @@ struct FksSaved {
     uint32_t psN[FR_FKS_PMAX];
 };
 
+// What the host looks at after a batch of replays, in host-coherent pinned memory the kernels write straight into (a device-to-host
+// copy of a few bytes costs a blit kernel plus a staging copy per readback, ~27 of them per iteration before this)
+struct FksHost {
+    uint32_t hist[FR_MAX_ROUNDS];   // per replay: did anything change
+    uint32_t overflow, pad;
+    double G_last, psG0, G_neg;
+    int n_pass;
+};
+
 struct Fks2Work {
+    FksHost *hm;                            // device-visible address of the host block
     uint32_t nb8_cap;
     uint32_t *dk8; double *dg8, *ws8;       // [FR_FKS_PMAX][nb8_cap] group deltas of the latest evaluation of every group
     // Per (group of 8 elements, sweep): the start state the group was last evaluated with -- running norm and remaining budget at its
@@ -83,11 +93,12 @@ static_assert(sizeof(FksMsg) <= 2048, "FksMsg must fit FRIES_COMM_SMALL_BYTES");
 
 // Sweep bookkeeping of compress_utils.cpp:153-158, 251-265 for the next replay from every rank's totals:
 // glob_one_norm = sum_mpi(loc_one_norm) and glob_sampled = sum_mpi(loc_sampled), added in rank order.
-__device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, int n_ranks, uint32_t *hist_it) {
+__device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, int n_ranks, uint32_t *hist_it, FksHost *hm = nullptr, int it = -1) {
     double L[FR_MAX_RANKS];
     uint32_t ch = 0;
     for (int r = 0; r < n_ranks; r++) { L[r] = msgs[r].L0; ch |= msgs[r].changed; }
     if (hist_it) *hist_it = ch;
+    if (hm && it >= 0 && it < FR_MAX_ROUNDS) hm->hist[it] = ch;
     uint32_t n = S->n0;
     int last_pass = 0, p = 0;
     S->G_neg = INFINITY;
@@ -108,6 +119,7 @@ __device__ __forceinline__ void fr_fks2_passes(FksScal *S, const FksMsg *msgs, i
     S->n_pass = p;
     if (p >= FR_FKS_PMAX) S->overflow = 1;
     S->G_last = S->psG[p > 0 ? p - 1 : 0]; S->n_last = n;
+    if (hm) { hm->overflow = S->overflow; hm->G_last = S->G_last; hm->psG0 = S->psG[0]; hm->G_neg = S->G_neg; hm->n_pass = S->n_pass; }
 }
 
 // Replay 0 from the previous iteration's record instead of "nothing kept anywhere" (psG[0] is already this stage's norm)
@@ -142,7 +154,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_init(CompWork W, Fks2Wo
 static __global__ void __launch_bounds__(64) k_fks_passes(Fks2Work F, const FksMsg *msgs, int n_ranks, int it, uint32_t *err, int warm) {
     FksScal *S = F.scal;
     if (threadIdx.x != 0) return;
-    fr_fks2_passes(S, msgs, n_ranks, it >= 0 ? &F.hist[it] : nullptr);
+    fr_fks2_passes(S, msgs, n_ranks, it >= 0 ? &F.hist[it] : nullptr, F.hm, it);
     if (it < 0) fr_fks2_warm(S, F.saved, warm);
     if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
 }
@@ -524,7 +536,7 @@ __device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg 
         msg->L0 = L0; msg->changed = ch; msg->pad = 0;
         sm->L0 = L0; sm->changed = ch;
         if (inline_passes) {
-            fr_fks2_passes(S, sm, 1, nullptr);
+            fr_fks2_passes(S, sm, 1, nullptr, F.hm, it);
             if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
         }
     }

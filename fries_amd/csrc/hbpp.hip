@@ -2,6 +2,7 @@
 // stages with on-the-fly sub-weight rows, then weight / matrix element / parity and an
 // order-preserving compaction of the surviving samples.
 #include "ctx.hpp"
+#include <cstring>
 #include "fks2.hpp"
 #include "fks_seq.hpp"
 
@@ -285,6 +286,13 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         size_t n8 = (size_t)FR_FKS_PMAX * F.nb8_cap;
         F.dk8 = fr_alloc<uint32_t>(n8); F.dg8 = fr_alloc<double>(n8); F.ws8 = fr_alloc<double>(n8);
         F.cdirty = fr_alloc<uint32_t>(FR_FKS_MAXCHUNK);
+        {   // the replay loop's readback block: pinned, host-coherent, mapped into the device's address space
+            void *hp = nullptr, *dp = nullptr;
+            FR_HIP(hipHostMalloc(&hp, sizeof(FksHost), hipHostMallocMapped | hipHostMallocCoherent));
+            for (size_t q = 0; q < sizeof(FksHost); q++) ((volatile uint8_t *)hp)[q] = 0;
+            FR_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+            c->h_fks = (FksHost *)hp; F.hm = (FksHost *)dp;
+        }
         F.gG = fr_alloc<double>(n8); F.gR = fr_alloc<float>(n8); F.gM = fr_alloc<float>(n8); F.gK = fr_alloc<uint32_t>(n8); F.gNp = fr_alloc<uint32_t>(F.nb8_cap);
         FR_HIP(hipMemset(F.gNp, 0xff, 4 * (size_t)F.nb8_cap));
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
@@ -418,8 +426,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // Replays are enqueued in batches (a host round trip costs a fraction of a replay); the per-replay "changed" flags tell
     // afterwards which replay was the first to reproduce its predecessor, and that count is the next iteration's first batch.
     int it = 0, batch = c->rounds_hint[STAGE], needed = 0;
-    uint32_t hh[FR_MAX_ROUNDS];
-    FksScal hscal;
+    FksScal hscal{};
     bool sequential = c->fks_force_seq;
     while (!needed && !sequential) {
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
@@ -441,11 +448,11 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             }
             it++;
         }
-        FR_HIP(hipMemcpyAsync(hh, F.hist, 4 * (size_t)it, hipMemcpyDeviceToHost, st));
-        FR_HIP(hipMemcpyAsync(&hscal, F.scal, sizeof(hscal), hipMemcpyDeviceToHost, st));
-        FR_HIP(hipStreamSynchronize(st));
-        for (int j = 1; j < it && !needed; j++) if (hh[j] == 0) needed = j + 1;      // replay 0 always counts as changed
+        FR_HIP(hipStreamSynchronize(st));       // the kernels wrote the flags and the stage's closing scalars into c->h_fks themselves
+        const volatile FksHost *hm = c->h_fks;
+        for (int j = 1; j < it && !needed; j++) if (hm->hist[j] == 0) needed = j + 1;      // replay 0 always counts as changed
         batch = 1;
+        hscal.overflow = hm->overflow; hscal.G_last = hm->G_last; hscal.psG[0] = hm->psG0; hscal.G_neg = hm->G_neg; hscal.n_pass = hm->n_pass;
         if (hscal.overflow) sequential = true;
     }
     // A stage that removes (almost) all of its norm: the reference's running norm is then its own rounding noise, which only the
@@ -572,8 +579,11 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     double *f_val = W.S; uint32_t *f_orbs = W.kin;
     FR_LAUNCH(c, "k_final_eval", (k_final_eval<NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
     FR_LAUNCH(c, "k_final_compact", k_final_compact, dim3(grid), dim3(FR_BLOCK), W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
-    FR_HIP(hipMemcpyAsync(&c->num_success, c->d_nsucc, 4, hipMemcpyDeviceToHost, st));
-    FR_HIP(hipStreamSynchronize(st));
+    {
+        const void *h_ns = fr_readback(c, c->d_nsucc, 4);
+        FR_HIP(hipStreamSynchronize(st));
+        memcpy(&c->num_success, h_ns, 4);
+    }
 }
 
 void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]) {
