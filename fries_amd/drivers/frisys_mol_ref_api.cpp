@@ -17,6 +17,7 @@
 #include <FRIES/Hamiltonians/molecule.hpp>
 #include <chrono>
 #include <iomanip>
+#include <sstream>
 #include <stdexcept>
 
 struct MyArgs : public argparse::Args {
@@ -36,6 +37,7 @@ struct MyArgs : public argparse::Args {
     std::string &point_group = kwarg("point_group", "point group of the FCIDUMP irrep labels").set_default<std::string>("C1");
     std::shared_ptr<double> &ham_shift = kwarg("ham_shift", "energy subtracted from the diagonal");
     std::shared_ptr<uint32_t> &seed = kwarg("seed", "mt19937 seed (default: the clock, as in the reference)");
+    std::shared_ptr<std::string> &piv_after = kwarg("piv_after", "after the last iteration: apply_HBPP_piv on the vector for every seed:n_samp of this comma-separated list, results to <result_dir>piv<k>.bin");
 };
 
 int main(int argc, char *argv[]) {
@@ -252,6 +254,25 @@ int main(int argc, char *argv[]) {
             }
         }
         sol_vec.save(args.result_dir);
+        if (args.piv_after) {
+            // the pivotal variant of the H compression through the same surface (heat_bathPP.hpp:353-357), each case with a generator of its own
+            HBCompressPiv piv_vecs(spawn_length, n_states);
+            std::stringstream list(*args.piv_after);
+            std::string item;
+            for (int k = 0; std::getline(list, item, ','); k++) {
+                const size_t colon = item.find(':');
+                std::mt19937 mt_piv((unsigned int)std::stoul(item.substr(0, colon)));
+                const uint32_t n_piv = (uint32_t)std::stoul(item.substr(colon + 1));
+                piv_vecs.vec_len = sol_vec.curr_size();
+                apply_HBPP_piv(sol_vec.occ_orbs(), sol_vec.indices(), &piv_vecs, hb_probs, &basis_symm, p_doub, new_hb, mt_piv, n_piv, sing_shortcut, doub_shortcut, 0);
+                std::ofstream f(args.result_dir + "piv" + std::to_string(k) + ".bin", std::ios::binary);
+                const uint64_t n_out = piv_vecs.vec_len, next_draw = mt_piv();
+                f.write((const char *)&n_out, 8); f.write((const char *)&next_draw, 8);
+                for (size_t i = 0; i < n_out; i++) { const uint64_t d = piv_vecs.det_indices2[i]; f.write((const char *)&d, 8); }
+                f.write((const char *)piv_vecs.orb_indices1, 4 * n_out);
+                f.write((const char *)piv_vecs.vec1.data(), 8 * n_out);
+            }
+        }
         MPI_Finalize();
     } catch (std::exception &ex) {
         std::cerr << "\nException : " << ex.what() << "\n";

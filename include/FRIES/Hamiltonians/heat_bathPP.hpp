@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <functional>
 #include <random>
+#include <sstream>
+#include <string>
 #include <stdexcept>
 #include <vector>
 #include <FRIES/ndarr.hpp>
@@ -98,6 +100,43 @@ inline void apply_HBPP_sys(Matrix<uint8_t> & /*all_orbs*/, Matrix<uint8_t> &all_
     size_t n_out = 0;
     uint32_t stage_len[5];
     fries_hip::ck(fries_apply_hbpp_sys(v->ctx(), n_samp, rn, 0, comp_scratch->pos32.data(), (uint8_t *)comp_scratch->orb_indices1, comp_scratch->vec1.data(), spawn_length, &n_out, stage_len));
+    for (size_t i = 0; i < n_out; i++) comp_scratch->det_indices2[i] = comp_scratch->pos32[i];
+    comp_scratch->vec_len = n_out;
+}
+/* pivotal variant (heat_bathPP.hpp:303-310, 353-357): every factor multiplied out into long_vec, compressed by piv_comp_parallel and
+ * collapsed.  The number of uniforms drawn depends on the data, so the caller's generator is lent to the device context (its state
+ * travels as text, the standard's operator<< format) and taken back afterwards.  spin_parity != 0 is not supported. */
+struct HBCompressPiv : HBCompress {
+    std::vector<double> long_vec;
+    std::vector<bool> keep_idx;
+    std::vector<size_t> cmp_srt;
+    std::vector<uint32_t> pos32;
+    HBCompressPiv(size_t length, size_t /*n_subwt*/) : HBCompress(length), pos32(length) {}
+};
+inline void apply_HBPP_piv(Matrix<uint8_t> & /*all_orbs*/, Matrix<uint8_t> &all_dets, HBCompressPiv *comp_scratch,
+                           hb_info * /*hb_probs*/, SymmInfo * /*symm*/, double p_doub, bool new_hb,
+                           std::mt19937 &mt_obj, uint32_t n_samp,
+                           std::function<double(uint8_t *, uint8_t *)> /*sing_mat_fxn*/,
+                           std::function<double(uint8_t *)> /*doub_mat_fxn*/, int spin_parity) {
+    if (spin_parity) throw std::runtime_error("apply_HBPP_piv: time-reversal symmetrised vectors (spin_parity != 0) are not supported by this build");
+    fries_hip::DeviceVecBase *v = fries_hip::Backend::get().by_indices(&all_dets);
+    if (!v) throw std::runtime_error("apply_HBPP_piv: all_dets must be the indices() matrix of the solution DistVec (this build runs the operator on the device-resident vector; there is no host implementation)");
+    const size_t cap = comp_scratch->vec1.size();
+    if (!v->bound()) {
+        v->bind((uint32_t)(cap / 4 > n_samp ? cap / 4 : n_samp), new_hb);
+        if (fries_p_doub(v->ctx()) != p_doub) throw std::runtime_error("apply_HBPP_piv: p_doub differs from the Hartree-Fock excitation counts the device computed");
+    }
+    v->before_device_op();
+    std::ostringstream os; os << mt_obj;
+    fries_hip::ck(fries_rng_set_state(v->ctx(), os.str().c_str()));
+    size_t n_out = 0;
+    uint32_t stage_len[5];
+    fries_hip::ck(fries_apply_hbpp_piv(v->ctx(), n_samp, 0, comp_scratch->pos32.data(), (uint8_t *)comp_scratch->orb_indices1, comp_scratch->vec1.data(), cap, &n_out, stage_len));
+    size_t need = 0;
+    fries_hip::ck(fries_rng_get_state(v->ctx(), nullptr, 0, &need));
+    std::string st(need + 1, '\0');
+    fries_hip::ck(fries_rng_get_state(v->ctx(), &st[0], st.size(), &need));
+    std::istringstream is(st.c_str()); is >> mt_obj;
     for (size_t i = 0; i < n_out; i++) comp_scratch->det_indices2[i] = comp_scratch->pos32[i];
     comp_scratch->vec_len = n_out;
 }

@@ -143,3 +143,30 @@ def test_reference_driver_source_options_on_the_engine(name, tmp_path):
         assert num[i] == six(row["numer"]) and den[i] == six(row["denom"]), (i, num[i], row["numer"], den[i], row["denom"])
     dets, vals = _saved_vector(out, mol)
     assert golden_io.vec_hash(dets, vals) == g["rows"][n_it - 1]["hash"]
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest()["hbpiv_runs"]))
+def test_ref_api_apply_hbpp_piv(name, tmp_path):
+    """The reference's 12-argument apply_HBPP_piv (HBCompressPiv, the caller's std::mt19937 lent to the device and taken back) through
+    include/FRIES/Hamiltonians/heat_bathPP.hpp, on the vector the ref-API driver holds after a golden run's iterations: positions,
+    orbitals and values of the reference's own apply_HBPP_piv (tests/golden/hbpiv_*.txt), and the generator left in the right state."""
+    from fries_amd import build
+    h = golden_io.manifest()["hbpiv_runs"][name]
+    r = golden_io.manifest()["runs"][h["run"]]
+    cases = golden_io.read_hbpiv(name)
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "run") + "/"
+    os.makedirs(out)
+    spec = ",".join("%d:%d" % (c["seed"], c["n_samp"]) for c in cases)
+    res = subprocess.run(_cmd(build.REF_API_DRIVER, fc, mol, r, h["n_iter"], out) + ["--seed", str(r["seed"]), "--piv_after", spec], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    for k, c in enumerate(cases):
+        raw = np.fromfile(out + "piv%d.bin" % k, dtype=np.uint8)
+        n_out = int(raw[:8].view(np.uint64)[0])
+        assert n_out == c["n_out"], (k, n_out, c["n_out"])
+        pos = raw[16:16 + 8 * n_out].view(np.uint64)
+        orbs = raw[16 + 8 * n_out:16 + 12 * n_out].reshape(-1, 4)
+        vals = raw[16 + 12 * n_out:16 + 20 * n_out].view(np.float64)
+        assert np.array_equal(pos, c["pos"].astype(np.uint64)) and np.array_equal(orbs, c["orbs"]) and vals.tobytes() == c["val"].tobytes(), (name, k)
