@@ -198,7 +198,8 @@ struct FriesCtx {
     // --det_space (semi-stochastic, one rank): the dense determinants (positions 0 .. n-1 of the vector) and H inside that space
     // times -eps, per determinant its singles then its doubles (frisys_mol.cpp:236-239, 347-401)
     std::vector<det_t> in_det_space;
-    uint32_t n_dense_h = 0, n_dense_h_nz = 0;       // symmetry-allowed excitations (what the sample budget is reduced by) / those with a non-zero element
+    uint32_t n_dense_h = 0, n_dense_h_nz = 0;       // symmetry-allowed excitations of this rank's dense determinants / those with a non-zero element
+    uint32_t n_dense_h_glob = 0;                    // the former summed over the ranks: what the matrix sample budget is reduced by
     uint32_t *d_dh_from = nullptr; det_t *d_dh_to = nullptr; double *d_dh_el = nullptr, *d_dense_norm = nullptr;
     bool ham_shift_set = false; double ham_shift_hf_en = 0;
     // trial vectors (replicated, small)

@@ -142,20 +142,38 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     if (!c->in_det_space.empty()) {
         // --det_space (frisys_mol.cpp:236-239): DistVec::init_dense adds every determinant of the file with value 1 (they take positions
         // 0 .. n - 1 of the empty vector), then zeroes the values; the entries stay
-        if (c->n_ranks > 1) throw FriesError("the dense (semi-stochastic) space runs on one rank in this version");
-        const uint32_t m = (uint32_t)c->in_det_space.size();
+        // With ranks: rank 0 adds the whole file and the adds travel to their owners (vec_utils.hpp:866-872), i.e. every rank receives the
+        // determinants it owns in file order; each rank then has a dense space of its own length.
+        std::vector<det_t> mine;
+        for (det_t d : c->in_det_space) if (fr_host_idx_to_proc(c, d) == c->rank) mine.push_back(d);
+        const uint32_t m = (uint32_t)mine.size();
         if (m > c->sp.cap || m > p->max_dets) throw FriesError("dense space larger than the vector / spawn buffer");
-        std::vector<double> v(m, 1.0); std::vector<uint8_t> f(m, 1);
-        FR_HIP(hipMemcpyAsync(c->sp.det, c->in_det_space.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
-        FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
-        FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
-        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
-        fr_vec_merge(c, &c->vec, m, true);
+        if (m) {
+            std::vector<double> v(m, 1.0); std::vector<uint8_t> f(m, 1);
+            FR_HIP(hipMemcpyAsync(c->sp.det, mine.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.val, v.data(), 8 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.ini, f.data(), m, hipMemcpyHostToDevice, c->stream));
+            FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &m, 4, hipMemcpyHostToDevice, c->stream));
+            fr_vec_merge(c, &c->vec, m, true);
+        }
         fr_vec_sync_state(c, &c->vec, &c->h_vst);
         c->vec.n_dense = c->h_vst.curr_size;          // (a determinant listed twice takes one position)
-        FR_HIP(hipMemsetAsync(c->vec.v0, 0, 8 * (size_t)c->vec.n_dense, c->stream));
+        if (c->vec.n_dense) FR_HIP(hipMemsetAsync(c->vec.v0, 0, 8 * (size_t)c->vec.n_dense, c->stream));
         fr_dense_h_setup(c);
-        if (c->n_dense_h >= p->mat_nonz) throw FriesError("mat_nonz must exceed the number of matrix elements inside the dense space (the compression gets mat_nonz minus that many samples)");
+        // tot_dense_h = sum_mpi(n_determ_h) (frisys_mol.cpp:399): what the matrix sample budget is reduced by, on every rank
+        c->n_dense_h_glob = c->n_dense_h;
+        if (c->use_comm) {
+            FR_HIP(hipMemcpyAsync(c->comm.small_send, &c->n_dense_h, 4, hipMemcpyHostToDevice, c->stream));
+            const uint32_t *all = (const uint32_t *)fr_allgather(c, 4);
+            std::vector<uint32_t> cnt(c->n_ranks);
+            FR_HIP(hipMemcpyAsync(cnt.data(), all, 4 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+            FR_HIP(hipStreamSynchronize(c->stream));
+            uint64_t tot = 0;
+            for (uint32_t x : cnt) tot += x;
+            if (tot > 0xffffffffull) throw FriesError("dense block of H too large");
+            c->n_dense_h_glob = (uint32_t)tot;
+        }
+        if (c->n_dense_h_glob >= p->mat_nonz) throw FriesError("mat_nonz must exceed the number of matrix elements inside the dense space (the compression gets mat_nonz minus that many samples)");
     }
     if (!c->in_ini_det.empty()) {
         // --ini_vec (:264-274): rank 0 add()s every entry in file order; each rank receives the ones it owns in that order
@@ -219,7 +237,7 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     // systematic matrix compression (:414-422)
     double rn[5];
     for (int k = 0; k < 5; k++) rn[k] = uni(c->mt);
-    fr_hbpp_apply(c, c->mat_nonz - c->n_dense_h, rn);      // :421 matr_samp - tot_dense_h
+    fr_hbpp_apply(c, c->mat_nonz - c->n_dense_h_glob, rn);      // :421 matr_samp - tot_dense_h
     uint32_t vec_size = c->h_vst.curr_size;
     // spawning + annihilation (:429-471)
     if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
@@ -227,19 +245,23 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     uint32_t n_merge = c->num_success;
     if (c->use_comm) n_merge = fr_spawn_exchange(c, c->num_success);      // every rank takes part, also with nothing to send
     if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false);
-    if (c->n_dense_h_nz) {
+    uint32_t n_merge_dense = 0;
+    if (c->n_dense_h_glob) {
         // the dense block of H applied exactly (:480-485): value at the origin x stored element, added as initiator contributions in
-        // the stored order, as a perform_add of its own
-        FR_LAUNCH(c, "k_dense_spawn", k_dense_spawn, dim3(1), dim3(FR_BLOCK), c->vec, c->sp, c->d_dh_from, c->d_dh_to, c->d_dh_el, c->n_dense_h_nz);
+        // the stored order, as a perform_add of its own (with ranks: an exchange of its own, every rank taking part)
         uint32_t m = 0;
-        FR_HIP(hipMemcpyAsync(&m, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
-        FR_HIP(hipStreamSynchronize(st));
-        if (m) fr_vec_merge(c, &c->vec, m, false);
+        if (c->n_dense_h_nz) {
+            FR_LAUNCH(c, "k_dense_spawn", k_dense_spawn, dim3(1), dim3(FR_BLOCK), c->vec, c->sp, c->d_dh_from, c->d_dh_to, c->d_dh_el, c->n_dense_h_nz);
+            FR_HIP(hipMemcpyAsync(&m, c->sp.n_spawn, 4, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+        }
+        n_merge_dense = c->use_comm ? fr_spawn_exchange(c, m) : m;      // all of them carry the initiator flag: one pass in effect
+        if (n_merge_dense) fr_vec_merge(c, &c->vec, n_merge_dense, false);
     }
     // no host look at the vector's state here: the kernels read the stored size themselves, the launches only need an upper bound of it
     // (every merged spawn may have taken a new position); an overflow raised by the merge is reported at the end of the iteration
     {
-        const uint64_t ub = (uint64_t)c->h_vst.curr_size + n_merge + c->n_dense_h_nz;
+        const uint64_t ub = (uint64_t)c->h_vst.curr_size + n_merge + n_merge_dense;
         c->h_vst.curr_size = ub < c->vec.cap ? (uint32_t)ub : c->vec.cap;
     }
     // death / cloning, column add (:487-499)
@@ -252,11 +274,18 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     double glob_norm = 0;
     fr_find_preserve(c, &n_samp, &glob_norm);
     fr_dots_collect(c, h_dots, &c->numer, &c->denom);
-    if (c->vec.n_dense) {       // glob_norm += sol_vec.dense_norm() (:503, vec_utils.hpp:903-918)
-        double dn = 0;
+    if (c->n_dense_h_glob || c->vec.n_dense) {       // glob_norm += sol_vec.dense_norm() (:503, vec_utils.hpp:903-918: sum_mpi of the ranks' sums)
         FR_LAUNCH(c, "k_dense_norm", k_dense_norm, dim3(1), dim3(1), c->vec, c->d_dense_norm);
-        FR_HIP(hipMemcpyAsync(&dn, c->d_dense_norm, 8, hipMemcpyDeviceToHost, st));
+        const double *src = c->d_dense_norm;
+        if (c->use_comm) {
+            FR_HIP(hipMemcpyAsync(c->comm.small_send, c->d_dense_norm, 8, hipMemcpyDeviceToDevice, st));
+            src = (const double *)fr_allgather(c, 8);
+        }
+        double h[FR_MAX_RANKS];
+        FR_HIP(hipMemcpyAsync(h, src, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, st));
         FR_HIP(hipStreamSynchronize(st));
+        double dn = 0;
+        for (int p = 0; p < c->n_ranks; p++) dn += h[p];
         glob_norm += dn;
     }
     c->glob_norm = glob_norm;

@@ -183,6 +183,7 @@ void fr_dense_h_setup(FriesCtx *c) {
     hipStream_t st = c->stream;
     const uint32_t ns = c->vec.n_dense;
     c->n_dense_h = c->n_dense_h_nz = 0;
+    if (!c->d_dense_norm) c->d_dense_norm = fr_alloc<double>(1);
     if (!ns) return;
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
     std::vector<double> ones(ns, 1.0);
@@ -203,7 +204,6 @@ void fr_dense_h_setup(FriesCtx *c) {
     if (tot > 0xffffffffull) throw FriesError("dense block of H too large");
     c->n_dense_h = (uint32_t)tot; c->n_dense_h_nz = o;
     c->d_dh_from = fr_alloc<uint32_t>(o ? o : 1); c->d_dh_to = fr_alloc<det_t>(o ? o : 1); c->d_dh_el = fr_alloc<double>(o ? o : 1);
-    c->d_dense_norm = fr_alloc<double>(1);
     if (o) {
         FR_HIP(hipMemcpyAsync(d_off, off.data(), 8 * (size_t)ns, hipMemcpyHostToDevice, st));
         FR_HIP(hipMemcpyAsync(c->d_dh_from, from.data(), 4 * (size_t)o, hipMemcpyHostToDevice, st));

@@ -10,7 +10,8 @@
 // (frisys_mol.cpp:288-345, 505-531) and the binary checkpoint dets0.dat / vals0.dat / dense.txt / hash.dat
 // (DistVec::save / load, FRIES/vec_utils.hpp:703-844; save_proc_hash, io_utils.cpp:589-606).  Everything numeric runs on
 // the GPU.  --ini_vec / --trial_vec read the reference's text vectors (<prefix>dets, <prefix>vals; load_vec_txt, io_utils.cpp:447-482).
-// --det_space FILE: the semi-stochastic dense space (one rank; with --load_dir the checkpoint must not hold one).
+// --det_space FILE: the semi-stochastic dense space (every rank reads the file and keeps the determinants it owns; with --load_dir the
+// checkpoint must not hold one).
 //
 // Ranks (the reference under mpiexec -n P: hash-sharded vector, MPI_Alltoallv of the adds, rank-ordered sums):
 //   * one process per MI355X over librccl: start P copies with RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun's names;
@@ -125,7 +126,6 @@ static void run_rank(const Args &args, const Fcidump &in, uint32_t seed, int ran
     if (args.load_dir.empty() && !args.ini_vec.empty()) { load_vec_txt(args.ini_vec, tdets, tvals); ck(fries_set_initial_vector(ctx, tdets.data(), tvals.data(), tvals.size())); }   // :264-274
     if (args.have_ham_shift) ck(fries_set_ham_shift(ctx, args.ham_shift - in.core_en));      // :95-98
     if (args.load_dir.empty() && !args.det_space.empty()) {     // --det_space (:236-239): the integers read_dets reads (io_utils.cpp:565-586)
-        if (n_ranks > 1) throw std::runtime_error("--det_space runs on one rank in this version");
         std::ifstream f(args.det_space);
         if (!f.is_open()) throw std::runtime_error("Could not open file: " + args.det_space);
         std::vector<uint64_t> space;

@@ -132,7 +132,7 @@ int fries_set_ham_shift(fries_ctx *ctx, double hf_en);
 /* --det_space (frisys_mol.cpp:236-239, 347-401, 480-485; DistVec::init_dense, vec_utils.hpp:858-897): the determinants of the semi-stochastic
  * dense space.  They take positions 0 .. n - 1 of the vector, are never compressed or deleted, H restricted to them is applied exactly every
  * iteration, and the matrix compression gets mat_nonz minus the number of (symmetry-allowed) matrix elements inside the space.  Before
- * fries_frisys_setup; one rank. */
+ * fries_frisys_setup.  With ranks: pass the whole list on every rank; each keeps the determinants it owns, in list order. */
 int fries_set_det_space(fries_ctx *ctx, const uint64_t *dets, size_t n);
 /* frisys_mol.cpp:76-346: scramblers, solution vector, HF trial vector and H*trial, p_doub, HF start.
  * With ranks: vec_nonz / mat_nonz / target_norm are the GLOBAL budgets, max_dets is per rank, and every rank

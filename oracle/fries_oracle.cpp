@@ -1813,8 +1813,7 @@ void Frisys::setup() {
     n_determ = 0; determ_from.clear(); determ_to.clear(); determ_el.clear();
     if (!det_space.empty()) {
         // init_dense (vec_utils.hpp:858-873): add every determinant with value 1, then zero the values; they stay stored
-        if (cm.size != 1) throw std::runtime_error("the dense subspace of the restatement is one rank");
-        for (det_t d : det_space) sol.add(d, 1, 1);
+        if (cm.rank == 0) for (det_t d : det_space) sol.add(d, 1, 1);       // rank 0 reads the file; the adds travel to their owners
         sol.perform_add(0);
         n_determ = sol.curr_size;
         for (auto &col : sol.vals) std::fill(col.begin(), col.begin() + n_determ, 0.0);
@@ -1827,6 +1826,7 @@ void Frisys::setup() {
     en_shift = 0; last_one_norm = 0; iterat = 0;
     // H inside the dense space, times -eps (frisys_mol.cpp:347-397): per determinant its singles, then its doubles
     std::vector<uint8_t> ex;
+    tot_dense_h = 0;
     for (size_t di = 0; di < n_determ; di++) {
         const det_t cur = sol.dets[di];
         const uint8_t *occ = sol.orbs_at(di);
@@ -1845,6 +1845,7 @@ void Frisys::setup() {
             determ_from.push_back(di); determ_to.push_back(nd); determ_el.push_back(m);
         }
     }
+    tot_dense_h = (uint32_t)cm.sum((int)determ_el.size());       // :399
 }
 
 void Frisys::iterate(unsigned n_iter) {
@@ -1860,7 +1861,7 @@ void Frisys::iterate(unsigned n_iter) {
         double rn[5];
         for (int k = 0; k < 5; k++) rn[k] = uni(mt);     // comp_sub broadcasts rank 0's draw (compress_utils.cpp:806);
                                                            // all ranks seed alike here, so the streams agree
-        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz - (uint32_t)determ_el.size(), false, cm);      // :421 matr_samp - tot_dense_h
+        apply_HBPP_sys(sol, sc, sys, p_doub, par.new_hb, rn, par.mat_nonz - tot_dense_h, false, cm);      // :421 matr_samp - tot_dense_h
         size_t comp_len = sc.vec_len;
         lg.num_success = comp_len;
         for (int k = 0; k < 5; k++) lg.comp_len[k] = sc.stage_len[k];

@@ -286,11 +286,12 @@ struct Frisys {
     std::vector<det_t> trial_in_det, ini_det;
     std::vector<double> trial_in_val, ini_val;
     bool has_ham_shift = false; double ham_shift = 0;
-    // --det_space (semi-stochastic, one rank): the determinants of the file take positions 0 .. n_determ - 1 (DistVec::init_dense,
+    // --det_space (semi-stochastic): the determinants of the file take positions 0 .. n_determ - 1 (DistVec::init_dense,
     // vec_utils.hpp:858-897), are never compressed or deleted, and H restricted to them is applied exactly every iteration
     // (frisys_mol.cpp:236-239, 347-401, 414-421, 480-485, 502-539)
     std::vector<det_t> det_space;
     size_t n_determ = 0;
+    uint32_t tot_dense_h = 0;
     std::vector<size_t> determ_from; std::vector<det_t> determ_to; std::vector<double> determ_el;
     double p_doub = 0, en_shift = 0, last_one_norm = 0;
     det_t hf_det = 0;

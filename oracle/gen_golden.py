@@ -221,6 +221,9 @@ DENSE_RUNS = {
 }
 
 
+DENSE_RANKS = {"ne_m2000_dense": (2, 3)}
+
+
 def gen_dense(manifest):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -240,6 +243,12 @@ def gen_dense(manifest):
                             os.path.join(GOLD, name + ".traj")], check=True, env=env)
             manifest["dense_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini,
                                                 target_norm=tgt, distribution=dist, det_space=space, n_dense=n_dense)
+            # the same run under mpiexec: rank 0 reads the file, the dense determinants travel to their owners, every rank holds its share
+            for n_ranks in DENSE_RANKS.get(name, ()):
+                rname = "%s_p%d" % (name, n_ranks)
+                subprocess.run([MPIEXEC, "-n", str(n_ranks), HARNESS, "frisys_mpi", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd),
+                                repr(ini), repr(tgt), dist, os.path.join(GOLD, rname + ".traj")], check=True, env=env)
+                manifest.setdefault("dense_mpi_runs", {})[rname] = dict(manifest["dense_runs"][name], n_ranks=n_ranks)
 
 
 def gen_reload(manifest):

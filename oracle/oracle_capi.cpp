@@ -326,11 +326,15 @@ static void fill_log(const IterLog &l, OracleLog &o) {
     o.err = 0;
 }
 
+static std::vector<det_t> g_ranks_det_space;      // consumed by the next fo_ranks_create
+void fo_ranks_set_det_space(const uint64_t *space, size_t n) { g_ranks_det_space.assign(space, space + n); }
 void *fo_ranks_create(uint32_t n_ranks, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                       double eps, double target, double init, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, int hb_unnorm) {
     OracleRanks *R = new OracleRanks();
+    std::vector<det_t> space; space.swap(g_ranks_det_space);
     for (uint32_t r = 0; r < n_ranks; r++) {
         Frisys *f = new Frisys();
+        f->det_space = space;
         f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
         f->sys.ints.n_orb = n_orb;
         f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);

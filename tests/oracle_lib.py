@@ -286,12 +286,16 @@ class OracleRanks:
     """P in-process ranks of fo::Frisys sharing one communicator -- the reference under `mpiexec -n P`
     (hash-sharded determinants, all-to-all spawns, rank-ordered sum_mpi)."""
 
-    def __init__(self, n_ranks, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm"):
+    def __init__(self, n_ranks, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, distribution="HB_unnorm", det_space=None):
         self.lib = load()
         self.n_ranks = n_ranks
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+        if det_space is not None:
+            sp = np.ascontiguousarray(det_space, dtype=np.uint64)
+            self.lib.fo_ranks_set_det_space.argtypes = [C.c_void_p, C.c_size_t]
+            self.lib.fo_ranks_set_det_space(_p(sp), sp.size)
         self.h = self.lib.fo_ranks_create(n_ranks, mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_norm, initiator,
                                           vec_nonz, mat_nonz, max_dets, seed, 1 if distribution == "HB_unnorm" else 0)
         if not self.h:

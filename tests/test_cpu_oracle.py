@@ -609,3 +609,26 @@ def test_fries_headers_host_logic(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fails=0" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("dense_mpi_runs", {})))
+def test_oracle_dense_space_over_ranks(oracle, mols, name):
+    """--det_space under `mpiexec -n P`: rank 0 reads the file, the dense determinants travel to their owners and every rank keeps its
+    share in front of its shard; tot_dense_h and dense_norm are sums over the ranks.  The restatement's in-process ranks against what
+    every rank of the real reference logged."""
+    r = golden_io.manifest()["dense_mpi_runs"][name]
+    P = r["n_ranks"]
+    g = [golden_io.read_traj(name, rank=k) for k in range(P)]
+    space = np.array([int(x) for x in open(os.path.join(golden_io.GOLD, r["det_space"])).read().split()], dtype=np.uint64)
+    orc = oracle.OracleRanks(P, mols(r["shape"]), det_space=space, **_run_params(r))
+    n_it = min(len(g[0]["rows"]), 30)
+    logs = orc.iterate(n_it)
+    for k in range(P):
+        for i in range(n_it):
+            row, lg = g[k]["rows"][i], logs[k, i]
+            for f in ("numer", "denom", "norm", "shift"):
+                assert float(lg[f]) == row[f], (name, k, i, f)
+            for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+                assert int(lg[f]) == row[f], (name, k, i, f)
+        d, v = orc.vector(k)
+        assert golden_io.vec_hash(d, v) == g[k]["rows"][n_it - 1]["hash"], (name, k)

@@ -303,3 +303,50 @@ def test_frifull_cli_from_legacy_hf_directory(tmp_path):
     assert num.size == r["n_iter"]
     for i, row in enumerate(g["rows"]):
         assert abs(num[i] / den[i] - row["numer"] / row["denom"]) < 1e-10 and den[i] == row["denom"] and int(nk[i]) == row["nkept"], i
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("dense_mpi_runs", {})))
+def test_dense_space_over_ranks_matches_reference(name):
+    """--det_space over ranks (rank threads of this process on the native local transport): every rank keeps its share of the dense
+    determinants in front of its shard, the dense block of H is exchanged as a perform_add of its own, tot_dense_h and dense_norm are
+    sums over the ranks -- per rank against what that rank of the real reference logged under `mpiexec -n P`."""
+    import threading
+    from fries_amd.comm import LocalGroup
+    from fries_amd.engine import FriEngine
+    r = golden_io.manifest()["dense_mpi_runs"][name]
+    P = r["n_ranks"]
+    space = np.array([int(x) for x in open(os.path.join(golden_io.GOLD, r["det_space"])).read().split()], dtype=np.uint64)
+    mol = fcidump.synthetic(r["shape"])
+    grp = LocalGroup(P, r["mat_nonz"])
+    comms = [grp.comm(k, 0) for k in range(P)]
+    out = [None] * P
+
+    def work(k):
+        fails = []
+        try:
+            g = golden_io.read_traj(name, rank=k)
+            eng = FriEngine(mol, device=0, comm=comms[k])
+            eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+                      initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"], det_space=space)
+            for row in g["rows"]:
+                lg = eng.iterate(1)[0]
+                pin_replay._check_row(lg, row, fails, "dense")
+                if row["it"] % 10 == 9 or row is g["rows"][-1]:
+                    d, v = eng.vector()
+                    if golden_io.vec_hash(d, v) != row["hash"]:
+                        fails.append(("dense", row["it"], "digest"))
+                if len(fails) > 6:
+                    break
+            eng.close()
+        except Exception as e:      # the other ranks then time out in their next collective instead of hanging
+            fails.append(("exception", repr(e)))
+        out[k] = fails
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    grp.destroy()
+    for k in range(P):
+        assert not out[k], (name, k, out[k][:6])
