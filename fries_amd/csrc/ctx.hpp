@@ -93,6 +93,7 @@ struct PivBuf {
     PivUnit *unit = nullptr;
     PivScal *scal = nullptr;
     void *tile_dd = nullptr;                                 // double-double tile sums / offsets of the parallel cut-point search
+    uint32_t *tile_nz = nullptr, *nz_start = nullptr;        // non-zero unpreserved elements per tile (then: before each tile) / before each unit: adds that can round
     uint64_t n_certified = 0, n_fallback = 0; uint32_t last_reason = 0;                // calls settled by the parallel search / by the sequential chain
 };
 // a plain device array compressed by the vector's pivotal kernels (apply_HBPP_piv's long_vec; pivotal.hip: fr_piv_comp_flat)

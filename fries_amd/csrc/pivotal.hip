@@ -14,10 +14,11 @@
 struct DD_host { double hi, lo; };
 static void piv_alloc(FriesCtx *c, PivBuf &P, uint32_t cap) {
     if (P.cap >= cap) return;
-    if (P.start) { FR_HIP(hipFree(P.start)); FR_HIP(hipFree(P.carry)); FR_HIP(hipFree(P.U)); FR_HIP(hipFree(P.unit)); FR_HIP(hipFree(P.scal)); }
+    if (P.start) { FR_HIP(hipFree(P.start)); FR_HIP(hipFree(P.carry)); FR_HIP(hipFree(P.U)); FR_HIP(hipFree(P.unit)); FR_HIP(hipFree(P.scal)); FR_HIP(hipFree(P.nz_start)); }
     P.start = fr_alloc<uint32_t>(cap); P.carry = fr_alloc<double>(cap); P.U = fr_alloc<double>(2 * (size_t)cap); P.unit = fr_alloc<PivUnit>(cap);
+    P.nz_start = fr_alloc<uint32_t>(cap);
     P.scal = fr_alloc<PivScal>(1);
-    if (!P.tile_dd) P.tile_dd = fr_alloc<DD_host>(FR_MAX_PART);
+    if (!P.tile_dd) { P.tile_dd = fr_alloc<DD_host>(FR_MAX_PART); P.tile_nz = fr_alloc<uint32_t>(FR_MAX_PART); }
     P.cap = cap;
 }
 
@@ -147,8 +148,12 @@ __global__ void __launch_bounds__(64) k_piv_chain(VecDev V, VcompBuf B, PivBuf P
 // ------------------------------------------------------------------ the cut points in parallel
 // In exact arithmetic element i closes a unit iff floor(P_i / unit) > floor(P_{i-1} / unit), P = inclusive prefix sums of the
 // unpreserved magnitudes, and the overshoot carried on is P_i mod unit.  The reference's running sum differs from that ideal
-// by its accumulated rounding: every add rounds by at most 2^-53 * 2 unit, the subtraction of unit at a border is exact
-// (Sterbenz), so after i adds |drift| <= i * 2.3e-16 * unit.  The prefix sums are formed in double-double (error ~1e-32
+// by its accumulated rounding.  Adding an exact zero does not round.  A non-zero add that stays below unit lands below 2 eu,
+// eu = the largest power of two <= unit, and rounds by at most h = eu * 2^-53; an add that crosses a border lands below 4 eu and
+// rounds by at most 2 h; the subtraction of unit at a border is exact (Sterbenz).  So the drift at an element is at most
+// h * (non-zero unpreserved elements so far + borders crossed so far) -- counted exactly (tile_nz, nz_start) instead of charging
+// 2.5e-16 unit to every array position (round 1), which was 3-6 x looser on apply_HBPP_piv's long vectors where most positions hold
+// zeros, and sent 1 compression in 8 to the sequential chain.  The prefix sums are formed in double-double (error ~1e-32
 // relative, negligible), every element checks that its distance to the nearest unit border exceeds that drift bound, and
 // k_piv_decide checks its own comparisons the same way.  If all clear, the decisions -- the only thing the outputs depend
 // on -- are provably the reference's; otherwise the caller falls back to the sequential k_piv_chain.
@@ -178,31 +183,38 @@ __device__ __forceinline__ DD dd_block_scan(DD x, DD *sh, DD *total) {
 }
 __device__ __forceinline__ double piv_weight(const VecDev &V, const VcompBuf &B, uint32_t i, uint32_t n) { return (i < n && !B.keep[i]) ? fabs(V.v0[i]) : 0.0; }
 
-__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_tiles(VecDev V, VcompBuf B, DD *tile_sum) {
+__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_tiles(VecDev V, VcompBuf B, DD *tile_sum, uint32_t *tile_nz) {
     __shared__ DD sh[4];
+    __shared__ uint32_t shu[4];
     const uint32_t n = V.st->curr_size;
     const uint32_t base = blockIdx.x * FR_TILE + threadIdx.x * FR_ITEMS;
     DD s = dd_make(0.0);
-    for (int it = 0; it < FR_ITEMS; it++) s = dd_add(s, dd_make(piv_weight(V, B, base + it, n)));
+    uint32_t nz = 0;
+    for (int it = 0; it < FR_ITEMS; it++) { const double w = piv_weight(V, B, base + it, n); s = dd_add(s, dd_make(w)); nz += w != 0.0; }
     DD tot;
     dd_block_scan(s, sh, &tot);
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+    const uint32_t tnz = fr_block_sum_u32(nz, shu);
+    if (threadIdx.x == 0) { tile_sum[blockIdx.x] = tot; tile_nz[blockIdx.x] = tnz; }
 }
 // exclusive prefix over the tiles (one workgroup; <= FR_MAX_PART tiles)
-__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_scan(DD *tile_sum, uint32_t n_tiles) {
+__global__ void __launch_bounds__(FR_BLOCK) k_pivdd_scan(DD *tile_sum, uint32_t *tile_nz, uint32_t n_tiles) {
     __shared__ DD sh[4];
+    __shared__ uint32_t shu[4];
     const uint32_t per = (n_tiles + FR_BLOCK - 1) / FR_BLOCK;
     const uint32_t t0 = threadIdx.x * per;
     DD s = dd_make(0.0);
-    for (uint32_t t = t0; t < t0 + per && t < n_tiles; t++) s = dd_add(s, tile_sum[t]);
+    uint32_t c = 0;
+    for (uint32_t t = t0; t < t0 + per && t < n_tiles; t++) { s = dd_add(s, tile_sum[t]); c += tile_nz[t]; }
     DD tot;
     DD incl = dd_block_scan(s, sh, &tot);
     DD run = dd_add(incl, DD{-s.hi, -s.lo});
-    for (uint32_t t = t0; t < t0 + per && t < n_tiles; t++) { DD x = tile_sum[t]; tile_sum[t] = run; run = dd_add(run, x); }
+    uint32_t ctot;
+    uint32_t crun = fr_block_scan_u32(c, shu, &ctot) - c;
+    for (uint32_t t = t0; t < t0 + per && t < n_tiles; t++) { DD x = tile_sum[t]; tile_sum[t] = run; run = dd_add(run, x); const uint32_t y = tile_nz[t]; tile_nz[t] = crun; crun += y; }
 }
 __global__ void k_pivdd_init(PivBuf P, VecDev V) {
     P.scal->n_units = V.st->curr_size ? 1u : 0u; P.scal->end_pos = V.st->curr_size; P.scal->uncertain = 0;
-    P.start[0] = 0; P.carry[0] = 0;
+    P.start[0] = 0; P.carry[0] = 0; P.nz_start[0] = 0;
 }
 // floor(P / unit) and the remainder, P >= 0
 __device__ __forceinline__ void dd_divmod(DD Pv, double unit, double *q_out, double *r_out) {
@@ -229,6 +241,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_pivdd_cuts(VecDev V, VcompBuf B, P
     DD tot;
     DD incl = dd_block_scan(s, sh, &tot);
     DD run = dd_add(dd_add(tile_off[blockIdx.x], incl), DD{-s.hi, -s.lo});      // exclusive prefix at my first element
+    uint32_t my_nz = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) my_nz += w[it] != 0.0;
+    __shared__ uint32_t shu[4];
+    uint32_t nz_tot;
+    uint32_t nz_run = P.tile_nz[blockIdx.x] + fr_block_scan_u32(my_nz, shu, &nz_tot) - my_nz;       // non-zero unpreserved elements before my first one
     uint32_t unsure_bits = 0; bool toobig = false;
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
@@ -239,15 +257,18 @@ __global__ void __launch_bounds__(FR_BLOCK) k_pivdd_cuts(VecDev V, VcompBuf B, P
         dd_divmod(run, unit, &q0, &r0);
         run = dd_add(run, dd_make(w[it]));
         dd_divmod(run, unit, &q1, &r1);
+        nz_run++;
+        // rounding drift the reference's running sum can have accumulated by this add: adds that can round + borders crossed (see above)
+        const double drift = tol_per_add * ((double)nz_run + q1 + 64.0);
         // whether the very last element closes its unit changes nothing: either way the unit ends with the vector (:425-428)
-        const double tol = (i + 1 == n) ? -1.0 : tol_per_add * ((double)i + 64.0);
+        const double tol = (i + 1 == n) ? -1.0 : drift;
         if (r0 < 0 || r1 < 0) { unsure_bits |= 2u; continue; }
         if (q1 > q0) {           // closes unit q1 - 1; the running sum lands r1 above the border
             if (q1 != q0 + 1) toobig = true;
-            if (r1 <= tol || (unit - r0 <= tol_per_add * ((double)i + 64.0))) { unsure_bits |= 1u; if (dbg) printf("[piv] crossing i=%u of %u q0=%.0f q1=%.0f r0/unit=%.3e r1/unit=%.3e tol/unit=%.3e w/unit=%.3e\n", i, n, q0, q1, r0 / unit, r1 / unit, tol / unit, w[it] / unit); }
+            if (r1 <= tol || (unit - r0 <= drift)) { unsure_bits |= 1u; if (dbg) printf("[piv] crossing i=%u of %u q0=%.0f q1=%.0f r0/unit=%.3e r1/unit=%.3e tol/unit=%.3e w/unit=%.3e\n", i, n, q0, q1, r0 / unit, r1 / unit, tol / unit, w[it] / unit); }
             const double m = q1;
             const uint32_t nxt = i + 1;
-            if (m < (double)n_samp && nxt < n) { const uint32_t mi = (uint32_t)m; P.start[mi] = nxt; P.carry[mi] = r1; atomicAdd(&P.scal->n_units, 1u); }
+            if (m < (double)n_samp && nxt < n) { const uint32_t mi = (uint32_t)m; P.start[mi] = nxt; P.carry[mi] = r1; P.nz_start[mi] = nz_run; atomicAdd(&P.scal->n_units, 1u); }
             if (m == (double)n_samp) P.scal->end_pos = nxt < n ? nxt : n;
         }
         else if (unit - r1 <= tol) { unsure_bits |= 1u; if (dbg) printf("[piv] inside i=%u of %u q=%.0f (unit-r1)/unit=%.3e tol/unit=%.3e\n", i, n, q1, (unit - r1) / unit, tol / unit); }
@@ -280,7 +301,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_piv_decide(VecDev V, VcompBuf B, P
     }
     const bool at_end = pos + used == n;
     if (used == 0) { atomicOr(err, FR_ERR_PIV); return; }
-    const double tol = certify ? tol_per_add * ((double)pos + (double)used + 64.0) * 2.0 : -1.0;      // carried drift + this unit's own adds; < 0: nothing to certify
+    const double tol = certify ? tol_per_add * ((double)P.nz_start[k] + (double)n_wt + (double)k + 64.0) * 2.0 : -1.0;      // carried drift + this unit's own adds; < 0: nothing to certify
     uint32_t n_inner = used - 1;
     if (at_end) n_inner++;
     if (certify) {      // the walk must end where the cut-point search put the border
@@ -527,7 +548,7 @@ static void piv_comp_core(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept,
     if (loc_samp == 0) FR_LAUNCH(c, "k_piv_none", k_piv_none, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, B);
     else {
         const double unit = new_norm / loc_samp;
-        const double tol_per_add = 2.5e-16 * unit;          // rounding drift of the reference's running sum per add (see k_pivdd_*)
+        const double tol_per_add = ldexp(1.0, ilogb(unit) - 53) * 1.0001;     // h: what one non-crossing add of the reference's running sum can round by (see k_pivdd_*)
         bool chain = getenv("FRIES_PIV_CHAIN") != nullptr;  // force the sequential search (tests)
         const std::mt19937 mt_saved = c->mt;
         const unsigned n_tiles = fr_blocks(bound, FR_TILE);
@@ -543,8 +564,8 @@ static void piv_comp_core(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept,
         if (!chain) {
             DD *td = (DD *)P.tile_dd;
             FR_LAUNCH(c, "k_pivdd_init", k_pivdd_init, dim3(1), dim3(1), P, c->vec);
-            FR_LAUNCH(c, "k_pivdd_tiles", k_pivdd_tiles, dim3(n_tiles), dim3(FR_BLOCK), c->vec, B, td);
-            FR_LAUNCH(c, "k_pivdd_scan", k_pivdd_scan, dim3(1), dim3(FR_BLOCK), td, n_tiles);
+            FR_LAUNCH(c, "k_pivdd_tiles", k_pivdd_tiles, dim3(n_tiles), dim3(FR_BLOCK), c->vec, B, td, P.tile_nz);
+            FR_LAUNCH(c, "k_pivdd_scan", k_pivdd_scan, dim3(1), dim3(FR_BLOCK), td, P.tile_nz, n_tiles);
             FR_LAUNCH(c, "k_pivdd_cuts", k_pivdd_cuts, dim3(n_tiles), dim3(FR_BLOCK), c->vec, B, P, td, unit, loc_samp, tol_per_add, c->d_err, c->dbg == 7 ? 1 : 0);
             read_scal();
             if (hs.uncertain) { chain = true; P.last_reason = hs.uncertain; }
