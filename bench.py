@@ -230,7 +230,8 @@ def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, 
         tot_ms = sum(v[0] for v in rep.values())
         # the dominant COMPUTE kernel: with ranks, the small kernels that follow a collective also absorb the wait for it in their
         # event times and would otherwise come out on top without saying anything about the hardware
-        known = {k: v for k, v in rep.items() if any(k.startswith(b) for b in ALG_BYTES)}
+        # (k_fks_sweep_light is not a pass over the stage: it re-decides the few waves k_fks_check marks and has no per-element byte count)
+        known = {k: v for k, v in rep.items() if any(k.startswith(b) for b in ALG_BYTES) and k != "k_fks_sweep_light"}
         dom = max((known or rep).items(), key=lambda kv: kv[1][0])
         name, (ms, calls) = dom
         avg_s = ms / calls * 1e-3

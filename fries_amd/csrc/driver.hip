@@ -462,6 +462,9 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     h->c.device = device;
     if (getenv("FRIES_DBG")) h->c.dbg = atoi(getenv("FRIES_DBG"));
     if (getenv("FRIES_FKS_REC_AT")) h->c.fks_rec_at = atoi(getenv("FRIES_FKS_REC_AT"));
+    if (getenv("FRIES_GROUP_WARM_ALL")) h->c.fks_group_warm_all = atoi(getenv("FRIES_GROUP_WARM_ALL")) != 0;
+    if (getenv("FRIES_NO_GROUP_WARM")) h->c.fks_no_group_warm = true;
+    if (getenv("FRIES_FKS_NO_EXT")) h->c.fks_no_ext = true;
     if (getenv("FRIES_FKS_NO_LIGHT")) h->c.fks_no_light = atoi(getenv("FRIES_FKS_NO_LIGHT")) != 0;
     if (getenv("FRIES_FKS_COLLAPSE_WALK")) h->c.fks_no_collapse_walk = atoi(getenv("FRIES_FKS_COLLAPSE_WALK")) == 0;
     if (getenv("FRIES_FKS_SEQ")) h->c.fks_force_seq = atoi(getenv("FRIES_FKS_SEQ")) != 0;
@@ -490,6 +493,14 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     CompWork &W = h->c.W;
     for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.el[k].rinv); hipFree(W.el[k].raux); hipFree(W.el[k].det); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
     hipFree(W.wt_remain); hipFree(W.keep); hipFree(W.S); hipFree(W.kin); hipFree(W.cnt); hipFree(W.e_wi); hipFree(W.e_sub); hipFree(W.e_val); hipFree(W.state); hipFree(W.teeth); hipFree(W.fix_list);
+    {   // the find_keep_sub replay's arrays (allocated with the work arrays: hbpp.hip)
+        Fks2Work &F = h->c.F2;
+        if (F.dk8) {
+            hipFree(F.dk8); hipFree(F.dg8); hipFree(F.ws8); hipFree(F.cdirty); hipFree(F.wG); hipFree(F.wR); hipFree(F.wM); hipFree(F.wK); hipFree(F.wdK); hipFree(F.wdG); hipFree(F.wNp);
+            hipFree(F.xk8); hipFree(F.xg8); hipFree(F.scal); hipFree(F.hist); hipFree(F.ck); hipFree(F.cg); hipFree(F.cw); hipFree(F.ckx); hipFree(F.cgx); hipFree(F.dbg_cnt);
+            hipFree(h->c.fks_wkx); hipFree(h->c.fks_wgx); hipFree(h->c.fks_wk); hipFree(h->c.fks_wg); hipFree(h->c.fks_sxk8); hipFree(h->c.fks_sxg8); hipFree(h->c.fks_saved);
+        }
+    }
     hipFree(h->c.c_pos); hipFree(h->c.c_orbs); hipFree(h->c.c_val); hipFree(h->c.d_nsucc);
     SpawnBuf &s = h->c.sp;
     hipFree(s.det); hipFree(s.val); hipFree(s.ini); hipFree(s.slot); hipFree(s.flag);

@@ -62,11 +62,13 @@ struct Fks2Work {
     FksHost *hm;                            // device-visible address of the host block
     uint32_t nb8_cap;
     uint32_t *dk8; double *dg8, *ws8;       // [FR_FKS_PMAX][nb8_cap] group deltas of the latest evaluation of every group
-    // Per (group of 8 elements, sweep): the start state the group was last evaluated with -- running norm and remaining budget at its
-    // first element -- and the smallest relative distance of any of its comparisons from flipping.  A later replay whose start state
-    // for the group differs by less cannot change any decision of the group and skips it ("light" replays).
-    // gG / gK: start state; gR = tightest relative margin; gM = smallest norm compared against: [FR_FKS_PMAX][nb8_cap]; gNp[nb8_cap] = sweeps the group last ran
-    double *gG; float *gR, *gM; uint32_t *gK; uint32_t *gNp;
+    // Per (wave of 64 elements = 8 groups, sweep): the start state the wave was last evaluated with -- running norm and remaining budget at
+    // its first element -- the smallest relative distance of any of its comparisons from flipping and the smallest norm one of them
+    // compared against.  A later replay whose start state for the wave moved the comparisons' threshold by less cannot change any
+    // decision of the wave and skips it ("light" replays).  wdK / wdG: by how much that evaluation moved the wave's own deltas (samples,
+    // norm; summed over its groups) -- the prefixes INSIDE the wave have moved by at most that much since its groups were evaluated.
+    // [FR_FKS_PMAX][nwv_cap]; wNp[nwv_cap] = sweeps the wave last ran.
+    double *wG; float *wR, *wM, *wdG; uint32_t *wK, *wdK; uint32_t *wNp; uint32_t nwv_cap;
     uint32_t *cdirty;                       // [FR_FKS_MAXCHUNK] it + 1 of the last replay that changed a delta inside the chunk
     uint32_t *xk8; double *xg8;             // exclusive prefixes over the groups of a chunk, same shape
     uint32_t *ck; double *cg, *cw;          // [FR_FKS_PMAX][FR_FKS_MAXCHUNK] totals per chunk of 2048 groups
@@ -75,10 +77,12 @@ struct Fks2Work {
     uint32_t *hist;                         // [FR_MAX_ROUNDS] changed flag per replay, for the host
     uint32_t *dbg_cnt;                      // [FR_MAX_ROUNDS][4] FRIES_DBG=3 statistics
     FksSaved *saved; uint32_t *wk, *wkx; double *wg, *wgx;     // this stage's warm-start record: saved ck / cg / ckx / cgx
-    uint32_t *sxk8; double *sxg8;           // stage 1 only: the settled per-group prefixes inside the chunks (vector positions persist between iterations)
+    uint32_t *sxk8; double *sxg8;           // [FR_FKS_SROWS][nb8_cap] the settled per-group prefixes inside the chunks, kept for the next iteration's first replay
 };
 #define FR_FKS_CHUNK 2048                   // groups per scan workgroup
 #define FR_FKS_MAXCHUNK 1024
+#define FR_FKS_PF 8                        // sweeps whose stored deltas a wave of k_fks_sweep<.., 1> prefetches into LDS
+#define FR_FKS_SROWS 16                    // sweeps of a stage whose settled per-group prefixes are kept for the next iteration's first replay
 
 // What a rank tells the others about its shard: the norm entering sweep 0 and, per sweep of the replay that just
 // ran, how many samples it preserved, by how much its norm dropped and what its wt_remain re-sums to.
@@ -163,6 +167,7 @@ static __global__ void __launch_bounds__(64) k_fks_passes(Fks2Work F, const FksM
 #define FR_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
 #define FR_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
 #define FR_DPP_HMIRROR 0x141      // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
+#define FR_DPP_ROR8 0x128          // row_ror:8: lane i <- lane (i + 8) % 16 inside each row of 16
 template <int CTRL> __device__ __forceinline__ uint32_t fr_dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
@@ -227,19 +232,24 @@ __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32
 #define FR_FKS_GRP_MAXK 256u        // a group of 8 elements likewise
 
 template <int STAGE, bool NEW_HB, int MODE>
-__global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
+__global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
     __shared__ HbTables T;
     __shared__ FksScal S;
+    // MODE 1: the deltas my wave's 8 groups stored for sweeps 0 .. FR_FKS_PF-1, fetched in one go when the tile starts (compared with the new
+    // ones sweep by sweep: fetched there, each comparison is a dependent global-load latency on the wave's critical path)
+    __shared__ double sh_dg[MODE == 1 ? FR_BLOCK / 64 : 1][MODE == 1 ? FR_FKS_PF * 8 : 1], sh_ws[MODE == 1 ? FR_BLOCK / 64 : 1][MODE == 1 ? FR_FKS_PF * 8 : 1];
+    __shared__ uint32_t sh_dk[MODE == 1 ? FR_BLOCK / 64 : 1][MODE == 1 ? FR_FKS_PF * 8 : 1];
     {
         const uint32_t *src = (const uint32_t *)F.scal;
         uint32_t *dst = (uint32_t *)&S;
         for (unsigned i = threadIdx.x; i < sizeof(FksScal) / 4; i += blockDim.x) dst[i] = src[i];
     }
-    if (STAGE != 1) fr_stage_tables(&T, Tg); else __syncthreads();
+    __syncthreads();
     const unsigned n_in = S.n_in;
     const unsigned nb8 = n_in / 8 + 1;                       // the reference also visits the (possibly empty) tail group
     const unsigned ntile = (unsigned)(((size_t)nb8 * 8 + FR_BLOCK - 1) / FR_BLOCK);
     const size_t stride = F.nb8_cap;
+    const size_t wstride = F.nwv_cap;
     const StageElems E = W.el[cur];
     const int n_pass = S.n_pass;
     const bool zp = S.zero_prefix != 0;
@@ -253,59 +263,141 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
     const int lane = fr_lane(), f = lane & 7;
     // a replay without comparison, or with a different number of sweeps than its predecessor, always counts as changed
     if (MODE != 2 && (MODE == 0 || S.n_pass != S.valid_upto) && blockIdx.x == 0 && threadIdx.x == 0) F.hist[it] = 1u;
+    if (MODE != 2 && dbg == 3 && it < FR_MAX_ROUNDS && blockIdx.x == 0 && threadIdx.x == 0) F.dbg_cnt[it * 4] = (uint32_t)n_pass;
 
-    for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    // Light replay: has anything this WAVE's decisions depend on moved by more than its tightest comparison tolerates?
+    // A group of 8 elements is evaluated exactly in the reference's order from its start state (running norm G and remaining budget wf
+    // at its first element), and the start state of group j of a wave is the wave's minus what groups 0 .. j-1 of the wave removed
+    // (gamma_j) and used (kappa_j) according to the stored deltas.  Every comparison reads
+    //     c >= (G_w - gamma_j - g) / (wf_w - kappa_j),      g = what the group itself removed before that point,
+    // so what matters is by how much the right-hand side moves when (G_w, wf_w) become (G_w', wf_w') with gamma, kappa, g unchanged --
+    // they are unchanged as long as no decision of the wave changes, which is the induction: group 0 first, then group 1, ...
+    //     new / old = (1 + a)(1 + bb),   a = (G_w' - G_w) / (old numerator),   bb = (wf_w - wf_w') / (wf_w' - kappa_j).
+    // The old numerator lies in [gmin, G_w] (gmin = the smallest norm any comparison of the wave saw), kappa_j in [0, kappa_7], and
+    // a + bb + a bb is bilinear: its extremes are at the four corners.  Decisions that flipped upstream sit at the threshold, i.e. they
+    // remove norm and budget in the threshold's own proportion, so a and bb cancel to first order -- the ratio moves ~1e3 x less than
+    // norm and budget do one by one (which is what the first version of this test added up).  No comparison whose two sides differ by
+    // more than that, relative to the larger side, can flip.  The evaluation that wrote the records may itself have moved the wave's
+    // deltas, i.e. the prefixes inside the wave are no longer the ones its groups were evaluated with: group j's state has moved by the
+    // wave's shift -+ at most (wdK, wdG), the summed moves of the wave's deltas, and a, bb become intervals (still bilinear: corners).
+    // Lane p checks sweep p.  Returns the same value in every lane.
+    auto wave_stands = [&](unsigned tile) -> bool {
+        const size_t wv = (size_t)tile * (FR_BLOCK / 64) + (threadIdx.x >> 6);
+        const size_t b0 = wv * 8;
+        if (b0 >= nb8) return true;                              // no group here
+        const unsigned chunk = tile / FR_FKS_TILES_PER_CHUNK;
+        // The stage may run another number of sweeps than the wave last ran (the late sweeps preserve a handful of samples; whether a last
+        // one with a single sample exists changes from replay to replay until the early ones have settled):
+        //  * fewer (n_pass < rec_np): the sweeps that remain are checked as usual; row n_pass of the wave's deltas, a real sweep when the
+        //    wave ran, must already read "nothing preserved, nothing removed" -- it then is the row beyond the last sweep, as it stands;
+        //  * more  (n_pass > rec_np): every comparison of a new sweep was also made in the wave's last recorded sweep q (an element that is
+        //    still compared was compared then, with the same left-hand side c), so the new sweeps preserve nothing in this wave if their
+        //    threshold G / wf lies within q's tightest margin of q's thresholds (old numerator in [gmin, G_w], old denominator
+        //    wf_w - kappa, kappa in [0, kappa_7]; the new sweep removes nothing inside the wave).  The wave then gets its rows and records
+        //    of the new sweeps written here: deltas (0, 0, remaining weight as after sweep q), margin = q's minus what was used up.
+        const uint32_t rec_np = F.wNp[wv];
+        int ok = 1;
+        double ext_G = 0.0, ext_r = 0.0, ext_m = 0.0; uint32_t ext_K = 0u;       // lanes of new sweeps: what their record will say
+        if (rec_np == 0u || rec_np > (uint32_t)FR_FKS_PMAX || n_pass == 0 || (rec_np < (uint32_t)n_pass && (int)rec_np - 1 > vup) || (light == 2 && rec_np != (uint32_t)n_pass) || rec_np > (uint32_t)n_pass + 1u) ok = 0;      // (two sweeps fewer: the wave's decisions of the first dropped sweep are not looked at below)
+        else if (lane < n_pass) {
+            const int p = lane;
+            const bool ext = p >= (int)rec_np;                       // a sweep the wave has not run: checked against its last recorded sweep
+            const int q = ext ? (int)rec_np - 1 : p;
+            double xg = 0.0; uint32_t xk = 0u, k7 = 0u;
+            const size_t bl = b0 + 7 < nb8 ? b0 + 7 : (size_t)nb8 - 1;
+            if (p <= vup) {
+                const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + chunk;
+                const uint32_t x0 = F.xk8[(size_t)p * stride + b0];
+                xg = F.cgx[cx] + F.xg8[(size_t)p * stride + b0]; xk = F.ckx[cx] + x0; k7 = F.xk8[(size_t)p * stride + bl] - x0;
+            }
+            if (ext) k7 = F.xk8[(size_t)q * stride + bl] - F.xk8[(size_t)q * stride + b0];      // (q <= vup: checked above)
+            const double G_in = S.psG[p] - xg; const uint32_t K_in = S.psN[p] - xk;
+            const size_t wx = (size_t)q * wstride + wv;
+            const uint32_t K_old = F.wK[wx]; const double G_old = F.wG[wx];
+            const double rmar = (double)F.wR[wx];
+            const double ik = (double)F.wdK[wx], ig_ = (double)F.wdG[wx];       // the wave's own deltas moved by this much after its groups were evaluated
+            const double gmin = (double)F.wM[wx] - ig_;
+            int okp = 0;
+            if (rmar == INFINITY) okp = 1;                  // the wave compared nothing in this sweep
+            else if ((double)K_in > 2.0 * ((double)k7 + ik) + 64.0 && (double)K_old > 2.0 * ((double)k7 + ik) + 64.0 && gmin > 0 && G_old >= gmin) {
+                const double dK = (double)K_old - (double)K_in, dG = G_in - G_old;
+                const double dG_lo = dG - ig_, dG_hi = dG + ig_;
+                const double h1 = 1.0 / G_old, h2 = 1.0 / gmin;
+                double b_lo, b_hi;
+                if (!ext) {
+                    const double dK_lo = dK - ik, dK_hi = dK + ik;
+                    const double q1 = 1.0 / (double)K_in, q2 = 1.0 / ((double)K_in - (double)k7 - ik);
+                    b_lo = fmin(dK_lo * q1, dK_lo * q2); b_hi = fmax(dK_hi * q1, dK_hi * q2);
+                }
+                else { const double q1 = 1.0 / (double)K_in; b_lo = (dK - (double)k7 - ik) * q1; b_hi = (dK + ik) * q1; }       // (wf_w - kappa) / wf' - 1
+                // a in [a_lo, a_hi], bb in [b_lo, b_hi]; a + bb + a bb is bilinear: extremes at the corners
+                const double a_lo = fmin(dG_lo * h1, dG_lo * h2), a_hi = fmax(dG_hi * h1, dG_hi * h2);
+                double r = fabs(a_lo + b_lo + a_lo * b_lo), t;
+                t = fabs(a_lo + b_hi + a_lo * b_hi); r = t > r ? t : r;
+                t = fabs(a_hi + b_lo + a_hi * b_lo); r = t > r ? t : r;
+                t = fabs(a_hi + b_hi + a_hi * b_hi); r = t > r ? t : r;
+                const double noise = 1e-12 * S.psG[0] * h2 * (1.0 + fabs(b_lo) + fabs(b_hi)) + 1e-13;     // prefix sums carry ~1e-16 of the stage's norm
+                const double used = (r + noise) * 1.0001;
+                okp = used < rmar;
+                ext_r = (rmar - used) * 0.999;
+            }
+            else if (rmar != INFINITY) ext_r = 0.0;
+            if (rmar == INFINITY) ext_r = INFINITY;
+            if (!ext && K_in == K_old && G_in == G_old && ik == 0.0 && ig_ == 0.0) okp = 1;         // nothing moved at all
+            ok = okp;
+            ext_G = G_in; ext_K = K_in; ext_m = G_in * 0.9999;
+        }
+        if (ok && rec_np > (uint32_t)n_pass && lane >= 32 && lane < 40 && n_pass < FR_FKS_PMAX) {       // fewer sweeps: is row n_pass of my group empty?
+            const size_t bj = b0 + (size_t)(lane - 32);
+            if (bj < nb8) { const size_t ix = (size_t)n_pass * stride + bj; if (F.dk8[ix] != 0u || F.dg8[ix] != 0.0) ok = 0; }
+        }
+        const bool stands = __all(ok) != 0;
+        if (stands && rec_np != (uint32_t)n_pass) {
+            if (rec_np < (uint32_t)n_pass) {
+                if (lane >= 32 && lane < 40) {               // the rows of the new sweeps and the new row beyond them
+                    const size_t bj = b0 + (size_t)(lane - 32);
+                    if (bj < nb8) {
+                        const double gw = F.ws8[(size_t)rec_np * stride + bj];
+                        for (int p = (int)rec_np + 1; p <= n_pass && p < FR_FKS_PMAX; p++) { const size_t ix = (size_t)p * stride + bj; F.dk8[ix] = 0u; F.dg8[ix] = 0.0; F.ws8[ix] = gw; }
+                    }
+                }
+                if (lane >= (int)rec_np && lane < n_pass) {
+                    const size_t wx = (size_t)lane * wstride + wv;
+                    F.wG[wx] = ext_G; F.wK[wx] = ext_K; F.wR[wx] = (float)ext_r * 0.9999f; F.wM[wx] = (float)ext_m; F.wdK[wx] = 0u; F.wdG[wx] = 0.0f;
+                }
+            }
+            if (lane == 0) F.wNp[wv] = (uint32_t)n_pass;
+        }
+        return stands;
+    };
+    // Which of my tiles decide again is settled before the tables are staged: a workgroup with nothing to decide leaves at once
+    // (late replays: almost all of them).  Bit k of `decide` = the k-th tile of this workgroup's stride (tiles beyond 32 are asked again below).
+    uint32_t decide = 0;
+    if (MODE == 1 && light) {
+        int any = 0;
+        unsigned k = 0;
+        for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x, k++) {
+            const bool d = !wave_stands(tile);
+            if (d) { any = 1; if (k < 32) decide |= 1u << k; }
+            if (dbg == 3 && it < FR_MAX_ROUNDS && lane == 0 && (size_t)tile * FR_BLOCK + threadIdx.x < (size_t)nb8 * 8) { atomicAdd(&F.dbg_cnt[it * 4 + 3], 1u); if (d) atomicAdd(&F.dbg_cnt[it * 4 + 2], 1u); }
+        }
+        if (!__syncthreads_or(any)) return;
+    }
+    if (STAGE != 1) fr_stage_tables(&T, Tg);
+
+    unsigned tile_k = 0;
+    for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x, tile_k++) {
         const size_t e = (size_t)tile * FR_BLOCK + threadIdx.x;
         const size_t b = e >> 3;
         const bool in_grp = b < nb8;
         const bool live = e < n_in;
         const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
-        bool act = true;            // MODE 1: my group decides in this replay
-        if (MODE == 1) {
-            // Light replay: has anything this GROUP's decisions depend on moved by more than its tightest comparison tolerates?
-            // A group of 8 elements is evaluated exactly in the reference's order from its start state (running norm and remaining
-            // budget at its first element), so its decisions are a function of that start state alone.  Every comparison has the form
-            //   c * (budget - k) >= norm - g   with (k, g) = what the group itself used up before that point;
-            // if no decision changes, (k, g) stay as they were, so a change of the start state moves the left side by a factor within
-            // 1 +- eps1 and the right side within 1 +- eps2, and no comparison whose two sides differ by more than (eps1 + eps2) x the
-            // larger side can flip.  Lane f of the group checks sweeps f, f + 8, ...
-            if (light) {
-                int ok = 1;
-                if (in_grp) {
-                    if (F.gNp[b] != (uint32_t)n_pass) ok = 0;         // the stage has a different number of sweeps than the group ran
-                    else for (int p = f; p < n_pass; p += 8) {
-                        double xg = 0.0; uint32_t xk = 0u;
-                        if (p <= vup) {
-                            const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
-                            xg = F.cgx[cx] + F.xg8[(size_t)p * stride + b]; xk = F.ckx[cx] + F.xk8[(size_t)p * stride + b];
-                        }
-                        const double G_in = S.psG[p] - xg; const uint32_t K_in = S.psN[p] - xk;
-                        const size_t gx = (size_t)p * stride + b;
-                        const uint32_t K_old = F.gK[gx]; const double G_old = F.gG[gx];
-                        const double gmin = (double)F.gM[gx], rmar = (double)F.gR[gx];
-                        const uint32_t k_lo = K_in < K_old ? K_in : K_old, dk = K_in < K_old ? K_old - K_in : K_in - K_old;
-                        int okp = 0;
-                        if (rmar == INFINITY) okp = 1;                  // the group compared nothing in this sweep
-                        else if (k_lo > 2u * FR_FKS_GRP_MAXK && gmin > 0) {
-                            const double eps1 = (double)dk / (double)(k_lo - FR_FKS_GRP_MAXK);
-                            const double eps2 = (fabs(G_in - G_old) + 1e-12 * S.psG[0]) / gmin;     // prefix sums carry ~1e-16 of the stage's norm
-                            okp = (eps1 + eps2) * 1.0001 < rmar;
-                        }
-                        if (dk == 0u && G_in == G_old) okp = 1;         // nothing moved at all
-                        ok &= okp;
-                    }
-                }
-                uint32_t u = (uint32_t)ok, t;
-                t = fr_dpp_u32<FR_DPP_HMIRROR>(u); u &= t; t = fr_dpp_u32<FR_DPP_XOR1>(u); u &= t; t = fr_dpp_u32<FR_DPP_XOR2>(u); u &= t;
-                act = in_grp && u == 0u;
-            }
-            if (dbg == 3 && it < FR_MAX_ROUNDS) {
-                if (f == 0 && in_grp) { atomicAdd(&F.dbg_cnt[it * 4 + 1], 1u); if (act) atomicAdd(&F.dbg_cnt[it * 4], 1u); }
-                if (lane == 0) { atomicAdd(&F.dbg_cnt[it * 4 + 3], 1u); if (__any(act)) atomicAdd(&F.dbg_cnt[it * 4 + 2], 1u); }
-            }
-            if (light && !__any(act)) continue;         // nothing to decide in this wave
+        const size_t my_wave = e >> 6;
+        if (MODE == 1 && light) {
+            const bool d = tile_k < 32 ? ((decide >> tile_k) & 1u) != 0 : !wave_stands(tile);
+            if (!d) continue;                           // nothing to decide in this wave
         }
-        const bool lv = live && act, ig = in_grp && act;      // (MODE 1: lanes of groups that stand are passive from here on)
+        const bool lv = live, ig = in_grp;
         const double chunk_frac = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
         // group start state of sweep p: what the groups before mine removed (norm) and used (samples) in that sweep
         // The loads are issued one sweep ahead and only added up when the sweep starts: any arithmetic on them here would make the
@@ -315,7 +407,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             o->a = 0.0; o->b = 0.0; o->c = 0u; o->d = 0u;
             if (MODE == 0 && warm0) {        // previous iteration's chunk profile, linear inside the chunk (replay 0 only: resolved on the spot)
                 double xg = 0.0; uint32_t xk = 0u;
-                if (F.sxk8 && b < saved_nb8 && my_chunk < n_chunk_saved) {       // stage 1: the same elements sat in this group last time
+                if (F.sxk8 && p < FR_FKS_SROWS && b < saved_nb8 && my_chunk < n_chunk_saved) {       // the same (stage 1) or the corresponding elements sat in this group last time
                     const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + my_chunk;
                     xg = (F.wgx[cx] + F.sxg8[(size_t)p * stride + b]) * wsc;
                     xk = F.wkx[cx] + F.sxk8[(size_t)p * stride + b];
@@ -338,13 +430,23 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 o->c = F.ckx[cx]; o->d = F.xk8[(size_t)p * stride + b];
             }
         };
+        // the deltas my wave stored before (lane = 8 x sweep + group)
+        const int wslot = threadIdx.x >> 6;
+        if (MODE == 1) {
+            const int ps = lane >> 3;
+            const size_t bj = (my_wave << 3) + (size_t)f;
+            uint32_t ok_ = 0u; double og = 0.0, ow = 0.0;
+            if (ps <= n_pass && ps < FR_FKS_PMAX && bj < nb8) { const size_t ix = (size_t)ps * stride + bj; ok_ = dk8[ix]; og = dg8[ix]; ow = ws8[ix]; }
+            sh_dk[wslot][lane] = ok_; sh_dg[wslot][lane] = og; sh_ws[wslot][lane] = ow;
+        }
         // my element
         double v = lv ? E.val[e] : 0.0;
         uint32_t nd = lv ? E.ndiv[e] : 1u;
         double wr = v;
         uint32_t kp = (MODE == 2 && lv) ? W.keep[e] : 0u;
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
-        if (STAGE != 1 && lv && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
+        if (MODE == 1 && light) { if (STAGE != 1 && lv) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); } }       // few waves, alone on their CU: one round of loads instead of two
+        else if (STAGE != 1 && lv && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
         if (MODE == 2) {
             double lastwf = 0;
             Pfx nx;
@@ -451,7 +553,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 kp = new_kp; wr = new_wr;
             }
             else { add = 0; change = 0; }
-            // the tile's tightest comparison and smallest norm of this sweep: 8-lane minima, then one LDS atomic per group
+            // the wave's tightest comparison and smallest norm of this sweep: minima over the 8 lanes of a group, over the two groups of a
+            // 16-lane row (DPP), then over the four rows by lane reads -- the result is wave-uniform
+            uint32_t rec_r = 0u, rec_g = 0u;
             if (MODE == 1) {
                 float gm = cmp ? (float)gl_mine * 0.99999f : INFINITY;      // gl_mine <= glob0: the smaller of my two right-hand sides
                 if (!(mr >= 0.0f)) mr = 0.0f;
@@ -459,8 +563,14 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 uint32_t ur = __float_as_uint(mr * 0.9999f), ug = __float_as_uint(gm), t;
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR1>(ur); ur = t < ur ? t : ur; t = fr_dpp_u32<FR_DPP_XOR2>(ur); ur = t < ur ? t : ur;
                 t = fr_dpp_u32<FR_DPP_HMIRROR>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR1>(ug); ug = t < ug ? t : ug; t = fr_dpp_u32<FR_DPP_XOR2>(ug); ug = t < ug ? t : ug;
-                // what this evaluation of the group was based on and how close its tightest comparison came, for the light replays
-                if (f == 0 && ig) { const size_t gx = (size_t)p * stride + b; F.gG[gx] = glob0; F.gK[gx] = S.psN[p] - xk; F.gR[gx] = __uint_as_float(ur); F.gM[gx] = __uint_as_float(ug); }
+                t = fr_dpp_u32<FR_DPP_ROR8>(ur); ur = t < ur ? t : ur;
+                t = fr_dpp_u32<FR_DPP_ROR8>(ug); ug = t < ug ? t : ug;
+                rec_r = (uint32_t)__builtin_amdgcn_readlane((int)ur, 0); rec_g = (uint32_t)__builtin_amdgcn_readlane((int)ug, 0);
+#pragma unroll
+                for (int q = 16; q < 64; q += 16) {
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ur, q), y = (uint32_t)__builtin_amdgcn_readlane((int)ug, q);
+                    rec_r = x < rec_r ? x : rec_r; rec_g = y < rec_g ? y : rec_g;
+                }
             }
             // group totals (a wave without a flagged lane, the usual case from the third sweep on, has nothing new to add up)
             uint32_t gk = 0; double gg = 0.0, gw = gw_last;
@@ -470,14 +580,31 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
                 gw = fr_grp8_sum(lv ? wr : 0.0);
                 gw_last = gw;
             }
+            uint32_t dki = 0u; float dgi = 0.0f;        // MODE 1: by how much my group's deltas of this sweep moved
             if (f == 0 && ig) {
                 size_t ix = (size_t)p * stride + b;
                 if (MODE == 1) {
-                    if (dk8[ix] != gk || __double_as_longlong(dg8[ix]) != __double_as_longlong(gg) || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
+                    uint32_t ok_; double og, ow;
+                    if (p < FR_FKS_PF) { const int sl = (p << 3) + (lane >> 3); ok_ = sh_dk[wslot][sl]; og = sh_dg[wslot][sl]; ow = sh_ws[wslot][sl]; }
+                    else { ok_ = dk8[ix]; og = dg8[ix]; ow = ws8[ix]; }
+                    if (ok_ != gk || __double_as_longlong(og) != __double_as_longlong(gg) || __double_as_longlong(ow) != __double_as_longlong(gw)) {
+                        dki = gk > ok_ ? gk - ok_ : ok_ - gk; dgi = (float)fabs(gg - og) * 1.0001f;
                         dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw; out_changed = true;
                     }
                 }
                 else { dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw; }
+            }
+            if (MODE == 1) {
+                // the wave's record of this sweep (lane 0 stores): start state, tightest comparison, smallest norm, moves of its deltas
+                uint32_t sk = 0u; float sg = 0.0f;
+                if (__any(dki != 0u || dgi != 0.0f)) {      // the leaders sit in lanes 0, 8, ..., 56
+                    dki += fr_dpp_u32<FR_DPP_ROR8>(dki);
+                    dgi += __uint_as_float(fr_dpp_u32<FR_DPP_ROR8>(__float_as_uint(dgi)));
+#pragma unroll
+                    for (int q = 0; q < 64; q += 16) { sk += (uint32_t)__builtin_amdgcn_readlane((int)dki, q); sg += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dgi), q)); }
+                    sg *= 1.0001f;
+                }
+                if (lane == 0 && ig) { const size_t wx = (size_t)p * wstride + my_wave; F.wG[wx] = glob0; F.wK[wx] = S.psN[p] - xk; F.wR[wx] = __uint_as_float(rec_r); F.wM[wx] = __uint_as_float(rec_g); F.wdK[wx] = sk; F.wdG[wx] = sg; }
             }
         }
         // one sweep beyond: keeps nothing, but its wt_remain sum is what a re-summed norm would be
@@ -486,19 +613,24 @@ __global__ void __launch_bounds__(FR_BLOCK) k_fks_sweep(CompWork W, Fks2Work F, 
             if (f == 0 && ig) {
                 size_t ix = (size_t)n_pass * stride + b;
                 if (MODE == 1) {
-                    if (dk8[ix] != 0u || __double_as_longlong(dg8[ix]) != 0ll || __double_as_longlong(ws8[ix]) != __double_as_longlong(gw)) {
+                    uint32_t ok_; double og, ow;
+                    if (n_pass < FR_FKS_PF) { const int sl = (n_pass << 3) + (lane >> 3); ok_ = sh_dk[wslot][sl]; og = sh_dg[wslot][sl]; ow = sh_ws[wslot][sl]; }
+                    else { ok_ = dk8[ix]; og = dg8[ix]; ow = ws8[ix]; }
+                    if (ok_ != 0u || __double_as_longlong(og) != 0ll || __double_as_longlong(ow) != __double_as_longlong(gw)) {
                         dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw; out_changed = true;
                     }
                 }
                 else { dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw; }
             }
         }
-        if (MODE == 1 && __any(out_changed) && lane == 0) {
-            if (F.hist[it] == 0) atomicOr(&F.hist[it], 1u);
-            F.cdirty[my_chunk] = (uint32_t)it + 1u;
+        if (MODE == 1) {
+            const bool chg = __any(out_changed) != 0;
+            if (lane == 0) {
+                if (chg) { if (F.hist[it] == 0) atomicOr(&F.hist[it], 1u); F.cdirty[my_chunk] = (uint32_t)it + 1u; }
+                if (ig) F.wNp[my_wave] = (uint32_t)n_pass;
+            }
         }
         if (lv) { W.keep[e] = kp; W.wt_remain[e] = wr; }
-        if (MODE == 1 && f == 0 && ig) F.gNp[b] = (uint32_t)n_pass;
     }
 }
 
@@ -610,10 +742,10 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_
     const FksScal *S = F.scal;
     const unsigned nb8 = S->n_in / 8 + 1;
     const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
-    const size_t stride = F.nb8_cap;
+    const size_t stride = F.nwv_cap, nwv = ((size_t)nb8 + 7) / 8;
     float m = INFINITY;
     for (int p = 0; p < n_pass; p++)
-        for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb8; b += (size_t)gridDim.x * blockDim.x) { const float r = F.gR[(size_t)p * stride + b]; m = r < m ? r : m; }
+        for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwv; w += (size_t)gridDim.x * blockDim.x) { const float r = F.wR[(size_t)p * stride + w]; m = r < m ? r : m; }
     for (int off = 32; off > 0; off >>= 1) { const float t = __shfl_xor(m, off); m = t < m ? t : m; }
     if (fr_lane() == 0 && m < INFINITY) atomicMin(&tie[0], __float_as_uint(m));
 }
@@ -643,7 +775,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save_groups(Fks2Work F)
     const unsigned nb8 = S->n_in / 8 + 1;
     const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
     const size_t stride = F.nb8_cap;
-    for (int p = blockIdx.y; p < n_pass; p += gridDim.y)
+    for (int p = blockIdx.y; p < n_pass && p < FR_FKS_SROWS; p += gridDim.y)
         for (unsigned b = blockIdx.x * blockDim.x + threadIdx.x; b < nb8; b += gridDim.x * blockDim.x) {
             F.sxk8[(size_t)p * stride + b] = F.xk8[(size_t)p * stride + b];
             F.sxg8[(size_t)p * stride + b] = F.xg8[(size_t)p * stride + b];

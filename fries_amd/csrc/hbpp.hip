@@ -280,6 +280,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.teeth = fr_alloc<Teeth>(1);
     W.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
+    W.seq.dbg = getenv("FRIES_SEQ_DBG") ? 1 : 0;
     {
         Fks2Work &F = c->F2;
         F.nb8_cap = (uint32_t)(((size_t)cap / 8 + 2 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK * FR_FKS_CHUNK);     // whole chunks: k_fks_scan uses unguarded vector loads
@@ -293,8 +294,10 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
             FR_HIP(hipHostGetDevicePointer(&dp, hp, 0));
             c->h_fks = (FksHost *)hp; F.hm = (FksHost *)dp;
         }
-        F.gG = fr_alloc<double>(n8); F.gR = fr_alloc<float>(n8); F.gM = fr_alloc<float>(n8); F.gK = fr_alloc<uint32_t>(n8); F.gNp = fr_alloc<uint32_t>(F.nb8_cap);
-        FR_HIP(hipMemset(F.gNp, 0xff, 4 * (size_t)F.nb8_cap));
+        F.nwv_cap = F.nb8_cap / 8;
+        const size_t nw = (size_t)FR_FKS_PMAX * F.nwv_cap;
+        F.wG = fr_alloc<double>(nw); F.wR = fr_alloc<float>(nw); F.wM = fr_alloc<float>(nw); F.wK = fr_alloc<uint32_t>(nw); F.wdK = fr_alloc<uint32_t>(nw); F.wdG = fr_alloc<float>(nw); F.wNp = fr_alloc<uint32_t>(F.nwv_cap);
+        FR_HIP(hipMemset(F.wNp, 0xff, 4 * (size_t)F.nwv_cap));
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
         F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
         F.ck = fr_alloc<uint32_t>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cg = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK); F.cw = fr_alloc<double>((size_t)FR_FKS_PMAX * FR_FKS_MAXCHUNK);
@@ -303,7 +306,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         FR_HIP(hipMemset(F.hist, 0, 4 * (FR_MAX_ROUNDS + 2)));
         F.dbg_cnt = fr_alloc<uint32_t>((size_t)FR_MAX_ROUNDS * 4);
         FR_HIP(hipMemset(F.dbg_cnt, 0, (size_t)FR_MAX_ROUNDS * 16));
-        c->fks_sxk8 = fr_alloc<uint32_t>(n8); c->fks_sxg8 = fr_alloc<double>(n8);
+        c->fks_sxk8 = fr_alloc<uint32_t>((size_t)6 * FR_FKS_SROWS * F.nb8_cap); c->fks_sxg8 = fr_alloc<double>((size_t)6 * FR_FKS_SROWS * F.nb8_cap);
         c->fks_saved = fr_alloc<FksSaved>(8);
         FR_HIP(hipMemset(c->fks_saved, 0, 8 * sizeof(FksSaved)));
         c->fks_wk = fr_alloc<uint32_t>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK); c->fks_wg = fr_alloc<double>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK);
@@ -409,7 +412,10 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     Fks2Work F = c->F2;
     F.saved = c->fks_saved + STAGE; F.wk = c->fks_wk + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wg = c->fks_wg + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
     F.wkx = c->fks_wkx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wgx = c->fks_wgx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
-    F.sxk8 = (STAGE == 1 && !getenv("FRIES_NO_GROUP_WARM")) ? c->fks_sxk8 : nullptr; F.sxg8 = F.sxk8 ? c->fks_sxg8 : nullptr;
+    // the settled per-group prefixes of this stage in the previous iteration (stage 1: vector positions persist; later stages: the head of
+    // the stage holds the children of the same heavy determinants in the same order, and that is where the prefixes are least linear)
+    F.sxk8 = ((STAGE == 1 || c->fks_group_warm_all) && !c->fks_no_group_warm) ? c->fks_sxk8 + (size_t)STAGE * FR_FKS_SROWS * F.nb8_cap : nullptr;
+    F.sxg8 = F.sxk8 ? c->fks_sxg8 + (size_t)STAGE * FR_FKS_SROWS * F.nb8_cap : nullptr;
     const int warm = c->warm_start ? 1 : 0;
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
     if (gridE > c->fks_grid) gridE = c->fks_grid;          // persistent workgroups (5 per CU), each strides over the tiles
@@ -436,8 +442,8 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             // The replay needs about as many rounds as the reference runs sweeps (a sweep's start state is only right once the sweep
             // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
             // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
-            const int rec_at = c->fks_no_light ? 1 : c->fks_rec_at >= 1 ? c->fks_rec_at : (c->rounds_hint[STAGE] > 3 ? c->rounds_hint[STAGE] - 2 : 1);
-            const int light = (it > rec_at && !c->fks_no_light) ? 1 : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
+            const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
+            const int light = (it > rec_at && !c->fks_no_light) ? (c->fks_no_ext ? 2 : 1) : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
             if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             else FR_LAUNCH(c, light ? "k_fks_sweep_light" : "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
             FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0);
@@ -472,17 +478,17 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         fprintf(stderr, "[fks] stage %d n_in %u replays %d needed %d n_pass %d lane_evals %u wave_eval_rounds %u (per replay %.0f / %.0f) psN:", STAGE, hs.n_in, it, needed, hs.n_pass,
                 hh[FR_MAX_ROUNDS], hh[FR_MAX_ROUNDS + 1], hh[FR_MAX_ROUNDS] / (double)it, hh[FR_MAX_ROUNDS + 1] / (double)it);
         for (int p = 0; p < hs.n_pass; p++) fprintf(stderr, " %u", hs.psN[p]);
-        fprintf(stderr, "\n   groups deciding (waves with such a group) / groups per replay:");
+        fprintf(stderr, "\n   waves deciding / waves per light replay:");
         std::vector<uint32_t> dc((size_t)FR_MAX_ROUNDS * 4);
         FR_HIP(hipMemcpy(dc.data(), F.dbg_cnt, dc.size() * 4, hipMemcpyDeviceToHost));
-        for (int k = 0; k < it; k++) fprintf(stderr, "  [%d] %u(%u)/%u chg %u", k, dc[k * 4], dc[k * 4 + 2], dc[k * 4 + 1], hh[k]);
+        for (int k = 0; k < it; k++) fprintf(stderr, "  [%d] %u/%u np %u chg %u", k, dc[k * 4 + 2], dc[k * 4 + 3], dc[k * 4], hh[k]);
         fprintf(stderr, "\n");
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
     if (!sequential) {
         if (c->d_tie) FR_LAUNCH(c, "k_fks_tie", k_fks_tie, dim3(64), dim3(FR_BLOCK), F, c->d_tie);
         FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
-        if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_PMAX), dim3(FR_BLOCK), F);
+        if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_SROWS), dim3(FR_BLOCK), F);
         // settled: recompute every wt_remain with the budget of its last flagged sweep
         FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB, 2>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, 0);
     }

@@ -33,6 +33,7 @@ struct SeqWork {
     SeqRec *tiles;      // [FR_MAX_PART]
     SeqRec *subs;       // [FR_MAX_PART * 16]
     double *total;      // [1] exact sum of everything (+ start)
+    int dbg = 0;        // FRIES_SEQ_DBG: k_seq_chain prints where its time goes
 };
 
 // where a chain starts: 0 + norms[0] + ... + norms[n-1], added left to right -- the lbound a rank inherits from the
@@ -262,6 +263,19 @@ __device__ __forceinline__ void fr_seq_stage(const SeqWork &Q, const Acc &acc, S
         sh->subs[i] = l;
     }
     __syncthreads();
+    // Runs of clean sub-tiles in one binade, composed ahead of the walk: every clean sub-tile's (d0, d1) becomes the map of its run up to
+    // and including itself (one thread per staged tile, 16 compositions), so that the walking wave reads a run's map instead of scanning for it
+    if (threadIdx.x < n_dt) {
+        SeqSubL *q = &sh->subs[threadIdx.x * FR_SUBS_PER_TILE];
+        PMap run = fr_pm_id(); int run_e = 0; bool in_run = false;
+        for (int j = 0; j < FR_SUBS_PER_TILE; j++) {
+            if (q[j].dirty) { in_run = false; continue; }
+            PMap m; m.d0 = q[j].d0; m.d1 = q[j].d1;
+            if (in_run && q[j].e == run_e) run = fr_pm_compose(run, m);
+            else { run = m; run_e = q[j].e; in_run = true; }
+            q[j].d0 = run.d0; q[j].d1 = run.d1;
+        }
+    }
     for (unsigned i = threadIdx.x; i < n_dt * FR_SUBS_PER_TILE * 64; i += FR_BLOCK) {
         const unsigned si = i >> 6, k = i & 63;
         const int slot = sh->subs[si].slot;         // uniform over the wave: 64 consecutive i share one sub-tile
@@ -278,7 +292,7 @@ struct SeqTileL { long long d0, d1; int e; uint32_t dirty; };
 
 // wave 0: walks tiles [c0, c1) whose records sit in tl[0, c1 - c0); *di_io = dirty tiles met so far == index into the staged list
 template <class Acc>
-__device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start, const SeqStage *sh, const SeqTileL *tl, unsigned c0, unsigned c1, unsigned *di_io) {
+__device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start, const SeqStage *sh, const SeqTileL *tl, unsigned c0, unsigned c1, unsigned *di_io, unsigned long long *t_dirty = nullptr) {
     const unsigned n = acc.count();
     const int lane = fr_lane();
     double carry = start;
@@ -295,6 +309,7 @@ __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double s
             const unsigned dflag = (unsigned)__builtin_amdgcn_readlane((int)r.dirty, pos);
             const unsigned t = t0 + pos;
             if (dflag) {
+                const unsigned long long td0 = Q.dbg ? wall_clock64() : 0ull;
                 // tile t may straddle a power of two: walk its sub-tiles -- runs of clean sub-tiles in one binade are composed by
                 // a scan over lanes (as for tiles), only a sub-tile that may straddle one is added element by element
                 const bool staged = di < n_dt;          // then sh->dt_list[di] == t
@@ -329,6 +344,7 @@ __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double s
                     const int run = (~shm == 0ull) ? 64 : (__ffsll((long long)~shm) - 1);
                     PMap m; m.d0 = sl.d0; m.d1 = sl.d1;
                     if (lane < jp || lane >= jp + run) m = fr_pm_id();
+                    if (!staged)                                                        // (staged tiles carry their runs' inclusive maps already: fr_seq_stage)
                     for (int off = 1; off < FR_SUBS_PER_TILE; off <<= 1) {              // inclusive ordered scan of maps over the 16 lanes
                         PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
                         if (lane >= off) m = fr_pm_compose(o, m);
@@ -343,30 +359,18 @@ __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double s
                 if (lane >= n_sub_here && lane < FR_SUBS_PER_TILE) Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane].carry = carry;
                 di++;
                 pos++;
+                if (Q.dbg && t_dirty) *t_dirty += wall_clock64() - td0;
                 continue;
             }
             // run of clean tiles in binade e0 starting at lane `pos`
             const unsigned long long ok = __ballot(lane >= pos && lane < n_here && !r.dirty && r.e == e0);
             const unsigned long long sh_ = ok >> pos;
             int run = (~sh_ == 0ull) ? 64 : (__ffsll((long long)~sh_) - 1);        // lanes pos .. pos+run-1 (run >= 1)
+            // (d0, d1) of a clean tile = the map of its run up to and including it (fr_seq_runs, all four waves, before the walk)
             PMap m; m.d0 = r.d0; m.d1 = r.d1;
-            if (lane < pos || lane >= pos + run) m = fr_pm_id();
             PMap ex;                                                             // exclusive map of my tile
-            if (!__any(m.d0 != m.d1)) {
-                // no exact tie anywhere in the run: every map is "add d", composition is integer addition
-                const long long own = m.d0;
-                const long long inc = fr_wave_incl_i64(own);
-                m.d0 = m.d1 = inc;
-                ex.d0 = ex.d1 = inc - own;
-            }
-            else {
-                for (int off = 1; off < 64; off <<= 1) {                         // inclusive ordered scan of maps over lanes
-                    PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
-                    if (lane >= off) m = fr_pm_compose(o, m);
-                }
-                ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
-                if (lane == 0 || lane == pos) ex = fr_pm_id();
-            }
+            ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
+            if (lane == 0 || lane == pos) ex = fr_pm_id();
             if (lane >= pos && lane < pos + run) Q.tiles[t0 + lane].carry = fr_seq_apply_map(carry, e0, ex.d0, ex.d1);
             const int last = pos + run - 1;
             carry = fr_seq_apply_map(carry, e0, fr_bcast_i64(m.d0, last), fr_bcast_i64(m.d1, last));
@@ -377,12 +381,49 @@ __device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double s
     return carry;
 }
 
+// Inclusive maps of the runs of clean same-binade tiles inside every batch of 64 staged tile records, in place (a run = what the walking
+// wave composes in one step: it ends at a tile that may straddle a power of two, at a change of binade and at the batch's end).  The four
+// waves take the batches in turn; segmented scan over lanes -- integer sums when no map of the batch holds an exact tie (the usual case).
+__device__ __forceinline__ void fr_seq_runs(SeqTileL *tl, unsigned n_here_total) {
+    const int lane = fr_lane(), w = threadIdx.x >> 6;
+    for (unsigned t0 = w * 64u; t0 < n_here_total; t0 += FR_BLOCK) {
+        const bool in = t0 + lane < n_here_total;
+        SeqTileL r; r.dirty = 1; r.e = 0; r.d0 = r.d1 = 0;
+        if (in) r = tl[t0 + lane];
+        const int e_prev = __shfl_up(r.e, 1); const unsigned d_prev = (unsigned)__shfl_up((int)r.dirty, 1);
+        const bool head = lane == 0 || r.dirty || d_prev || r.e != e_prev;
+        const unsigned long long H = __ballot(head);
+        const bool clean = in && !r.dirty;
+        PMap m; m.d0 = clean ? r.d0 : 0; m.d1 = clean ? r.d1 : 0;
+        if (!__any(m.d0 != m.d1)) {
+            const long long inc = fr_wave_incl_i64(m.d0);
+            // start of my run: the highest head at or below my lane
+            const unsigned long long below = H & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+            const int hpos = 63 - __builtin_clzll(below);                // lane 0 is always a head
+            const long long before = __shfl(inc, hpos > 0 ? hpos - 1 : 0);
+            m.d0 = m.d1 = inc - (hpos > 0 ? before : 0ll);
+        }
+        else {
+            int flag = head ? 1 : 0;
+            for (int off = 1; off < 64; off <<= 1) {
+                PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
+                const int of = __shfl_up(flag, off);
+                if (lane >= off && !flag) { m = fr_pm_compose(o, m); flag |= of; }
+            }
+        }
+        if (clean) { tl[t0 + lane].d0 = m.d0; tl[t0 + lane].d1 = m.d1; }
+    }
+}
+
 // one workgroup: everybody stages (dirty tiles once, tile records in rounds of FR_SEQ_LCHUNK), wave 0 walks
 template <class Acc>
 __global__ void __launch_bounds__(FR_BLOCK) k_seq_chain(SeqWork Q, Acc acc, SeqStart st) {
     __shared__ SeqStage sh;
     __shared__ SeqTileL tl[FR_SEQ_LCHUNK];
+    const unsigned long long tq0 = Q.dbg ? wall_clock64() : 0ull;
     fr_seq_stage(Q, acc, &sh);
+    const unsigned long long tq1 = Q.dbg ? wall_clock64() : 0ull;
+    unsigned long long t_load = 0, t_walk = 0, t_dirty = 0;
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
     double carry = st.value();
@@ -390,14 +431,20 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seq_chain(SeqWork Q, Acc acc, SeqS
     for (unsigned c0 = 0; c0 < ntile; c0 += FR_SEQ_LCHUNK) {
         const unsigned c1 = c0 + FR_SEQ_LCHUNK < ntile ? c0 + FR_SEQ_LCHUNK : ntile;
         if (c0) __syncthreads();        // wave 0 is done with the previous round's records
+        const unsigned long long ta = Q.dbg ? wall_clock64() : 0ull;
         for (unsigned t = c0 + threadIdx.x; t < c1; t += FR_BLOCK) {
             const SeqRec q = Q.tiles[t];
             SeqTileL l; l.d0 = q.d0; l.d1 = q.d1; l.e = q.e; l.dirty = q.dirty;
             tl[t - c0] = l;
         }
         __syncthreads();
-        if (threadIdx.x < 64) carry = fr_seq_chain_wave(Q, acc, carry, &sh, tl, c0, c1, &di);
+        fr_seq_runs(tl, c1 - c0);
+        __syncthreads();
+        const unsigned long long tb = Q.dbg ? wall_clock64() : 0ull;
+        if (threadIdx.x < 64) carry = fr_seq_chain_wave(Q, acc, carry, &sh, tl, c0, c1, &di, &t_dirty);
+        if (Q.dbg) { t_load += tb - ta; t_walk += wall_clock64() - tb; }
     }
+    if (Q.dbg && threadIdx.x == 0) printf("[seq_chain] n %u tiles %u dirty tiles %u dirty subs %u: stage %llu load %llu walk %llu of which dirty tiles %llu (x10 ns)\n", n, ntile, sh.n_dt, sh.n_ds, tq1 - tq0, t_load, t_walk, t_dirty);
     if (threadIdx.x == 0) *Q.total = carry;
 }
 
