@@ -247,7 +247,7 @@ def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, 
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     tk = json.load(f)["kernels"]
                 # the bench's label "k_fks_sweep" is the lean replay = template instantiations <stage, *, 0> of the kernel
-                want_mode = {"k_fks_sweep": ", 0>", "k_fks_sweep_rec": ", 1>", "k_fks_sweep_light": ", 1>", "k_fks_final": ", 2>"}.get(name)
+                want_mode = {"k_fks_sweep": ", 0>", "k_fks_sweep_rec": ", 1>", "k_fks_sweep_light": ", 3>", "k_fks_final": ", 2>"}.get(name)
                 kname = "k_fks_sweep" if want_mode else name
                 vals_t = [v["bytes_per_launch"] for k, v in tk.items() if (k.startswith(kname + "<") and (want_mode is None or k.endswith(want_mode))) or k == kname]
                 if vals_t and m == 1_000_000 and world == 1:

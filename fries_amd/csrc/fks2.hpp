@@ -225,20 +225,24 @@ __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32
 
 // MODE 0: early replays -- every tile, prefixes zero / from the warm start / from the previous replay, deltas written without
 //         comparison (the replay counts as changed), no margins recorded: the lean kernel.
-// MODE 1: late replays -- margins recorded, deltas compared with the stored ones (hist[it] / cdirty raised on a difference);
-//         with `light` a tile whose inputs moved by less than its tightest comparison tolerates is skipped.
+// MODE 1: the first comparing replay -- every wave decides, margins recorded, deltas compared with the stored ones (hist[it] / cdirty
+//         raised on a difference).
+// MODE 3: light replays -- MODE 1 for the waves whose inputs moved by more than their tightest comparison tolerates, the others stand
+//         (a template instantiation of its own: the test costs registers the recording replay does not have).  light == 2: no allowance
+//         for a changed number of sweeps.
 // MODE 2: final pass -- wt_remain with the budget of the last sweep that flagged the element.
 #define FR_FKS_TILE_MAXK 8192u      // a tile of FR_BLOCK elements preserves at most 32 sub-weights per element
 #define FR_FKS_GRP_MAXK 256u        // a group of 8 elements likewise
 
 template <int STAGE, bool NEW_HB, int MODE>
 __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
+    constexpr bool M1 = MODE == 1 || MODE == 3, LIGHT = MODE == 3;       // comparing replays; MODE 3 also skips the waves that stand
     __shared__ HbTables T;
     __shared__ FksScal S;
     // MODE 1: the deltas my wave's 8 groups stored for sweeps 0 .. FR_FKS_PF-1, fetched in one go when the tile starts (compared with the new
     // ones sweep by sweep: fetched there, each comparison is a dependent global-load latency on the wave's critical path)
-    __shared__ double sh_dg[MODE == 1 ? FR_BLOCK / 64 : 1][MODE == 1 ? FR_FKS_PF * 8 : 1], sh_ws[MODE == 1 ? FR_BLOCK / 64 : 1][MODE == 1 ? FR_FKS_PF * 8 : 1];
-    __shared__ uint32_t sh_dk[MODE == 1 ? FR_BLOCK / 64 : 1][MODE == 1 ? FR_FKS_PF * 8 : 1];
+    __shared__ double sh_dg[M1 ? FR_BLOCK / 64 : 1][M1 ? FR_FKS_PF * 8 : 1], sh_ws[M1 ? FR_BLOCK / 64 : 1][M1 ? FR_FKS_PF * 8 : 1];
+    __shared__ uint32_t sh_dk[M1 ? FR_BLOCK / 64 : 1][M1 ? FR_FKS_PF * 8 : 1];
     {
         const uint32_t *src = (const uint32_t *)F.scal;
         uint32_t *dst = (uint32_t *)&S;
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
     // Which of my tiles decide again is settled before the tables are staged: a workgroup with nothing to decide leaves at once
     // (late replays: almost all of them).  Bit k of `decide` = the k-th tile of this workgroup's stride (tiles beyond 32 are asked again below).
     uint32_t decide = 0;
-    if (MODE == 1 && light) {
+    if (LIGHT) {
         int any = 0;
         unsigned k = 0;
         for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x, k++) {
@@ -393,7 +397,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         const bool live = e < n_in;
         const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
         const size_t my_wave = e >> 6;
-        if (MODE == 1 && light) {
+        if (LIGHT) {
             const bool d = tile_k < 32 ? ((decide >> tile_k) & 1u) != 0 : !wave_stands(tile);
             if (!d) continue;                           // nothing to decide in this wave
         }
@@ -432,7 +436,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         };
         // the deltas my wave stored before (lane = 8 x sweep + group)
         const int wslot = threadIdx.x >> 6;
-        if (MODE == 1) {
+        if (M1) {
             const int ps = lane >> 3;
             const size_t bj = (my_wave << 3) + (size_t)f;
             uint32_t ok_ = 0u; double og = 0.0, ow = 0.0;
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         double wr = v;
         uint32_t kp = (MODE == 2 && lv) ? W.keep[e] : 0u;
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
-        if (MODE == 1 && light) { if (STAGE != 1 && lv) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); } }       // few waves, alone on their CU: one round of loads instead of two
+        if (LIGHT) { if (STAGE != 1 && lv) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); } }       // few waves, alone on their CU: one round of loads instead of two
         else if (STAGE != 1 && lv && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
         if (MODE == 2) {
             double lastwf = 0;
@@ -493,7 +497,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
             const bool flagged = cmp && cw >= glob0;
             // distance of my comparisons from flipping, relative to their larger side (float is plenty; rounded down)
             float mr = INFINITY;
-            if (MODE == 1 && cmp) mr = (float)fabs(cw - glob0) * __frcp_rn((float)(cw > glob0 ? cw : glob0));
+            if (M1 && cmp) mr = (float)fabs(cw - glob0) * __frcp_rn((float)(cw > glob0 ? cw : glob0));
             // --- speculate with the start norm, then validate against the running norm
             double change = 0, new_wr = wr, mu = 0, mk = INFINITY;
             uint32_t add = 0, new_kp = kp;
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
                     if (!__any(need_eval)) break;
                 }
                 // the row comparisons, against the running norm they were finally decided with
-                if (MODE == 1 && flagged && nd == 0) {
+                if (M1 && flagged && nd == 0) {
                     float m2;
                     if (need_eval || !(gl_mine > 0)) m2 = 0.0f;          // the validation loop ran out of rounds / the norm is gone: never skip this tile
                     else if (skipped) m2 = (float)(gl_mine - cw * (double)wmax) * __frcp_rn((float)gl_mine);
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
             // the wave's tightest comparison and smallest norm of this sweep: minima over the 8 lanes of a group, over the two groups of a
             // 16-lane row (DPP), then over the four rows by lane reads -- the result is wave-uniform
             uint32_t rec_r = 0u, rec_g = 0u;
-            if (MODE == 1) {
+            if (M1) {
                 float gm = cmp ? (float)gl_mine * 0.99999f : INFINITY;      // gl_mine <= glob0: the smaller of my two right-hand sides
                 if (!(mr >= 0.0f)) mr = 0.0f;
                 if (!(gm >= 0.0f)) gm = 0.0f;
@@ -583,7 +587,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
             uint32_t dki = 0u; float dgi = 0.0f;        // MODE 1: by how much my group's deltas of this sweep moved
             if (f == 0 && ig) {
                 size_t ix = (size_t)p * stride + b;
-                if (MODE == 1) {
+                if (M1) {
                     uint32_t ok_; double og, ow;
                     if (p < FR_FKS_PF) { const int sl = (p << 3) + (lane >> 3); ok_ = sh_dk[wslot][sl]; og = sh_dg[wslot][sl]; ow = sh_ws[wslot][sl]; }
                     else { ok_ = dk8[ix]; og = dg8[ix]; ow = ws8[ix]; }
@@ -594,7 +598,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
                 }
                 else { dk8[ix] = gk; dg8[ix] = gg; ws8[ix] = gw; }
             }
-            if (MODE == 1) {
+            if (M1) {
                 // the wave's record of this sweep (lane 0 stores): start state, tightest comparison, smallest norm, moves of its deltas
                 uint32_t sk = 0u; float sg = 0.0f;
                 if (__any(dki != 0u || dgi != 0.0f)) {      // the leaders sit in lanes 0, 8, ..., 56
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
             const double gw = gw_last;
             if (f == 0 && ig) {
                 size_t ix = (size_t)n_pass * stride + b;
-                if (MODE == 1) {
+                if (M1) {
                     uint32_t ok_; double og, ow;
                     if (n_pass < FR_FKS_PF) { const int sl = (n_pass << 3) + (lane >> 3); ok_ = sh_dk[wslot][sl]; og = sh_dg[wslot][sl]; ow = sh_ws[wslot][sl]; }
                     else { ok_ = dk8[ix]; og = dg8[ix]; ow = ws8[ix]; }
@@ -623,7 +627,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
                 else { dk8[ix] = 0; dg8[ix] = 0; ws8[ix] = gw; }
             }
         }
-        if (MODE == 1) {
+        if (M1) {
             const bool chg = __any(out_changed) != 0;
             if (lane == 0) {
                 if (chg) { if (F.hist[it] == 0) atomicOr(&F.hist[it], 1u); F.cdirty[my_chunk] = (uint32_t)it + 1u; }
@@ -633,6 +637,15 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         if (lv) { W.keep[e] = kp; W.wt_remain[e] = wr; }
     }
 }
+
+// Chunk totals cross from the workgroups of k_fks_scan to the one that finishes last (fused totals) as relaxed device-scope atomics:
+// written through to memory and read past the reader's L2, so no release fence -- which on this part writes the whole dirty L2 back, the
+// 10 MB of prefixes the scan has just stored included (68 us per replay when every workgroup fenced) -- is needed for them to be seen;
+// the writer waits for its stores to be acknowledged before it takes its ticket.
+__device__ __forceinline__ void fr_st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fr_st_agent(double *p, double v) { __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t fr_ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double fr_ld_agent(const double *p) { return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 
 // Exclusive prefixes over the chunks and sweep totals (one wave per sweep) into this rank's FksMsg; with one rank, also the sweep
 // scalars of the next replay.
@@ -648,8 +661,8 @@ __device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg 
             for (unsigned c0 = 0; c0 < nchunk; c0 += 64) {
                 unsigned c = c0 + lane;
                 size_t ix = (size_t)q * FR_FKS_MAXCHUNK + c;
-                uint32_t k = c < nchunk ? F.ck[ix] : 0u;
-                double g = c < nchunk ? F.cg[ix] : 0.0, w = c < nchunk ? F.cw[ix] : 0.0;
+                uint32_t k = c < nchunk ? fr_ld_agent(&F.ck[ix]) : 0u;
+                double g = c < nchunk ? fr_ld_agent(&F.cg[ix]) : 0.0, w = c < nchunk ? fr_ld_agent(&F.cw[ix]) : 0.0;
                 uint32_t tk; double tg, tw;
                 uint32_t ek = fr_wave_excl_u32(k, &tk);
                 double eg = fr_wave_excl_f64(g, &tg);
@@ -676,9 +689,11 @@ __device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg 
 
 // Exclusive prefixes over the 8-blocks inside chunks of 2048 groups (grid: chunks x a few sweep lanes, each looping over the
 // sweeps); chunk totals go to (ck, cg, cw).
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it, int light) {
+static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it, int light, int fuse, uint32_t *err, FksMsg *msg, int inline_passes) {
     __shared__ double shd[12];
     __shared__ uint32_t shu[4];
+    __shared__ uint32_t last_wg;
+    __shared__ FksMsg sm_tot;
     const FksScal *S = F.scal;
     const unsigned c = blockIdx.x;
     const unsigned nb8 = S->n_in / 8 + 1;
@@ -724,10 +739,23 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
             for (int j = 0; j < 4; j++) qg[j] = make_double2(xg[2 * j], xg[2 * j + 1]);
         }
         if (threadIdx.x == 0) {
-            F.ck[(size_t)p * FR_FKS_MAXCHUNK + c] = totk; F.cg[(size_t)p * FR_FKS_MAXCHUNK + c] = totg; F.cw[(size_t)p * FR_FKS_MAXCHUNK + c] = totw;
+            const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + c;
+            fr_st_agent(&F.ck[cx], totk); fr_st_agent(&F.cg[cx], totg); fr_st_agent(&F.cw[cx], totw);
         }
         __syncthreads();        // shd / shu are reused by the next sweep
     }
+    if (!fuse) return;
+    // the workgroup that finishes last turns the chunk totals into this replay's sweep totals and the next replay's sweep scalars
+    // (k_fks_totals, one launch less per replay); everybody else has read the scalars it is about to overwrite before taking a ticket
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);          // my chunk totals have been acknowledged
+        const uint32_t t = atomicAdd(&F.scal->done_ctr, 1u);
+        last_wg = (t + 1u == gridDim.x * gridDim.y) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_wg) return;
+    if (threadIdx.x == 0) F.scal->done_ctr = 0u;
+    fr_fks_totals(F, err, msg, inline_passes, it, &sm_tot);
 }
 
 // (a separate launch: folding it into the last workgroup of k_fks_scan needs a device-scope fence in every workgroup, which on this part

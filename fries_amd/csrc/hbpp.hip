@@ -445,9 +445,10 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
             const int light = (it > rec_at && !c->fks_no_light) ? (c->fks_no_ext ? 2 : 1) : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
             if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
-            else FR_LAUNCH(c, light ? "k_fks_sweep_light" : "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
-            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0);
-            FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
+            else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
+            else FR_LAUNCH(c, "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
+            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0, c->fks_fuse_totals ? 1 : 0, c->d_err, msg, xr ? 0 : 1);
+            if (!c->fks_fuse_totals) FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
             if (xr) {
                 const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
                 FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, it, c->d_err, 0);
