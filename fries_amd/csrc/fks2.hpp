@@ -457,6 +457,8 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
             if (n_pass > 0) prefix_issue(0, &nx);
             for (int p = 0; p < n_pass; p++) {
                 const double xg = nx.a + nx.b; const uint32_t xk = nx.c + nx.d;
+                // the settled per-group prefixes inside the chunks, kept for the next iteration's first replay of this stage
+                if (F.sxk8 && f == 0 && in_grp && p < FR_FKS_SROWS) { F.sxk8[(size_t)p * stride + b] = nx.d; F.sxg8[(size_t)p * stride + b] = nx.b; }
                 if (p + 1 < n_pass) prefix_issue(p + 1, &nx);
                 double glob = S.psG[p] - xg, wf = (double)(S.psN[p] - xk);
                 if (live && nd == 0 && v > 0 && v * wf >= glob) lastwf = wf;
@@ -797,15 +799,3 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
     }
 }
 
-// stage 1: keeps the settled replay's per-group prefixes for the next iteration's first replay
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save_groups(Fks2Work F) {
-    const FksScal *S = F.scal;
-    const unsigned nb8 = S->n_in / 8 + 1;
-    const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
-    const size_t stride = F.nb8_cap;
-    for (int p = blockIdx.y; p < n_pass && p < FR_FKS_SROWS; p += gridDim.y)
-        for (unsigned b = blockIdx.x * blockDim.x + threadIdx.x; b < nb8; b += gridDim.x * blockDim.x) {
-            F.sxk8[(size_t)p * stride + b] = F.xk8[(size_t)p * stride + b];
-            F.sxg8[(size_t)p * stride + b] = F.xg8[(size_t)p * stride + b];
-        }
-}

@@ -280,7 +280,9 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.teeth = fr_alloc<Teeth>(1);
     W.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
+#ifdef FR_SEQ_TIMING
     W.seq.dbg = getenv("FRIES_SEQ_DBG") ? 1 : 0;
+#endif
     {
         Fks2Work &F = c->F2;
         F.nb8_cap = (uint32_t)(((size_t)cap / 8 + 2 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK * FR_FKS_CHUNK);     // whole chunks: k_fks_scan uses unguarded vector loads
@@ -443,7 +445,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
             // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
             const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
-            const int light = (it > rec_at && !c->fks_no_light) ? (c->fks_no_ext ? 2 : 1) : 0;       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
+            const int light = (it > rec_at && !c->fks_no_light && !c->d_tie) ? (c->fks_no_ext ? 2 : 1) : 0;       // (tie statistics: every wave decides in every replay, so that the records are those of the settled state)       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
             if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
             else FR_LAUNCH(c, "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
@@ -489,7 +491,6 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (!sequential) {
         if (c->d_tie) FR_LAUNCH(c, "k_fks_tie", k_fks_tie, dim3(64), dim3(FR_BLOCK), F, c->d_tie);
         FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
-        if (F.sxk8) FR_LAUNCH(c, "k_fks_save_groups", k_fks_save_groups, dim3(128, FR_FKS_SROWS), dim3(FR_BLOCK), F);
         // settled: recompute every wt_remain with the budget of its last flagged sweep
         FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB, 2>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, 0);
     }

@@ -33,7 +33,11 @@ struct SeqWork {
     SeqRec *tiles;      // [FR_MAX_PART]
     SeqRec *subs;       // [FR_MAX_PART * 16]
     double *total;      // [1] exact sum of everything (+ start)
-    int dbg = 0;        // FRIES_SEQ_DBG: k_seq_chain prints where its time goes
+#ifdef FR_SEQ_TIMING
+    int dbg = 0;        // FRIES_SEQ_DBG: k_seq_chain prints where its time goes (build with -DFR_SEQ_TIMING)
+#else
+    static constexpr int dbg = 0;
+#endif
 };
 
 // where a chain starts: 0 + norms[0] + ... + norms[n-1], added left to right -- the lbound a rank inherits from the
@@ -453,7 +457,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seq_chain(SeqWork Q, Acc acc, SeqS
         if (threadIdx.x < 64) carry = fr_seq_chain_wave(Q, acc, carry, &sh, tl, c0, c1, &di, &t_dirty);
         if (Q.dbg) { t_load += tb - ta; t_walk += wall_clock64() - tb; }
     }
+#ifdef FR_SEQ_TIMING
     if (Q.dbg && threadIdx.x == 0) printf("[seq_chain] n %u tiles %u dirty tiles %u dirty subs %u: stage %llu load %llu walk %llu of which dirty tiles %llu (x10 ns)\n", n, ntile, sh.n_dt, sh.n_ds, tq1 - tq0, t_load, t_walk, t_dirty);
+#endif
     if (threadIdx.x == 0) *Q.total = carry;
 }
 
