@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfries_hip.so")
 SOURCES = ["hbpp.hip", "vec.hip", "compress.hip", "pivotal.hip", "system.hip", "hh.hip", "fciqmc.hip", "driver.hip", "comm_native.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"] + os.environ.get("FRIES_EXTRA_HIPCC_FLAGS", "").split()      # (diagnostic builds: -DFR_SEQ_TIMING, -DFR_FKS_CHKDBG)
 
 
 def _stale(target: str, deps: list[str]) -> bool:

@@ -179,6 +179,7 @@ struct FriesCtx {
     uint32_t prop_tag = 0;                   // last tag handed to a comb-repair round (k_sys_walk)
     int fks_rec_at = -1;                     // FRIES_FKS_REC_AT=k: the replay that records the tiles' margins (default: rounds hint - 2)
     bool fks_group_warm_all = true;          // FRIES_GROUP_WARM_ALL=0: only stage 1 starts its first replay from the previous iteration's per-group prefixes
+    bool fks_light_full_grid = false;        // FRIES_FKS_LIGHT_FULL_GRID=1: light replays launch one workgroup per tile
     bool fks_fuse_totals = false;            // FRIES_FKS_FUSE_TOTALS=1: the last workgroup of k_fks_scan does k_fks_totals' work
     bool fks_no_ext = false;                 // FRIES_FKS_NO_EXT=1: a wave re-decides whenever the stage runs another number of sweeps than it last ran
     bool fks_no_group_warm = false;          // FRIES_NO_GROUP_WARM=1

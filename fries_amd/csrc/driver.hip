@@ -465,6 +465,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     if (getenv("FRIES_GROUP_WARM_ALL")) h->c.fks_group_warm_all = atoi(getenv("FRIES_GROUP_WARM_ALL")) != 0;
     if (getenv("FRIES_NO_GROUP_WARM")) h->c.fks_no_group_warm = true;
     if (getenv("FRIES_FKS_NO_EXT")) h->c.fks_no_ext = true;
+    if (getenv("FRIES_FKS_LIGHT_FULL_GRID")) h->c.fks_light_full_grid = atoi(getenv("FRIES_FKS_LIGHT_FULL_GRID")) != 0;
     if (getenv("FRIES_FKS_FUSE_TOTALS")) h->c.fks_fuse_totals = atoi(getenv("FRIES_FKS_FUSE_TOTALS")) != 0;
     if (getenv("FRIES_FKS_NO_LIGHT")) h->c.fks_no_light = atoi(getenv("FRIES_FKS_NO_LIGHT")) != 0;
     if (getenv("FRIES_FKS_COLLAPSE_WALK")) h->c.fks_no_collapse_walk = atoi(getenv("FRIES_FKS_COLLAPSE_WALK")) == 0;

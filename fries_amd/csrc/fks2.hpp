@@ -47,6 +47,12 @@ struct FksSaved {
     double G0;
     double psG[FR_FKS_PMAX];
     uint32_t psN[FR_FKS_PMAX];
+    // the settled replay before that one (same stage, one iteration earlier still), for the trend: right after a restart and while the shift
+    // moves, the budget left after the late sweeps drifts by 2-3 % per iteration in one direction
+    int valid2, n_pass2; uint32_t n02; double G02;
+    double psG2[FR_FKS_PMAX];
+    uint32_t psN2[FR_FKS_PMAX];
+    float extrap;                   // FRIES_FKS_WARM_EXTRAP: fraction of the last change added to the guess (0: last iteration's values as they are)
 };
 
 // What the host looks at after a batch of replays, in host-coherent pinned memory the kernels write straight into (a device-to-host
@@ -82,6 +88,7 @@ struct Fks2Work {
 #define FR_FKS_CHUNK 2048                   // groups per scan workgroup
 #define FR_FKS_MAXCHUNK 1024
 #define FR_FKS_PF 8                        // sweeps whose stored deltas a wave of k_fks_sweep<.., 1> prefetches into LDS
+#define FR_FKS_WARM_EXTRAP 0.0f             // default trend factor of the first replay's sweep scalars (FksSaved::extrap)
 #define FR_FKS_SROWS 16                    // sweeps of a stage whose settled per-group prefixes are kept for the next iteration's first replay
 
 // What a rank tells the others about its shard: the norm entering sweep 0 and, per sweep of the replay that just
@@ -131,7 +138,17 @@ __device__ __forceinline__ void fr_fks2_warm(FksScal *S, const FksSaved *Wv, int
     S->warm = 0; S->warm_scale = 1.0;
     if (!enable || !Wv->valid || Wv->n0 != S->n0 || !(Wv->G0 > 0) || !(S->psG[0] > 0) || Wv->n_pass < 1) return;
     const double sc = S->psG[0] / Wv->G0;
-    for (int p = 0; p < Wv->n_pass; p++) { S->psG[p] = Wv->psG[p] * sc; S->psN[p] = Wv->psN[p]; }
+    const bool trend = Wv->extrap > 0.0f && Wv->valid2 && Wv->n_pass2 == Wv->n_pass && Wv->n02 == Wv->n0 && Wv->G02 > 0;
+    for (int p = 0; p < Wv->n_pass; p++) {
+        double g = Wv->psG[p] / Wv->G0, k = (double)Wv->psN[p];
+        if (trend && p > 0) {
+            const double g2 = Wv->psG2[p] / Wv->G02, k2 = (double)Wv->psN2[p];
+            const double gn = g + (double)Wv->extrap * (g - g2), kn = k + (double)Wv->extrap * (k - k2);
+            if (gn > 0 && kn >= 1.0 && kn <= (double)Wv->n0) { g = gn; k = kn; }
+        }
+        S->psG[p] = g * S->psG[0]; S->psN[p] = (uint32_t)(k + 0.5);
+    }
+    (void)sc;
     S->n_pass = Wv->n_pass;
     S->warm = 1; S->warm_scale = sc;
 }
@@ -344,6 +361,9 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
                 const double used = (r + noise) * 1.0001;
                 okp = used < rmar;
                 ext_r = (rmar - used) * 0.999;
+#ifdef FR_FKS_CHKDBG
+                if (dbg == 3 && it == 2 && STAGE == 1 && wv % 1500 == 7) printf("[chk] st %d wv %u p %d ext %d ok %d: K_old %u K_in %u k7 %u ik %.0f | G_old %.9e dG/G %.3e ig/G %.3e gmin/G %.6f | a %.3e %.3e b %.3e %.3e r %.3e rmar %.3e\n", STAGE, (unsigned)wv, p, (int)ext, okp, K_old, K_in, k7, ik, G_old, dG / G_old, ig_ / G_old, gmin / G_old, a_lo, a_hi, b_lo, b_hi, r, rmar);
+#endif
             }
             else if (rmar != INFINITY) ext_r = 0.0;
             if (rmar == INFINITY) ext_r = INFINITY;
@@ -793,6 +813,8 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
         }
     if (threadIdx.x == 0) {
         FksSaved *V = F.saved;
+        V->valid2 = V->valid; V->n_pass2 = V->n_pass; V->n02 = V->n0; V->G02 = V->G0;
+        for (int p = 0; p < V->n_pass && p < FR_FKS_PMAX; p++) { V->psG2[p] = V->psG[p]; V->psN2[p] = V->psN[p]; }
         V->n_pass = n_pass; V->n0 = S->n0; V->nchunk = nchunk; V->nb8 = nb8; V->G0 = S->psG[0];
         for (int p = 0; p < n_pass; p++) { V->psG[p] = S->psG[p]; V->psN[p] = S->psN[p]; }
         V->valid = (S->overflow || !(S->psG[0] > 0)) ? 0 : 1;

@@ -311,6 +311,10 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         c->fks_sxk8 = fr_alloc<uint32_t>((size_t)6 * FR_FKS_SROWS * F.nb8_cap); c->fks_sxg8 = fr_alloc<double>((size_t)6 * FR_FKS_SROWS * F.nb8_cap);
         c->fks_saved = fr_alloc<FksSaved>(8);
         FR_HIP(hipMemset(c->fks_saved, 0, 8 * sizeof(FksSaved)));
+        {
+            const float ex = getenv("FRIES_FKS_WARM_EXTRAP") ? (float)atof(getenv("FRIES_FKS_WARM_EXTRAP")) : FR_FKS_WARM_EXTRAP;
+            if (ex > 0.0f) { FksSaved hsv{}; hsv.extrap = ex; for (int k = 0; k < 8; k++) FR_HIP(hipMemcpy(c->fks_saved + k, &hsv, sizeof(FksSaved), hipMemcpyHostToDevice)); }
+        }
         c->fks_wk = fr_alloc<uint32_t>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK); c->fks_wg = fr_alloc<double>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK);
         FR_HIP(hipMemset(F.scal, 0, sizeof(FksScal)));
     }
@@ -420,6 +424,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     F.sxg8 = F.sxk8 ? c->fks_sxg8 + (size_t)STAGE * FR_FKS_SROWS * F.nb8_cap : nullptr;
     const int warm = c->warm_start ? 1 : 0;
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
+    const unsigned gridL = c->fks_light_full_grid ? gridE : (gridE > c->fks_grid ? c->fks_grid : gridE);      // light replays: one tile per workgroup (the test of a tile is two dependent rounds of loads; a workgroup striding over three tiles pays them three times before it may leave)
     if (gridE > c->fks_grid) gridE = c->fks_grid;          // persistent workgroups (5 per CU), each strides over the tiles
     unsigned nchunk = fr_blocks((size_t)n_bound / 8 + 1, FR_FKS_CHUNK);
     if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
@@ -447,7 +452,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
             const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
             const int light = (it > rec_at && !c->fks_no_light && !c->d_tie) ? (c->fks_no_ext ? 2 : 1) : 0;       // (tie statistics: every wave decides in every replay, so that the records are those of the settled state)       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
             if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
-            else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
+            else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridL), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
             else FR_LAUNCH(c, "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
             FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0, c->fks_fuse_totals ? 1 : 0, c->d_err, msg, xr ? 0 : 1);
             if (!c->fks_fuse_totals) FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
