@@ -723,6 +723,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
     const int n_pass = S->n_pass;
     const size_t stride = F.nb8_cap;            // a multiple of FR_FKS_CHUNK: every chunk of a sweep's row is fully addressable
     // no delta of this chunk moved in this replay (and the sweeps are the same as before): its prefixes and totals stand
+    if (light && !fuse && n_pass == S->valid_upto && F.hist[it] == 0u) return;       // the replay changed no delta: nothing to scan anywhere
     const bool stands = light && n_pass == S->valid_upto && F.cdirty[c] != (uint32_t)it + 1u;
     if (!stands && c < nchunk)
     for (int p = blockIdx.y; p <= n_pass && p < FR_FKS_PMAX; p += gridDim.y) {
@@ -784,6 +785,11 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
 // writes the L2 back each time -- measured 68 us per replay instead of 9 + 9)
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
     __shared__ FksMsg sm;        // the bookkeeping is one thread chasing ~20 values per sweep: keep them in LDS
+    // a replay that changed no delta (the confirming one, and those the host enqueued beyond it) leaves every total and scalar as it is
+    if (it > 0 && F.hist[it] == 0u && F.scal->n_pass == F.scal->valid_upto && !F.scal->zero_prefix) {
+        if (threadIdx.x == 0) { msg->changed = 0u; if (inline_passes && F.hm && it < FR_MAX_ROUNDS) F.hm->hist[it] = 0u; }
+        return;
+    }
     fr_fks_totals(F, err, msg, inline_passes, it, &sm);
 }
 

@@ -215,6 +215,43 @@ def test_frisys_trajectory_matches_reference_golden(Engine, mols, name):
     eng.close()
 
 
+REPLAY_KNOBS = [
+    {"FRIES_FKS_NO_LIGHT": "1"},            # every wave decides in every replay (no margins used)
+    {"FRIES_FKS_NO_EXT": "1"},              # a changed number of sweeps sends every wave back to deciding
+    {"FRIES_GROUP_WARM_ALL": "0"},          # stages 2-5 start from the per-chunk profile
+    {"FRIES_NO_GROUP_WARM": "1"},
+    {"FRIES_FKS_FUSE_TOTALS": "1"},         # totals by the last workgroup of the scan
+    {"FRIES_FKS_LIGHT_FULL_GRID": "1"},
+    {"FRIES_FKS_WARM_EXTRAP": "1.0"},
+    {"FRIES_FKS_REC_AT": "3"},              # margins recorded by replay 3 instead of replay 1
+]
+
+
+@pytest.mark.parametrize("knob", range(len(REPLAY_KNOBS)))
+@pytest.mark.parametrize("name", ["n2_m30000_unnorm", "h2o_m5000_hb"])
+def test_every_replay_strategy_reproduces_the_reference(Engine, mols, name, knob, monkeypatch):
+    """find_keep_sub's fixed point is unique: whichever way the replay reaches it (which waves it lets stand, where it starts from, who adds
+    up the totals), the trajectory is the reference's.  The knobs are read when the context is created."""
+    for k, v in REPLAY_KNOBS[knob].items():
+        monkeypatch.setenv(k, v)
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    eng = Engine(mols(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    for row in g["rows"]:
+        lg = eng.iterate(1)[0]
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (REPLAY_KNOBS[knob], row["it"], f)
+        assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"], (REPLAY_KNOBS[knob], row["it"])
+        assert int(lg["err"]) == 0
+    d, v = eng.vector()
+    last = g["rows"][-1]
+    if last["it"] % 10 == 9:
+        assert golden_io.vec_hash(d, v) == last["hash"]
+    eng.close()
+
+
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["extra_runs"]))
 def test_frisys_driver_options_match_reference_golden(Engine, mols, name):
     """--trial_vec (a 25-determinant trial vector: H * trial by full enumeration of every entry), --ini_vec and --ham_shift on
