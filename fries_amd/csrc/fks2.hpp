@@ -251,6 +251,27 @@ __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32
 #define FR_FKS_TILE_MAXK 8192u      // a tile of FR_BLOCK elements preserves at most 32 sub-weights per element
 #define FR_FKS_GRP_MAXK 256u        // a group of 8 elements likewise
 
+// records the settled replay for the next iteration's warm start (one workgroup: the last one of the final pass)
+__device__ __forceinline__ void fr_fks_save(Fks2Work F) {
+    const FksScal *S = F.scal;
+    const unsigned nb8 = S->n_in / 8 + 1;
+    const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
+    const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
+    for (int p = 0; p < n_pass; p++)
+        for (unsigned c = threadIdx.x; c < nchunk; c += blockDim.x) {
+            const size_t ix = (size_t)p * FR_FKS_MAXCHUNK + c;
+            F.wk[ix] = F.ck[ix]; F.wg[ix] = F.cg[ix]; F.wkx[ix] = F.ckx[ix]; F.wgx[ix] = F.cgx[ix];
+        }
+    if (threadIdx.x == 0) {
+        FksSaved *V = F.saved;
+        V->valid2 = V->valid; V->n_pass2 = V->n_pass; V->n02 = V->n0; V->G02 = V->G0;
+        for (int p = 0; p < V->n_pass && p < FR_FKS_PMAX; p++) { V->psG2[p] = V->psG[p]; V->psN2[p] = V->psN[p]; }
+        V->n_pass = n_pass; V->n0 = S->n0; V->nchunk = nchunk; V->nb8 = nb8; V->G0 = S->psG[0];
+        for (int p = 0; p < n_pass; p++) { V->psG[p] = S->psG[p]; V->psN[p] = S->psN[p]; }
+        V->valid = (S->overflow || !(S->psG[0] > 0)) ? 0 : 1;
+    }
+}
+
 template <int STAGE, bool NEW_HB, int MODE>
 __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
     constexpr bool M1 = MODE == 1 || MODE == 3, LIGHT = MODE == 3;       // comparing replays; MODE 3 also skips the waves that stand
@@ -407,6 +428,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         }
         if (!__syncthreads_or(any)) return;
     }
+    if (MODE == 2 && blockIdx.x == gridDim.x - 1) fr_fks_save(F);       // (reads the settled chunk totals and scalars; nobody writes them in this launch)
     if (STAGE != 1) fr_stage_tables(&T, Tg);
 
     unsigned tile_k = 0;
@@ -806,24 +828,4 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_
     if (fr_lane() == 0 && m < INFINITY) atomicMin(&tie[0], __float_as_uint(m));
 }
 
-// records the settled replay for the next iteration's warm start (one workgroup)
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_save(Fks2Work F) {
-    const FksScal *S = F.scal;
-    const unsigned nb8 = S->n_in / 8 + 1;
-    const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
-    const int n_pass = S->n_pass < FR_FKS_PMAX ? S->n_pass : FR_FKS_PMAX;
-    for (int p = 0; p < n_pass; p++)
-        for (unsigned c = threadIdx.x; c < nchunk; c += blockDim.x) {
-            const size_t ix = (size_t)p * FR_FKS_MAXCHUNK + c;
-            F.wk[ix] = F.ck[ix]; F.wg[ix] = F.cg[ix]; F.wkx[ix] = F.ckx[ix]; F.wgx[ix] = F.cgx[ix];
-        }
-    if (threadIdx.x == 0) {
-        FksSaved *V = F.saved;
-        V->valid2 = V->valid; V->n_pass2 = V->n_pass; V->n02 = V->n0; V->G02 = V->G0;
-        for (int p = 0; p < V->n_pass && p < FR_FKS_PMAX; p++) { V->psG2[p] = V->psG[p]; V->psN2[p] = V->psN[p]; }
-        V->n_pass = n_pass; V->n0 = S->n0; V->nchunk = nchunk; V->nb8 = nb8; V->G0 = S->psG[0];
-        for (int p = 0; p < n_pass; p++) { V->psG[p] = S->psG[p]; V->psN[p] = S->psN[p]; }
-        V->valid = (S->overflow || !(S->psG[0] > 0)) ? 0 : 1;
-    }
-}
 

@@ -495,7 +495,6 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     }
     if (!sequential) {
         if (c->d_tie) FR_LAUNCH(c, "k_fks_tie", k_fks_tie, dim3(64), dim3(FR_BLOCK), F, c->d_tie);
-        FR_LAUNCH(c, "k_fks_save", k_fks_save, dim3(1), dim3(FR_BLOCK), F);
         // settled: recompute every wt_remain with the budget of its last flagged sweep
         FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB, 2>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, 0);
     }
