@@ -13,7 +13,7 @@ void fr_vcomp_alloc(FriesCtx *c, uint32_t cap) {
     B.teeth = fr_alloc<Teeth>(1);
     B.dots = fr_alloc<double>(2);
     B.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
-    B.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); B.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); B.seq.total = fr_alloc<double>(1);
+    B.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); B.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); B.seq.total = fr_alloc<double>(1); B.seq.tsum = fr_alloc<double>(FR_MAX_PART);
     B.gnorm = fr_alloc<double>(1);
     FR_HIP(hipMemsetAsync(B.keep, 0, cap, c->stream));
     FR_HIP(hipMemsetAsync(B.del, 0, cap, c->stream));
@@ -134,16 +134,14 @@ template <class Acc>
 static void run_seq(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound) {
     unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, fr_seq_from_zero());
-    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, fr_seq_from_zero());
 }
 // the chain again, starting from the lbound this rank inherits (classification and maps depend on the running sum's binade)
 template <class Acc>
 static void run_seq_from(FriesCtx *c, SeqWork Q, Acc acc, uint32_t n_bound, SeqStart from) {
     unsigned grid = fr_blocks(n_bound ? n_bound : 1, FR_SEQ_TILE);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
-    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<Acc>), dim3(grid), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<Acc>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
 }
 

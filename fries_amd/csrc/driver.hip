@@ -1151,7 +1151,7 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     unsigned ntile = fr_blocks(n ? n : 1, FR_SEQ_TILE);
     if (ntile > FR_MAX_PART) throw FriesError("too many elements");
     SeqWork Q;
-    Q.tiles = fr_alloc<SeqRec>(ntile); Q.subs = fr_alloc<SeqRec>((size_t)ntile * FR_SUBS_PER_TILE); Q.total = fr_alloc<double>(1);
+    Q.tiles = fr_alloc<SeqRec>(ntile); Q.subs = fr_alloc<SeqRec>((size_t)ntile * FR_SUBS_PER_TILE); Q.total = fr_alloc<double>(1); Q.tsum = fr_alloc<double>(ntile);
     double *da = fr_alloc<double>(n), *dout = fr_alloc<double>(n);
     FR_HIP(hipMemcpy(da, vals, 8 * (size_t)n, hipMemcpyHostToDevice));
     FR_HIP(hipMemset(Q.subs, 0, sizeof(SeqRec) * (size_t)ntile * FR_SUBS_PER_TILE));
@@ -1160,8 +1160,7 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     FR_HIP(hipMemcpy(dstart, &start, 8, hipMemcpyHostToDevice));
     SeqStart from; from.norms = dstart; from.n = 1;      // 0 + start == start
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
-    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccArr>), dim3(ntile), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccArr>), dim3(1), dim3(FR_BLOCK), Q, acc, from);
     FR_LAUNCH(c, "k_test_seq_apply", k_test_seq_apply, dim3(ntile), dim3(FR_BLOCK), Q, acc, dout);
     FR_HIP(hipStreamSynchronize(c->stream));
@@ -1174,7 +1173,7 @@ extern "C" int fries_test_seqsum(fries_ctx *h, const double *vals, uint32_t n, d
     for (unsigned t = 0; t < ntile; t++) if (tl[t].dirty) { dt++; for (int j = 0; j < FR_SUBS_PER_TILE; j++) if (sb[(size_t)t * FR_SUBS_PER_TILE + j].dirty) ds++; }
     if (n_dirty_tiles) *n_dirty_tiles = dt;
     if (n_dirty_subs) *n_dirty_subs = ds;
-    hipFree(Q.tiles); hipFree(Q.subs); hipFree(Q.total); hipFree(da); hipFree(dout); hipFree(dstart);
+    hipFree(Q.tiles); hipFree(Q.subs); hipFree(Q.total); hipFree(Q.tsum); hipFree(da); hipFree(dout); hipFree(dstart);
     FR_API_END
 }
 

@@ -279,7 +279,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
     W.teeth = fr_alloc<Teeth>(1);
     W.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
-    W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1);
+    W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1); W.seq.tsum = fr_alloc<double>(FR_MAX_PART);
 #ifdef FR_SEQ_TIMING
     W.seq.dbg = getenv("FRIES_SEQ_DBG") ? 1 : 0;
 #endif
@@ -377,8 +377,7 @@ static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) 
     FR_LAUNCH(c, "k_fks_seq_reset", k_fks_seq_reset, dim3(grid < 1024 ? grid : 1024), dim3(FR_BLOCK), W, cur);
     AccVal av{W.el[cur].val, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccVal>), dim3(1), dim3(FR_BLOCK), W.seq, av, fr_seq_from_zero());
-    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccVal>), dim3(1), dim3(FR_BLOCK), W.seq, av, fr_seq_from_zero());
     FR_LAUNCH(c, "k_fks_seq_begin", k_fks_seq_begin, dim3(1), dim3(1), W, Q, W.seq.total, (double *)c->comm.small_send);
     AccWt acc{W.wt_remain, &W.state[0]};
@@ -396,8 +395,7 @@ static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) 
         if (!h.go) break;
         if (h.resum) {      // loc_one_norm re-summed from wt_remain, in order (compress_utils.cpp:258-264)
             FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-            FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
-            FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+            FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
             FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
             FR_LAUNCH(c, "k_fks_seq_take_resum", k_fks_seq_take_resum, dim3(1), dim3(1), Q, W.seq.total, (double *)c->comm.small_send);
         }
@@ -500,8 +498,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     }
     AccWt acc{W.wt_remain, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-    FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
-    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
     FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
     const double *norms = W.seq.total;
     if (xr) {
@@ -515,8 +512,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
         SeqWork Q2 = W.seq; Q2.total = c->d_seq_scratch;
         FR_LAUNCH(c, "k_keep_norms", k_keep_norms, dim3(1), dim3(64), norms, P, c->d_norms_keep, W, F);
-        FR_LAUNCH(c, "k_seq_classify", (k_seq_classify<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
-        FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc);
+        FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc, from);
         FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
     }
     if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));

@@ -33,6 +33,7 @@ struct SeqWork {
     SeqRec *tiles;      // [FR_MAX_PART]
     SeqRec *subs;       // [FR_MAX_PART * 16]
     double *total;      // [1] exact sum of everything (+ start)
+    double *tsum;       // [FR_MAX_PART] the tiles' tree sums again, contiguous (k_seq_maps adds up the ones before its tile)
 #ifdef FR_SEQ_TIMING
     int dbg = 0;        // FRIES_SEQ_DBG: k_seq_chain prints where its time goes (build with -DFR_SEQ_TIMING)
 #else
@@ -115,50 +116,30 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seq_sums(SeqWork Q, Acc acc) {
     for (int off = 8; off > 0; off >>= 1) g += __shfl_xor(g, off);
     if ((threadIdx.x & 15) == 0) Q.subs[(size_t)blockIdx.x * FR_SUBS_PER_TILE + (threadIdx.x >> 4)].approx = g;
     double t = fr_block_sum(s, shd);
-    if (threadIdx.x == 0) Q.tiles[blockIdx.x].approx = t;
-}
-
-// ---- S2: approximate carries per tile, clean / dirty classification (one workgroup)
-template <class Acc>
-__global__ void __launch_bounds__(FR_BLOCK) k_seq_classify(SeqWork Q, Acc acc, SeqStart st) {
-    const double start = st.value();
-    __shared__ double shd[12];
-    const unsigned n = acc.count();
-    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
-    const double eps = fr_seq_eps(n);
-    double carry = start;
-    for (unsigned t0 = 0; t0 < ntile; t0 += FR_BLOCK) {
-        unsigned t = t0 + threadIdx.x;
-        double a = t < ntile ? Q.tiles[t].approx : 0.0;
-        // inclusive scan of this chunk
-        int lane = fr_lane(), w = threadIdx.x >> 6;
-        double v = a;
-        for (int off = 1; off < 64; off <<= 1) { double x = __shfl_up(v, off); if (lane >= off) v += x; }
-        if (lane == 63) shd[w] = v;
-        __syncthreads();
-        double basev = 0;
-        for (int k = 0; k < w; k++) basev += shd[k];
-        double chunk_tot = shd[0] + shd[1] + shd[2] + shd[3];
-        double incl = basev + v;
-        if (t < ntile) {
-            double c_in = carry + (incl - a), c_out = carry + incl;
-            int e = 0;
-            bool clean = fr_seq_clean(c_in, c_out, eps, &e);
-            Q.tiles[t].carry = c_in; Q.tiles[t].e = e; Q.tiles[t].dirty = clean ? 0u : 1u;
-        }
-        carry += chunk_tot;
-        __syncthreads();
-    }
+    if (threadIdx.x == 0) { Q.tiles[blockIdx.x].approx = t; Q.tsum[blockIdx.x] = t; }
 }
 
 // ---- S3: parity maps of clean tiles; sub-tile classification + maps inside dirty tiles
+// The tile's approximate carry and its clean / dirty classification are formed here as well (they were a one-workgroup launch of their own,
+// k_seq_classify): the workgroup adds up the tree sums of the tiles before its own -- any fixed order of n non-negative terms stays inside
+// fr_seq_eps(n), and which tiles get classified "may straddle" only decides who is walked sub-tile by sub-tile, never the sum.
 template <class Acc>
-__global__ void __launch_bounds__(FR_BLOCK) k_seq_maps(SeqWork Q, Acc acc) {
+__global__ void __launch_bounds__(FR_BLOCK) k_seq_maps(SeqWork Q, Acc acc, SeqStart st) {
     __shared__ PMap shm[FR_BLOCK];
+    __shared__ double shc[4];
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
     if (blockIdx.x >= ntile) return;
-    const SeqRec tr = Q.tiles[blockIdx.x];
+    SeqRec tr;
+    {
+        double x = 0;
+        for (unsigned i = threadIdx.x; i < blockIdx.x; i += FR_BLOCK) x += Q.tsum[i];
+        const double c_in = st.value() + fr_block_sum(x, shc);
+        int e_t = 0;
+        const bool clean_t = fr_seq_clean(c_in, c_in + Q.tsum[blockIdx.x], fr_seq_eps(n), &e_t);
+        tr.carry = c_in; tr.e = e_t; tr.dirty = clean_t ? 0u : 1u;
+        if (threadIdx.x == 0) { Q.tiles[blockIdx.x].carry = c_in; Q.tiles[blockIdx.x].e = e_t; Q.tiles[blockIdx.x].dirty = tr.dirty; }
+    }
     size_t base = (size_t)blockIdx.x * FR_SEQ_TILE + (size_t)threadIdx.x * 4;
     double a[4];
     for (int it = 0; it < 4; it++) { size_t i = base + it; a[it] = i < n ? acc.get(i) : 0.0; }
