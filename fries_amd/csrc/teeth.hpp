@@ -44,8 +44,14 @@ __device__ inline void fr_build_teeth(Teeth *t, double r0, double u, uint32_t km
         if (x2 >= top) { emit(x, x1 - x, k, 1); emit(x1, x2 - x1, k + 1, 1); k += 2; x = x2; continue; }
         double inc = x2 - x1;              // exact: both multiples of ulp in one binade
         emit(x, x1 - x, k, 1);
-        long long A = (long long)((top - x1) / ulp), B = (long long)(inc / ulp);   // exact integers
-        long long m = (A - 1) / B;         // largest m with x1 + m*inc < top
+        const double iulp = ldexp(1.0, 52 - e);                                    // 1 / ulp: scaling by a power of two is exact
+        long long A = (long long)((top - x1) * iulp), B = (long long)(inc * iulp);  // exact integers (< 2^53)
+        // largest m with x1 + m*inc < top: (A - 1) / B.  The one thread that builds the comb would spend most of its time in the
+        // software 64-bit division; the double quotient of two integers below 2^53 is off by less than one, and the two products
+        // that settle it stay below 2^54.
+        long long m = (long long)floor((double)(A - 1) / (double)B);
+        while (m * B > A - 1) m--;
+        while ((m + 1) * B <= A - 1) m++;
         emit(x1, inc, k + 1, (uint32_t)(m + 1));
         x = x1 + (double)m * inc;          // exact
         k = k + 1 + (uint32_t)m;
