@@ -433,7 +433,7 @@ const void *fr_dots_enqueue(FriesCtx *c) {
         FR_HIP(hipMemcpyAsync(c->comm.small_send, c->vc.dots, 16, hipMemcpyDeviceToDevice, c->stream));
         src = (const double *)fr_allgather(c, 16);
     }
-    return fr_readback(c, src, 16 * (size_t)c->n_ranks);
+    return fr_readback(c, src, 16 * (size_t)c->n_ranks, true);      // read after find_preserve's rounds, each of which takes ring slots
 }
 void fr_dots_collect(FriesCtx *c, const void *h_d, double *numer, double *denom) {
     const int P = c->n_ranks;

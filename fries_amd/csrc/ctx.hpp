@@ -175,7 +175,7 @@ struct FriesCtx {
     // mapped into the device's address space; the host reads it after the stream synchronisation it needs anyway.  (hipMemcpy of a few
     // bytes into pageable memory costs a blit kernel, a staging buffer and a host copy per call.)
     uint8_t *h_rb = nullptr, *d_rb = nullptr; size_t rb_used = 0;
-    static constexpr size_t RB_BYTES = 8192;
+    static constexpr size_t RB_BYTES = 8192, RB_HELD_BYTES = 2048;     // the ring, and one slot for a readback that is held across other readbacks (fr_dots_enqueue)
     uint32_t prop_tag = 0;                   // last tag handed to a comb-repair round (k_sys_walk)
     int fks_rec_at = -1;                     // FRIES_FKS_REC_AT=k: the replay that records the tiles' margins (default: rounds hint - 2)
     bool fks_group_warm_all = true;          // FRIES_GROUP_WARM_ALL=0: only stage 1 starts its first replay from the previous iteration's per-group prefixes
@@ -207,6 +207,7 @@ struct FriesCtx {
     uint32_t n_dense_h = 0, n_dense_h_nz = 0;       // symmetry-allowed excitations of this rank's dense determinants / those with a non-zero element
     uint32_t n_dense_h_glob = 0;                    // the former summed over the ranks: what the matrix sample budget is reduced by
     uint32_t *d_dh_from = nullptr; det_t *d_dh_to = nullptr; double *d_dh_el = nullptr, *d_dense_norm = nullptr;
+    std::vector<uint32_t> dense_sizes;      // every rank's n_dense (dense.txt of a checkpoint)
     bool ham_shift_set = false; double ham_shift_hf_en = 0;
     // trial vectors (replicated, small)
     uint32_t n_trial = 0, n_htrial = 0;
@@ -282,7 +283,7 @@ int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 void fr_dense_h_setup(FriesCtx *c);      // system.hip
 // enqueue a copy of `bytes` (a multiple of 4, <= 2 KB) at device address src into the readback block; -> host address to read AFTER the next
 // synchronisation of the stream.  The block is a ring: a slot stays valid until ~RB_BYTES more have been asked for.  (vec.hip)
-const void *fr_readback(FriesCtx *c, const void *src, size_t bytes);
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held = false);
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);
 void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac);

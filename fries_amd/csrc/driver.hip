@@ -112,6 +112,32 @@ int fr_host_idx_to_proc(const FriesCtx *c, det_t d) {
     return (int)(hash % (uint64_t)c->n_ranks);
 }
 
+
+// The first n positions of the vector become the dense (semi-stochastic) space: H inside it is tabulated (fr_dense_h_setup), every rank learns
+// tot_dense_h = sum_mpi(n_determ_h) (frisys_mol.cpp:399: what the matrix sample budget is reduced by) and every rank's n_dense (what
+// DistVec::save writes to dense.txt, vec_utils.hpp:736-745).  zero: init_dense zeroes the values (:876-879), DistVec::load keeps them.
+static void fr_dense_declare(FriesCtx *c, uint32_t n, bool zero) {
+    if (n > c->h_vst.curr_size) throw FriesError("dense space larger than the stored vector");
+    c->vec.n_dense = n;
+    if (n && zero) FR_HIP(hipMemsetAsync(c->vec.v0, 0, 8 * (size_t)n, c->stream));
+    fr_dense_h_setup(c);
+    c->n_dense_h_glob = c->n_dense_h;
+    c->dense_sizes.assign((size_t)c->n_ranks, n);
+    if (c->use_comm) {
+        const uint32_t mine[2] = {c->n_dense_h, n};
+        FR_HIP(hipMemcpyAsync(c->comm.small_send, mine, 8, hipMemcpyHostToDevice, c->stream));
+        const uint32_t *all = (const uint32_t *)fr_allgather(c, 8);
+        std::vector<uint32_t> got(2 * (size_t)c->n_ranks);
+        FR_HIP(hipMemcpyAsync(got.data(), all, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+        FR_HIP(hipStreamSynchronize(c->stream));
+        uint64_t tot = 0;
+        for (int r = 0; r < c->n_ranks; r++) { tot += got[2 * r]; c->dense_sizes[r] = got[2 * r + 1]; }
+        if (tot > 0xffffffffull) throw FriesError("dense block of H too large");
+        c->n_dense_h_glob = (uint32_t)tot;
+    }
+    if (c->n_dense_h_glob >= c->mat_nonz) throw FriesError("mat_nonz must exceed the number of matrix elements inside the dense space (the compression gets mat_nonz minus that many samples)");
+}
+
 static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
     c->eps = p->epsilon; c->target_norm = p->target_norm; c->init_thresh = p->initiator;
@@ -157,23 +183,7 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
             fr_vec_merge(c, &c->vec, m, true);
         }
         fr_vec_sync_state(c, &c->vec, &c->h_vst);
-        c->vec.n_dense = c->h_vst.curr_size;          // (a determinant listed twice takes one position)
-        if (c->vec.n_dense) FR_HIP(hipMemsetAsync(c->vec.v0, 0, 8 * (size_t)c->vec.n_dense, c->stream));
-        fr_dense_h_setup(c);
-        // tot_dense_h = sum_mpi(n_determ_h) (frisys_mol.cpp:399): what the matrix sample budget is reduced by, on every rank
-        c->n_dense_h_glob = c->n_dense_h;
-        if (c->use_comm) {
-            FR_HIP(hipMemcpyAsync(c->comm.small_send, &c->n_dense_h, 4, hipMemcpyHostToDevice, c->stream));
-            const uint32_t *all = (const uint32_t *)fr_allgather(c, 4);
-            std::vector<uint32_t> cnt(c->n_ranks);
-            FR_HIP(hipMemcpyAsync(cnt.data(), all, 4 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
-            FR_HIP(hipStreamSynchronize(c->stream));
-            uint64_t tot = 0;
-            for (uint32_t x : cnt) tot += x;
-            if (tot > 0xffffffffull) throw FriesError("dense block of H too large");
-            c->n_dense_h_glob = (uint32_t)tot;
-        }
-        if (c->n_dense_h_glob >= p->mat_nonz) throw FriesError("mat_nonz must exceed the number of matrix elements inside the dense space (the compression gets mat_nonz minus that many samples)");
+        fr_dense_declare(c, c->h_vst.curr_size, true);          // (a determinant listed twice takes one position)
     }
     if (!c->in_ini_det.empty()) {
         // --ini_vec (:264-274): rank 0 add()s every entry in file order; each rank receives the ones it owns in that order
@@ -513,7 +523,8 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     for (int k = 0; k < 2; k++) { hipFree(b.psum[k]); hipFree(b.pcnt[k]); }
     hipFree(b.state); hipFree(b.teeth); hipFree(b.dots); hipFree(b.fix_list);
     PivBuf &pv = h->c.piv;
-    if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); hipFree(pv.tile_dd); }
+    if (pv.start) { hipFree(pv.start); hipFree(pv.carry); hipFree(pv.U); hipFree(pv.unit); hipFree(pv.scal); hipFree(pv.tile_dd); hipFree(pv.tile_nz); hipFree(pv.nz_start); }
+    hipFree(h->c.d_dh_from); hipFree(h->c.d_dh_to); hipFree(h->c.d_dh_el); hipFree(h->c.d_dense_norm);
     hipFree(h->c.d_h); hipFree(h->c.d_eris); hipFree(h->c.d_hb); hipFree(h->c.d_err);
     if (h->c.full_cnt) { hipFree(h->c.full_cnt); hipFree(h->c.full_nz); hipFree(h->c.full_off); hipFree(h->c.full_list); }
     fr_piv_flat_free(&h->c);
@@ -673,6 +684,7 @@ extern "C" int fries_frisys_iterate(fries_ctx *h, uint32_t n_iter, fries_iter_lo
     if (h->c.hh_mode) throw FriesError("this context runs frisys_hh: use fries_hh_iterate");
     if (h->c.fq_mode) throw FriesError("this context runs fciqmc_mol: use fries_fciqmc_iterate");
     for (uint32_t i = 0; i < n_iter; i++) frisys_iterate(&h->c, logs ? &logs[i] : nullptr);
+    if (n_iter && !logs) fr_vec_sync_state(&h->c, &h->c.vec, &h->c.h_vst);       // the last iteration's merges may have raised a flag in the vector state: one readback per batch
     check_dev_err(&h->c);
     FR_API_END
 }
@@ -997,6 +1009,26 @@ extern "C" int fries_vec_load(fries_ctx *h, const uint64_t *dets, const double *
     fr_vec_maybe_rebuild(c, &v);
     fr_vec_sync_state(c, &v, &c->h_vst);
     check_dev_err(c);
+    FR_API_END
+}
+
+extern "C" int fries_vec_set_dense(fries_ctx *h, uint32_t n_dense) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->vec.dets || c->hh_mode || c->fq_mode || c->full_mode) throw FriesError("fries_vec_set_dense needs a frisys_mol context (after fries_frisys_setup and fries_vec_load)");
+    if (c->d_dh_from) { hipFree(c->d_dh_from); hipFree(c->d_dh_to); hipFree(c->d_dh_el); c->d_dh_from = nullptr; c->d_dh_to = nullptr; c->d_dh_el = nullptr; }
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    fr_dense_declare(c, n_dense, false);
+    check_dev_err(c);
+    FR_API_END
+}
+extern "C" int fries_dense_sizes(fries_ctx *h, uint32_t *sizes, size_t cap, size_t *n_ranks) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (n_ranks) *n_ranks = (size_t)c->n_ranks;
+    if (cap < (size_t)c->n_ranks) throw FriesError("fries_dense_sizes: buffer smaller than the number of ranks");
+    for (int r = 0; r < c->n_ranks; r++) sizes[r] = (size_t)r < c->dense_sizes.size() ? c->dense_sizes[r] : 0u;
     FR_API_END
 }
 

@@ -366,6 +366,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_prep_hh2(CompWork W, VecDev V, int
     if (threadIdx.x == 0) { W.psum[0][blockIdx.x] = bs; W.pcnt[0][blockIdx.x] = 0; }
 }
 
+// drops some flags of the device error word and leaves the others standing
+static __global__ void k_err_clear(uint32_t *err, uint32_t bits) { atomicAnd(err, ~bits); }
+
 // find_keep_sub of this stage in the reference's order (fks_seq.hpp): sweeps driven from the host, one sum_mpi before and one
 // after each, as in compress_utils.cpp:153-265
 template <int STAGE, bool NEW_HB>
@@ -472,7 +475,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // (a norm that went negative did so by rounding noise of the same kind)
     if (!sequential && !c->fks_no_collapse_walk && (!(hscal.G_last >= 1e-3 * hscal.psG[0]) || hscal.G_neg < 0) && hscal.psG[0] > 0) sequential = true;
     if (sequential) {
-        if (hscal.overflow) { uint32_t z = 0; FR_HIP(hipMemcpyAsync(c->d_err, &z, 4, hipMemcpyHostToDevice, st)); }     // FR_ERR_ROUNDS of the abandoned replay (nothing else can have raised a flag: the iteration checks d_err at its end)
+        if (hscal.overflow) FR_LAUNCH(c, "k_err_clear", k_err_clear, dim3(1), dim3(1), c->d_err, (uint32_t)FR_ERR_ROUNDS);     // FR_ERR_ROUNDS of the abandoned replay only: d_err also carries the flags of earlier stages and iterations of the batch
         run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
     }
     else c->rounds_hint[STAGE] = needed > 2 ? needed : 2;

@@ -36,18 +36,22 @@ void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
 static __global__ void __launch_bounds__(64) k_readback(const uint32_t *src, uint32_t *dst, unsigned n_words) {
     for (unsigned i = threadIdx.x; i < n_words; i += 64) dst[i] = src[i];
 }
-const void *fr_readback(FriesCtx *c, const void *src, size_t bytes) {
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
     if (!c->h_rb) {
         void *hp = nullptr, *dp = nullptr;
-        FR_HIP(hipHostMalloc(&hp, FriesCtx::RB_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+        FR_HIP(hipHostMalloc(&hp, FriesCtx::RB_BYTES + FriesCtx::RB_HELD_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
         FR_HIP(hipHostGetDevicePointer(&dp, hp, 0));
         c->h_rb = (uint8_t *)hp; c->d_rb = (uint8_t *)dp; c->rb_used = 0;
     }
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (bytes == 0 || (bytes & 3) || need > 2048) throw FriesError("fr_readback: bad size");
-    if (c->rb_used + need > FriesCtx::RB_BYTES) c->rb_used = 0;
-    const size_t off = c->rb_used;
-    c->rb_used += need;
+    size_t off;
+    if (held) off = FriesCtx::RB_BYTES;         // a slot of its own behind the ring: the ring may wrap any number of times before the caller reads it
+    else {
+        if (c->rb_used + need > FriesCtx::RB_BYTES) c->rb_used = 0;
+        off = c->rb_used;
+        c->rb_used += need;
+    }
     FR_LAUNCH(c, "k_readback", k_readback, dim3(1), dim3(64), (const uint32_t *)src, (uint32_t *)(c->d_rb + off), (unsigned)(bytes / 4));
     return c->h_rb + off;
 }

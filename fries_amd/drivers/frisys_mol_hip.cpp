@@ -11,7 +11,7 @@
 // (DistVec::save / load, FRIES/vec_utils.hpp:703-844; save_proc_hash, io_utils.cpp:589-606).  Everything numeric runs on
 // the GPU.  --ini_vec / --trial_vec read the reference's text vectors (<prefix>dets, <prefix>vals; load_vec_txt, io_utils.cpp:447-482).
 // --det_space FILE: the semi-stochastic dense space (every rank reads the file and keeps the determinants it owns; with --load_dir the
-// checkpoint must not hold one).
+// dense space is the one the checkpoint's dense.txt records, as in the reference).
 //
 // Ranks (the reference under mpiexec -n P: hash-sharded vector, MPI_Alltoallv of the adds, rank-ordered sums):
 //   * one process per MI355X over librccl: start P copies with RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun's names;
@@ -78,16 +78,30 @@ static void save_vector(fries_ctx *ctx, const std::string &dir, unsigned n_orb, 
     std::vector<double> zeros(m, 0.0);                                  // column 1 is zero between iterations (frisys_mol.cpp:498)
     fv.write((const char *)zeros.data(), (std::streamsize)(8 * m));
     if (rank == 0) {        // one dense-space size per rank (vec_utils.hpp:736-745)
+        std::vector<uint32_t> ds((size_t)n_ranks, 0u);
+        size_t nr = 0;
+        ck(fries_dense_sizes(ctx, ds.data(), ds.size(), &nr));
         std::ofstream fx(dir + "dense.txt");
-        for (int p = 0; p < n_ranks - 1; p++) fx << 0 << ",";
-        fx << 0 << '\n';
+        for (int p = 0; p < n_ranks - 1; p++) fx << ds[p] << ",";
+        fx << ds[n_ranks - 1] << '\n';
     }
 }
 
-// DistVec::load (:739-844): positions 0.. hold the stored elements with |value| > 1e-9, in file order
+// DistVec::load (:761-844): dense.txt gives every rank its n_dense; positions 0.. hold the first n_dense stored elements whatever their value,
+// then those with |value| > 1e-9, in file order; the dense space is declared again on the device (fries_vec_set_dense: H inside it, the budget)
 static size_t load_vector(fries_ctx *ctx, const std::string &dir, unsigned n_orb, int rank = 0) {
     const size_t n_bytes = (2 * n_orb + 7) / 8;
     const std::string rk = std::to_string(rank);
+    size_t n_dense = 0;
+    {
+        std::ifstream fx(dir + "dense.txt");       // read_csv (io_utils.cpp:75-113): comma-separated integers, one per rank
+        std::string tok; int col = 0;
+        while (fx.is_open() && std::getline(fx, tok, ',')) {
+            if (tok.find_first_of("0123456789") == std::string::npos) continue;
+            if (col == rank) n_dense = (size_t)std::stoul(tok);
+            col++;
+        }
+    }
     std::ifstream fd(dir + "dets" + rk + ".dat", std::ios::binary | std::ios::ate);
     if (!fd.is_open()) throw std::runtime_error("Could not open saved binary vector file at path " + dir + "dets" + rk + ".dat");
     size_t n = (size_t)fd.tellg() / n_bytes;
@@ -97,9 +111,11 @@ static size_t load_vector(fries_ctx *ctx, const std::string &dir, unsigned n_orb
     std::ifstream fv(dir + "vals" + rk + ".dat", std::ios::binary);
     if (!fv.is_open()) throw std::runtime_error("Could not open saved binary vector file at path " + dir + "vals" + rk + ".dat");
     fv.read((char *)vals.data(), (std::streamsize)(8 * n));
+    if (n_dense > n) throw std::runtime_error("dense.txt names more dense determinants than " + dir + "dets" + rk + ".dat holds");
     std::vector<uint64_t> d2; std::vector<double> v2;
-    for (size_t i = 0; i < n; i++) if (fabs(vals[i]) > 1e-9) { d2.push_back(dets[i]); v2.push_back(vals[i]); }
+    for (size_t i = 0; i < n; i++) if (i < n_dense || fabs(vals[i]) > 1e-9) { d2.push_back(dets[i]); v2.push_back(vals[i]); }
     ck(fries_vec_load(ctx, d2.data(), v2.data(), d2.size()));
+    ck(fries_vec_set_dense(ctx, (uint32_t)n_dense));        // every rank calls it (collective), also with n_dense == 0
     return d2.size();
 }
 

@@ -240,6 +240,12 @@ int fries_find_preserve(fries_ctx *ctx, uint32_t *n_samp, double *glob_norm);
 int fries_sys_comp(fries_ctx *ctx, uint32_t n_samp, double rn);
 /* replaces the stored vector: determinants land in positions 0..n-1 (DistVec::load, vec_utils.hpp:761-844) */
 int fries_vec_load(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n);
+/* A checkpoint that holds a dense (semi-stochastic) space (DistVec::load returns n_dense_, vec_utils.hpp:766-779, 844; frisys_mol.cpp:257-263,
+ * 347-401): after fries_vec_load, the first n_dense positions become this rank's dense space -- kept whatever their value, H inside the
+ * space tabulated again, the matrix sample budget reduced by the number of its elements over all ranks.  Collective with ranks.
+ * fries_dense_sizes: every rank's n_dense, what DistVec::save writes to dense.txt (:736-745). */
+int fries_vec_set_dense(fries_ctx *ctx, uint32_t n_dense);
+int fries_dense_sizes(fries_ctx *ctx, uint32_t *sizes, size_t cap, size_t *n_ranks);
 /* Column mirrors for hosts that keep the reference's pointer semantics (DistVec::values(), operator[], zero_vec, matr_el_at_pos,
  * dot: vec_utils.hpp:506-508, 647-649, 577-579, 672-677, 228-238) -- what include/FRIES/vec_utils.hpp is built on.
  * fries_vec_dot_list sums in list order, bit-identical to the reference's loop. */
