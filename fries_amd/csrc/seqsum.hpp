@@ -216,168 +216,42 @@ __device__ __forceinline__ long long fr_wave_incl_i64(long long v) {
     return v;
 }
 
-// What the chain needs about the tiles that may straddle a power of two, staged in LDS by the whole workgroup before wave 0
-// starts walking: their sub-tile records and the 64 elements of every sub-tile that has to be added one by one.  Fetched on
-// demand by the one walking wave, each of these costs a dependent global-load latency (~2 us) -- with ~15 such tiles per sum
-// that was most of the kernel's 70 us.
-#define FR_SEQ_DT_CAP 64            // dirty tiles staged (more are handled from global memory, correct but slow)
-#define FR_SEQ_DS_CAP 64            // dirty sub-tiles whose elements are staged
+// ---- S4: the chain, one workgroup.  Only what is inherently sequential is walked by one wave: the SEGMENTS --
+//   * a run of clean tiles in one binade (inside a batch of 64 tile records): one parity-map application,
+//   * inside a tile that may straddle a power of two: a run of clean sub-tiles in one binade (one application), or a sub-tile that may
+//     straddle one: its 64 elements added one by one --
+// about 100 of them per million elements.  Everything else is done by all four waves around the walk: the records are staged in LDS,
+// the runs' maps composed, the segments listed in order (integer scan), and afterwards every tile and sub-tile forms its own entry
+// carry from its segment's entry carry and the map of the part of the run before it.  (Until round 3 the walking wave also found the
+// runs by ballots, composed the sub-tile runs by shuffles and stored every tile's carry itself: 46 us per sum at a million elements,
+// all of it dependent scalar-like work on one wave.)
+// Tiles are taken in chunks of FR_SEQ_LCHUNK records; a chunk ends early after FR_SEQ_DT_CAP tiles that may straddle.
+#define FR_SEQ_DT_CAP 64            // dirty tiles per chunk
+#define FR_SEQ_DS_CAP 64            // dirty sub-tiles whose elements are staged per chunk (the others are read from global memory by the walk)
+#define FR_SEQ_LCHUNK 1024          // tile records per chunk
+#define FR_SEQ_SEG_CAP (FR_SEQ_LCHUNK + FR_SEQ_DT_CAP * FR_SUBS_PER_TILE)
+#define FR_SEG_TILE_RUN 0u          // low 30 bits: chunk-relative index of the run's LAST tile (its record holds the run's map)
+#define FR_SEG_SUB_RUN 1u           // index into subs[] of the run's last sub-tile
+#define FR_SEG_SUB_SEQ 2u           // index into subs[] of the sub-tile to add element by element
 struct SeqSubL { long long d0, d1; int e; uint32_t dirty; int slot; int pad; };
-struct SeqStage {
-    uint32_t n_dt, n_ds;
-    uint32_t dt_list[FR_SEQ_DT_CAP];
+struct SeqTileL { long long d0, d1; int e; uint32_t dirty; };
+struct SeqChainSh {
+    SeqTileL tl[FR_SEQ_LCHUNK];
     SeqSubL subs[FR_SEQ_DT_CAP * FR_SUBS_PER_TILE];
     double elems[FR_SEQ_DS_CAP * 64];
+    double seg_in[FR_SEQ_SEG_CAP + 1];          // exact running sum entering each segment; [nseg] = leaving the chunk
+    uint32_t segs[FR_SEQ_SEG_CAP];
+    uint32_t segoff[FR_SEQ_LCHUNK];             // segments started before this tile
+    uint32_t dt_list[FR_SEQ_DT_CAP];            // chunk-relative tile indices, ascending
+    uint32_t dt_nseg[FR_SEQ_DT_CAP];            // segments each of them starts
+    uint32_t slot_sub[FR_SEQ_DS_CAP];           // which sub-tile's elements a slot holds (index into subs[])
     uint32_t scan[8];
+    uint32_t n_ds, cut, nseg;
 };
 
-// all FR_BLOCK threads: ordered list of the first FR_SEQ_DT_CAP dirty tiles, their sub-tile records, the elements of their dirty sub-tiles
-template <class Acc>
-__device__ __forceinline__ void fr_seq_stage(const SeqWork &Q, const Acc &acc, SeqStage *sh) {
-    const unsigned n = acc.count();
-    const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
-    const unsigned per = (ntile + FR_BLOCK - 1) / FR_BLOCK;
-    const unsigned lo = threadIdx.x * per, hi = lo + per < ntile ? lo + per : ntile;
-    uint32_t cnt = 0;
-    for (unsigned t = lo; t < hi; t++) cnt += Q.tiles[t].dirty ? 1u : 0u;
-    uint32_t tot;
-    uint32_t o = fr_block_scan_u32(cnt, sh->scan, &tot) - cnt;
-    for (unsigned t = lo; t < hi && o < FR_SEQ_DT_CAP; t++) if (Q.tiles[t].dirty) sh->dt_list[o++] = t;
-    if (threadIdx.x == 0) { sh->n_dt = tot < FR_SEQ_DT_CAP ? tot : FR_SEQ_DT_CAP; sh->n_ds = 0; }
-    __syncthreads();
-    const unsigned n_dt = sh->n_dt;
-    for (unsigned i = threadIdx.x; i < n_dt * FR_SUBS_PER_TILE; i += FR_BLOCK) {
-        const unsigned t = sh->dt_list[i / FR_SUBS_PER_TILE], j = i % FR_SUBS_PER_TILE;
-        const SeqRec r = Q.subs[(size_t)t * FR_SUBS_PER_TILE + j];
-        SeqSubL l; l.d0 = r.d0; l.d1 = r.d1; l.e = r.e; l.dirty = r.dirty; l.slot = -1; l.pad = 0;
-        if (r.dirty && (size_t)t * FR_SEQ_TILE + (size_t)j * 64 < n) {
-            const uint32_t slot = atomicAdd(&sh->n_ds, 1u);
-            if (slot < FR_SEQ_DS_CAP) l.slot = (int)slot;
-        }
-        sh->subs[i] = l;
-    }
-    __syncthreads();
-    // Runs of clean sub-tiles in one binade, composed ahead of the walk: every clean sub-tile's (d0, d1) becomes the map of its run up to
-    // and including itself (one thread per staged tile, 16 compositions), so that the walking wave reads a run's map instead of scanning for it
-    if (threadIdx.x < n_dt) {
-        SeqSubL *q = &sh->subs[threadIdx.x * FR_SUBS_PER_TILE];
-        PMap run = fr_pm_id(); int run_e = 0; bool in_run = false;
-        for (int j = 0; j < FR_SUBS_PER_TILE; j++) {
-            if (q[j].dirty) { in_run = false; continue; }
-            PMap m; m.d0 = q[j].d0; m.d1 = q[j].d1;
-            if (in_run && q[j].e == run_e) run = fr_pm_compose(run, m);
-            else { run = m; run_e = q[j].e; in_run = true; }
-            q[j].d0 = run.d0; q[j].d1 = run.d1;
-        }
-    }
-    for (unsigned i = threadIdx.x; i < n_dt * FR_SUBS_PER_TILE * 64; i += FR_BLOCK) {
-        const unsigned si = i >> 6, k = i & 63;
-        const int slot = sh->subs[si].slot;         // uniform over the wave: 64 consecutive i share one sub-tile
-        if (slot < 0) continue;
-        const unsigned t = sh->dt_list[si / FR_SUBS_PER_TILE], j = si % FR_SUBS_PER_TILE;
-        const size_t e = (size_t)t * FR_SEQ_TILE + (size_t)j * 64 + k;
-        sh->elems[slot * 64 + k] = e < n ? acc.get(e) : 0.0;
-    }
-    __syncthreads();
-}
-
-#define FR_SEQ_LCHUNK 2048          // tile records staged per round
-struct SeqTileL { long long d0, d1; int e; uint32_t dirty; };
-
-// wave 0: walks tiles [c0, c1) whose records sit in tl[0, c1 - c0); *di_io = dirty tiles met so far == index into the staged list
-template <class Acc>
-__device__ __forceinline__ double fr_seq_chain_wave(SeqWork Q, Acc acc, double start, const SeqStage *sh, const SeqTileL *tl, unsigned c0, unsigned c1, unsigned *di_io, unsigned long long *t_dirty = nullptr) {
-    const unsigned n = acc.count();
-    const int lane = fr_lane();
-    double carry = start;
-    unsigned di = *di_io;
-    const unsigned n_dt = sh->n_dt;
-    for (unsigned t0 = c0; t0 < c1; t0 += 64) {
-        SeqTileL r;
-        r.dirty = 1; r.e = 0; r.d0 = r.d1 = 0;
-        if (t0 + lane < c1) r = tl[t0 - c0 + lane];
-        const int n_here = (c1 - t0) < 64u ? (int)(c1 - t0) : 64;
-        int pos = 0;
-        while (pos < n_here) {
-            const int e0 = __builtin_amdgcn_readlane(r.e, pos);
-            const unsigned dflag = (unsigned)__builtin_amdgcn_readlane((int)r.dirty, pos);
-            const unsigned t = t0 + pos;
-            if (dflag) {
-                const unsigned long long td0 = Q.dbg ? wall_clock64() : 0ull;
-                // tile t may straddle a power of two: walk its sub-tiles -- runs of clean sub-tiles in one binade are composed by
-                // a scan over lanes (as for tiles), only a sub-tile that may straddle one is added element by element
-                const bool staged = di < n_dt;          // then sh->dt_list[di] == t
-                SeqSubL sl;
-                sl.dirty = 1; sl.e = 0; sl.d0 = sl.d1 = 0; sl.slot = -1; sl.pad = 0;
-                if (lane < FR_SUBS_PER_TILE) {
-                    if (staged) sl = sh->subs[di * FR_SUBS_PER_TILE + lane];
-                    else { const SeqRec q = Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane]; sl.d0 = q.d0; sl.d1 = q.d1; sl.e = q.e; sl.dirty = q.dirty; }
-                }
-                if (lane == 0) Q.tiles[t].carry = carry;
-                const size_t t_lo = (size_t)t * FR_SEQ_TILE;
-                const int n_sub_here = (int)(((n - t_lo) + 63) / 64 < (size_t)FR_SUBS_PER_TILE ? ((n - t_lo) + 63) / 64 : (size_t)FR_SUBS_PER_TILE);
-                int jp = 0;
-                while (jp < n_sub_here) {
-                    const unsigned sd = (unsigned)__builtin_amdgcn_readlane((int)sl.dirty, jp);
-                    if (sd) {
-                        const size_t e_lo = t_lo + (size_t)jp * 64;
-                        const size_t e_hi = e_lo + 64 < n ? e_lo + 64 : n;
-                        const int slot = __builtin_amdgcn_readlane(sl.slot, jp);
-                        if (lane == 0) Q.subs[(size_t)t * FR_SUBS_PER_TILE + jp].carry = carry;
-                        double mine_a;
-                        if (slot >= 0) mine_a = sh->elems[slot * 64 + lane];
-                        else mine_a = (e_lo + lane < e_hi) ? acc.get(e_lo + lane) : 0.0;
-#pragma unroll
-                        for (int k = 0; k < 64; k++) carry = carry + fr_bcast_f64(mine_a, k);
-                        jp++;
-                        continue;
-                    }
-                    const int se = __builtin_amdgcn_readlane(sl.e, jp);
-                    const unsigned long long okm = __ballot(lane >= jp && lane < n_sub_here && !sl.dirty && sl.e == se);
-                    const unsigned long long shm = okm >> jp;
-                    const int run = (~shm == 0ull) ? 64 : (__ffsll((long long)~shm) - 1);
-                    PMap m; m.d0 = sl.d0; m.d1 = sl.d1;
-                    if (lane < jp || lane >= jp + run) m = fr_pm_id();
-                    if (!staged)                                                        // (staged tiles carry their runs' inclusive maps already: fr_seq_stage)
-                    for (int off = 1; off < FR_SUBS_PER_TILE; off <<= 1) {              // inclusive ordered scan of maps over the 16 lanes
-                        PMap o; o.d0 = __shfl_up(m.d0, off); o.d1 = __shfl_up(m.d1, off);
-                        if (lane >= off) m = fr_pm_compose(o, m);
-                    }
-                    PMap ex; ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
-                    if (lane == 0 || lane == jp) ex = fr_pm_id();
-                    if (lane >= jp && lane < jp + run) Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane].carry = fr_seq_apply_map(carry, se, ex.d0, ex.d1);
-                    const int last = jp + run - 1;
-                    carry = fr_seq_apply_map(carry, se, fr_bcast_i64(m.d0, last), fr_bcast_i64(m.d1, last));
-                    jp += run;
-                }
-                if (lane >= n_sub_here && lane < FR_SUBS_PER_TILE) Q.subs[(size_t)t * FR_SUBS_PER_TILE + lane].carry = carry;
-                di++;
-                pos++;
-                if (Q.dbg && t_dirty) *t_dirty += wall_clock64() - td0;
-                continue;
-            }
-            // run of clean tiles in binade e0 starting at lane `pos`
-            const unsigned long long ok = __ballot(lane >= pos && lane < n_here && !r.dirty && r.e == e0);
-            const unsigned long long sh_ = ok >> pos;
-            int run = (~sh_ == 0ull) ? 64 : (__ffsll((long long)~sh_) - 1);        // lanes pos .. pos+run-1 (run >= 1)
-            // (d0, d1) of a clean tile = the map of its run up to and including it (fr_seq_runs, all four waves, before the walk)
-            PMap m; m.d0 = r.d0; m.d1 = r.d1;
-            PMap ex;                                                             // exclusive map of my tile
-            ex.d0 = __shfl_up(m.d0, 1); ex.d1 = __shfl_up(m.d1, 1);
-            if (lane == 0 || lane == pos) ex = fr_pm_id();
-            if (lane >= pos && lane < pos + run) Q.tiles[t0 + lane].carry = fr_seq_apply_map(carry, e0, ex.d0, ex.d1);
-            const int last = pos + run - 1;
-            carry = fr_seq_apply_map(carry, e0, fr_bcast_i64(m.d0, last), fr_bcast_i64(m.d1, last));
-            pos += run;
-        }
-    }
-    *di_io = di;
-    return carry;
-}
-
-// Inclusive maps of the runs of clean same-binade tiles inside every batch of 64 staged tile records, in place (a run = what the walking
-// wave composes in one step: it ends at a tile that may straddle a power of two, at a change of binade and at the batch's end).  The four
-// waves take the batches in turn; segmented scan over lanes -- integer sums when no map of the batch holds an exact tie (the usual case).
+// Inclusive maps of the runs of clean same-binade tiles inside every batch of 64 staged tile records, in place (a run ends at a tile
+// that may straddle a power of two, at a change of binade and at the batch's end).  The four waves take the batches in turn; segmented
+// scan over lanes -- integer sums when no map of the batch holds an exact tie (the usual case).
 __device__ __forceinline__ void fr_seq_runs(SeqTileL *tl, unsigned n_here_total) {
     const int lane = fr_lane(), w = threadIdx.x >> 6;
     for (unsigned t0 = w * 64u; t0 < n_here_total; t0 += FR_BLOCK) {
@@ -408,40 +282,236 @@ __device__ __forceinline__ void fr_seq_runs(SeqTileL *tl, unsigned n_here_total)
         if (clean) { tl[t0 + lane].d0 = m.d0; tl[t0 + lane].d1 = m.d1; }
     }
 }
+// does clean tile t (chunk-relative) start / end a run?  (the same rule fr_seq_runs applies)
+__device__ __forceinline__ bool fr_seq_tile_head(const SeqTileL *tl, unsigned t) { return (t & 63u) == 0u || tl[t - 1].dirty || tl[t - 1].e != tl[t].e; }
+__device__ __forceinline__ bool fr_seq_tile_last(const SeqTileL *tl, unsigned t, unsigned L) { return t + 1 == L || ((t + 1) & 63u) == 0u || tl[t + 1].dirty || tl[t + 1].e != tl[t].e; }
 
-// one workgroup: everybody stages (dirty tiles once, tile records in rounds of FR_SEQ_LCHUNK), wave 0 walks
+// fr_seq_apply_map on wave-uniform operands: everything stays in scalar registers (the walk is one dependent chain; on the vector
+// unit every step of it waits out the VALU's issue latency)
+__device__ __forceinline__ unsigned long long fr_seq_apply_map_u(unsigned long long cb, int e, long long d0, long long d1) {
+    if ((long long)((cb >> 52) & 0x7ffull) == (long long)(e + 1023)) {
+        const long long Mi = (long long)((cb & 0xFFFFFFFFFFFFFull) | (1ull << 52));
+        const long long R = Mi + ((Mi & 1) ? d1 : d0);
+        if (R >= (1ll << 52) && R < (1ll << 53)) return ((unsigned long long)(e + 1023) << 52) | ((unsigned long long)R & 0xFFFFFFFFFFFFFull);
+    }
+    return (unsigned long long)__double_as_longlong(fr_seq_apply_map(__longlong_as_double((long long)cb), e, d0, d1));
+}
+__device__ __forceinline__ unsigned long long fr_uniform_u64(unsigned long long v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// sub-tiles of a tile that hold elements
+__device__ __forceinline__ int fr_seq_n_sub(unsigned n, size_t t_lo) {
+    const size_t left = ((size_t)n - t_lo + 63) / 64;
+    return (int)(left < (size_t)FR_SUBS_PER_TILE ? left : (size_t)FR_SUBS_PER_TILE);
+}
+
 template <class Acc>
 __global__ void __launch_bounds__(FR_BLOCK) k_seq_chain(SeqWork Q, Acc acc, SeqStart st) {
-    __shared__ SeqStage sh;
-    __shared__ SeqTileL tl[FR_SEQ_LCHUNK];
-    const unsigned long long tq0 = Q.dbg ? wall_clock64() : 0ull;
-    fr_seq_stage(Q, acc, &sh);
-    const unsigned long long tq1 = Q.dbg ? wall_clock64() : 0ull;
-    unsigned long long t_load = 0, t_walk = 0, t_dirty = 0;
+    __shared__ SeqChainSh sh;
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
-    double carry = st.value();
-    unsigned di = 0;
-    for (unsigned c0 = 0; c0 < ntile; c0 += FR_SEQ_LCHUNK) {
-        const unsigned c1 = c0 + FR_SEQ_LCHUNK < ntile ? c0 + FR_SEQ_LCHUNK : ntile;
-        if (c0) __syncthreads();        // wave 0 is done with the previous round's records
-        const unsigned long long ta = Q.dbg ? wall_clock64() : 0ull;
-        for (unsigned t = c0 + threadIdx.x; t < c1; t += FR_BLOCK) {
-            const SeqRec q = Q.tiles[t];
+    const int lane = fr_lane();
+    const int grp = threadIdx.x >> 4, j16 = threadIdx.x & 15;     // 16-lane groups: one tile that may straddle each, lane = sub-tile
+    constexpr unsigned PER = FR_SEQ_LCHUNK / FR_BLOCK;          // tile records per thread
+    unsigned long long carry = (unsigned long long)__double_as_longlong(st.value());          // the exact running sum, as bits (wave 0's copy is walked on)
+#ifdef FR_SEQ_TIMING
+    unsigned long long tq[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl0 = wall_clock64();
+#define FR_SEQ_T(i) do { if (Q.dbg) { const unsigned long long now_ = wall_clock64(); tq[i] += now_ - tl0; tl0 = now_; } } while (0)
+#else
+#define FR_SEQ_T(i) do { } while (0)
+#endif
+    for (unsigned c0 = 0; c0 < ntile; ) {
+        unsigned L = ntile - c0 < FR_SEQ_LCHUNK ? ntile - c0 : FR_SEQ_LCHUNK;
+        if (c0) __syncthreads();
+        // A: tile records of the chunk
+        for (unsigned t = threadIdx.x; t < L; t += FR_BLOCK) {
+            const SeqRec q = Q.tiles[c0 + t];
             SeqTileL l; l.d0 = q.d0; l.d1 = q.d1; l.e = q.e; l.dirty = q.dirty;
-            tl[t - c0] = l;
+            sh.tl[t] = l;
+        }
+        if (threadIdx.x == 0) { sh.n_ds = 0; sh.cut = L; }
+        __syncthreads();
+        FR_SEQ_T(0);
+        // B: the tiles that may straddle a power of two, in order (a listed tile's `dirty` becomes 1 + its place in the list); the chunk
+        // ends in front of the (FR_SEQ_DT_CAP + 1)-th
+        const unsigned lo = threadIdx.x * PER;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (unsigned k = 0; k < PER; k++) if (lo + k < L && sh.tl[lo + k].dirty) cnt++;
+        uint32_t tot_dt;
+        uint32_t o = fr_block_scan_u32(cnt, sh.scan, &tot_dt) - cnt;
+#pragma unroll
+        for (unsigned k = 0; k < PER; k++) if (lo + k < L && sh.tl[lo + k].dirty) { if (o < FR_SEQ_DT_CAP) { sh.dt_list[o] = lo + k; sh.tl[lo + k].dirty = 1u + o; } else if (o == FR_SEQ_DT_CAP) sh.cut = lo + k; o++; }
+        __syncthreads();
+        L = sh.cut;
+        const unsigned n_dt = tot_dt < FR_SEQ_DT_CAP ? tot_dt : FR_SEQ_DT_CAP;
+        FR_SEQ_T(1);
+        // C: their sub-tile records; a slot for the elements of every sub-tile that has to be added one by one
+        for (unsigned i = threadIdx.x; i < n_dt * FR_SUBS_PER_TILE; i += FR_BLOCK) {
+            const unsigned t = c0 + sh.dt_list[i / FR_SUBS_PER_TILE], j = i % FR_SUBS_PER_TILE;
+            const SeqRec r = Q.subs[(size_t)t * FR_SUBS_PER_TILE + j];
+            SeqSubL l; l.d0 = r.d0; l.d1 = r.d1; l.e = r.e; l.dirty = r.dirty; l.slot = -1; l.pad = 0;
+            if (r.dirty && (size_t)t * FR_SEQ_TILE + (size_t)j * 64 < n) {
+                const uint32_t slot = atomicAdd(&sh.n_ds, 1u);
+                if (slot < FR_SEQ_DS_CAP) { l.slot = (int)slot; sh.slot_sub[slot] = i; }
+            }
+            sh.subs[i] = l;
         }
         __syncthreads();
-        fr_seq_runs(tl, c1 - c0);
+        FR_SEQ_T(2);
+        // D: the staged elements; the runs' maps of the clean tiles (in place, all waves)
+        {
+            const unsigned n_st = sh.n_ds < FR_SEQ_DS_CAP ? sh.n_ds : FR_SEQ_DS_CAP;
+            for (unsigned i = threadIdx.x; i < n_st * 64; i += FR_BLOCK) {
+                const unsigned slot = i >> 6, k = i & 63, si = sh.slot_sub[slot];
+                const size_t e = (size_t)(c0 + sh.dt_list[si / FR_SUBS_PER_TILE]) * FR_SEQ_TILE + (size_t)(si % FR_SUBS_PER_TILE) * 64 + k;
+                sh.elems[slot * 64 + k] = e < n ? acc.get(e) : 0.0;
+            }
+        }
+        fr_seq_runs(sh.tl, L);
+        FR_SEQ_T(3);
+        // E: inside the tiles that may straddle (16 lanes each): the runs' maps of the clean sub-tiles, which segment of its tile every
+        // sub-tile belongs to (pad), how many segments the tile starts (pad of its sub-tile 0 ... kept in dt_nseg)
+        for (unsigned di = (unsigned)grp; di < ((n_dt + 15u) & ~15u); di += FR_BLOCK / 16) {
+            const bool have = di < n_dt;
+            const int n_sub_here = have ? fr_seq_n_sub(n, (size_t)(c0 + sh.dt_list[di]) * FR_SEQ_TILE) : 0;
+            SeqSubL q; q.d0 = q.d1 = 0; q.e = 0; q.dirty = 1; q.slot = -1; q.pad = 0;
+            const bool valid = j16 < n_sub_here;
+            if (valid) q = sh.subs[di * FR_SUBS_PER_TILE + j16];
+            const int e_prev = __shfl_up(q.e, 1, 16); const unsigned d_prev = (unsigned)__shfl_up((int)q.dirty, 1, 16);
+            const bool head = valid && (j16 == 0 || q.dirty || d_prev || q.e != e_prev);
+            PMap m; m.d0 = (valid && !q.dirty) ? q.d0 : 0; m.d1 = (valid && !q.dirty) ? q.d1 : 0;
+            int flag = head ? 1 : 0;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                PMap o2; o2.d0 = __shfl_up(m.d0, off, 16); o2.d1 = __shfl_up(m.d1, off, 16);
+                const int of = __shfl_up(flag, off, 16);
+                if (j16 >= off && !flag) { m = fr_pm_compose(o2, m); flag |= of; }
+            }
+            const unsigned hb = (unsigned)((__ballot(head) >> ((lane >> 4) << 4)) & 0xFFFFull);      // heads of my 16 lanes
+            if (valid) {
+                SeqSubL *w = &sh.subs[di * FR_SUBS_PER_TILE + j16];
+                if (!q.dirty) { w->d0 = m.d0; w->d1 = m.d1; }
+                w->pad = __popc(hb & ((2u << j16) - 1u)) - 1;
+            }
+            if (have && j16 == 0) sh.dt_nseg[di] = (uint32_t)__popc(hb);
+        }
         __syncthreads();
-        const unsigned long long tb = Q.dbg ? wall_clock64() : 0ull;
-        if (threadIdx.x < 64) carry = fr_seq_chain_wave(Q, acc, carry, &sh, tl, c0, c1, &di, &t_dirty);
-        if (Q.dbg) { t_load += tb - ta; t_walk += wall_clock64() - tb; }
-    }
+        FR_SEQ_T(4);
+        // F: segments started per tile -> offsets, and the segment list.  A clean tile starts one where its run starts; a tile that may
+        // straddle starts one per run of clean sub-tiles and per sub-tile added one by one.
+        uint32_t sc = 0;
+#pragma unroll
+        for (unsigned k = 0; k < PER; k++) {
+            const unsigned t = lo + k;
+            if (t >= L) continue;
+            const uint32_t dd = sh.tl[t].dirty;
+            sc += dd ? sh.dt_nseg[dd - 1u] : (fr_seq_tile_head(sh.tl, t) ? 1u : 0u);
+        }
+        uint32_t nseg;
+        uint32_t so = fr_block_scan_u32(sc, sh.scan, &nseg) - sc;
+#pragma unroll
+        for (unsigned k = 0; k < PER; k++) {
+            const unsigned t = lo + k;
+            if (t >= L) continue;
+            sh.segoff[t] = so;
+            const uint32_t dd = sh.tl[t].dirty;
+            if (!dd) {
+                const bool head = fr_seq_tile_head(sh.tl, t);
+                if (fr_seq_tile_last(sh.tl, t, L)) sh.segs[head ? so : so - 1] = (FR_SEG_TILE_RUN << 30) | t;
+                so += head ? 1u : 0u;
+            }
+            else so += sh.dt_nseg[dd - 1u];
+        }
+        __syncthreads();
+        for (unsigned di = (unsigned)grp; di < n_dt; di += FR_BLOCK / 16) {
+            const unsigned t = sh.dt_list[di];
+            const int n_sub_here = fr_seq_n_sub(n, (size_t)(c0 + t) * FR_SEQ_TILE);
+            if (j16 < n_sub_here) {
+                const SeqSubL *q = &sh.subs[di * FR_SUBS_PER_TILE];
+                const bool last = q[j16].dirty || j16 + 1 == n_sub_here || q[j16 + 1].pad != q[j16].pad;
+                if (last) sh.segs[sh.segoff[t] + (uint32_t)q[j16].pad] = ((q[j16].dirty ? FR_SEG_SUB_SEQ : FR_SEG_SUB_RUN) << 30) | (di * FR_SUBS_PER_TILE + (unsigned)j16);
+            }
+        }
+        __syncthreads();
+        FR_SEQ_T(5);
+        // G: the walk (wave 0): 64 segments per batch, lane k fetches segment k's record, the wave then applies them one after the other --
+        // on the scalar unit, except for the 64 floating-point additions of a sub-tile that is added one by one
+        if (threadIdx.x < 64) {
+            carry = fr_uniform_u64(carry);
+            for (unsigned s0 = 0; s0 < nseg; s0 += 64) {
+                const unsigned n_here = nseg - s0 < 64u ? nseg - s0 : 64u;
+                uint32_t kind = 3u, idx = 0; long long d0 = 0, d1 = 0; int e = 0, slot = -1;
+                if ((unsigned)lane < n_here) {
+                    const uint32_t sg = sh.segs[s0 + lane];
+                    kind = sg >> 30; idx = sg & 0x3FFFFFFFu;
+                    if (kind == FR_SEG_TILE_RUN) { const SeqTileL r = sh.tl[idx]; d0 = r.d0; d1 = r.d1; e = r.e; }
+                    else { const SeqSubL r = sh.subs[idx]; d0 = r.d0; d1 = r.d1; e = r.e; slot = r.slot; }
+                }
+                unsigned long long my_in = 0;
+                for (unsigned k = 0; k < n_here; k++) {
+                    if ((unsigned)lane == k) my_in = carry;
+                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)kind, (int)k);
+                    if (kk == FR_SEG_SUB_SEQ) {
+                        const int sl = __builtin_amdgcn_readlane(slot, (int)k);
+                        double mine_a;
+                        if (sl >= 0) mine_a = sh.elems[sl * 64 + lane];
+                        else {
+                            const uint32_t ix = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)k);
+                            const size_t e_lo = (size_t)(c0 + sh.dt_list[ix / FR_SUBS_PER_TILE]) * FR_SEQ_TILE + (size_t)(ix % FR_SUBS_PER_TILE) * 64;
+                            mine_a = e_lo + lane < n ? acc.get(e_lo + lane) : 0.0;
+                        }
+                        double cv = __longlong_as_double((long long)carry);
+#pragma unroll
+                        for (int q = 0; q < 64; q++) cv = cv + fr_bcast_f64(mine_a, q);
+                        carry = fr_uniform_u64((unsigned long long)__double_as_longlong(cv));
+                    }
+                    else {
+                        const long long a0 = fr_bcast_i64(d0, (int)k), a1 = fr_bcast_i64(d1, (int)k);
+                        if (a0 | a1) carry = fr_uniform_u64(fr_seq_apply_map_u(carry, __builtin_amdgcn_readlane(e, (int)k), a0, a1));
+                    }
+                }
+                if ((unsigned)lane < n_here) sh.seg_in[s0 + lane] = __longlong_as_double((long long)my_in);
+            }
+            if (lane == 0) sh.seg_in[nseg] = __longlong_as_double((long long)carry);
+        }
+        __syncthreads();
+        FR_SEQ_T(6);
+        // H: every tile's and sub-tile's entry carry from its segment's (all threads; the tiles that may straddle by 16 lanes each)
+#pragma unroll
+        for (unsigned k = 0; k < PER; k++) {
+            const unsigned t = lo + k;
+            if (t >= L) continue;
+            const uint32_t so_t = sh.segoff[t];
+            if (!sh.tl[t].dirty) {
+                const bool head = fr_seq_tile_head(sh.tl, t);
+                const double cin = sh.seg_in[head ? so_t : so_t - 1];
+                Q.tiles[c0 + t].carry = head ? cin : fr_seq_apply_map(cin, sh.tl[t].e, sh.tl[t - 1].d0, sh.tl[t - 1].d1);
+            }
+            else Q.tiles[c0 + t].carry = sh.seg_in[so_t];
+        }
+        for (unsigned di = (unsigned)grp; di < n_dt; di += FR_BLOCK / 16) {
+            const unsigned t = sh.dt_list[di];
+            const int n_sub_here = fr_seq_n_sub(n, (size_t)(c0 + t) * FR_SEQ_TILE);
+            const SeqSubL *q = &sh.subs[di * FR_SUBS_PER_TILE];
+            const uint32_t so_t = sh.segoff[t];
+            double cin;
+            if (j16 < n_sub_here) {
+                const SeqSubL me = q[j16];
+                cin = sh.seg_in[so_t + (uint32_t)me.pad];
+                if (!me.dirty && j16 > 0 && q[j16 - 1].pad == me.pad) cin = fr_seq_apply_map(cin, me.e, q[j16 - 1].d0, q[j16 - 1].d1);
+            }
+            else cin = sh.seg_in[so_t + sh.dt_nseg[di]];        // the sum leaving the tile
+            Q.subs[(size_t)(c0 + t) * FR_SUBS_PER_TILE + j16].carry = cin;
+        }
+        FR_SEQ_T(7);
 #ifdef FR_SEQ_TIMING
-    if (Q.dbg && threadIdx.x == 0) printf("[seq_chain] n %u tiles %u dirty tiles %u dirty subs %u: stage %llu load %llu walk %llu of which dirty tiles %llu (x10 ns)\n", n, ntile, sh.n_dt, sh.n_ds, tq1 - tq0, t_load, t_walk, t_dirty);
+        if (Q.dbg && threadIdx.x == 0) printf("[seq_chain] n %u tiles %u chunk %u+%u dirty tiles %u dirty subs %u segments %u | A %llu B %llu C %llu D %llu E %llu F %llu G %llu H %llu (x10 ns, cumulative over chunks)\n", n, ntile, c0, L, n_dt, sh.n_ds, nseg, tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[7]);
 #endif
-    if (threadIdx.x == 0) *Q.total = carry;
+        c0 += L;
+    }
+    if (threadIdx.x == 0) *Q.total = __longlong_as_double((long long)carry);
 }
 
 // ---- S5: exact running sums for the 4 consecutive elements of this thread.
