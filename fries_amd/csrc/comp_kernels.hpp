@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_walk(CompWork W, VecDev V, con
 }
 
 template <int STAGE, bool NEW_HB>
-__global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err) {
+__global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err, uint32_t *host_out) {
     __shared__ HbTables T;
     __shared__ uint32_t shu[4];
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
@@ -474,6 +474,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     }
     if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) {
         fin->n_out = (uint32_t)o;
+        if (host_out) *host_out = (uint32_t)o;          // host-coherent pinned memory: read by the host after its next wait on the stream
         if (o > W.cap) atomicOr(err, FR_ERR_SPAWN_CAP);
     }
 }

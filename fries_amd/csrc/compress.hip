@@ -192,7 +192,7 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
         }
         const void *h_cs = fr_readback(c, &B.state[r], sizeof(CompState));
         const void *h_gn = fr_readback(c, B.gnorm, 8);
-        FR_HIP(hipStreamSynchronize(st));
+        fr_stream_wait(c);
         memcpy(&hs, h_cs, sizeof(CompState)); memcpy(glob_norm, h_gn, 8);
         batch = 2;
     }

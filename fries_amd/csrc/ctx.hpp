@@ -176,6 +176,12 @@ struct FriesCtx {
     // bytes into pageable memory costs a blit kernel, a staging buffer and a host copy per call.)
     uint8_t *h_rb = nullptr, *d_rb = nullptr; size_t rb_used = 0;
     static constexpr size_t RB_BYTES = 8192, RB_HELD_BYTES = 2048;     // the ring, and one slot for a readback that is held across other readbacks (fr_dots_enqueue)
+    // behind them: MISC_BYTES that kernels write for the host -- word 0 the ticket of fr_stream_wait, words 16.. the five stages' emission counts
+    static constexpr size_t MISC_BYTES = 256;
+    uint32_t ticket = 0;                     // last ticket handed to k_ticket
+    bool wait_by_sync = false;               // FRIES_WAIT_SYNC=1: hipStreamSynchronize instead of polling the ticket word
+    volatile uint32_t *h_misc() const { return (volatile uint32_t *)(h_rb + RB_BYTES + RB_HELD_BYTES); }
+    uint32_t *d_misc() const { return (uint32_t *)(d_rb + RB_BYTES + RB_HELD_BYTES); }
     uint32_t prop_tag = 0;                   // last tag handed to a comb-repair round (k_sys_walk)
     int fks_rec_at = -1;                     // FRIES_FKS_REC_AT=k: the replay that records the tiles' margins (default: rounds hint - 2)
     bool fks_group_warm_all = true;          // FRIES_GROUP_WARM_ALL=0: only stage 1 starts its first replay from the previous iteration's per-group prefixes
@@ -184,6 +190,7 @@ struct FriesCtx {
     bool fks_no_ext = false;                 // FRIES_FKS_NO_EXT=1: a wave re-decides whenever the stage runs another number of sweeps than it last ran
     bool fks_no_group_warm = false;          // FRIES_NO_GROUP_WARM=1
     bool fks_no_light = false;               // FRIES_FKS_NO_LIGHT=1: every replay evaluates every tile (tests, comparisons)
+    bool fks_no_closing = false;             // FRIES_FKS_NO_CLOSING=1: a confirming replay and a final pass of its own instead of the closing pass (k_fks_sweep MODE 4)
     bool fks_no_collapse_walk = false;       // FRIES_FKS_COLLAPSE_WALK=0: keep the parallel replay's result in collapsing stages (fast, not bit-identical to the reference there)
     bool fks_force_seq = false;              // FRIES_FKS_SEQ=1: every stage through the in-order walk (tests)
     uint64_t n_fks_sequential = 0;
@@ -284,6 +291,11 @@ void fr_dense_h_setup(FriesCtx *c);      // system.hip
 // enqueue a copy of `bytes` (a multiple of 4, <= 2 KB) at device address src into the readback block; -> host address to read AFTER the next
 // synchronisation of the stream.  The block is a ring: a slot stays valid until ~RB_BYTES more have been asked for.  (vec.hip)
 const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held = false);
+// Waits until everything enqueued on the context's stream so far has run: a one-thread kernel stores a ticket into host-coherent pinned
+// memory and the host polls that word.  (hipStreamSynchronize returns ~20 us after the stream has drained; the iteration has about a
+// dozen such waits, during each of which the GPU idles.)
+void fr_stream_wait(FriesCtx *c);
+void fr_rb_init(FriesCtx *c);
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);
 void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac);

@@ -478,6 +478,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     if (getenv("FRIES_FKS_LIGHT_FULL_GRID")) h->c.fks_light_full_grid = atoi(getenv("FRIES_FKS_LIGHT_FULL_GRID")) != 0;
     if (getenv("FRIES_FKS_FUSE_TOTALS")) h->c.fks_fuse_totals = atoi(getenv("FRIES_FKS_FUSE_TOTALS")) != 0;
     if (getenv("FRIES_FKS_NO_LIGHT")) h->c.fks_no_light = atoi(getenv("FRIES_FKS_NO_LIGHT")) != 0;
+    if (getenv("FRIES_FKS_NO_CLOSING")) h->c.fks_no_closing = atoi(getenv("FRIES_FKS_NO_CLOSING")) != 0;
     if (getenv("FRIES_FKS_COLLAPSE_WALK")) h->c.fks_no_collapse_walk = atoi(getenv("FRIES_FKS_COLLAPSE_WALK")) == 0;
     if (getenv("FRIES_FKS_SEQ")) h->c.fks_force_seq = atoi(getenv("FRIES_FKS_SEQ")) != 0;
     if (getenv("FRIES_NO_WARM")) h->c.warm_start = false;

@@ -248,6 +248,10 @@ __device__ __forceinline__ void fr_fks2_row(const HbTables &T, det_t det, uint32
 //         (a template instantiation of its own: the test costs registers the recording replay does not have).  light == 2: no allowance
 //         for a changed number of sweeps.
 // MODE 2: final pass -- wt_remain with the budget of the last sweep that flagged the element.
+// MODE 4: a light replay and the final pass in one launch ("closing pass"): the waves whose inputs moved beyond their margins decide again
+//         (MODE 3), every tile then gets its final wt_remain (MODE 2).  If no delta changed -- hist[it] stays 0 -- the stage has settled and
+//         the final values stand: the confirming replay (sweep + scan + totals, which only establishes that nothing changes) is not launched
+//         at all.  If one did change, the host scans, adds up and launches the closing pass again; what this one wrote is overwritten.
 #define FR_FKS_TILE_MAXK 8192u      // a tile of FR_BLOCK elements preserves at most 32 sub-weights per element
 #define FR_FKS_GRP_MAXK 256u        // a group of 8 elements likewise
 
@@ -274,7 +278,7 @@ __device__ __forceinline__ void fr_fks_save(Fks2Work F) {
 
 template <int STAGE, bool NEW_HB, int MODE>
 __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
-    constexpr bool M1 = MODE == 1 || MODE == 3, LIGHT = MODE == 3;       // comparing replays; MODE 3 also skips the waves that stand
+    constexpr bool M1 = MODE == 1 || MODE == 3 || MODE == 4, LIGHT = MODE == 3 || MODE == 4, FIN = MODE == 2 || MODE == 4;       // comparing replays; MODE 3 / 4 skip the waves that stand; MODE 2 / 4 end with the final wt_remain
     __shared__ HbTables T;
     __shared__ FksScal S;
     // MODE 1: the deltas my wave's 8 groups stored for sweeps 0 .. FR_FKS_PF-1, fetched in one go when the tile starts (compared with the new
@@ -426,9 +430,9 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
             if (d) { any = 1; if (k < 32) decide |= 1u << k; }
             if (dbg == 3 && it < FR_MAX_ROUNDS && lane == 0 && (size_t)tile * FR_BLOCK + threadIdx.x < (size_t)nb8 * 8) { atomicAdd(&F.dbg_cnt[it * 4 + 3], 1u); if (d) atomicAdd(&F.dbg_cnt[it * 4 + 2], 1u); }
         }
-        if (!__syncthreads_or(any)) return;
+        if (MODE == 3 && !__syncthreads_or(any)) return;
     }
-    if (MODE == 2 && blockIdx.x == gridDim.x - 1) fr_fks_save(F);       // (reads the settled chunk totals and scalars; nobody writes them in this launch)
+    if (FIN && blockIdx.x == gridDim.x - 1) fr_fks_save(F);       // (reads the settled chunk totals and scalars; nobody writes them in this launch)
     if (STAGE != 1) fr_stage_tables(&T, Tg);
 
     unsigned tile_k = 0;
@@ -439,9 +443,10 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         const bool live = e < n_in;
         const unsigned my_chunk = tile / FR_FKS_TILES_PER_CHUNK;                 // uniform over the workgroup
         const size_t my_wave = e >> 6;
+        bool decide_this = MODE != 2;                   // (wave-uniform)
         if (LIGHT) {
             const bool d = tile_k < 32 ? ((decide >> tile_k) & 1u) != 0 : !wave_stands(tile);
-            if (!d) continue;                           // nothing to decide in this wave
+            if (!d) { if (MODE == 3) continue; decide_this = false; }      // nothing to decide in this wave
         }
         const bool lv = live, ig = in_grp;
         const double chunk_frac = (double)(b - (size_t)my_chunk * FR_FKS_CHUNK) * (1.0 / FR_FKS_CHUNK);
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         };
         // the deltas my wave stored before (lane = 8 x sweep + group)
         const int wslot = threadIdx.x >> 6;
-        if (M1) {
+        if (M1 && decide_this) {
             const int ps = lane >> 3;
             const size_t bj = (my_wave << 3) + (size_t)f;
             uint32_t ok_ = 0u; double og = 0.0, ow = 0.0;
@@ -489,11 +494,11 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         double v = lv ? E.val[e] : 0.0;
         uint32_t nd = lv ? E.ndiv[e] : 1u;
         double wr = v;
-        uint32_t kp = (MODE == 2 && lv) ? W.keep[e] : 0u;
+        uint32_t kp = (FIN && !decide_this && lv) ? W.keep[e] : 0u;
         det_t det = 0; uint32_t code = 0; RowInfo ri = fr_row1(W.row1);
-        if (LIGHT) { if (STAGE != 1 && lv) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); } }       // few waves, alone on their CU: one round of loads instead of two
+        if (MODE == 3) { if (STAGE != 1 && lv) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); } }       // few waves, alone on their CU: one round of loads instead of two
         else if (STAGE != 1 && lv && nd == 0 && v > 0) { code = E.code[e]; det = E.det[e]; ri = fr_row_cached(E, e); }
-        if (MODE == 2) {
+        auto final_part = [&]() {
             double lastwf = 0;
             Pfx nx;
             if (n_pass > 0) prefix_issue(0, &nx);
@@ -520,8 +525,8 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
                 }
                 W.wt_remain[e] = out;
             }
-            continue;
-        }
+        };
+        if (!decide_this) { if (FIN) final_part(); continue; }
         bool out_changed = false;
         float wmax = -1.0f;         // upper bound of the largest unpreserved normalised weight; < 0: row not looked at yet
         // (in this loop the sums are formed at once: measured faster than deferring them -- 62 vs 69 us -- while the final loop
@@ -678,7 +683,8 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
                 if (ig) F.wNp[my_wave] = (uint32_t)n_pass;
             }
         }
-        if (lv) { W.keep[e] = kp; W.wt_remain[e] = wr; }
+        if (lv) { W.keep[e] = kp; if (!FIN) W.wt_remain[e] = wr; }
+        if (FIN) final_part();          // MODE 4: with the keep bits just decided
     }
 }
 
@@ -813,6 +819,15 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint
         return;
     }
     fr_fks_totals(F, err, msg, inline_passes, it, &sm);
+}
+
+// after the closing pass (k_fks_sweep MODE 4): did any rank change a delta?  The host reads hm->hist[it].
+static __global__ void k_fks_close_put(Fks2Work F, uint32_t *send, int it) { send[0] = F.hist[it]; send[1] = 0u; send[2] = 0u; send[3] = 0u; }
+static __global__ void k_fks_close_flag(Fks2Work F, const uint32_t *all, int n_ranks, int it) {
+    uint32_t ch = F.hist[it];
+    for (int r = 0; r < n_ranks; r++) ch |= all[4 * r];
+    F.hist[it] = ch;
+    if (it < FR_MAX_ROUNDS) F.hm->hist[it] = ch;
 }
 
 // tie statistics (optional): the smallest relative margin any comparison of the settled stage has (the tiles' records of their last evaluation)

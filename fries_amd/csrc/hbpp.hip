@@ -408,7 +408,7 @@ static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) 
 }
 
 template <int STAGE, bool NEW_HB>
-static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, double rn, uint32_t *n_out_host, bool hh_stage2 = false) {
+static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, double rn, int out_slot, bool hh_stage2 = false) {
     CompWork &W = c->W;
     hipStream_t st = c->stream;
     unsigned grid = fr_blocks(n_bound, FR_TILE);
@@ -442,33 +442,70 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     int it = 0, batch = c->rounds_hint[STAGE], needed = 0;
     FksScal hscal{};
     bool sequential = c->fks_force_seq;
+    bool closed = false;        // the closing pass has settled the stage and written the final wt_remain
+    // replay 0 evaluates every tile; later replays only the tiles whose inputs moved by more than their tightest comparison allows
+    // The replay needs about as many rounds as the reference runs sweeps (a sweep's start state is only right once the sweep
+    // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
+    // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
+    const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
+    auto scan_totals = [&](int k) {
+        FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, k, k >= rec_at ? 1 : 0, c->fks_fuse_totals ? 1 : 0, c->d_err, msg, xr ? 0 : 1);
+        if (!c->fks_fuse_totals) FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, k);
+        if (xr) {
+            const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
+            FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, k, c->d_err, 0);
+        }
+    };
+    auto replay = [&](int k) {
+        const int light = (k > rec_at && !c->fks_no_light && !c->d_tie) ? (c->fks_no_ext ? 2 : 1) : 0;       // (tie statistics: every wave decides in every replay, so that the records are those of the settled state)       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
+        if (k < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, 0, c->dbg);
+        else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridL), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, light, c->dbg);
+        else FR_LAUNCH(c, "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, 0, c->dbg);
+        scan_totals(k);
+    };
+    auto read_host = [&]() {
+        const volatile FksHost *hm = c->h_fks;
+        hscal.overflow = hm->overflow; hscal.G_last = hm->G_last; hscal.psG[0] = hm->psG0; hscal.G_neg = hm->G_neg; hscal.n_pass = hm->n_pass;
+        if (hscal.overflow) sequential = true;
+    };
+    // The closing pass (k_fks_sweep MODE 4): the light replay that is expected to change nothing and the final pass in one launch.  When it
+    // changes no delta the stage has settled and its output stands -- the confirming sweep + scan + totals are never launched.
+    const bool closing = !c->fks_no_light && !c->d_tie && !c->fks_no_closing && !c->fks_fuse_totals && rec_at == 1 && !sequential;
+    if (closing) {
+        int plain = batch < 2 ? 2 : batch;       // replays before the closing pass (replay 1 writes the records the light test needs)
+        while (!closed && !sequential) {
+            if (plain > 47) { sequential = true; break; }       // does not settle (e.g. the reference's own 0/0 corner): walk the stage in order instead
+            for (; it < plain; it++) replay(it);
+            FR_LAUNCH(c, "k_fks_close", (k_fks_sweep<STAGE, NEW_HB, 4>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, c->fks_no_ext ? 2 : 1, c->dbg);
+            if (xr) {       // every rank must see whether ANY rank changed a delta
+                FR_LAUNCH(c, "k_fks_close_put", k_fks_close_put, dim3(1), dim3(1), F, (uint32_t *)c->comm.small_send, it);
+                const uint32_t *all = (const uint32_t *)fr_allgather(c, 16);
+                FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, all, P, it);
+            }
+            else FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, (const uint32_t *)nullptr, 0, it);
+            fr_stream_wait(c);
+            read_host();
+            if (sequential) break;
+            const volatile FksHost *hm = c->h_fks;
+            if (hm->hist[it] == 0) {
+                closed = true;
+                needed = it;
+                for (int j = 2; j < it; j++) if (hm->hist[j] == 0) { needed = j; break; }      // a plain replay already reproduced its predecessor: the closing pass could have come there
+            }
+            else { scan_totals(it); it++; plain = it; }       // it was a replay like any other: scan, add up, close again
+        }
+        if (closed) c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
+    }
+    else
     while (!needed && !sequential) {
         if (it + batch > FR_MAX_ROUNDS) batch = FR_MAX_ROUNDS - it;
         if (batch <= 0 || it >= 48) { sequential = true; break; }       // the replay does not settle (e.g. the reference's own 0/0 corner): walk the stage in order instead
-        for (int k = 0; k < batch; k++) {
-            // replay 0 evaluates every tile; later replays only the tiles whose inputs moved by more than their tightest comparison allows
-            // The replay needs about as many rounds as the reference runs sweeps (a sweep's start state is only right once the sweep
-            // before it is): the early ones run lean (no margins, counted as changed), the round before the expected end records the
-            // tiles' margins, and from then on only tiles whose inputs moved beyond their margin are evaluated.
-            const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
-            const int light = (it > rec_at && !c->fks_no_light && !c->d_tie) ? (c->fks_no_ext ? 2 : 1) : 0;       // (tie statistics: every wave decides in every replay, so that the records are those of the settled state)       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
-            if (it < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
-            else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridL), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, light, c->dbg);
-            else FR_LAUNCH(c, "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, c->dbg);
-            FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, it, it >= rec_at ? 1 : 0, c->fks_fuse_totals ? 1 : 0, c->d_err, msg, xr ? 0 : 1);
-            if (!c->fks_fuse_totals) FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, it);
-            if (xr) {
-                const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
-                FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, it, c->d_err, 0);
-            }
-            it++;
-        }
-        FR_HIP(hipStreamSynchronize(st));       // the kernels wrote the flags and the stage's closing scalars into c->h_fks themselves
+        for (int k = 0; k < batch; k++) { replay(it); it++; }
+        fr_stream_wait(c);       // the kernels wrote the flags and the stage's closing scalars into c->h_fks themselves
         const volatile FksHost *hm = c->h_fks;
         for (int j = 1; j < it && !needed; j++) if (hm->hist[j] == 0) needed = j + 1;      // replay 0 always counts as changed
         batch = 1;
-        hscal.overflow = hm->overflow; hscal.G_last = hm->G_last; hscal.psG[0] = hm->psG0; hscal.G_neg = hm->G_neg; hscal.n_pass = hm->n_pass;
-        if (hscal.overflow) sequential = true;
+        read_host();
     }
     // A stage that removes (almost) all of its norm: the reference's running norm is then its own rounding noise, which only the
     // in-order walk reproduces (fks_seq.hpp).  psG[0] / G_last are sums over the ranks, so every rank decides alike.
@@ -478,7 +515,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         if (hscal.overflow) FR_LAUNCH(c, "k_err_clear", k_err_clear, dim3(1), dim3(1), c->d_err, (uint32_t)FR_ERR_ROUNDS);     // FR_ERR_ROUNDS of the abandoned replay only: d_err also carries the flags of earlier stages and iterations of the batch
         run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
     }
-    else c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
+    else if (!closing) c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
     c->fks_iters[STAGE] = it;
     if (c->dbg == 3) {
         FksScal hs; uint32_t hh[FR_MAX_ROUNDS + 2];
@@ -494,7 +531,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         fprintf(stderr, "\n");
         FR_HIP(hipMemset(F.dbg_cnt, 0, dc.size() * 4));
     }
-    if (!sequential) {
+    if (!sequential && !closed) {
         if (c->d_tie) FR_LAUNCH(c, "k_fks_tie", k_fks_tie, dim3(64), dim3(FR_BLOCK), F, c->d_tie);
         // settled: recompute every wt_remain with the budget of its last flagged sweep
         FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB, 2>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, 0);
@@ -546,10 +583,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         }
     }
     else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
-    FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
-    if (n_out_host) {
-        FR_HIP(hipMemcpyAsync(n_out_host, &W.state[FR_MAX_ROUNDS + 1].n_out, 4, hipMemcpyDeviceToHost, st));
-    }
+    // the stage's emission count also goes to the host block (word 16 + slot): a copy into pageable memory would hold the host until it is done
+    fr_rb_init(c);
+    FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err, out_slot >= 0 ? c->d_misc() + 16 + out_slot : nullptr);
     if (c->dbg == 5) {
         CompState fs; FksScal hs;
         FR_HIP(hipMemcpy(&fs, &W.state[FR_MAX_ROUNDS + 1], sizeof(fs), hipMemcpyDeviceToHost));
@@ -570,19 +606,20 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     const uint32_t bound_max = bound;
     auto next_bound = [&](int k) {
         if (!c->use_comm) return bound_max;
-        FR_HIP(hipStreamSynchronize(st));
+        fr_stream_wait(c);
+        c->comp_len[k] = c->h_misc()[16 + k];
         uint32_t b = c->comp_len[k] + 64;
         return b < bound_max ? b : bound_max;
     };
-    run_stage<1, NEW_HB>(c, 0, bound1, n_samp, rn[0], &c->comp_len[0]);
+    run_stage<1, NEW_HB>(c, 0, bound1, n_samp, rn[0], 0);
     bound = next_bound(0);
-    run_stage<2, NEW_HB>(c, 1, bound, n_samp, rn[1], &c->comp_len[1]);
+    run_stage<2, NEW_HB>(c, 1, bound, n_samp, rn[1], 1);
     bound = next_bound(1);
-    run_stage<3, NEW_HB>(c, 0, bound, n_samp, rn[2], &c->comp_len[2]);
+    run_stage<3, NEW_HB>(c, 0, bound, n_samp, rn[2], 2);
     bound = next_bound(2);
-    run_stage<4, NEW_HB>(c, 1, bound, n_samp, rn[3], &c->comp_len[3]);
+    run_stage<4, NEW_HB>(c, 1, bound, n_samp, rn[3], 3);
     bound = next_bound(3);
-    run_stage<5, NEW_HB>(c, 0, bound, n_samp, rn[4], &c->comp_len[4]);
+    run_stage<5, NEW_HB>(c, 0, bound, n_samp, rn[4], 4);
     bound = next_bound(4);
     unsigned grid = fr_blocks(bound, FR_TILE);
     SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
@@ -592,8 +629,9 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     FR_LAUNCH(c, "k_final_compact", k_final_compact, dim3(grid), dim3(FR_BLOCK), W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
     {
         const void *h_ns = fr_readback(c, c->d_nsucc, 4);
-        FR_HIP(hipStreamSynchronize(st));
+        fr_stream_wait(c);
         memcpy(&c->num_success, h_ns, 4);
+        for (int k = 0; k < 5; k++) c->comp_len[k] = c->h_misc()[16 + k];
     }
 }
 
@@ -612,10 +650,11 @@ void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]) {
     uint32_t bound1 = c->h_vst.curr_size;
     uint32_t bound = n_samp + 64 < W.cap ? n_samp + 64 : W.cap;
     if (bound1 > W.cap) throw FriesError("vector larger than the compression work capacity");
-    run_stage<1, true>(c, 0, bound1, n_samp, rn[0], &c->comp_len[0]);
-    if (c->use_comm) { FR_HIP(hipStreamSynchronize(c->stream)); uint32_t b = c->comp_len[0] + 64; if (b < bound) bound = b; }
-    run_stage<2, true>(c, 1, bound, n_samp, rn[1], &c->comp_len[1], true);
-    FR_HIP(hipStreamSynchronize(c->stream));
+    run_stage<1, true>(c, 0, bound1, n_samp, rn[0], 0);
+    if (c->use_comm) { fr_stream_wait(c); c->comp_len[0] = c->h_misc()[16]; uint32_t b = c->comp_len[0] + 64; if (b < bound) bound = b; }
+    run_stage<2, true>(c, 1, bound, n_samp, rn[1], 1, true);
+    fr_stream_wait(c);
+    c->comp_len[0] = c->h_misc()[16]; c->comp_len[1] = c->h_misc()[17];
     c->num_success = c->comp_len[1];
 }
 

@@ -9,6 +9,7 @@
 // atomicMin on the new hash slot plus a prefix sum, and accumulation runs over a stable
 // radix sort of (position, pass) keys so each position sums its contributions sequentially.
 #include "ctx.hpp"
+#include <chrono>
 #include <cstring>
 
 // ------------------------------------------------------------------ allocation / state
@@ -36,13 +37,35 @@ void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
 static __global__ void __launch_bounds__(64) k_readback(const uint32_t *src, uint32_t *dst, unsigned n_words) {
     for (unsigned i = threadIdx.x; i < n_words; i += 64) dst[i] = src[i];
 }
-const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
-    if (!c->h_rb) {
-        void *hp = nullptr, *dp = nullptr;
-        FR_HIP(hipHostMalloc(&hp, FriesCtx::RB_BYTES + FriesCtx::RB_HELD_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
-        FR_HIP(hipHostGetDevicePointer(&dp, hp, 0));
-        c->h_rb = (uint8_t *)hp; c->d_rb = (uint8_t *)dp; c->rb_used = 0;
+void fr_rb_init(FriesCtx *c) {
+    if (c->h_rb) return;
+    void *hp = nullptr, *dp = nullptr;
+    const size_t tot = FriesCtx::RB_BYTES + FriesCtx::RB_HELD_BYTES + FriesCtx::MISC_BYTES;
+    FR_HIP(hipHostMalloc(&hp, tot, hipHostMallocMapped | hipHostMallocCoherent));
+    FR_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    memset(hp, 0, tot);
+    c->h_rb = (uint8_t *)hp; c->d_rb = (uint8_t *)dp; c->rb_used = 0;
+    c->wait_by_sync = getenv("FRIES_WAIT_SYNC") && atoi(getenv("FRIES_WAIT_SYNC")) != 0;
+}
+static __global__ void k_ticket(uint32_t *word, uint32_t ticket) { __hip_atomic_store(word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+void fr_stream_wait(FriesCtx *c) {
+    fr_rb_init(c);
+    if (c->wait_by_sync) { FR_HIP(hipStreamSynchronize(c->stream)); return; }
+    const uint32_t t = ++c->ticket;
+    FR_LAUNCH(c, "k_ticket", k_ticket, dim3(1), dim3(1), c->d_misc(), t);
+    volatile uint32_t *w = c->h_misc();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0; __atomic_load_n((const uint32_t *)w, __ATOMIC_ACQUIRE) != t; spin++) {
+        __builtin_ia32_pause();
+        if ((spin & 0xFFFFF) == 0xFFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {      // a long kernel, or a fault: let the runtime say which
+            FR_HIP(hipStreamSynchronize(c->stream));
+            if (__atomic_load_n((const uint32_t *)w, __ATOMIC_ACQUIRE) != t) throw FriesError("fr_stream_wait: the stream drained without the ticket kernel having run");
+            break;
+        }
     }
+}
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
+    fr_rb_init(c);
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (bytes == 0 || (bytes & 3) || need > 2048) throw FriesError("fr_readback: bad size");
     size_t off;
@@ -58,7 +81,7 @@ const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
 
 void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out) {
     const void *hp = fr_readback(c, v->st, sizeof(VecState));
-    FR_HIP(hipStreamSynchronize(c->stream));
+    fr_stream_wait(c);
     memcpy(out, hp, sizeof(VecState));
     v->used_ub = out->n_used;
 }
