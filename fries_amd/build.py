@@ -58,8 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 DRIVER = os.path.join(HERE, "frisys_mol_hip")
-FACADE_TEST = os.path.join(HERE, "..", "tests", "cpp", "test_facade")
-REF_API_DRIVER = os.path.join(HERE, "frisys_mol_ref_api")
+REF_API_DRIVER = os.path.join(HERE, "..", "tests", "cpp", "frisys_mol_ref_api")        # a TEST consumer of include/FRIES (tests/cpp/frisys_mol_ref_api.cpp), not part of the product
 FIXED_CLOCK = os.path.join(HERE, "..", "tests", "cpp", "libfixed_clock.so")
 DRIVERS = {name: os.path.join(HERE, name) for name in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip", "frifull_mol_hip", "frimulti_mol_hip")}
 
@@ -75,21 +74,13 @@ def build_drivers(force: bool = False) -> str:
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"g++ failed on {name}.cpp:\n{r.stdout}\n{r.stderr}")
-    # host-side facade test (include/fries_facade.hpp), run by tests/test_gpu_parity.py on the GPU box
-    src = os.path.join(HERE, "..", "tests", "cpp", "test_facade.cpp")
-    if force or _stale(FACADE_TEST, [src, LIB, os.path.join(HERE, "..", "include", "fries_facade.hpp")] + hdrs):
-        cmd = ["g++", "-std=c++17", "-O2", "-o", FACADE_TEST, src, "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN/../../fries_amd", "-Wl,-rpath,/opt/rocm/lib",
-               "-Wl,-rpath-link,/opt/rocm/lib"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"g++ failed on test_facade.cpp:\n{r.stdout}\n{r.stderr}")
-    # the same program written against the reference's own classes as this build ships them (include/FRIES/*.hpp)
+    # a test program written against the reference's own classes as this build ships them (include/FRIES/*.hpp)
     inc = os.path.join(HERE, "..", "include")
     fac_hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(inc, "FRIES")) for f in fs]
-    src = os.path.join(HERE, "drivers", "frisys_mol_ref_api.cpp")
+    src = os.path.join(HERE, "..", "tests", "cpp", "frisys_mol_ref_api.cpp")
     if force or _stale(REF_API_DRIVER, [src, LIB] + hdrs + fac_hdrs):
         cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + inc, "-I" + os.path.join(inc, "FRIES", "compat"), "-o", REF_API_DRIVER, src,
-               "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+               "-L" + HERE, "-lfries_hip", "-Wl,-rpath,$ORIGIN/../../fries_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"g++ failed on frisys_mol_ref_api.cpp:\n{r.stdout}\n{r.stderr}")

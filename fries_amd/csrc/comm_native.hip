@@ -28,6 +28,9 @@ struct fries_transport {
     // local
     struct fries_local_group *grp = nullptr;
     std::vector<uint64_t> send_off;         // byte offset of every destination's segment in my big_send (this collective)
+    // host collectives (an MPI program's own MPI_Allgather / MPI_Alltoallv on host memory)
+    fries_host_collectives host{};
+    uint8_t *h_small = nullptr, *h_small_all = nullptr, *h_big_send = nullptr, *h_big_recv = nullptr;       // pinned
 };
 
 struct fries_local_group {
@@ -170,14 +173,55 @@ extern "C" int fries_local_create(fries_transport **out, fries_local_group *g, i
     } catch (const std::exception &e) { fr_set_error(e.what()); return 1; }
 }
 
+// ------------------------------------------------------------------ host collectives (kind 3)
+// The staging blocks cross to pinned host memory, the caller's collective runs there (MPI on host buffers: no GPU-aware MPI needed),
+// the result goes back: stream-ordered on both sides, two host synchronisations per collective.  This is what lets an MPI program
+// written against include/FRIES run the engine on one GPU per rank with nothing but its own MPI_COMM_WORLD.
+static int host_allgather(void *user, uint64_t bytes, void *stream) {
+    fries_transport *t = (fries_transport *)user;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(t->h_small, t->small_send, (size_t)bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { fr_set_error("host transport: staging copy failed"); return 1; }
+    if (t->host.allgather(t->host.user, t->h_small, t->h_small_all, bytes)) { fr_set_error("host transport: the caller's all-gather failed"); return 1; }
+    if (hipMemcpyAsync(t->small_recv, t->h_small_all, (size_t)bytes * t->size, hipMemcpyHostToDevice, st) != hipSuccess) { fr_set_error("host transport: staging copy failed"); return 1; }
+    t->n_allgather++;
+    return 0;
+}
+static int host_alltoallv(void *user, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *stream) {
+    fries_transport *t = (fries_transport *)user;
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t so = 0, ro = 0;
+    for (int p = 0; p < t->size; p++) { so += send_bytes[p]; ro += recv_bytes[p]; }
+    if (so > t->big_bytes || ro > t->big_bytes) { fr_set_error("all-to-all segments exceed the staging buffers"); return 1; }
+    if ((so && hipMemcpyAsync(t->h_big_send, t->big_send, (size_t)so, hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess) { fr_set_error("host transport: staging copy failed"); return 1; }
+    if (t->host.alltoallv(t->host.user, t->h_big_send, send_bytes, t->h_big_recv, recv_bytes)) { fr_set_error("host transport: the caller's all-to-all failed"); return 1; }
+    if (ro && hipMemcpyAsync(t->big_recv, t->h_big_recv, (size_t)ro, hipMemcpyHostToDevice, st) != hipSuccess) { fr_set_error("host transport: staging copy failed"); return 1; }
+    t->n_alltoallv++;
+    return 0;
+}
+extern "C" int fries_hostcomm_create(fries_transport **out, const fries_host_collectives *cb, int rank, int size, int device, uint64_t big_bytes) {
+    try {
+        if (!cb || !cb->allgather || !cb->alltoallv) throw FriesError("both host collectives are required");
+        if (size < 1 || rank < 0 || rank >= size || size > FRIES_COMM_MAX_RANKS) throw FriesError("bad rank / size");
+        fries_transport *t = new fries_transport();
+        t->kind = 3; t->rank = rank; t->size = size; t->device = device; t->big_bytes = big_bytes; t->host = *cb;
+        tr_alloc(t);
+        FR_HIP(hipHostMalloc((void **)&t->h_small, FRIES_COMM_SMALL_BYTES, hipHostMallocDefault));
+        FR_HIP(hipHostMalloc((void **)&t->h_small_all, (size_t)FRIES_COMM_SMALL_BYTES * size, hipHostMallocDefault));
+        FR_HIP(hipHostMalloc((void **)&t->h_big_send, big_bytes, hipHostMallocDefault));
+        FR_HIP(hipHostMalloc((void **)&t->h_big_recv, big_bytes, hipHostMallocDefault));
+        *out = t;
+        return 0;
+    } catch (const std::exception &e) { fr_set_error(e.what()); return 1; }
+}
+
 // ------------------------------------------------------------------ common
 extern "C" int fries_transport_comm(fries_transport *t, fries_comm *cm) {
     if (!t || !cm) { fr_set_error("null transport"); return 1; }
     cm->user = t; cm->rank = t->rank; cm->size = t->size;
     cm->small_send = t->small_send; cm->small_recv = t->small_recv; cm->big_send = t->big_send; cm->big_recv = t->big_recv;
     cm->big_bytes = t->big_bytes;
-    cm->allgather = t->kind == 1 ? rccl_allgather : local_allgather;
-    cm->alltoallv = t->kind == 1 ? rccl_alltoallv : local_alltoallv;
+    cm->allgather = t->kind == 1 ? rccl_allgather : (t->kind == 3 ? host_allgather : local_allgather);
+    cm->alltoallv = t->kind == 1 ? rccl_alltoallv : (t->kind == 3 ? host_alltoallv : local_alltoallv);
     return 0;
 }
 extern "C" int fries_transport_counts(fries_transport *t, uint64_t *n_allgather, uint64_t *n_alltoallv) {
@@ -191,5 +235,6 @@ extern "C" void fries_transport_destroy(fries_transport *t) {
     hipSetDevice(t->device);
     if (t->nccl) ncclCommDestroy(t->nccl);
     hipFree(t->small_send); hipFree(t->small_recv); hipFree(t->big_send); hipFree(t->big_recv);
+    if (t->h_small) { hipHostFree(t->h_small); hipHostFree(t->h_small_all); hipHostFree(t->h_big_send); hipHostFree(t->h_big_recv); }
     delete t;
 }

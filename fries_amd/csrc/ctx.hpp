@@ -224,6 +224,7 @@ struct FriesCtx {
     std::mt19937 mt;
     std::vector<uint32_t> proc_scr, vec_scr;
     std::vector<uint32_t> in_proc_scr;       // --load_dir: the proc scrambler of hash.dat instead of fresh draws (fries_set_proc_scrambler)
+    std::vector<uint32_t> in_vec_scr;        // fries_set_vec_scrambler: the vector hash's scrambler (frisys_hh keys its table on it)
     double eps = 0, target_norm = 0, init_thresh = 0, en_shift = 0, last_one_norm = 0;
     uint32_t vec_nonz = 0, mat_nonz = 0;
     bool new_hb = true;
@@ -285,6 +286,8 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p);
 void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg);
 void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]);
 void fr_hh_clear_pos0(FriesCtx *c);
+void fr_hh_stage(FriesCtx *c, int stage, uint32_t n_samp, double rn);
+void fr_hh_ref_ovlp(FriesCtx *c, double out[3]);
 int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 // system.hip
 void fr_dense_h_setup(FriesCtx *c);      // system.hip

@@ -918,7 +918,6 @@ extern "C" int fries_vec_add_to(fries_ctx *h, int column, const uint64_t *dets, 
     FR_HIP(hipSetDevice(c->device));
     if (column != 0 && column != 1) throw FriesError("column must be 0 or 1");
     if (n > c->sp.cap) throw FriesError("Too many elements added to Adder - must call perform_add() more frequently.");
-    if (c->use_comm) throw FriesError("fries_vec_add_to is a one-rank entry point; with ranks, adds travel inside fries_frisys_iterate");
     std::vector<det_t> d; std::vector<double> v; std::vector<uint8_t> f;
     for (size_t i = 0; i < n; i++) if (vals[i] != 0) { d.push_back(dets[i]); v.push_back(vals[i]); f.push_back(ini[i]); }
     uint32_t m = (uint32_t)d.size();
@@ -984,9 +983,48 @@ extern "C" int fries_sys_comp(fries_ctx *h, uint32_t n_samp, double rn) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;
     FR_HIP(hipSetDevice(c->device));
+    if (c->hh_mode) c->hh_keep0 = c->rank == 0;      // frisys_hh.cpp:356: position 0 of rank 0 (the Neel state) is never released
     fr_sys_comp(c, n_samp, rn);
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     check_dev_err(c);
+    FR_API_END
+}
+
+extern "C" int fries_set_vec_scrambler(fries_ctx *h, const uint32_t *vec_scr, size_t n) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    if (c->vec.dets) throw FriesError("fries_set_vec_scrambler must be called before the driver's setup");
+    c->in_vec_scr.assign(vec_scr, vec_scr + n);
+    FR_API_END
+}
+extern "C" int fries_hh_comp_sub(fries_ctx *h, int stage, uint32_t n_samp, double rn, uint32_t *idx0, uint32_t *idx1, double *vals, size_t cap, size_t *n_out) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->hh_mode) throw FriesError("fries_hh_setup must be called first");
+    if (stage != 1 && stage != 2) throw FriesError("stage must be 1 or 2");
+    if (stage == 1) { fr_vec_sync_state(c, &c->vec, &c->h_vst); fr_vec_maybe_rebuild(c, &c->vec); }
+    fr_hh_stage(c, stage, n_samp, rn);
+    const size_t m = c->comp_len[stage - 1];
+    if (m > cap || m > c->W.cap) throw FriesError("Error: insufficient memory allocated for matrix compression.");
+    if (m) {
+        FR_HIP(hipMemcpyAsync(idx0, c->W.e_wi, 4 * m, hipMemcpyDeviceToHost, c->stream));
+        FR_HIP(hipMemcpyAsync(idx1, c->W.e_sub, 4 * m, hipMemcpyDeviceToHost, c->stream));
+        FR_HIP(hipMemcpyAsync(vals, c->W.e_val, 8 * m, hipMemcpyDeviceToHost, c->stream));
+        FR_HIP(hipStreamSynchronize(c->stream));
+    }
+    *n_out = m;
+    check_dev_err(c);
+    FR_API_END
+}
+extern "C" int fries_hh_ref_ovlp(fries_ctx *h, double *ovlp) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->hh_mode) throw FriesError("fries_hh_setup must be called first");
+    double o3[3];
+    fr_hh_ref_ovlp(c, o3);
+    *ovlp = o3[0];
     FR_API_END
 }
 

@@ -658,6 +658,26 @@ void fr_hh_apply(FriesCtx *c, uint32_t n_samp, const double rn[2]) {
     c->num_success = c->comp_len[1];
 }
 
+// one of the two comp_sub calls of frisys_hh.cpp:187-224 on its own (the reference's driver source behind include/FRIES calls them one by
+// one): stage 1 = hop / phonon on the stored vector, stage 2 = which hop / which phonon move on stage 1's emissions.  Emissions stay in
+// W.e_wi / e_sub / e_val; comp_len[stage - 1] = their number.
+void fr_hh_stage(FriesCtx *c, int stage, uint32_t n_samp, double rn) {
+    CompWork &W = c->W;
+    if (stage == 1) {
+        const uint32_t bound1 = c->h_vst.curr_size;
+        if (bound1 > W.cap) throw FriesError("vector larger than the compression work capacity");
+        run_stage<1, true>(c, 0, bound1, n_samp, rn, 0);
+    }
+    else {
+        uint32_t bound = n_samp + 64 < W.cap ? n_samp + 64 : W.cap;
+        const uint32_t b = c->comp_len[0] + 64;
+        if (b < bound) bound = b;
+        run_stage<2, true>(c, 1, bound, n_samp, rn, 1, true);
+    }
+    fr_stream_wait(c);
+    c->comp_len[stage - 1] = c->h_misc()[16 + stage - 1];
+}
+
 // ------------------------------------------------------------------ apply_HBPP_piv (heat_bathPP.cpp:1014-1419, spin_parity 0)
 // Every factor of the HB-PP factorisation is multiplied out -- element e of the short vector becomes a group of values in
 // the long vector (long_vec) -- the long vector is compressed by piv_comp_parallel (find_preserve + pivotal sampling,

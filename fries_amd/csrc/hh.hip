@@ -287,8 +287,9 @@ void fr_hh_setup(FriesCtx *c, const fries_hh_params *p) {
     c->mt.seed(p->seed);
     const unsigned L = p->n_sites;
     c->proc_scr.resize(2 * L); c->vec_scr.resize(2 * L);
-    for (auto &x : c->proc_scr) x = c->mt();        // frisys_hh.cpp:80-83
-    for (auto &x : c->vec_scr) x = c->mt();         // :88-91
+    // frisys_hh.cpp:80-83, :88-91; a caller that drew them itself (the reference's driver behind include/FRIES) hands them in
+    if (c->in_proc_scr.size() == c->proc_scr.size()) c->proc_scr = c->in_proc_scr; else for (auto &x : c->proc_scr) x = c->mt();
+    if (c->in_vec_scr.size() == c->vec_scr.size()) c->vec_scr = c->in_vec_scr; else for (auto &x : c->vec_scr) x = c->mt();
     uint32_t wcap = p->max_dets > p->vec_nonz + 4096 ? p->max_dets : p->vec_nonz + 4096;
     if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
     if (!c->d_proc_scr) c->d_proc_scr = fr_alloc<uint32_t>(64);
@@ -435,4 +436,12 @@ void fr_hh_iterate(FriesCtx *c, fries_iter_log *lg) {
     }
 }
 
+// calc_ref_ovlp of this rank's shard (hub_holstein.hpp:93-186): out = {overlap sum, value at position 0, diagonal element at position 0}
+void fr_hh_ref_ovlp(FriesCtx *c, double out[3]) {
+    const fries_hh_params &P = c->hh;
+    FR_LAUNCH(c, "k_hh_ref_ovlp", k_hh_ref_ovlp, dim3(FR_HH_OVLP_BLOCKS), dim3(FR_BLOCK), c->vec, c->hf_det, P.g / 1.0, c->hh_ovlp + 4);
+    FR_LAUNCH(c, "k_hh_ref_ovlp_sum", k_hh_ref_ovlp_sum, dim3(1), dim3(64), c->vec, c->hh_ovlp + 4, c->hh_ovlp);
+    FR_HIP(hipMemcpyAsync(out, c->hh_ovlp, 24, hipMemcpyDeviceToHost, c->stream));
+    FR_HIP(hipStreamSynchronize(c->stream));
+}
 void fr_hh_clear_pos0(FriesCtx *c) { FR_LAUNCH(c, "k_hh_keep_pos0", k_hh_keep_pos0, dim3(1), dim3(1), c->vc.del); }

@@ -26,7 +26,7 @@ EXPORTS = [
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
     "fries_set_proc_scrambler", "fries_tie_margins", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
-    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs", "fries_set_det_space", "fries_vec_set_dense", "fries_dense_sizes",
+    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs", "fries_set_det_space", "fries_vec_set_dense", "fries_dense_sizes", "fries_hostcomm_create", "fries_set_vec_scrambler", "fries_hh_comp_sub", "fries_hh_ref_ovlp",
 ]
 
 

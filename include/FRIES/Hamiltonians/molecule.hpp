@@ -1,9 +1,10 @@
 /*! \file  FRIES/Hamiltonians/molecule.hpp for the MI355X build: the molecular-Hamiltonian helpers the drivers call, with the reference's
  * names and signatures (FRIES/Hamiltonians/molecule.hpp:43-301).
  *
- *   - Slater-Condon elements (diag_matrel, sing_matr_el_nosgn, doub_matr_el_nosgn; molecule.cpp:26-105, 983-1029) are evaluated by the
- *     device functions the engine itself uses (fries_matrel_batch), on the integrals parse_fcidump handed to the device: the eris / h_core
- *     arguments must be the objects parse_fcidump returned, frozen orbitals are not supported;
+ *   - diag_matrel (molecule.cpp:983-1029) is evaluated by the device function the engine itself uses (fries_matrel_batch); the single /
+ *     double elements without sign (molecule.cpp:26-105), which the reference's drivers call once per sampled excitation, are host
+ *     arithmetic on the same integrals.  The eris / h_core arguments must be the objects parse_fcidump returned; frozen orbitals are
+ *     not supported;
  *   - symmetry-allowed excitation lists (sing_ex_symm, doub_ex_symm, count_singex, SymmInfo; molecule.cpp:108-203, 914-933) are host
  *     integer loops in the reference's enumeration order (they size buffers and define the order of H * trial);
  *   - h_op_offdiag / h_op_diag (molecule.cpp:205-219, 448-665) for HOST vectors -- the trial vector times H at start-up -- with the
@@ -17,6 +18,7 @@
 #include <FRIES/fci_utils.h>
 #include <FRIES/ndarr.hpp>
 #include <FRIES/vec_utils.hpp>
+#include <FRIES/compress_utils.hpp>
 #include <FRIES/backend.hpp>
 
 #define n_irreps 8
@@ -33,19 +35,28 @@ inline void check_mol(const void *eris, const void *hcore, unsigned n_frozen) {
 inline uint64_t det_of_occ(const uint8_t *occ_orbs, unsigned n_elec) { uint64_t d = 0; for (unsigned i = 0; i < n_elec; i++) d |= 1ull << occ_orbs[i]; return d; }
 }
 
-inline double doub_matr_el_nosgn(uint8_t *chosen_orbs, unsigned int /*n_orbs*/, const SymmERIs &eris, unsigned int n_frozen) {
+/* <o1 o2 || u1 u2> without its sign: the direct integral, minus the exchange one for parallel spins (molecule.cpp:26-42).  Host
+ * arithmetic on the integrals parse_fcidump read -- the reference's drivers call this once per sampled excitation; the engine's own
+ * loops evaluate the same expression per lane (csrc/fries_dev.hpp: fr_doub_matrel). */
+inline double doub_matr_el_nosgn(uint8_t *chosen_orbs, unsigned int n_orbs, const SymmERIs &eris, unsigned int n_frozen) {
     fries_hip::check_mol(&eris, nullptr, n_frozen);
-    uint64_t det = 0; double out = 0;
-    uint8_t o[4] = {chosen_orbs[0], chosen_orbs[1], chosen_orbs[2], chosen_orbs[3]};
-    fries_hip::ck(fries_matrel_batch(fries_hip::Backend::get().ctx(), 2, &det, o, 1, &out, nullptr));
-    return out;
+    const unsigned int a = chosen_orbs[0] % n_orbs, b = chosen_orbs[1] % n_orbs, c = chosen_orbs[2] % n_orbs, d = chosen_orbs[3] % n_orbs;
+    double el = eris.physicist(a, b, c, d);
+    if (chosen_orbs[0] / n_orbs == chosen_orbs[1] / n_orbs) el -= eris.physicist(a, b, d, c);
+    return el;
 }
-inline double sing_matr_el_nosgn(uint8_t *chosen_orbs, uint8_t *occ_orbs, unsigned int /*n_orbs*/, const SymmERIs &eris, const Matrix<double> &h_core, unsigned int n_frozen, unsigned int n_elec) {
+/* <D| H |D(o -> u)> without its sign: the one-electron integral plus, electron by electron in the order of the occupied list, the
+ * Coulomb integral and (same spin) minus the exchange integral (molecule.cpp:76-105) */
+inline double sing_matr_el_nosgn(uint8_t *chosen_orbs, uint8_t *occ_orbs, unsigned int n_orbs, const SymmERIs &eris, const Matrix<double> &h_core, unsigned int n_frozen, unsigned int n_elec) {
     fries_hip::check_mol(&eris, &h_core, n_frozen);
-    uint64_t det = fries_hip::det_of_occ(occ_orbs, n_elec); double out = 0;
-    uint8_t o[4] = {chosen_orbs[0], chosen_orbs[1], 0, 0};
-    fries_hip::ck(fries_matrel_batch(fries_hip::Backend::get().ctx(), 1, &det, o, 1, &out, nullptr));
-    return out;
+    const unsigned int o = chosen_orbs[0] % n_orbs, u = chosen_orbs[1] % n_orbs, spin = chosen_orbs[0] / n_orbs;
+    double el = h_core(o, u);
+    for (unsigned int j = 0; j < n_elec; j++) {
+        const unsigned int p = occ_orbs[j] % n_orbs;
+        el += eris.physicist(o, p, u, p);
+        if (occ_orbs[j] / n_orbs == spin) el -= eris.physicist(o, p, p, u);
+    }
+    return el;
 }
 inline double diag_matrel(const uint8_t *occ_orbs, unsigned int /*n_orbs*/, const SymmERIs &eris, const Matrix<double> &h_core, unsigned int n_frozen, unsigned int n_elec) {
     fries_hip::check_mol(&eris, &h_core, n_frozen);
@@ -188,6 +199,7 @@ inline void h_op_offdiag(DistVec<double> &vec, size_t vec_size, uint8_t *symm, u
                 matr_el *= curr_el * h_fac;
                 if (!vec.add(new_det, matr_el, 1)) break;
             }
+            keep_going = sum_mpi(keep_going, fries_hip::mpi_rank(), fries_hip::mpi_size());     // every rank takes part in every round (molecule.cpp:607, 661)
             vec.perform_add(0);
         }
     }

@@ -14,6 +14,19 @@
 #include <FRIES/ndarr.hpp>
 #include <FRIES/backend.hpp>
 
+/* the Hubbard-Holstein parameter file (io_utils.hpp:44-53, io_utils.cpp:320-405): keyword lines n_elec, lat_len, n_dim, eps, U, omega, g,
+ * gs_energy, each followed by a line with its value, in that order */
+struct hh_input {
+    unsigned int n_elec;    ///< Total number of electrons in the system
+    unsigned int lat_len;   ///< Number of sites along one dimension of the lattice
+    unsigned int n_dim;     ///< Dimensionality of the lattice
+    double elec_int;        ///< On-site repulsion term
+    double eps;             ///< Suggested imaginary time step
+    double hf_en;           ///< HF electronic energy
+    double elec_ph;         ///< Electron-phonon coupling
+    double ph_freq;         ///< Phonon energy
+};
+
 struct fcidump_input {
     uint32_t n_elec;            ///< Total number of electrons in the system
     uint32_t n_orb_;            ///< Number of spatial orbitals in the HF basis
@@ -172,5 +185,27 @@ inline size_t load_last_line(const std::string &path, double *vals) {
         while (std::getline(ss, tok, ',')) { std::stringstream num(tok); if (num >> vals[n_read]) n_read++; }
     }
     return n_read;
+}
+inline void parse_hh_input(const std::string &hh_path, hh_input *in_struct) {
+    std::ifstream in(hh_path);
+    if (!in.is_open()) throw std::runtime_error("Could not open file containing Hubbard-Holstein parameters");
+    std::string line;
+    auto keyword = [&](const char *key, const char *what) {
+        if (!std::getline(in, line) || line != key) throw std::runtime_error(std::string("Could not find ") + what + " in file containing Hubbard-Holstein parameters");
+    };
+    auto value_of = [&](const char *key, const char *what) { keyword(key, what); double v = 0; in >> v; std::getline(in, line); return v; };
+    in_struct->n_elec = (unsigned int)value_of("n_elec", "n_elec parameter");
+    in_struct->lat_len = (unsigned int)value_of("lat_len", "lat_len parameter");
+    in_struct->n_dim = (unsigned int)value_of("n_dim", "n_dim parameter");
+    in_struct->eps = value_of("eps", "eps parameter");
+    in_struct->elec_int = value_of("U", "electron interaction parameter (U)");
+    in_struct->ph_freq = value_of("omega", "phonon frequency parameter (omega)");
+    in_struct->elec_ph = value_of("g", "electron-phonon interaction parameter (g)");
+    in_struct->hf_en = value_of("gs_energy", "gs_energy parameter");
+    // MI355X build: the device context of the Hubbard-Holstein vector is set up from these (HubHolVec::device_setup)
+    fries_hip::HHParams &P = fries_hip::hh_params();
+    P.n_elec = in_struct->n_elec; P.lat_len = in_struct->lat_len; P.eps = in_struct->eps; P.U = in_struct->elec_int; P.omega = in_struct->ph_freq;
+    P.g = in_struct->elec_ph; P.gs_energy = in_struct->hf_en; P.set = true;
+    fries_hip::Backend::get().hh_mode = true;
 }
 #endif /* io_utils_h */

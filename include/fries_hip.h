@@ -88,6 +88,18 @@ int fries_rccl_create(fries_transport **out, const uint8_t id[128], int rank, in
 int fries_local_group_create(fries_local_group **out, int size, uint64_t big_bytes);
 void fries_local_group_destroy(fries_local_group *g);
 int fries_local_create(fries_transport **out, fries_local_group *g, int rank, int device);
+/*   host: the caller's own collectives on HOST buffers -- for a program that already lives in an MPI communicator (the reference's
+ *   drivers call MPI directly: MPI_Allgather inside sum_mpi, MPI_Alltoallv inside Adder::perform_add).  The transport moves the staging
+ *   blocks to pinned host memory, calls back, and moves the result to the device; no GPU-aware MPI is needed.  allgather: every rank
+ *   contributes `bytes` bytes, rank p's block lands at recv + p * bytes.  alltoallv: send holds the segments for ranks 0 .. size-1 back to
+ *   back (send_bytes[d] each), recv receives the segments from ranks 0 .. size-1 back to back (recv_bytes[s] each).  Return 0 on success.
+ *   include/FRIES/backend.hpp builds these two from MPI_Allgather / MPI_Alltoallv when the program runs on more than one rank. */
+typedef struct {
+    void *user;
+    int (*allgather)(void *user, const void *send, void *recv, uint64_t bytes);
+    int (*alltoallv)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+} fries_host_collectives;
+int fries_hostcomm_create(fries_transport **out, const fries_host_collectives *cb, int rank, int size, int device, uint64_t big_bytes);
 /* fills *comm for fries_set_comm; the transport must outlive the context */
 int fries_transport_comm(fries_transport *t, fries_comm *comm);
 int fries_transport_counts(fries_transport *t, uint64_t *n_allgather, uint64_t *n_alltoallv);
@@ -181,6 +193,16 @@ typedef struct {
 } fries_hh_params;
 int fries_hh_setup(fries_ctx *ctx, const fries_hh_params *p);
 int fries_hh_iterate(fries_ctx *ctx, uint32_t n_iter, fries_iter_log *logs);
+/* The same driver's operators one by one, for a host loop that keeps the reference's shape (FRIES_bin/frisys_hh.cpp behind include/FRIES):
+ *   fries_set_vec_scrambler   the vector hash's scrambler (the reference's table compares a truncated index inside a bucket chosen by that hash,
+ *                             det_hash.hpp:47, so which states share an entry depends on it); with fries_set_proc_scrambler, before fries_hh_setup;
+ *   fries_hh_comp_sub         one of the two comp_sub calls (:187-224): stage 1 on the magnitudes of the stored vector with the rows (t, g),
+ *                             stage 2 on stage 1's emissions with their uniform subdivisions; outputs as comp_idx[k][0..1] and the value array;
+ *   fries_hh_ref_ovlp         calc_ref_ovlp of this rank's shard against the Neel state (hub_holstein.hpp:93-186);
+ * the vector itself goes through fries_vec_load / fries_vec_add_to / fries_vec_add_vecs / fries_find_preserve / fries_sys_comp. */
+int fries_set_vec_scrambler(fries_ctx *ctx, const uint32_t *vec_scrambler, size_t n);
+int fries_hh_comp_sub(fries_ctx *ctx, int stage, uint32_t n_samp, double rn, uint32_t *idx0, uint32_t *idx1, double *vals, size_t cap, size_t *n_out);
+int fries_hh_ref_ovlp(fries_ctx *ctx, double *ovlp);
 
 /* ---- fciqmc_mol: FCIQMC with the near-uniform or the heat-bath excitation generator (FRIES_bin/fciqmc_mol.cpp), HF trial
  * vector, start from 100 walkers on HF; one rank or hash-sharded ranks (fries_set_comm: one all-to-all of the spawns per
@@ -228,7 +250,9 @@ int fries_vec_info(fries_ctx *ctx, uint32_t *curr_size, int32_t *n_nonz, uint32_
 int fries_vec_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
 /* DistVec::add + perform_add(0) into column 0 with one rank (vec_utils.hpp:418-440, 606-641) */
 int fries_vec_add(fries_ctx *ctx, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n);
-/* the same with curr_vec_idx = column (0 or 1): column 1 collects the spawns under the initiator rule (frisys_mol.cpp:424-471) */
+/* the same with curr_vec_idx = column (0 or 1): column 1 collects the spawns under the initiator rule (frisys_mol.cpp:424-471).
+ * With ranks the list is what THIS rank received (DistVec::add_elements, vec_utils.hpp:606-641): the caller has routed the adds
+ * (MPI_Alltoallv inside Adder::perform_add) and passes them in arrival order; nothing is exchanged here. */
 int fries_vec_add_to(fries_ctx *ctx, int column, const uint64_t *dets, const double *vals, const uint8_t *ini, size_t n);
 /* frisys_mol.cpp:487-499: death / cloning of the first vec_size positions, add_vecs(0, 1), zero_vec on column 1 */
 int fries_death_clone(fries_ctx *ctx, double eps, double shift, uint32_t vec_size);

@@ -451,14 +451,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(dll, s), s
 
 
-def test_facade_header_and_drivers_compile_on_the_host(tmp_path):
-    """include/fries_facade.hpp and the C++ drivers are plain host C++17 over the C ABI: they must compile without hipcc."""
+def test_reference_headers_and_drivers_compile_on_the_host(tmp_path):
+    """include/FRIES (the reference's own header names over the C ABI) and the C++ drivers are plain host C++17: they must compile without
+    hipcc, against the one-rank MPI stand-in and -- where the image has one -- against the real <mpi.h>."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "t.cpp"
-    src.write_text('#include "fries_facade.hpp"\nint main() { fries_hip::Matrix<double> m(2, 2); m(1, 1) = 1; double s = 0, l = 0; fries_hip::adjust_shift(&s, 2.0, &l, 1.0, 0.1); return (int)m(0, 0); }\n')
-    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+    src.write_text('#include <FRIES/Hamiltonians/heat_bathPP.hpp>\n#include <FRIES/Hamiltonians/hub_holstein.hpp>\n#include <FRIES/hh_vec.hpp>\n'
+                   'int main() { Matrix<double> m(2, 2); m(1, 1) = 1; double s = 0, l = 0; adjust_shift(&s, 2.0, &l, 1.0, 0.1); std::mt19937 mt(1); return (int)m(0, 0) + round_binomially(0.0, 3, mt); }\n')
+    inc = os.path.join(root, "include")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", inc, "-I", os.path.join(inc, "FRIES", "compat"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+    if os.path.exists("/opt/conda/include/mpi.h"):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", inc, "-I", "/opt/conda/include", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
     for drv in ("frisys_mol_hip", "fciqmc_mol_hip", "frisys_hh_hip", "frifull_mol_hip"):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(root, "fries_amd", "drivers", drv + ".cpp")], capture_output=True, text=True)
         assert r.returncode == 0, (drv, r.stderr[-2000:])

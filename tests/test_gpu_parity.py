@@ -854,20 +854,6 @@ def test_cli_driver_frifull(mols, tmp_path):
     assert bad.returncode == 1 and "missing required option" in bad.stderr
 
 
-def test_cpp_facade_operator_level_loop(mols, tmp_path):
-    """include/fries_facade.hpp (the reference's names over the C ABI): tests/cpp/test_facade.cpp mirrors the reference's
-    "[vector_add]" test and assembles the frisys_mol iteration from the operator-level calls with host-built spawns; every
-    iteration must equal the fused fries_frisys_iterate bit for bit."""
-    import subprocess
-    from fries_amd import build
-    assert os.path.exists(build.FACADE_TEST), "tests/cpp/test_facade has not been built"
-    mol = mols("Ne")
-    fc = str(tmp_path / "ne.FCIDUMP")
-    fcidump.write_fcidump(fc, mol)
-    res = subprocess.run([build.FACADE_TEST, fc, mol.point_group, "30"], capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and "fails=0" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
-
-
 def test_cli_driver_text_vectors_and_ham_shift(mols, tmp_path):
     """frisys_mol_hip --trial_vec / --ini_vec read the reference's text vector files; --ham_shift: the written files against the
     reference's trajectories."""
