@@ -54,13 +54,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
 }
 
 void fr_death_clone(FriesCtx *c, uint32_t vec_size_before) {
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     uint32_t bound = c->h_vst.curr_size;
     FR_LAUNCH(c, "k_death_clone", k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), c->vec, c->vc, S, vec_size_before, c->eps, c->en_shift, c->vec_nonz, 1);
 }
 // round 0 of find_preserve on column 0 as it stands
 void fr_abs_sums(FriesCtx *c) {
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     uint32_t bound = c->h_vst.curr_size;
     FR_LAUNCH(c, "k_abs_sums", k_death_clone, dim3(fr_blocks(bound ? bound : 1, FR_TILE)), dim3(FR_BLOCK), c->vec, c->vc, S, 0u, c->eps, c->en_shift, c->vec_nonz, 0);
 }

@@ -146,6 +146,7 @@ struct FriesCtx {
     FqWork fqw{};
     // Hubbard-Holstein driver (hh.hip)
     bool hh_mode = false, hh_keep0 = false;
+    int spin_parity = 0;                     // fries_set_spin_parity: +-1 = time-reversal symmetrised vectors (k_enum, k_final_eval_piv)
     fries_hh_params hh{};
     uint32_t *d_vec_scr = nullptr;
     det_t *hh_fdet = nullptr; double *hh_ovlp = nullptr;

@@ -13,7 +13,7 @@ extern "C" const char *fries_last_error(void) { return g_err.c_str(); }
 struct fries_ctx { FriesCtx c; };
 
 void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vector<double> &val,
-                     std::vector<det_t> &out_det, std::vector<double> &out_val, uint32_t *n_sing0, uint32_t *n_doub0);
+                     std::vector<det_t> &out_det, std::vector<double> &out_val, uint32_t *n_sing0, uint32_t *n_doub0, bool with_diag = true);
 void fr_hbpp_apply_unit(FriesCtx *c, uint32_t n_samp, const double rn[5]);
 
 // ------------------------------------------------------------------ per-kernel HIP-event timing
@@ -830,7 +830,7 @@ extern "C" int fries_vec_diag_download(fries_ctx *h, double *out, size_t cap, si
     if (n) *n = m;
     if (cap < m) throw FriesError("output buffer too small");
     if (m) {
-        SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+        SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
         FR_LAUNCH(c, "k_fill_diag", k_fill_diag, dim3(fr_blocks(m, FR_BLOCK) > 2048 ? 2048 : fr_blocks(m, FR_BLOCK)), dim3(FR_BLOCK), c->vec, S);
         FR_HIP(hipStreamSynchronize(c->stream));
         FR_HIP(hipMemcpy(out, c->vec.diag, 8 * m, hipMemcpyDeviceToHost));
@@ -990,6 +990,29 @@ extern "C" int fries_sys_comp(fries_ctx *h, uint32_t n_samp, double rn) {
     FR_API_END
 }
 
+// Time-reversal symmetry (the subspace drivers' spin_parity argument of h_op_offdiag / apply_HBPP_piv, molecule.cpp:298-369, heat_bathPP.cpp:1326-1407)
+extern "C" int fries_set_spin_parity(fries_ctx *h, int spin_parity) {
+    FR_API_BEGIN
+    if (spin_parity < -1 || spin_parity > 1) throw FriesError("spin_parity must be -1, 0 or 1");
+    h->c.spin_parity = spin_parity;
+    FR_API_END
+}
+// h_op_offdiag(vec, ..., dest_idx = 1, h_fac = 1, spin_parity) on a fresh two-column vector that holds the list in column 0 (molecule.cpp:448-665):
+// the stored determinants in position order and column 1
+extern "C" int fries_h_offdiag_list(fries_ctx *h, const uint64_t *dets, const double *vals, size_t n, uint64_t *out_dets, double *out_vals, size_t cap, size_t *n_out) {
+    FR_API_BEGIN
+    FriesCtx *c = &h->c;
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
+    std::vector<det_t> src(dets, dets + n), od;
+    std::vector<double> val(vals, vals + n), ov;
+    fr_h_apply_list(c, src, val, od, ov, nullptr, nullptr, false);
+    if (od.size() > cap) throw FriesError("fries_h_offdiag_list: output buffers too small");
+    std::copy(od.begin(), od.end(), out_dets); std::copy(ov.begin(), ov.end(), out_vals);
+    *n_out = od.size();
+    FR_API_END
+}
+
 extern "C" int fries_set_vec_scrambler(fries_ctx *h, const uint32_t *vec_scr, size_t n) {
     FR_API_BEGIN
     FriesCtx *c = &h->c;
@@ -1095,6 +1118,7 @@ extern "C" int fries_apply_hbpp_piv(fries_ctx *h, uint32_t n_samp, int unit_matr
     FriesCtx *c = &h->c;
     FR_HIP(hipSetDevice(c->device));
     if (c->hh_mode || c->fq_mode || !c->W.cap) throw FriesError("fries_apply_hbpp_piv needs a context set up by fries_frisys_setup");
+    if (c->spin_parity && !c->new_hb) throw FriesError("Time-reversal symmetry is only implemented for the unnormalized heat-bath distribution");       // heat_bathPP.cpp:1019-1021
     uint32_t sl[5] = {0, 0, 0, 0, 0};
     fr_hbpp_piv_apply(c, n_samp, unit_matrel, sl);
     size_t m = c->num_success;

@@ -606,7 +606,7 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     fr_vec_maybe_rebuild(c, &c->vec);
     const uint32_t n = c->h_vst.curr_size;
     if (n > Q.cap_d) throw FriesError("vector larger than the FCIQMC work arrays");
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     const unsigned gd = fr_blocks(n ? n : 1, FR_BLOCK);
     FR_HIP(hipMemsetAsync(&Q.totals[3], 0, 4, st));
     FR_LAUNCH(c, "k_fq_count", k_fq_count, dim3(gd), dim3(FR_BLOCK), c->vec, S, Q, (unsigned long long)P.seed, (unsigned long long)c->iterat, c->p_doub, c->eps, c->en_shift, P.initiator);
@@ -713,7 +713,7 @@ void fr_multi_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
     fr_vec_maybe_rebuild(c, &c->vec);
     const uint32_t n = c->h_vst.curr_size;
     if (n > Q.cap_d) throw FriesError("vector larger than the work arrays");
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     // samples per column (:301-322)
     double rn_sys = c->mt() / (1. + UINT32_MAX);
     const uint32_t curr_mat_samp = c->iterat < 10 ? P.mat_nonz / 10 : P.mat_nonz;

@@ -40,6 +40,7 @@ struct SysDev {
     const double *eris;     // 8-fold packed (FRIES/ndarr.hpp:206-244)
     const HbTables *hb;     // device copy
     double hf_en;
+    int spin_parity = 0;    // +-1: time-reversal symmetrised vectors (fr_adjust_tr, hbpp_rows.hpp)
 };
 
 // Device-resident sparse vector (reference DistVec<double>, FRIES/vec_utils.hpp:121-141).

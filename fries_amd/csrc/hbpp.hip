@@ -622,7 +622,7 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     run_stage<5, NEW_HB>(c, 0, bound, n_samp, rn[4], 4);
     bound = next_bound(4);
     unsigned grid = fr_blocks(bound, FR_TILE);
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     // f_val / f_orbs reuse the S / kin arrays of the (finished) last stage
     double *f_val = W.S; uint32_t *f_orbs = W.kin;
     FR_LAUNCH(c, "k_final_eval", (k_final_eval<NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
@@ -836,7 +836,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_eval_piv(CompWork W, VecDev 
                 tw *= p_doub;
                 double mel = unit_matrel ? 1.0 : fr_doub_matrel(o1, o2, u1, u2, S.eris, n_orb);
                 mel *= fr_doub_parity(det, o1, o2, u1, u2);
-                el = val * mel / tw;
+                bool keep = true;
+                if (S.spin_parity) { det_t tgt; keep = fr_adjust_tr(T, S, det, (det & ~(1ull << o1) & ~(1ull << o2)) | (1ull << u1) | (1ull << u2), &mel, S.spin_parity, &tgt, unit_matrel, &tw, p_doub); }
+                el = keep ? val * mel / tw : 0.0;
             }
         }
         else {
@@ -848,7 +850,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_eval_piv(CompWork W, VecDev 
                 double tw = (1 - p_doub) / n_occ / fr_c(pc, 3);
                 double mel = unit_matrel ? 1.0 : fr_sing_matrel(det, o1, u1, S.h_core, S.eris, n_orb);
                 mel *= fr_sing_parity(det, o1, u1);
-                el = val * mel / tw;
+                bool keep = true;
+                if (S.spin_parity) { det_t tgt; keep = fr_adjust_tr(T, S, det, (det & ~(1ull << o1)) | (1ull << u1), &mel, S.spin_parity, &tgt, unit_matrel, &tw, p_doub); }
+                el = keep ? val * mel / tw : 0.0;
             }
         }
         if (!(fabs(el) > 1e-12)) el = 0;
@@ -907,7 +911,7 @@ static void hbpp_piv_t(FriesCtx *c, uint32_t n_samp, int unit_matrel, uint32_t s
     n = pv_stage<4, NEW_HB>(c, 1, n, n_samp); stage_len[3] = n;
     n = pv_stage<5, NEW_HB>(c, 0, n, n_samp); stage_len[4] = n;
     const unsigned grid = fr_blocks(n ? n : 1, FR_TILE);
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     double *f_val = W.S; uint32_t *f_orbs = W.kin;
     FR_LAUNCH(c, "k_final_eval_piv", (k_final_eval_piv<NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
     FR_LAUNCH(c, "k_final_compact", k_final_compact, dim3(grid), dim3(FR_BLOCK), W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);

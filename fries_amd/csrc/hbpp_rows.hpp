@@ -273,3 +273,75 @@ __device__ inline double fr_norm_wt(const HbTables &T, det_t det, unsigned O1, u
     }
     return w;
 }
+
+// ------------------------------------------------------------------ time-reversal symmetry
+// FRIES/fci_utils.c:158-204: the alpha and the beta string trade places -- with the reference's own slip for strings that are whole bytes
+// long and at least three of them (n_orb = 24, 32): bytes mid + 1 .. n_bytes - 2 of the result receive alpha byte b - mid - 1.
+__device__ __forceinline__ det_t fr_flip_spins(det_t det, unsigned n) {
+    const det_t half = (1ull << n) - 1ull;
+    det_t out = n >= 32 ? (det >> 32) | (det << 32) : ((det >> n) & half) | ((det & half) << n);
+    if ((n & 7u) == 0 && n >= 24) {
+        const unsigned mid = n / 8, nb = 2 * mid;
+        for (unsigned b = mid + 1; b + 1 < nb; b++) out = (out & ~(0xffull << (8 * b))) | (((det >> (8 * (b - mid - 1))) & 0xffull) << (8 * b));
+    }
+    return out;
+}
+// memcmp over the little-endian byte strings
+__device__ __forceinline__ int fr_det_memcmp(det_t a, det_t b) {
+    const det_t x = a ^ b;
+    if (!x) return 0;
+    const int byte = (__ffsll((long long)x) - 1) >> 3;
+    return ((a >> (8 * byte)) & 255ull) > ((b >> (8 * byte)) & 255ull) ? 1 : -1;
+}
+// The adjust_tr lambda of h_op_offdiag (molecule.cpp:298-369, 472-552) and the same block of apply_HBPP_piv (heat_bathPP.cpp:1326-1407):
+// <new|H|cur> -> the element between the symmetrised functions.  false: no contribution.  *target = the representative the element goes
+// to (the byte-wise smaller of new and its image).  tw != nullptr selects apply_HBPP_piv's form: the image's selection probability is added to
+// *tw and the "two excitations" factor of h_op_offdiag is left out.  (`a ^ b ^ c ^ d == 0` in the reference parses as a ^ b ^ c ^ (d == 0): kept.)
+__device__ inline bool fr_adjust_tr(const HbTables &T, const SysDev &S, det_t cur, det_t nd, double *matr_el, int spin_parity, det_t *target,
+                                    int unit_matrel, double *tw, double p_doub) {
+    const unsigned n = T.n_orb;
+    double norm = fr_flip_spins(cur, n) == cur ? 1.4142135623730951 : 1.0;           // sqrt(2)
+    const det_t img = fr_flip_spins(nd, n);
+    if (img == cur) { *matr_el = 0; return false; }
+    const int cmp = fr_det_memcmp(nd, img);
+    if (cmp == 0) {
+        if (spin_parity == -1) { *matr_el = 0; return false; }
+        *matr_el *= 2;
+        norm *= 1.4142135623730951;
+    }
+    else {
+        const det_t x = cur ^ img;
+        const int n_diff = __popcll(x);
+        unsigned d[4] = {0, 0, 0, 0};
+        if (n_diff <= 4) { int k = 0; for (det_t y = x; y; y &= y - 1) d[k++] = (unsigned)(__ffsll((long long)y) - 1); }
+        if (n_diff == 2) {
+            if (T.irrep[d[0] % n] == T.irrep[d[1] % n]) {
+                if (fr_bit(cur, d[1])) { const unsigned t = d[0]; d[0] = d[1]; d[1] = t; }
+                if (tw) { SymCounts sc; fr_count_symm_virt(sc, T, cur); *tw += (1 - p_doub) / fr_count_sing_allowed(T, cur) / sc.c[T.irrep[d[0] % n]][0]; }
+                double rev = unit_matrel ? 1.0 : fr_sing_matrel(cur, d[0], d[1], S.h_core, S.eris, n);
+                rev *= fr_sing_parity(cur, d[0], d[1]);
+                *matr_el += rev * spin_parity;
+                if (!tw) norm *= 2;
+            }
+        }
+        else if (n_diff == 4) {
+            if ((T.irrep[d[0] % n] ^ T.irrep[d[1] % n] ^ T.irrep[d[2] % n] ^ (unsigned)(T.irrep[d[3] % n] == 0)) != 0) {
+                unsigned t;
+                if (fr_bit(cur, d[2])) { if (fr_bit(cur, d[0])) { t = d[1]; d[1] = d[2]; d[2] = t; } else { t = d[0]; d[0] = d[2]; d[2] = t; } }
+                if (fr_bit(cur, d[3])) { if (fr_bit(cur, d[0])) { t = d[1]; d[1] = d[3]; d[3] = t; } else { t = d[0]; d[0] = d[3]; d[3] = t; } }
+                if (d[0] > d[1]) { t = d[0]; d[0] = d[1]; d[1] = t; }
+                if (d[2] > d[3]) { t = d[2]; d[2] = d[3]; d[3] = t; }
+                if (tw) *tw += fr_unnorm_wt(T, d[0], d[1], d[2], d[3]) * p_doub;
+                double rev = unit_matrel ? 1.0 : fr_doub_matrel(d[0], d[1], d[2], d[3], S.eris, n);
+                rev *= fr_doub_parity(cur, d[0], d[1], d[2], d[3]);
+                *matr_el += rev * spin_parity;
+                if (!tw) norm *= 2;
+            }
+        }
+    }
+    if (cmp > 0) norm *= spin_parity;
+    *matr_el /= norm;
+    *target = cmp > 0 ? img : nd;
+    return true;
+}
+

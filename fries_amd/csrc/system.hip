@@ -4,6 +4,7 @@
 // 448-665).  Every sum below runs in the reference's loop order inside one lane, so the
 // tables are bit-identical to the CPU ones.
 #include "ctx.hpp"
+#include "hbpp_rows.hpp"
 #include <cstring>
 
 __global__ void k_hb_pairs(HbTables *T, const double *eris, unsigned n) {
@@ -160,6 +161,8 @@ __global__ void __launch_bounds__(FR_BLOCK) k_enum(const det_t *src, const doubl
                 m *= fr_doub_parity(det, o1, o2, u1, u2);                   // doub_det_parity, fci_utils.c:66-75
                 nd = (det & ~(1ull << o1) & ~(1ull << o2)) | (1ull << u1) | (1ull << u2);
             }
+            // time-reversal symmetrised vectors: the element between the symmetrised functions, added to the pair's representative
+            if (S.spin_parity) { det_t tgt = nd; if (fr_adjust_tr(T, S, det, nd, &m, S.spin_parity, &tgt, 0, nullptr, 0.0)) nd = tgt; else m = 0; }
             m *= cur * h_fac;
         }
         uint32_t f = (ok && m != 0) ? 1u : 0u, tot, tot_ok;
@@ -185,7 +188,7 @@ void fr_dense_h_setup(FriesCtx *c) {
     c->n_dense_h = c->n_dense_h_nz = 0;
     if (!c->d_dense_norm) c->d_dense_norm = fr_alloc<double>(1);
     if (!ns) return;
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     std::vector<double> ones(ns, 1.0);
     double *d_val = fr_alloc<double>(ns);
     uint32_t *d_cnt = fr_alloc<uint32_t>(2 * ns), *d_nz = fr_alloc<uint32_t>(2 * ns), *d_off = fr_alloc<uint32_t>(2 * ns);
@@ -219,10 +222,10 @@ void fr_dense_h_setup(FriesCtx *c) {
 // list in the reference's storage order, i.e. what htrial_vec holds after
 // h_op_offdiag / h_op_diag / add_vecs (frisys_mol.cpp:205-210).
 void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vector<double> &val,
-                     std::vector<det_t> &out_det, std::vector<double> &out_val, uint32_t *n_sing0, uint32_t *n_doub0) {
+                     std::vector<det_t> &out_det, std::vector<double> &out_val, uint32_t *n_sing0, uint32_t *n_doub0, bool with_diag) {
     hipStream_t st = c->stream;
     uint32_t ns = (uint32_t)src.size();
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     det_t *d_src = fr_alloc<det_t>(ns); double *d_val = fr_alloc<double>(ns);
     uint32_t *d_cnt = fr_alloc<uint32_t>(2 * ns), *d_nz = fr_alloc<uint32_t>(2 * ns), *d_off = fr_alloc<uint32_t>(2 * ns);
     FR_HIP(hipMemcpyAsync(d_src, src.data(), 8 * (size_t)ns, hipMemcpyHostToDevice, st));
@@ -276,7 +279,7 @@ void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vect
     // positions 0..ns-1 are the sources in order (they arrived first); duplicates among sources are not supported
     for (uint32_t i = 0; i < nout; i++) {
         double c0 = 0;
-        if (i < ns && val[i] != 0) c0 = val[i] * (0 + 1 * dg[i]);
+        if (with_diag && i < ns && val[i] != 0) c0 = val[i] * (0 + 1 * dg[i]);
         out_val[i] = c0 + v1[i] * 1.0;
     }
     // release temporaries
@@ -293,7 +296,7 @@ void fr_h_trial_setup(FriesCtx *c) {
     std::vector<det_t> src{c->hf_det}, od;
     std::vector<double> val{1.0}, ov;
     uint32_t n_sing = 0, n_doub = 0;
-    fr_h_apply_list(c, src, val, od, ov, &n_sing, &n_doub);
+    fr_h_apply_list(c, src, val, od, ov, &n_sing, &n_doub, true);
     c->p_doub = (double)n_doub / (n_sing + n_doub);        // frisys_mol.cpp:216-220 (always from the HF determinant)
     c->W.row1[0] = c->p_doub; c->W.row1[1] = 1 - c->p_doub;    // heat_bathPP.cpp:714-727
     if (!c->in_trial_det.empty()) {
@@ -308,7 +311,7 @@ void fr_h_trial_setup(FriesCtx *c) {
             else val[j] += c->in_trial_val[i];
         }
         if (src.empty()) throw FriesError("the trial vector holds no non-zero element");
-        fr_h_apply_list(c, src, val, od, ov, nullptr, nullptr);
+        fr_h_apply_list(c, src, val, od, ov, nullptr, nullptr, true);
         if (c->fq_mode) {
             // fciqmc_mol.cpp:163-170 stores every entry with `while (!trial_vec.add(...)) trial_vec.perform_add(0)`; add() reports a full
             // Adder AFTER storing, so the entry that fills it is stored again.  trial_vec's Adder holds exactly as many entries as the
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_hop_diag(VecDev V, SysDev S, doubl
     V.v1[i] = o;
 }
 void fr_h_diag_vec(FriesCtx *c, double id_fac, double h_fac) {
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     uint32_t bound = c->h_vst.curr_size ? c->h_vst.curr_size : 1;
     FR_LAUNCH(c, "k_hop_diag", k_hop_diag, dim3(fr_blocks(bound, FR_BLOCK)), dim3(FR_BLOCK), c->vec, S, id_fac, h_fac);
 }
@@ -391,7 +394,7 @@ uint64_t fr_h_offdiag_vec(FriesCtx *c, double h_fac) {
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     const uint32_t ns = c->h_vst.curr_size;
     if (ns == 0) return 0;
-    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
     if (c->full_cap < ns) {
         if (c->full_cnt) { FR_HIP(hipFree(c->full_cnt)); FR_HIP(hipFree(c->full_nz)); FR_HIP(hipFree(c->full_off)); FR_HIP(hipFree(c->full_list)); }
         c->full_cap = c->vec.cap;

@@ -26,7 +26,7 @@ EXPORTS = [
     "fries_compress_vec_piv", "fries_next_draw", "fries_test_piv_adjust", "fries_frifull_setup", "fries_frifull_iterate",
     "fries_rccl_unique_id", "fries_rccl_create", "fries_local_group_create", "fries_local_group_destroy", "fries_local_create", "fries_transport_comm", "fries_transport_counts", "fries_transport_destroy",
     "fries_set_proc_scrambler", "fries_tie_margins", "fries_measure_copy_bandwidth", "fries_piv_stats", "fries_set_trial_vector", "fries_set_initial_vector", "fries_set_ham_shift", "fries_vec_add_to", "fries_death_clone", "fries_dots", "fries_find_preserve", "fries_sys_comp",
-    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs", "fries_set_det_space", "fries_vec_set_dense", "fries_dense_sizes", "fries_hostcomm_create", "fries_set_vec_scrambler", "fries_hh_comp_sub", "fries_hh_ref_ovlp",
+    "fries_vec_column_download", "fries_vec_column_upload", "fries_vec_column_zero", "fries_vec_diag_download", "fries_vec_dot_list", "fries_vec_add_vecs", "fries_set_det_space", "fries_vec_set_dense", "fries_dense_sizes", "fries_hostcomm_create", "fries_set_vec_scrambler", "fries_hh_comp_sub", "fries_hh_ref_ovlp", "fries_set_spin_parity", "fries_h_offdiag_list",
 ]
 
 
@@ -349,6 +349,21 @@ class FriEngine:
         m = C.c_size_t()
         self._ck(self.lib.fries_htrial_download(self.h, _ptr(d), _ptr(v), cap, C.byref(m)))
         return d[:m.value].copy(), v[:m.value].copy()
+
+    def set_spin_parity(self, spin_parity: int):
+        """Time-reversal symmetrised vectors (spin_parity = +-1; 0 = off): see fries_set_spin_parity."""
+        self._ck(self.lib.fries_set_spin_parity(self.h, int(spin_parity)))
+
+    def h_offdiag_list(self, dets, vals):
+        """h_op_offdiag (dest column 1, h_fac 1, the context's spin parity) on a fresh vector holding (dets, vals): stored determinants, column 1."""
+        d = np.ascontiguousarray(dets, dtype=np.uint64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        cap = d.size * (self.mol.n_orb ** 2 * self.mol.n_elec ** 2 + 2) + 64
+        od = np.zeros(cap, dtype=np.uint64)
+        ov = np.zeros(cap)
+        m = C.c_size_t()
+        self._ck(self.lib.fries_h_offdiag_list(self.h, _ptr(d), _ptr(v), d.size, _ptr(od), _ptr(ov), cap, C.byref(m)))
+        return od[:m.value].copy(), ov[:m.value].copy()
 
     def vec_add(self, dets, vals, ini):
         d = np.ascontiguousarray(dets, dtype=np.uint64)

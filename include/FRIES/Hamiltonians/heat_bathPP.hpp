@@ -328,7 +328,7 @@ inline void apply_HBPP_sys(Matrix<uint8_t> & /*all_orbs*/, Matrix<uint8_t> &all_
 }
 /* pivotal variant (heat_bathPP.hpp:303-310, 353-357): every factor multiplied out into long_vec, compressed by piv_comp_parallel and
  * collapsed.  The number of uniforms drawn depends on the data, so the caller's generator is lent to the device context (its state
- * travels as text, the standard's operator<< format) and taken back afterwards.  spin_parity != 0 is not supported. */
+ * travels as text, the standard's operator<< format) and taken back afterwards.  spin_parity = +-1: fries_set_spin_parity around the call. */
 struct HBCompressPiv : HBCompress {
     std::vector<double> long_vec;
     std::vector<bool> keep_idx;
@@ -341,7 +341,6 @@ inline void apply_HBPP_piv(Matrix<uint8_t> & /*all_orbs*/, Matrix<uint8_t> &all_
                            std::mt19937 &mt_obj, uint32_t n_samp,
                            std::function<double(uint8_t *, uint8_t *)> /*sing_mat_fxn*/,
                            std::function<double(uint8_t *)> /*doub_mat_fxn*/, int spin_parity) {
-    if (spin_parity) throw std::runtime_error("apply_HBPP_piv: time-reversal symmetrised vectors (spin_parity != 0) are not supported by this build");
     fries_hip::DeviceVecBase *v = fries_hip::Backend::get().by_indices(&all_dets);
     if (!v) throw std::runtime_error("apply_HBPP_piv: all_dets must be the indices() matrix of the solution DistVec (this build runs the operator on the device-resident vector; there is no host implementation)");
     const size_t cap = comp_scratch->vec1.size();
@@ -355,7 +354,10 @@ inline void apply_HBPP_piv(Matrix<uint8_t> & /*all_orbs*/, Matrix<uint8_t> &all_
     fries_hip::ck(fries_rng_set_state(v->ctx(), os.str().c_str()));
     size_t n_out = 0;
     uint32_t stage_len[5];
-    fries_hip::ck(fries_apply_hbpp_piv(v->ctx(), n_samp, 0, comp_scratch->pos32.data(), (uint8_t *)comp_scratch->orb_indices1, comp_scratch->vec1.data(), cap, &n_out, stage_len));
+    fries_hip::ck(fries_set_spin_parity(v->ctx(), spin_parity));       // time-reversal symmetry (heat_bathPP.cpp:1326-1407) for this call
+    const int rc = fries_apply_hbpp_piv(v->ctx(), n_samp, 0, comp_scratch->pos32.data(), (uint8_t *)comp_scratch->orb_indices1, comp_scratch->vec1.data(), cap, &n_out, stage_len);
+    fries_set_spin_parity(v->ctx(), 0);
+    fries_hip::ck(rc);
     size_t need = 0;
     fries_hip::ck(fries_rng_get_state(v->ctx(), nullptr, 0, &need));
     std::string st(need + 1, '\0');

@@ -8,10 +8,13 @@
  *   - symmetry-allowed excitation lists (sing_ex_symm, doub_ex_symm, count_singex, SymmInfo; molecule.cpp:108-203, 914-933) are host
  *     integer loops in the reference's enumeration order (they size buffers and define the order of H * trial);
  *   - h_op_offdiag / h_op_diag (molecule.cpp:205-219, 448-665) for HOST vectors -- the trial vector times H at start-up -- with the
- *     matrix elements of each determinant's excitations computed in one device batch.  spin_parity != 0 is not supported. */
+ *     matrix elements of each determinant's excitations computed in one device batch.  spin_parity = +-1 (time-reversal symmetrised vectors): fries_hip::tr_adjust below. */
 #ifndef molecule_h
 #define molecule_h
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <utility>
 #include <sstream>
 #include <stdexcept>
 #include <vector>
@@ -130,6 +133,54 @@ inline size_t count_singex(uint8_t *det, const uint8_t *occ_orbs, uint32_t num_e
     return n;
 }
 
+namespace fries_hip {
+/* time-reversal symmetrised vectors (the adjust_tr lambda of the reference's h_op_offdiag, molecule.cpp:298-369, 472-552): the element
+ * <new|H|cur> becomes the one between the symmetrised functions and *nw the representative it is added to (the byte-wise smaller of new and
+ * its spin-flipped image).  false: no contribution.  Host arithmetic for host vectors; the engine's enumeration kernels apply the same rule
+ * per candidate (csrc/hbpp_rows.hpp: fr_adjust_tr). */
+inline bool tr_adjust(uint64_t cur, uint64_t *nw, uint8_t *occ_orbs, double *matr_el, int spin_parity, uint8_t *symm, unsigned int n_orbs,
+                      const SymmERIs &eris, const Matrix<double> &h_core, unsigned int n_elec, uint8_t n_bytes) {
+    auto flipped = [&](uint64_t d) { uint8_t in[8], out[8] = {0, 0, 0, 0, 0, 0, 0, 0}; memcpy(in, &d, 8); flip_spins(in, out, (uint8_t)n_orbs); uint64_t r = 0; memcpy(&r, out, n_bytes); return r; };
+    auto cmp_bytes = [&](uint64_t a, uint64_t b) { return memcmp(&a, &b, n_bytes); };
+    double norm = flipped(cur) == cur ? sqrt(2) : 1;
+    const uint64_t img = flipped(*nw);
+    if (img == cur) { *matr_el = 0; return false; }
+    const int cmp = cmp_bytes(*nw, img);
+    if (cmp == 0) {
+        if (spin_parity == -1) { *matr_el = 0; return false; }
+        *matr_el *= 2;
+        norm *= sqrt(2);
+    }
+    else {
+        uint8_t d[4], cb[8], ib[8];
+        memcpy(cb, &cur, 8); memcpy(ib, &img, 8);
+        const uint8_t n_diff = find_diff_bits(cb, ib, d, n_bytes);
+        if (n_diff == 2 && symm[d[0] % n_orbs] == symm[d[1] % n_orbs]) {
+            if (read_bit(cb, d[1])) std::swap(d[0], d[1]);
+            double rev = sing_matr_el_nosgn(d, occ_orbs, n_orbs, eris, h_core, 0, n_elec);
+            rev *= sing_parity(cb, d);
+            *matr_el += rev * spin_parity;
+            norm *= 2;
+        }
+        // the reference writes `a ^ b ^ c ^ d == 0`, which C++ reads as a ^ b ^ c ^ (d == 0): kept as written
+        else if (n_diff == 4 && (symm[d[0] % n_orbs] ^ symm[d[1] % n_orbs] ^ symm[d[2] % n_orbs] ^ (unsigned)(symm[d[3] % n_orbs] == 0)) != 0) {
+            if (read_bit(cb, d[2])) std::swap(read_bit(cb, d[0]) ? d[1] : d[0], d[2]);
+            if (read_bit(cb, d[3])) std::swap(read_bit(cb, d[0]) ? d[1] : d[0], d[3]);
+            if (d[0] > d[1]) std::swap(d[0], d[1]);
+            if (d[2] > d[3]) std::swap(d[2], d[3]);
+            double rev = doub_matr_el_nosgn(d, n_orbs, eris, 0);
+            rev *= doub_parity(cb, d);
+            *matr_el += rev * spin_parity;
+            norm *= 2;
+        }
+    }
+    if (cmp > 0) norm *= spin_parity;
+    *matr_el /= norm;
+    if (cmp > 0) *nw = img;
+    return true;
+}
+}
+
 /* vec[dest_idx] = (id_fac + h_fac * H_ii) vec[curr]  (molecule.cpp:205-219) */
 inline void h_op_diag(DistVec<double> &vec, uint8_t dest_idx, double id_fac, double h_fac) {
     double *vals_before_mult = vec.values();
@@ -146,7 +197,6 @@ inline void h_op_diag(DistVec<double> &vec, uint8_t dest_idx, double id_fac, dou
 inline void h_op_offdiag(DistVec<double> &vec, size_t vec_size, uint8_t *symm, unsigned int n_orbs, const SymmERIs &eris, const Matrix<double> &h_core,
                          uint8_t *orbs_scratch, size_t scratch_size, unsigned int n_frozen, unsigned int n_elec, uint8_t dest_idx, double h_fac, int spin_parity) {
     fries_hip::check_mol(&eris, &h_core, n_frozen);
-    if (spin_parity) throw std::runtime_error("h_op_offdiag: time-reversal symmetrised vectors (spin_parity != 0) are not supported by this build");
     if (vec.bound()) throw std::runtime_error("h_op_offdiag on the device-bound vector: use the engine's frifull path (fries_frifull_iterate)");
     if (vec.num_vecs() <= dest_idx) throw std::runtime_error("The dest_idx argument exceeds the number of vectors stored in this object.");
     fries_ctx *cx = fries_hip::Backend::get().ctx();
@@ -155,6 +205,7 @@ inline void h_op_offdiag(DistVec<double> &vec, size_t vec_size, uint8_t *symm, u
     std::vector<uint64_t> dets; std::vector<double> els; std::vector<int32_t> sgn; std::vector<uint8_t> orbs4;
     for (int pass = 0; pass < 2; pass++) {
         size_t det_idx = 0, ex_idx = 0, n_ex_det = 0;
+        uint8_t *occ_now = nullptr;
         double curr_el = 0;
         uint64_t curr_word = 0;
         int keep_going = 1;
@@ -170,6 +221,7 @@ inline void h_op_offdiag(DistVec<double> &vec, size_t vec_size, uint8_t *symm, u
                     if (curr_el == 0) { det_idx++; continue; }
                     uint8_t *curr_det = vec.indices()[det_idx];
                     uint8_t *occ_orbs = vec.orbs_at_pos(det_idx);
+                    occ_now = occ_orbs;
                     n_ex_det = pass == 0 ? sing_ex_symm(curr_det, occ_orbs, n_elec, n_orbs, (uint8_t (*)[2])orbs_scratch, symm)
                                          : doub_ex_symm(curr_det, occ_orbs, n_elec, n_orbs, (uint8_t (*)[4])orbs_scratch, symm);
                     if (n_ex_det * (pass == 0 ? 2 : 4) > scratch_size) {
@@ -192,10 +244,11 @@ inline void h_op_offdiag(DistVec<double> &vec, size_t vec_size, uint8_t *symm, u
                 const uint8_t *o = &orbs4[4 * ex_idx];
                 if (pass == 0) new_word = (new_word & ~(1ull << o[0])) | (1ull << o[1]);
                 else new_word = (new_word & ~(1ull << o[0]) & ~(1ull << o[1])) | (1ull << o[2]) | (1ull << o[3]);
-                uint8_t new_det[8];
-                memcpy(new_det, &new_word, 8);
                 ex_idx++;
                 keep_going = 1;
+                if (spin_parity && !fries_hip::tr_adjust(curr_word, &new_word, occ_now, &matr_el, spin_parity, symm, n_orbs, eris, h_core, n_elec, n_bytes)) continue;
+                uint8_t new_det[8];
+                memcpy(new_det, &new_word, 8);
                 matr_el *= curr_el * h_fac;
                 if (!vec.add(new_det, matr_el, 1)) break;
             }

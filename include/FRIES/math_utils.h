@@ -20,10 +20,14 @@ static inline uint8_t find_bits(const uint8_t *bit_str, uint8_t *bits, uint8_t n
     for (uint8_t b = 0; b < n_bytes; b++) for (uint8_t k = 0; k < 8; k++) if (bit_str[b] & (1u << k)) bits[n++] = (uint8_t)(8 * b + k);
     return n;
 }
-/* positions where str1 has a 1 and str2 a 0 (math_utils.c:101-144) */
+/* positions where the two strings differ, ascending; their number, or UINT8_MAX when they differ in more than four places
+ * (math_utils.c:100-143) */
 static inline uint8_t find_diff_bits(const uint8_t *str1, const uint8_t *str2, uint8_t *bits, uint8_t n_bytes) {
     uint8_t n = 0;
-    for (uint8_t b = 0; b < n_bytes; b++) { uint8_t d = (uint8_t)(str1[b] & ~str2[b]); for (uint8_t k = 0; k < 8; k++) if (d & (1u << k)) bits[n++] = (uint8_t)(8 * b + k); }
+    for (uint8_t b = 0; b < n_bytes; b++) {
+        const uint8_t x = (uint8_t)(str1[b] ^ str2[b]);
+        for (uint8_t k = 0; k < 8; k++) if (x & (1u << k)) { if (n == 4) return UINT8_MAX; bits[n++] = (uint8_t)(8 * b + k); }
+    }
     return n;
 }
 /* number of 1 bits strictly between positions a and b (math_utils.c:9-58) */

@@ -281,6 +281,15 @@ int fries_vec_add_vecs(fries_ctx *ctx, int idx1, int idx2, double c);
 int fries_vec_diag_download(fries_ctx *ctx, double *out, size_t cap, size_t *n);
 int fries_vec_dot_list(fries_ctx *ctx, int column, const uint64_t *dets, const double *vals, size_t n, double *out);
 int fries_htrial_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t cap, size_t *n);
+/* Time-reversal symmetry: vectors that hold one representative of every pair {determinant, its spin-flipped image} (the spin_parity = +-1
+ * argument of the reference's h_op_offdiag and apply_HBPP_piv, FRIES/Hamiltonians/molecule.cpp:298-369, 472-552, heat_bathPP.cpp:1326-1407;
+ * flip_spins, FRIES/fci_utils.c:158-204).  fries_set_spin_parity(ctx, +-1) makes every full enumeration of H on this context (H * trial at
+ * setup, fries_frifull_iterate, the dense block of --det_space, fries_h_offdiag_list) and fries_apply_hbpp_piv (unnormalised heat bath
+ * only, as in the reference) form the elements between the symmetrised functions; 0 switches it off.
+ * fries_h_offdiag_list: h_op_offdiag(vec, dest_idx 1, h_fac 1, spin_parity) on a fresh two-column vector holding the list in column 0
+ * (molecule.cpp:448-665): the stored determinants in position order with column 1. */
+int fries_set_spin_parity(fries_ctx *ctx, int spin_parity);
+int fries_h_offdiag_list(fries_ctx *ctx, const uint64_t *dets, const double *vals, size_t n, uint64_t *out_dets, double *out_vals, size_t cap, size_t *n_out);
 
 /* The hot-path operators one by one, on the context's solution vector. */
 /* apply_HBPP_sys (heat_bathPP.cpp:686-992) with the five uniforms it would draw; outputs as
@@ -288,7 +297,7 @@ int fries_htrial_download(fries_ctx *ctx, uint64_t *dets, double *vals, size_t c
  * tests/test_hamiltonian.cpp:493-500. */
 int fries_apply_hbpp_sys(fries_ctx *ctx, uint32_t n_samp, const double rn[5], int unit_matrel,
                          uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out, uint32_t comp_len[5]);
-/* apply_HBPP_piv (heat_bathPP.cpp:1014-1419, spin_parity 0): every factor multiplied out into the long vector, compressed by
+/* apply_HBPP_piv (heat_bathPP.cpp:1014-1419; spin_parity = what fries_set_spin_parity set): every factor multiplied out into the long vector, compressed by
  * piv_comp_parallel to n_samp elements and collapsed; outputs as comp_scratch->{det_indices2, orb_indices1, vec1}.  The uniforms
  * come from the context's generator in the reference's order (seed it with fries_frisys_restart), because their number
  * depends on the data.  stage_len[k] = elements after the k-th compression.  One factor may expand to at most 33.5e6 values. */

@@ -1155,7 +1155,91 @@ double Vec::dot(const std::vector<det_t> &d2, const std::vector<double> &v2) con
 }
 
 // ------------------------------------------------------------------ deterministic H application, frifull_mol
-size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, double h_fac) {
+det_t flip_spins(det_t det, unsigned n_orb) {
+    const det_t half = n_orb >= 64 ? ~0ull : (1ull << n_orb) - 1ull;
+    det_t out = n_orb >= 32 ? (det >> 32) | (det << 32) : ((det >> n_orb) & half) | ((det & half) << n_orb);
+    // The reference's byte loop (fci_utils.c:173-178) is off by one byte when the strings are whole bytes long and at least three of them
+    // (n_orb = 24, 32): bytes mid + 1 .. n_bytes - 2 of the result receive alpha byte b - mid - 1 instead of b - mid.  Kept: a vector
+    // symmetrised by the reference is symmetrised under THIS map.
+    if (n_orb % 8 == 0 && n_orb >= 24) {
+        const unsigned mid = n_orb / 8, nb = 2 * mid;
+        for (unsigned b = mid + 1; b + 1 < nb; b++) out = (out & ~(0xffull << (8 * b))) | (((det >> (8 * (b - mid - 1))) & 0xffull) << (8 * b));
+    }
+    return out;
+}
+int det_memcmp(det_t a, det_t b) {
+    const det_t x = a ^ b;
+    if (!x) return 0;
+    const int byte = __builtin_ctzll(x) >> 3;
+    return ((a >> (8 * byte)) & 255ull) > ((b >> (8 * byte)) & 255ull) ? 1 : -1;
+}
+int tr_doub_connect(const uint8_t *occ, unsigned n_orb, unsigned n_elec, uint8_t *diff_idx) {
+    const unsigned half = n_elec / 2;
+    bool same = true;
+    for (unsigned k = 0; k < half && same; k++) same = occ[k] == occ[half + k] - n_orb;
+    if (same) return 0;
+    unsigned i1 = 0, i2 = 0;
+    bool s1 = false, s2 = false;
+    while (i1 < half && i2 < half) {
+        const int diff = (int)occ[i1] - (int)(occ[half + i2] - n_orb);
+        if (diff == 0) { i1++; i2++; }
+        else if (diff > 0) { if (s2) return 2; s2 = true; diff_idx[1] = (uint8_t)(half + i2); i2++; }
+        else { if (s1) return 2; s1 = true; diff_idx[0] = (uint8_t)i1; i1++; }
+    }
+    if (i1 < half) diff_idx[0] = (uint8_t)i1;
+    else if (i2 < half) diff_idx[1] = (uint8_t)(half + i2);
+    return 1;
+}
+int adjust_tr(const MolSys &sys, det_t cur, det_t nd, const uint8_t *occ, double *matr_el, int spin_parity, det_t *target, bool unit_matrel,
+              const std::function<void(int, const uint8_t *)> &weight_fix) {
+    const unsigned n = sys.n_orb;
+    const uint8_t *irr = sys.symm.irrep.data();
+    double norm = flip_spins(cur, n) == cur ? sqrt(2) : 1;               // i == i'
+    const det_t img = flip_spins(nd, n);
+    if (img == cur) { *matr_el = 0; return 0; }                            // (part of the diagonal)
+    const int cmp = det_memcmp(nd, img);
+    if (cmp == 0) {                                                         // j == j'
+        if (spin_parity == -1) { *matr_el = 0; return 0; }
+        *matr_el *= 2;
+        norm *= sqrt(2);
+    }
+    else {
+        const det_t x = cur ^ img;
+        const int n_diff = __builtin_popcountll(x);
+        uint8_t d[4] = {0, 0, 0, 0};
+        if (n_diff <= 4) { int k = 0; for (det_t y = x; y; y &= y - 1) d[k++] = (uint8_t)__builtin_ctzll(y); }
+        if (n_diff == 2) {
+            if (irr[d[0] % n] == irr[d[1] % n]) {
+                if (bit(cur, d[1])) std::swap(d[0], d[1]);
+                if (weight_fix) weight_fix(1, d);
+                double rev = unit_matrel ? 1.0 : sing_matrel_nosgn(d, occ, sys.ints, sys.n_elec);
+                rev *= sing_parity(cur, d);
+                *matr_el += rev * spin_parity;
+                if (!weight_fix) norm *= 2;             // h_op_offdiag: two excitations give this determinant (molecule.cpp:326); apply_HBPP_piv adds their probabilities instead
+            }
+        }
+        else if (n_diff == 4) {
+            // the reference writes `a ^ b ^ c ^ d == 0`, which C++ reads as a ^ b ^ c ^ (d == 0): kept as written
+            if ((irr[d[0] % n] ^ irr[d[1] % n] ^ irr[d[2] % n] ^ (unsigned)(irr[d[3] % n] == 0)) != 0) {
+                if (bit(cur, d[2])) { if (bit(cur, d[0])) std::swap(d[1], d[2]); else std::swap(d[0], d[2]); }
+                if (bit(cur, d[3])) { if (bit(cur, d[0])) std::swap(d[1], d[3]); else std::swap(d[0], d[3]); }
+                if (d[0] > d[1]) std::swap(d[0], d[1]);
+                if (d[2] > d[3]) std::swap(d[2], d[3]);
+                if (weight_fix) weight_fix(2, d);
+                double rev = unit_matrel ? 1.0 : doub_matrel_nosgn(d, sys.ints);
+                rev *= doub_parity(cur, d);
+                *matr_el += rev * spin_parity;
+                if (!weight_fix) norm *= 2;
+            }
+        }
+    }
+    if (cmp > 0) norm *= spin_parity;
+    *matr_el /= norm;
+    *target = cmp > 0 ? img : nd;
+    return 1;
+}
+
+size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, double h_fac, int spin_parity) {
     const unsigned n_elec = sys.n_elec, n_orb = sys.n_orb;
     const unsigned origin = v.cur;
     std::vector<uint8_t> ex;
@@ -1189,6 +1273,7 @@ size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, d
                 else { m = doub_matrel_nosgn(&ex[4 * ex_idx], sys.ints); m *= doub_det_parity(&nd, &ex[4 * ex_idx]); }
                 ex_idx++;
                 keep_going = 1;
+                if (spin_parity) { det_t tgt = nd; if (!adjust_tr(sys, cur_det, nd, occ, &m, spin_parity, &tgt)) continue; nd = tgt; }
                 m *= cur_el * h_fac;
                 n_calls++;
                 if (!v.add(nd, m, 1)) break;
@@ -1508,7 +1593,8 @@ static size_t collapse_long(std::vector<double> &short_vec, const std::vector<do
 }
 
 void apply_HBPP_piv(const Vec &v, HBPivScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
-                    std::mt19937 &mt, uint32_t n_samp, bool unit_matrel, const Comm &cm) {
+                    std::mt19937 &mt, uint32_t n_samp, bool unit_matrel, const Comm &cm, int spin_parity) {
+    if (spin_parity && !new_hb) throw std::runtime_error("Time-reversal symmetry is only implemented for the unnormalized heat-bath distribution");      // :1019-1021
     std::vector<double> &sv = sc.vec1, &lv = sc.long_vec;
     size_t n_short = sc.vec_len;
     std::vector<size_t> &di1 = sc.det_idx1, &di2 = sc.det_idx2;
@@ -1680,6 +1766,15 @@ void apply_HBPP_piv(const Vec &v, HBPivScratch &sc, const MolSys &sys, double p_
                 tw = (1 - p_doub) / n_occ / oi2[s][3];
                 mel = unit_matrel ? 1.0 : sing_matrel_nosgn(oi1[n_short], occ, sys.ints, n_elec);
                 mel *= sing_parity(cd, oi1[n_short]);
+            }
+            if (spin_parity) {          // :1326-1407: the element between the symmetrised functions, the image's probability added to the weight
+                det_t nd = oi2[s][0] == 0 ? doub_det(cd, oi1[n_short]) : sing_det(cd, oi1[n_short]), tgt;
+                count_symm_virt(cts, occ, n_elec, symm);
+                auto fix = [&](int kind, const uint8_t *d) {
+                    if (kind == 1) { const unsigned n_occ = count_sing_allowed(occ, n_elec, symm, cts); const unsigned n_virt = cts[symm.irrep[d[0] % n_orb]][0]; tw += (1 - p_doub) / n_occ / n_virt; }
+                    else tw += calc_unnorm_wt(hb, d) * p_doub;
+                };
+                if (!adjust_tr(sys, cd, nd, occ, &mel, spin_parity, &tgt, unit_matrel, fix)) continue;
             }
             double el = lv[li] * mel / tw;
             if (fabs(el) > 1e-12) { sv[n_short] = el; n_short++; }

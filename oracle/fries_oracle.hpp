@@ -254,7 +254,7 @@ struct HBPivScratch {
     void init(size_t length, size_t n_subwt);
 };
 void apply_HBPP_piv(const Vec &v, HBPivScratch &sc, const MolSys &sys, double p_doub, bool new_hb,
-                    std::mt19937 &mt, uint32_t n_samp, bool unit_matrel, const Comm &cm = Comm::self());
+                    std::mt19937 &mt, uint32_t n_samp, bool unit_matrel, const Comm &cm = Comm::self(), int spin_parity = 0);
 
 // ---------------------------------------------------------------- driver loop
 struct FrisysParams {
@@ -307,7 +307,19 @@ struct Frisys {
 // FRIES/Hamiltonians/molecule.cpp:448-665 without time-reversal symmetry (spin_parity 0): every symmetry-allowed single
 // excitation of every stored determinant, then every double, each added to column dest as value * h_fac * <j|H|i>.
 // Returns the number of add() calls.
-size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, double h_fac);
+size_t h_op_offdiag(Vec &v, size_t vec_size, const MolSys &sys, unsigned dest, double h_fac, int spin_parity = 0);
+// Time-reversal symmetry (spin_parity = +-1: the vector holds one representative of every pair {determinant, its spin-flipped image}).
+// FRIES/fci_utils.c:158-204 (flip_spins: alpha and beta strings trade places), :310-359 (tr_doub_connect), and the adjust_tr lambda of
+// h_op_offdiag (FRIES/Hamiltonians/molecule.cpp:298-369, 472-552): a matrix element <new|H|cur> becomes the element between the
+// symmetrised functions -- the image's contribution added with the parity, norms of self-paired functions, and the representative (the
+// byte-wise smaller of new and its image) as the target.  Returns 0: no contribution; 1: add to *target.
+det_t flip_spins(det_t det, unsigned n_orb);
+int det_memcmp(det_t a, det_t b);            // memcmp over the little-endian byte string
+int tr_doub_connect(const uint8_t *occ, unsigned n_orb, unsigned n_elec, uint8_t *diff_idx);
+// weight_fix (optional): called with (kind 1 single / 2 double, reordered diff orbitals) when the image contributes (apply_HBPP_piv adds
+// the image's selection probability to the weight there, heat_bathPP.cpp:1363, 1395)
+int adjust_tr(const MolSys &sys, det_t cur, det_t nd, const uint8_t *occ, double *matr_el, int spin_parity, det_t *target, bool unit_matrel = false,
+              const std::function<void(int, const uint8_t *)> &weight_fix = nullptr);
 // molecule.cpp:205-219
 void h_op_diag(Vec &v, unsigned dest, double id_fac, double h_fac, const MolSys &sys);
 struct FrifullParams { double eps = 0.01, target_norm = 0; uint32_t vec_nonz = 0; size_t max_dets = 0; uint32_t seed = 0; };

@@ -94,6 +94,17 @@ HBPIV_RUNS = {
 }
 
 
+# Time-reversal symmetry (spin_parity = +-1).  tr_*: h_op_offdiag with both parities on a small source vector (ref_harness tr; the harness also
+# checks flip_spins / tr_doub_connect there): name -> (shape, seed, n_src).  hbpiv_*_trp / _trm: apply_HBPP_piv with spin_parity +1 / -1
+# (unnormalised heat bath only, heat_bathPP.cpp:1019): name -> (run in RUNS, n_iter, parity, cases).  H2O-shaped systems (24 orbitals) are left out:
+# the reference's flip_spins is off by one byte for n_orb = 24 and 32 and its own h_op_offdiag then aborts on an invalid determinant.
+TR_RUNS = {"tr_n2": ("N2", 5, 5), "tr_ne": ("Ne", 9, 6)}
+HBPIV_TR_RUNS = {
+    "hbpiv_ne_unnorm_trp": ("ne_m2000_unnorm", 30, 1, [(1500, 11), (400, 12)]),
+    "hbpiv_ne_unnorm_trm": ("ne_m2000_unnorm", 30, -1, [(1500, 11), (3000, 13)]),
+    "hbpiv_n2_unnorm_trp": ("n2_m10000_unnorm_ini0", 20, 1, [(3000, 1)]),
+}
+
 # frimulti_mol (multinomial matrix compression, --distribution HB), one rank: name -> (shape, n_iter, seed, eps, vec_nonz, mat_nonz, max_dets, initiator, target)
 MULTI_RUNS = {
     "multi_ne_m1000": ("Ne", 60, 11, 0.01, 1000, 5000, 50000, 1.0, 500.0),
@@ -302,6 +313,28 @@ def gen_hbpiv(manifest):
             manifest["hbpiv_runs"][name] = dict(run=run, n_iter=n_iter, cases=[list(c) for c in cases])
 
 
+def gen_tr(manifest):
+    manifest["tr_runs"] = {}
+    manifest["hbpiv_tr_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (shape, seed, n_src) in TR_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            subprocess.run([HARNESS, "tr", path, mol.point_group, str(seed), str(n_src), os.path.join(GOLD, name + ".txt")], check=True)
+            manifest["tr_runs"][name] = dict(shape=shape, seed=seed, n_src=n_src)
+        for name, (run, n_iter, parity, cases) in HBPIV_TR_RUNS.items():
+            shape, _, seed, eps, vnz, mnz, maxd, ini, tgt, dist, _ = RUNS[run]
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            cmd = [HARNESS, "hbpiv", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist, os.path.join(GOLD, name + ".txt")]
+            for ns, ps in cases:
+                cmd += [str(ns), str(ps)]
+            subprocess.run(cmd, check=True, env=dict(os.environ, FRIES_SPIN_PARITY=str(parity)))
+            manifest["hbpiv_tr_runs"][name] = dict(run=run, n_iter=n_iter, spin_parity=parity, cases=[list(c) for c in cases])
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-reload":
         with open(os.path.join(GOLD, "manifest.json")) as f:
@@ -335,6 +368,13 @@ def main():
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
         {"--only-multi": gen_multi, "--only-fp": gen_fp, "--only-hhfull": gen_hhfull}[sys.argv[1]](manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-tr":
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_tr(manifest)
         with open(os.path.join(GOLD, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
@@ -471,6 +511,7 @@ def main():
     gen_pin(manifest)
     gen_hh_scale(manifest)
     gen_reload(manifest)
+    gen_tr(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("golden fixtures written to", GOLD)

@@ -159,6 +159,21 @@ size_t fo_apply_hbpp_sys(void *h, uint32_t n_samp, const double *rn, int unit_ma
     if (cap >= n) for (size_t i = 0; i < n; i++) { pos[i] = (uint32_t)sc.det_idx2[i]; memcpy(orbs + 4 * i, &sc.orb1[4 * i], 4); vals[i] = sc.vec1[i]; }
     return n;
 }
+// time-reversal symmetry for the calls below (spin_parity of the reference's h_op_offdiag / apply_HBPP_piv)
+static int g_spin_parity = 0;
+void fo_set_spin_parity(int sp) { g_spin_parity = sp; }
+// h_op_offdiag(vec, dest 1, h_fac 1, spin parity) on a fresh two-column vector holding (dets, vals): stored determinants and column 1
+size_t fo_h_offdiag_list(void *h, const uint64_t *dets, const double *vals, size_t n, uint64_t *out_dets, double *out_vals, size_t cap) {
+    Frisys *f = (Frisys *)h;
+    const size_t room = n * ((size_t)f->sys.n_orb * f->sys.n_orb * f->sys.n_elec * f->sys.n_elec + 2) + 64;
+    Vec v; v.init(room, room, f->sys.n_elec, 2);
+    for (size_t i = 0; i < n; i++) v.add(dets[i], vals[i], 1);
+    v.perform_add(0);
+    h_op_offdiag(v, v.curr_size, f->sys, 1, 1.0, g_spin_parity);
+    if (v.curr_size > cap) return (size_t)-1;
+    for (size_t i = 0; i < v.curr_size; i++) { out_dets[i] = v.dets[i]; out_vals[i] = v.vals[1][i]; }
+    return v.curr_size;
+}
 // apply_HBPP_piv on the handle's stored vector, drawing from the handle's generator (seed it with fo_frisys_restart)
 size_t fo_apply_hbpp_piv(void *h, uint32_t n_samp, int unit_matrel, uint32_t *pos, uint8_t *orbs, double *vals, size_t cap, uint64_t *stage_len) {
     Frisys *f = (Frisys *)h;
@@ -170,7 +185,7 @@ size_t fo_apply_hbpp_piv(void *h, uint32_t n_samp, int unit_matrel, uint32_t *po
     std::copy(f->sol.vals[0].begin(), f->sol.vals[0].begin() + n, ps.vec1.begin());
     for (size_t i = 0; i < n; i++) ps.det_idx1[i] = i;
     ps.vec_len = n;
-    apply_HBPP_piv(f->sol, ps, f->sys, f->p_doub, f->par.new_hb, f->mt, n_samp, unit_matrel != 0);
+    apply_HBPP_piv(f->sol, ps, f->sys, f->p_doub, f->par.new_hb, f->mt, n_samp, unit_matrel != 0, Comm::self(), g_spin_parity);
     size_t m = ps.vec_len;
     if (cap >= m) for (size_t i = 0; i < m; i++) { pos[i] = (uint32_t)ps.det_idx2[i]; memcpy(orbs + 4 * i, &ps.orb1[4 * i], 4); vals[i] = ps.vec1[i]; }
     if (stage_len) for (int k = 0; k < 5; k++) stage_len[k] = ps.stage_len[k];

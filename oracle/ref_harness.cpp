@@ -849,12 +849,13 @@ static int run_hbpiv(int argc, char **argv) {
         for (size_t i = 0; i < n; i++) pv.det_indices1[i] = i;
         pv.vec_len = n;
         std::mt19937 m1(pseed), m2(pseed);
-        apply_HBPP_piv(rr.sol->occ_orbs(), rr.sol->indices(), &pv, rr.hb, rr.basis_symm, rr.p_doub, nhb, m1, n_samp, rr.sing_sc, rr.doub_sc, 0);
+        const int spin_parity = getenv("FRIES_SPIN_PARITY") ? atoi(getenv("FRIES_SPIN_PARITY")) : 0;       // time-reversal symmetry (heat_bathPP.cpp:1326-1407)
+        apply_HBPP_piv(rr.sol->occ_orbs(), rr.sol->indices(), &pv, rr.hb, rr.basis_symm, rr.p_doub, nhb, m1, n_samp, rr.sing_sc, rr.doub_sc, spin_parity);
         fo::HBPivScratch ps; ps.init(len, n_states);
         std::copy(fr.sol.vals[0].begin(), fr.sol.vals[0].begin() + n, ps.vec1.begin());
         for (size_t i = 0; i < n; i++) ps.det_idx1[i] = i;
         ps.vec_len = n;
-        fo::apply_HBPP_piv(fr.sol, ps, fr.sys, fr.p_doub, nhb, m2, n_samp, false);
+        fo::apply_HBPP_piv(fr.sol, ps, fr.sys, fr.p_doub, nhb, m2, n_samp, false, fo::Comm::self(), spin_parity);
         CHECK(ps.vec_len == pv.vec_len, "hbpiv n_samp %u len %zu %zu", n_samp, ps.vec_len, (size_t)pv.vec_len);
         CHECK(m1() == m2(), "hbpiv n_samp %u generator state", n_samp);
         size_t bad = 0;
@@ -868,6 +869,86 @@ static int run_hbpiv(int argc, char **argv) {
     }
     fclose(f);
     printf("HBPIV checks=%d fails=%d\n", n_chk, n_fail);
+    return n_fail != 0;
+}
+
+// ------------------------------------------------------------------ time-reversal symmetry (spin_parity = +-1)
+// tr <fcidump> <pg> <seed> <n_src> <out>
+// Function level: flip_spins (fci_utils.c:158-204) on random determinants for every n_orb in 5 .. 32, tr_doub_connect (:310-359) on random
+// occupied lists.  Operator level: h_op_offdiag (molecule.cpp:448-665) with spin_parity +1 and -1 applied to a vector of n_src determinants
+// (HF and the first determinants H connects it to, random values) -- reference against restatement, result written to <out>:
+// SRC lines (determinant value), then for each parity a PARITY line and the stored (determinant value) pairs of column 1 in position order.
+static int run_tr(int argc, char **argv) {
+    if (argc < 7) { fprintf(stderr, "usage: tr <fcidump> <pg> <seed> <n_src> <out>\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    uint32_t seed = strtoul(argv[4], 0, 10); size_t n_src = strtoull(argv[5], 0, 10);
+    std::mt19937 rg(seed);
+    for (unsigned no = 5; no <= 32; no++) {
+        const unsigned nb = CEILING(2 * no, 8);
+        for (int trial = 0; trial < 400; trial++) {
+            fo::det_t d = ((fo::det_t)rg() << 32 | rg());
+            if (2 * no < 64) d &= ((fo::det_t)1 << (2 * no)) - 1;
+            uint8_t in[9] = {0}, out[9] = {0};
+            memcpy(in, &d, 8);
+            flip_spins(in, out, (uint8_t)no);
+            fo::det_t r = 0; memcpy(&r, out, nb);
+            if (2 * no < 64) r &= ((fo::det_t)1 << (2 * no)) - 1;
+            CHECK(r == fo::flip_spins(d, no), "flip_spins n_orb %u det %" PRIx64 ": %" PRIx64 " vs %" PRIx64, no, (uint64_t)d, (uint64_t)r, (uint64_t)fo::flip_spins(d, no));
+        }
+    }
+    fcidump_input *in = parse_fcidump(path, pg);
+    const unsigned n_orb = in->n_orb_, n_elec = in->n_elec;
+    const size_t det_size = CEILING(2 * n_orb, 8);
+    for (int trial = 0; trial < 4000; trial++) {
+        uint8_t occ[64]; unsigned k = 0;
+        for (int sp = 0; sp < 2; sp++) { std::vector<unsigned> o; while (o.size() < n_elec / 2) { unsigned c = rg() % n_orb; if (std::find(o.begin(), o.end(), c) == o.end()) o.push_back(c); }
+            if (sp == 1 && trial % 3 == 0) { for (unsigned q = 0; q < n_elec / 2; q++) o[q] = occ[q]; if (trial % 6 == 0) o[rg() % (n_elec / 2)] = rg() % n_orb; std::sort(o.begin(), o.end()); o.erase(std::unique(o.begin(), o.end()), o.end()); while (o.size() < n_elec / 2) { unsigned c = rg() % n_orb; if (std::find(o.begin(), o.end(), c) == o.end()) o.push_back(c); } }
+            std::sort(o.begin(), o.end()); for (unsigned q : o) occ[k++] = (uint8_t)(q + sp * n_orb); }
+        uint8_t d1[2] = {77, 77}, d2[2] = {77, 77};
+        int r1 = tr_doub_connect(occ, n_orb, n_elec, d1), r2 = fo::tr_doub_connect(occ, n_orb, n_elec, d2);
+        CHECK(r1 == r2 && (r1 != 1 || (d1[0] == d2[0] && d1[1] == d2[1])), "tr_doub_connect %d %d", r1, r2);
+    }
+    // the source vector: HF and what H connects it to, random values
+    Matrix<double> *h_core = in->hcore; SymmERIs *eris = &in->eris;
+    std::vector<uint32_t> pscr(2 * n_orb), vscr(2 * n_orb);
+    for (auto &x : pscr) x = rg();
+    for (auto &x : vscr) x = rg();
+    fo::MolSys sys; sys.n_orb = n_orb; sys.n_elec = n_elec;
+    fill_oracle_ints(sys.ints, *eris, *h_core, n_orb);
+    sys.symm.init(in->symm, n_orb);
+    uint8_t hf_det[8] = {0}, occ[64];
+    gen_hf_bitstring(n_orb, n_elec, hf_det);
+    find_bits(hf_det, occ, det_size);
+    std::vector<uint8_t> ex(4 * (size_t)n_orb * n_orb * n_elec * n_elec);
+    std::vector<fo::det_t> src; std::vector<double> val;
+    src.push_back(to_u64(hf_det, det_size));
+    size_t nd = doub_ex_symm(hf_det, occ, n_elec, n_orb, (uint8_t (*)[4])ex.data(), in->symm);
+    for (size_t e = 0; e < nd && src.size() < n_src; e += 3) { uint8_t nw[8]; memcpy(nw, hf_det, 8); doub_det(nw, &ex[4 * e]); src.push_back(to_u64(nw, det_size)); }
+    for (size_t i = 0; i < src.size(); i++) val.push_back((rg() % 2001 - 1000.0) / 250.0 + 0.013);
+    FILE *f = fopen(argv[6], "w");
+    fprintf(f, "# time-reversal symmetry through the reference: h_op_offdiag (molecule.cpp:448-665) with spin_parity +1 / -1 on the SRC vector; doubles as C99 hex floats\n");
+    for (size_t i = 0; i < src.size(); i++) fprintf(f, "SRC %" PRIu64 " %a\n", (uint64_t)src[i], val[i]);
+    const size_t cap = src.size() * (size_t)n_orb * n_orb * n_elec * n_elec + 64;
+    for (int sp = 1; sp >= -1; sp -= 2) {
+        std::function<double(const uint8_t *)> diag_sc = [n_orb, eris, h_core, n_elec](const uint8_t *o) { return diag_matrel(o, n_orb, *eris, *h_core, 0, n_elec); };
+        DistVec<double> rv(cap, cap, n_orb * 2, n_elec, 1, diag_sc, 2, pscr, vscr);
+        fo::Vec ov; ov.init(cap, cap, n_elec, 2);
+        for (size_t i = 0; i < src.size(); i++) { uint8_t d[8]; memcpy(d, &src[i], 8); rv.add(d, val[i], 1); ov.add(src[i], val[i], 1); }
+        rv.perform_add(0); ov.perform_add(0);
+        std::vector<uint8_t> scratch(4 * (size_t)n_orb * n_orb * n_elec * n_elec);
+        h_op_offdiag(rv, in->symm, n_orb, *eris, *h_core, scratch.data(), scratch.size(), 0, n_elec, 1, 1.0, sp);
+        fo::h_op_offdiag(ov, ov.curr_size, sys, 1, 1.0, sp);
+        CHECK(rv.curr_size() == ov.curr_size, "tr h_op parity %d sizes %zu %zu", sp, (size_t)rv.curr_size(), ov.curr_size);
+        rv.set_curr_vec_idx(1);
+        size_t bad = 0, n = std::min((size_t)rv.curr_size(), ov.curr_size);
+        for (size_t i = 0; i < n; i++) if (to_u64(rv.indices()[i], det_size) != ov.dets[i] || !same_bits(rv.values()[i], ov.vals[1][i])) bad++;
+        CHECK(bad == 0, "tr h_op parity %d: %zu entries differ", sp, bad);
+        fprintf(f, "PARITY %d %zu\n", sp, (size_t)rv.curr_size());
+        for (size_t i = 0; i < rv.curr_size(); i++) fprintf(f, "%" PRIu64 " %a\n", (uint64_t)to_u64(rv.indices()[i], det_size), rv.values()[i]);
+        printf("TR parity %d: %zu stored, %zu differ\n", sp, (size_t)rv.curr_size(), bad);
+    }
+    fclose(f);
+    printf("TR checks=%d fails=%d\n", n_chk, n_fail);
     return n_fail != 0;
 }
 
@@ -2024,6 +2105,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "pin")) rc = run_pin(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "reload")) rc = run_reload(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "tr")) rc = run_tr(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "hh")) rc = run_hh(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "fciqmc")) rc = run_fciqmc(argc, argv);
     else if (argc >= 5 && !strcmp(argv[1], "dump_ints")) rc = run_dump_ints(argv[2], argv[3], argv[4]);

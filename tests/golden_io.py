@@ -144,6 +144,24 @@ def read_hbpiv(name):
     return cases
 
 
+def read_tr(name):
+    """tests/golden/<name>.txt (oracle/ref_harness.cpp: run_tr): the source vector and, for spin parity +1 and -1, what the reference's
+    h_op_offdiag left in column 1 of the vector (stored determinants in position order)."""
+    src_d, src_v, out, cur = [], [], {}, None
+    with open(os.path.join(GOLD, name + ".txt")) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "SRC":
+                src_d.append(int(t[1])); src_v.append(float.fromhex(t[2]))
+            elif t[0] == "PARITY":
+                cur = int(t[1]); out[cur] = ([], [])
+            else:
+                out[cur][0].append(int(t[0])); out[cur][1].append(float.fromhex(t[1]))
+    return np.array(src_d, dtype=np.uint64), np.array(src_v), {k: (np.array(d, dtype=np.uint64), np.array(v)) for k, (d, v) in out.items()}
+
+
 def read_text_vector(prefix):
     """<prefix>dets / <prefix>vals under tests/golden: the reference's text vector format (io_utils.cpp:447-482, 565-586)."""
     with open(os.path.join(GOLD, prefix + "dets")) as f:

@@ -228,6 +228,20 @@ class OracleFrisys:
         n = self.lib.fo_apply_hbpp_sys(self.h, n_samp, _p(rn), int(unit_matrel), _p(pos), _p(orbs), _p(vals), cap)
         return pos[:n].copy(), orbs[:n].copy(), vals[:n].copy()
 
+    def set_spin_parity(self, sp):
+        self.lib.fo_set_spin_parity.argtypes = [C.c_int]
+        self.lib.fo_set_spin_parity(int(sp))
+
+    def h_offdiag_list(self, dets, vals):
+        d = np.ascontiguousarray(dets, dtype=np.uint64); v = np.ascontiguousarray(vals, dtype=np.float64)
+        cap = d.size * (self.mol.n_orb ** 2 * self.mol.n_elec ** 2 + 2) + 64
+        od = np.zeros(cap, dtype=np.uint64); ov = np.zeros(cap)
+        self.lib.fo_h_offdiag_list.restype = C.c_size_t
+        self.lib.fo_h_offdiag_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        n = self.lib.fo_h_offdiag_list(self.h, _p(d), _p(v), d.size, _p(od), _p(ov), cap)
+        assert n != 2 ** 64 - 1
+        return od[:n].copy(), ov[:n].copy()
+
     def apply_hbpp_piv(self, n_samp, unit_matrel=False, cap=None):
         """apply_HBPP_piv on the stored vector with the handle's generator (restart(seed) first): positions, orbitals, values, stage lengths."""
         cap = cap or (max(n_samp, self.vec_info()[0]) * 2 + 64)

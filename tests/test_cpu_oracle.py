@@ -393,6 +393,43 @@ def test_oracle_apply_hbpp_piv_matches_reference(oracle, mols, name):
         assert np.array_equal(pos, c["pos"]) and np.array_equal(orbs, c["orbs"]) and vals.tobytes() == c["val"].tobytes()
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("tr_runs", {})))
+def test_oracle_time_reversal_h_op_offdiag_matches_reference(oracle, mols, name):
+    """Time-reversal symmetry (spin_parity = +-1): fo::h_op_offdiag with the adjust_tr rule against what the reference's h_op_offdiag
+    (molecule.cpp:298-369, 448-665) left in the vector, for both parities: stored determinants in order and values bit for bit.  (The
+    harness that wrote the fixture also ran flip_spins on 400 random strings for every n_orb in 5 .. 32 and tr_doub_connect on 4000 occupied
+    lists, reference against restatement.)"""
+    import numpy as np
+    r = golden_io.manifest()["tr_runs"][name]
+    orc = oracle.OracleFrisys(mols(r["shape"]), epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=1000, seed=1, distribution="HB_unnorm")
+    sd, sv, out = golden_io.read_tr(name)
+    for sp in (1, -1):
+        orc.set_spin_parity(sp)
+        d, v = orc.h_offdiag_list(sd, sv)
+        assert np.array_equal(d, out[sp][0]) and v.tobytes() == out[sp][1].tobytes(), (name, sp)
+    orc.set_spin_parity(0)
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("hbpiv_tr_runs", {})))
+def test_oracle_apply_hbpp_piv_time_reversal_matches_reference(oracle, mols, name):
+    """fo::apply_HBPP_piv with spin_parity = +-1 (heat_bathPP.cpp:1326-1407) against the reference's function on the vector of a golden run."""
+    import numpy as np
+    h = golden_io.manifest()["hbpiv_tr_runs"][name]
+    r = golden_io.manifest()["runs"][h["run"]]
+    orc = oracle.OracleFrisys(mols(r["shape"]), epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"],
+                              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    orc.iterate(h["n_iter"])
+    orc.set_spin_parity(h["spin_parity"])
+    try:
+        for c in golden_io.read_hbpiv(name):
+            orc.restart(c["seed"])
+            pos, orbs, vals, st = orc.apply_hbpp_piv(c["n_samp"])
+            assert len(pos) == c["n_out"] and st.tolist() == c["stage_len"]
+            assert np.array_equal(pos, c["pos"]) and np.array_equal(orbs, c["orbs"]) and vals.tobytes() == c["val"].tobytes()
+    finally:
+        orc.set_spin_parity(0)
+
+
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["multi_runs"]))
 def test_oracle_frimulti_matches_reference(oracle, name):
     """fo::Fciqmc::iterate_multi on the reference's mt19937 stream against the trajectory of the reference's frimulti_mol loop

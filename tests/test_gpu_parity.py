@@ -162,6 +162,46 @@ def test_apply_hbpp_piv_matches_reference(Engine, name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("tr_runs", {})))
+def test_time_reversal_h_op_offdiag_matches_reference(Engine, name):
+    """Time-reversal symmetry on the device (fries_set_spin_parity; k_enum applies the adjust_tr rule per candidate, csrc/hbpp_rows.hpp:
+    fr_adjust_tr): the full off-diagonal action on the fixture's source vector for spin parity +1 and -1 against what the reference's
+    h_op_offdiag left in its vector -- stored determinants in order, values bit for bit."""
+    r = golden_io.manifest()["tr_runs"][name]
+    eng = Engine(fcidump.synthetic(r["shape"]))
+    eng.setup(epsilon=0.01, vec_nonz=100, mat_nonz=100, max_dets=1000, seed=1, distribution="HB_unnorm")
+    sd, sv, out = golden_io.read_tr(name)
+    for sp in (1, -1):
+        eng.set_spin_parity(sp)
+        d, v = eng.h_offdiag_list(sd, sv)
+        assert np.array_equal(d, out[sp][0]), (name, sp, d.size, out[sp][0].size)
+        assert v.tobytes() == out[sp][1].tobytes(), (name, sp, int(np.sum(v != out[sp][1])))
+    eng.set_spin_parity(0)
+    d0, v0 = eng.h_offdiag_list(sd, sv)
+    assert d0.size > out[1][0].size        # without the symmetry both members of every pair are stored
+    eng.close()
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("hbpiv_tr_runs", {})))
+def test_apply_hbpp_piv_time_reversal_matches_reference(Engine, name):
+    """apply_HBPP_piv with spin_parity = +-1 on the device against the reference's function (heat_bathPP.cpp:1326-1407) on the vector of a
+    golden frisys_mol run: positions, orbitals, values bit for bit."""
+    h = golden_io.manifest()["hbpiv_tr_runs"][name]
+    r = golden_io.manifest()["runs"][h["run"]]
+    eng = Engine(fcidump.synthetic(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"],
+              target_norm=r["target_norm"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    eng.iterate(h["n_iter"])
+    eng.set_spin_parity(h["spin_parity"])
+    for c in golden_io.read_hbpiv(name):
+        eng.restart(c["seed"])
+        pos, orbs, vals, sl = eng.apply_hbpp_piv(c["n_samp"])
+        assert sl.tolist() == c["stage_len"] and len(pos) == c["n_out"], (name, c["n_samp"], len(pos), c["n_out"])
+        assert np.array_equal(pos, c["pos"]) and np.array_equal(orbs, c["orbs"])
+        assert vals.tobytes() == c["val"].tobytes(), (name, c["n_samp"], int(np.sum(vals != c["val"])))
+    eng.close()
+
+
 RUNS = [
     ("Ne", dict(epsilon=0.01, vec_nonz=2000, mat_nonz=2000, max_dets=20000, target_norm=1000.0, initiator=1.0, seed=20250215, distribution="HB_unnorm"), 70),
     ("N2", dict(epsilon=0.01, vec_nonz=10000, mat_nonz=10000, max_dets=80000, target_norm=5000.0, initiator=0.0, seed=7, distribution="HB_unnorm"), 40),
