@@ -77,7 +77,7 @@ def cpu_baseline(args, mol, par, dets, vals, run_seed, m):
     import tempfile
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     from fries_amd import fcidump
-    n_cpu = args.cpu_iters if args.cpu_iters > 0 else max(4, min(40, int(14.0 * 1.0e6 / m)))
+    n_cpu = args.cpu_iters if args.cpu_iters > 0 else max(10, min(40, int(14.0 * 1.0e6 / m)))
     if os.path.exists(harness):
         try:
             tmp = tempfile.mkdtemp(prefix="fries_bench_")
@@ -242,23 +242,31 @@ def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, 
         # HBM bytes per launch from the PMC passes kept under profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # command, corrected as MI355X_MICROARCH.md prescribes); mean over the stage instantiations of the kernel
         traffic = None
-        for prof in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic_source = None
+        for prof in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     tk = json.load(f)["kernels"]
                 # the bench's label "k_fks_sweep" is the lean replay = template instantiations <stage, *, 0> of the kernel
-                want_mode = {"k_fks_sweep": ", 0>", "k_fks_sweep_rec": ", 1>", "k_fks_sweep_light": ", 3>", "k_fks_final": ", 2>"}.get(name)
+                want_mode = {"k_fks_sweep": ", 0>", "k_fks_sweep_rec": ", 1>", "k_fks_sweep_light": ", 3>", "k_fks_final": ", 2>", "k_fks_close": ", 4>"}.get(name)
                 kname = "k_fks_sweep" if want_mode else name
                 vals_t = [v["bytes_per_launch"] for k, v in tk.items() if (k.startswith(kname + "<") and (want_mode is None or k.endswith(want_mode))) or k == kname]
                 if vals_t and m == 1_000_000 and world == 1:
                     traffic = float(np.mean(vals_t))
+                    traffic_source = f"profiles/{prof}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in this run"
                     break
             except (OSError, KeyError, ValueError):
                 pass
         result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                              "traffic_source": traffic_source,
                               "avg_launch_us": avg_s * 1e6, "calls_per_iter": calls / args.profile_steps,
                               "share_of_kernel_time": ms / tot_ms, "n_nonz": info[1]}
+        # the other find_keep_sub launches beside the dominant one.  The light replays and the closing pass re-decide only the waves whose
+        # inputs moved beyond their margins, so they have no per-element byte count: reported as time per launch and launches per iteration.
+        result["roofline"]["find_keep_sub_launches"] = {k: {"avg_launch_us": v[0] / v[1] * 1e3, "calls_per_iter": v[1] / args.profile_steps,
+                                                "achieved_GBs": (ALG_BYTES["k_fks_sweep"](units) / (v[0] / v[1] * 1e-3) / 1e9) if (units and k in ("k_fks_sweep", "k_fks_sweep_rec")) else None}
+                                            for k, v in rep.items() if k.startswith("k_fks_") and v[1] > 0}
         # the measured device copy bandwidth of this box beside the nominal peak (read + write of 1 GiB on the
         # engine's stream, HIP events), and the whole iteration / the spawn term against it
         try:
@@ -281,8 +289,16 @@ def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, 
         # fallback where that binary cannot run.  Either way it is a checker / yardstick, never the product path.
         if args.cpu_iters != 0 and world == 1:
             result["cpu_baseline"], ref_log = cpu_baseline(args, mol, par, dets, vals, run_seed, m)
-            if first_logs is not None and ref_log is not None:
-                k = min(len(ref_log["numer"]), warmup)
+            if ref_log is not None:
+                # the parity leg is a replay of its own: a second engine from the same restart state and seed, as many iterations as the
+                # reference was given (at least 10 at the default sample), logged one by one -- independent of --warmup
+                k = len(ref_log["numer"])
+                eng2 = FriEngine(mol, device=device, comm=None)
+                eng2.setup(**par)
+                eng2.vec_load(dets, vals)
+                eng2.restart(run_seed, 0.0, 0.0, 0)
+                first_logs = eng2.iterate(k)
+                eng2.close()
                 same = all(int(first_logs[f][i]) == int(ref_log[f][i]) for i in range(k) for f in ("num_success", "n_nonz", "curr_size", "nkept"))
                 en_g = first_logs["numer"][:k] / first_logs["denom"][:k]
                 en_r = np.asarray(ref_log["numer"][:k]) / np.asarray(ref_log["denom"][:k])

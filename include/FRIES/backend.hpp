@@ -16,6 +16,7 @@
 #ifndef FRIES_BACKEND_HPP
 #define FRIES_BACKEND_HPP
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -93,13 +94,20 @@ struct Backend {
         ck(fries_set_comm(ctx(), &cm));
     }
     bool ctx_taken = false;                                 // one bound vector per context
+    /* bulk traffic of the mirrors over PCIe, per direction (FRIES_FACADE_STATS=1 prints the totals when the program ends) */
+    uint64_t bytes_to_device = 0, bytes_to_host = 0, device_ops = 0;
     bool hh_mode = false;                                   // parse_hh_input ran: the context runs the Hubbard-Holstein model
     DeviceVecBase *owner_of(const void *p) { for (auto *v : vecs) if (v->owns(p)) return v; return nullptr; }
     DeviceVecBase *by_indices(const void *key) { for (auto *v : vecs) if (v->indices_key() == key) return v; return nullptr; }
     DeviceVecBase *bound_vec() { for (auto *v : vecs) if (v->bound()) return v; return nullptr; }
     void add(DeviceVecBase *v) { vecs.push_back(v); }
     void remove(DeviceVecBase *v) { for (size_t i = 0; i < vecs.size(); i++) if (vecs[i] == v) { vecs.erase(vecs.begin() + i); return; } }
-    ~Backend() { if (ctx_) fries_ctx_destroy(ctx_); if (transport_) fries_transport_destroy(transport_); }
+    ~Backend() {
+        if (getenv("FRIES_FACADE_STATS")) fprintf(stderr, "fries facade: %llu bytes host->device, %llu bytes device->host, %llu device operators\n",
+                                                  (unsigned long long)bytes_to_device, (unsigned long long)bytes_to_host, (unsigned long long)device_ops);
+        if (ctx_) fries_ctx_destroy(ctx_);
+        if (transport_) fries_transport_destroy(transport_);
+    }
 private:
     fries_ctx *ctx_ = nullptr;
     fries_transport *transport_ = nullptr;

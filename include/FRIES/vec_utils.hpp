@@ -149,6 +149,7 @@ protected:
             fries_hip::ck(fries_vec_column_download(ctx_, c, xfer_.data(), max_size_, &n));
             for (size_t i = 0; i < n; i++) vals_(c, i) = (el_type)xfer_[i];
         }
+        fries_hip::Backend::get().bytes_to_host += 8 * n;
         col_len_[c] = n;
         col_fresh_[c] = true;
     }
@@ -158,6 +159,7 @@ protected:
         std::vector<uint64_t> w(curr_size_ ? curr_size_ : 1);
         size_t n = 0;
         fries_hip::ck(fries_vec_download(ctx_, w.data(), nullptr, w.size(), &n));
+        fries_hip::Backend::get().bytes_to_host += 8 * n;
         const size_t nb = indices_.cols();
         for (size_t i = 0; i < n; i++) memcpy(indices_[i], &w[i], nb);
         idx_fresh_ = true;
@@ -215,6 +217,7 @@ public:
         xfer_.assign(curr_size_ ? curr_size_ : 1, 0.0);
         for (size_t i = 0; i < curr_size_; i++) { w[i] = word_at(i); xfer_[i] = (double)vals_(0, i); }
         fries_hip::ck(fries_vec_load(cx, w.data(), xfer_.data(), curr_size_));
+        fries_hip::Backend::get().bytes_to_device += 16 * curr_size_;
         const int n_procs = fries_hip::mpi_size();
         if (n_dense_ || n_procs > 1) {       // every rank declares its share of the dense space, also an empty one (collective)
             const int my_rank = fries_hip::mpi_rank();
@@ -240,6 +243,7 @@ public:
                 fries_hip::ck(fries_vec_column_upload(ctx_, c, xfer_.data(), col_len_[c]));
             }
             col_dirty_[c] = false;
+            fries_hip::Backend::get().bytes_to_device += 8 * col_len_[c];
         }
     }
     void after_device_op(bool col0, bool col1, bool layout) override {
@@ -261,6 +265,7 @@ public:
             for (size_t i = 0; i < num2; i++) w[i] = fries_word_of(idx2[i], (uint8_t)idx2.cols());
             double r = 0;
             fries_hip::ck(fries_vec_dot_list(ctx_, col_, w.data(), vals2, num2, &r));
+            fries_hip::Backend::get().bytes_to_device += 16 * num2;
             return r;
         }
         double acc = 0;
@@ -429,6 +434,7 @@ public:
         }
         before_device_op();
         fries_hip::ck(fries_vec_add_to(ctx_, col_, w.data(), incoming.data(), ini.data(), count));
+        fries_hip::Backend::get().bytes_to_device += 17 * count;
         after_device_op(col_ == 0, col_ == 1, true);
         if (vals_.rows() == 2) {
             // a new position starts at zero in both columns: the other column's mirror only has to grow (positions re-used from the free
@@ -461,6 +467,7 @@ public:
             if (!diag_fresh_) {
                 size_t n = 0;
                 fries_hip::ck(fries_vec_diag_download(ctx_, matr_el_.data(), matr_el_.size(), &n));
+                fries_hip::Backend::get().bytes_to_host += 8 * n;
                 diag_fresh_ = true;
             }
             return matr_el_[pos];
