@@ -95,7 +95,15 @@ struct CompWork {
     uint32_t *fix_list;           // elements with a tooth backlog (rare)
     SeqWork seq;                  // exact in-order sum of wt_remain
     double row1[2];               // stage-1 sub-weights (fr_row1)
+#ifdef FR_SYS_TIMING
+    unsigned long long *tdbg;     // FRIES_SYS_DBG: [workgroup][8] time stamps of k_sys_count / k_sys_write (build with -DFR_SYS_TIMING)
+#endif
 };
+#ifdef FR_SYS_TIMING
+#define FR_SYS_T(i) do { if (W.tdbg && threadIdx.x == 0 && blockIdx.x < 8192) W.tdbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FR_SYS_T(i) do { } while (0)
+#endif
 
 // wt_remain of the current stage as the addend sequence of sys_sub's lbound (compress_utils.cpp:739)
 struct AccWt {
@@ -226,11 +234,11 @@ __device__ __forceinline__ void fr_load_elems(const CompWork &W, const VecDev &V
     for (int it = 0; it < N; it++) { const size_t e = base + it; x[it].det = (STAGE != 1) ? E.det[e < n_in ? e : last] : 0ull; }
 }
 
-// Returns the number of emissions; *k advances over consumed teeth.  When EMIT, writes
+// Returns the number of emissions; the cursor advances over consumed teeth.  When EMIT, writes
 // (wi, sub, value) triples starting at slot `out`.
 template <int STAGE, bool NEW_HB, bool EMIT>
 __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTables &T, const Teeth *th, const ElemIn &x,
-                                                   size_t e, double lbound, uint32_t *k, double unit, double p_doub, size_t out) {
+                                                   size_t e, double lbound, ToothCur &cur, double unit, double p_doub, size_t out) {
     const double v = x.v;
     if (v == 0) return 0;
     const uint32_t nd = x.nd, kp = x.kp;
@@ -246,19 +254,16 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTa
             for (uint32_t s = 0; s < nd; s++) emit(s, part);
         }
         else {
-            double rn = fr_tooth(th, *k);
-            while (rn < lbound) {
-                double q = (lbound - rn) * nd / v;
+            while (cur.rn < lbound) {
+                double q = (lbound - cur.rn) * nd / v;
                 uint32_t s = q >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)q;
                 if (s < nd) emit(s, unit);
-                (*k)++;
-                rn = fr_tooth(th, *k);
+                fr_cur_next(th, cur);
             }
         }
     }
     else {
-        double rn = fr_tooth(th, *k);
-        if (wr < v || rn < lbound) {
+        if (wr < v || cur.rn < lbound) {
             double sub_lbound = lbound - wr;
             RowInfo ri;
             if (STAGE == 1) ri = fr_row1(W.row1);
@@ -269,11 +274,21 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTa
                 if (((kp >> s) & 1u) && w != 0) emit(s, v * w);
                 else {
                     sub_lbound += v * w;
-                    if (rn < sub_lbound && w != 0) { emit(s, unit); (*k)++; rn = fr_tooth(th, *k); }
+                    if (cur.rn < sub_lbound && w != 0) { emit(s, unit); fr_cur_next(th, cur); }
                 }
             });
         }
     }
+    return n;
+}
+// the same from a comb index (the repair kernels, which re-evaluate single elements)
+template <int STAGE, bool NEW_HB, bool EMIT>
+__device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTables &T, const Teeth *th, const ElemIn &x,
+                                                   size_t e, double lbound, uint32_t *k, double unit, double p_doub, size_t out) {
+    ToothCur cur;
+    fr_cur_seek_k(th, cur, *k);
+    const uint32_t n = fr_sys_element<STAGE, NEW_HB, EMIT>(W, T, th, x, e, lbound, cur, unit, p_doub, out);
+    *k = cur.k;
     return n;
 }
 
@@ -287,6 +302,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     const unsigned n_in = fin->n_in;
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
+    FR_SYS_T(0);
     if (STAGE != 1) fr_stage_tables(&T, Tg);
     __shared__ Teeth Tsh;
     fr_stage_teeth(&Tsh, W.teeth);
@@ -294,31 +310,51 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     const double unit = fin->unit;
     AccWt acc{W.wt_remain, &W.state[0]};
     double Sx[4], Sprev;
+    FR_SYS_T(1);
     fr_seq_prefix4(W.seq, acc, blockIdx.x, &seqsh, Sx, &Sprev);
+    FR_SYS_T(2);
     size_t base = (size_t)blockIdx.x * FR_TILE + (size_t)threadIdx.x * FR_ITEMS;
     ElemIn x[FR_ITEMS];
     fr_load_elems<STAGE, FR_ITEMS>(W, V, cur, base, n_in, x);
+#ifdef FR_SYS_TIMING
+    if (W.tdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+    FR_SYS_T(3);
     uint32_t cnt_t = 0;
+    // The comb pointer an element starts from is T(lbound of its predecessor), the number of teeth below it (the assumption the repair
+    // kernels check).  A lane looks that up once, for its first element; where an element leaves the comb exactly there for its successor --
+    // the tooth it stands at is not below its lbound and the last one it took is -- the successor continues from the cursor.
+    ToothCur tc;
+    bool have = false;
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + it;
         if (e >= n_in) break;
         double Se = Sx[it];
-        uint32_t kin = (e == 0) ? 0u : fr_teeth_below(th, Sprev);
-        uint32_t k = kin;
-        uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x[it], e, Se, &k, unit, p_doub, 0);
+        if (!have) { if (e == 0) fr_cur_seek_k(th, tc, 0u); else fr_cur_seek_below(th, tc, Sprev); }
+        tc.last = -INFINITY;
+        const uint32_t kin = tc.k;
+        uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x[it], e, Se, tc, unit, p_doub, 0);
+        const uint32_t k = tc.k;
         W.S[e] = Se; W.kin[e] = kin; W.cnt[e] = c;
         cnt_t += c;
         if (W.prop) W.kend[e] = k;
-        if (k != fr_teeth_below(th, Se)) {      // the comb is not where the next lane assumes: repaired by k_sys_fixup / k_sys_prop
-            uint32_t slot = atomicAdd(&fin->n_fix, 1u);
-            if (W.prop) { if (e + 1 < n_in) W.act[0][atomicAdd(&W.act_n[0], 1u)] = (uint32_t)(e + 1); }
-            else if (slot < FR_MAX_FIX) W.fix_list[slot] = (uint32_t)e;
+        // k == T(Se)?  The teeth do not decrease: k teeth lie below Se iff tooth k does not and tooth k - 1 does (tooth kin - 1 < Sprev <= Se)
+        have = tc.rn >= Se && (k == kin ? (e == 0 || Sprev <= Se) : tc.last < Se);
+        if (!have) {      // the comb is not where the next lane assumes: repaired by k_sys_fixup / k_sys_prop
+            have = k == fr_teeth_below(th, Se);         // (the short test is sufficient, not necessary)
+            if (!have) {
+                uint32_t slot = atomicAdd(&fin->n_fix, 1u);
+                if (W.prop) { if (e + 1 < n_in) W.act[0][atomicAdd(&W.act_n[0], 1u)] = (uint32_t)(e + 1); }
+                else if (slot < FR_MAX_FIX) W.fix_list[slot] = (uint32_t)e;
+            }
         }
         Sprev = Se;
     }
+    FR_SYS_T(4);
     uint32_t bc = fr_block_sum_u32(cnt_t, shu);
     if (threadIdx.x == 0) W.pcnt[1][blockIdx.x] = bc;
+    FR_SYS_T(5);
 }
 
 // Repairs the (rare) elements after which the reference's comb lags behind lbound: walk
@@ -438,10 +474,12 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     const unsigned n_in = fin->n_in;
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
+    FR_SYS_T(0);
     if (STAGE != 1) fr_stage_tables(&T, Tg);
     __shared__ Teeth Tsh;
     fr_stage_teeth(&Tsh, W.teeth);
     const Teeth *th = &Tsh;
+    FR_SYS_T(1);
     const uint32_t *pc = W.pcnt[1];
     uint32_t off;
     {
@@ -456,22 +494,31 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     uint32_t tot;
     uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
     size_t o = (size_t)off + (incl - tsum);
+    FR_SYS_T(2);
     ElemIn x[FR_ITEMS];
     fr_load_elems<STAGE, FR_ITEMS>(W, V, cur, base, n_in, x);
     uint32_t kin4[FR_ITEMS]; double S4[FR_ITEMS];
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) { size_t e = base + it; size_t ec = e < n_in ? e : (n_in ? n_in - 1 : 0); kin4[it] = W.kin[ec]; S4[it] = W.S[ec]; }
+#ifdef FR_SYS_TIMING
+    if (W.tdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+    FR_SYS_T(3);
+    ToothCur tc;
+    bool have = false;
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + it;
         if (e >= n_in) break;
         if (c[it]) {
-            uint32_t k = kin4[it];
-            fr_sys_element<STAGE, NEW_HB, true>(W, T, th, x[it], e, S4[it], &k, fin->unit, p_doub, o);
+            if (!have || tc.k != kin4[it]) fr_cur_seek_k(th, tc, kin4[it]);
+            have = true;
+            fr_sys_element<STAGE, NEW_HB, true>(W, T, th, x[it], e, S4[it], tc, fin->unit, p_doub, o);
         }
         W.keep[e] = 0;
         o += c[it];
     }
+    FR_SYS_T(4);
     if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) {
         fin->n_out = (uint32_t)o;
         if (host_out) *host_out = (uint32_t)o;          // host-coherent pinned memory: read by the host after its next wait on the stream

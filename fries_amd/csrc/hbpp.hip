@@ -263,6 +263,36 @@ static __global__ void k_keep_norms(const double *norms, int n, double *keep, Co
 }
 
 // ------------------------------------------------------------------ host orchestration
+#ifdef FR_SYS_TIMING
+// where a workgroup of k_sys_count / k_sys_write spends its time (wall_clock64: 100 MHz), and how the workgroups are spread over the launch
+static void fr_sys_timing_dump(FriesCtx *c, const char *name, int stage, unsigned grid, int n_stamp) {
+    static int calls = 0;
+    if (!c->W.tdbg) return;
+    calls++;
+    if (calls < 400 || calls > 420) return;
+    FR_HIP(hipStreamSynchronize(c->stream));
+    const unsigned nb = grid < 8192 ? grid : 8192;
+    std::vector<unsigned long long> h((size_t)nb * 8);
+    FR_HIP(hipMemcpy(h.data(), c->W.tdbg, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (unsigned b = 0; b < nb; b++) { if (h[b * 8] && h[b * 8] < t0) t0 = h[b * 8]; if (h[b * 8 + n_stamp - 1] > t1) t1 = h[b * 8 + n_stamp - 1]; }
+    double ph[8] = {0}; unsigned cnt = 0;
+    double start_hist[8] = {0};
+    for (unsigned b = 0; b < nb; b++) {
+        if (!h[b * 8]) continue;
+        cnt++;
+        for (int k = 1; k < n_stamp; k++) ph[k] += (double)(h[b * 8 + k] - h[b * 8 + k - 1]) * 0.01;
+        const double rel = (double)(h[b * 8] - t0) / (double)(t1 - t0 + 1);
+        start_hist[(int)(rel * 8)]++;
+    }
+    fprintf(stderr, "[%s stage %d] %u workgroups, span %.1f us; mean us per phase:", name, stage, cnt, (double)(t1 - t0) * 0.01);
+    for (int k = 1; k < n_stamp; k++) fprintf(stderr, " %.2f", ph[k] / (cnt ? cnt : 1));
+    fprintf(stderr, " | starts by eighth of the span:");
+    for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", start_hist[k]);
+    fprintf(stderr, "\n");
+    FR_HIP(hipMemset(c->W.tdbg, 0, h.size() * 8));
+}
+#endif
 void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     CompWork &W = c->W;
     W.cap = cap;
@@ -282,6 +312,9 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1); W.seq.tsum = fr_alloc<double>(FR_MAX_PART);
 #ifdef FR_SEQ_TIMING
     W.seq.dbg = getenv("FRIES_SEQ_DBG") ? 1 : 0;
+#endif
+#ifdef FR_SYS_TIMING
+    W.tdbg = getenv("FRIES_SYS_DBG") ? fr_alloc<unsigned long long>(8192 * 8) : nullptr;
 #endif
     {
         Fks2Work &F = c->F2;
@@ -557,6 +590,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     }
     if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
     FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
+#ifdef FR_SYS_TIMING
+    fr_sys_timing_dump(c, "k_sys_count", STAGE, grid, 6);
+#endif
     if (W.prop) {
         // chains of repairs, each walked by one lane (k_sys_walk); a round ends where chains ran into one another, and those are walked
         // on in the next round.  This is the frisys_hh path, where one stage needs ~1e4 repairs in chains of up to a few hundred
@@ -586,6 +622,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // the stage's emission count also goes to the host block (word 16 + slot): a copy into pageable memory would hold the host until it is done
     fr_rb_init(c);
     FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err, out_slot >= 0 ? c->d_misc() + 16 + out_slot : nullptr);
+#ifdef FR_SYS_TIMING
+    fr_sys_timing_dump(c, "k_sys_write", STAGE, grid, 5);
+#endif
     if (c->dbg == 5) {
         CompState fs; FksScal hs;
         FR_HIP(hipMemcpy(&fs, &W.state[FR_MAX_ROUNDS + 1], sizeof(fs), hipMemcpyDeviceToHost));

@@ -108,6 +108,62 @@ __device__ inline uint32_t fr_teeth_below(const Teeth *t, double S) {
     return k < t->kmax ? k : t->kmax;
 }
 
+// A lane's position on the comb while it walks forward: the tooth it is at and the segment that tooth lies in, in registers.  The kernels
+// that replay sys_sub take teeth one after the other (compress_utils.cpp:766-790); looking each one up by binary search over ~60
+// segments in LDS was most of their instruction count.  rn = position of tooth k (infinity beyond the last one), last = position of the
+// tooth taken last.  The values are those of fr_tooth: x0 + (double)(k - k0) * inc of the last segment that starts at or before k.
+struct ToothCur { uint32_t k, k0, kend, seg; double x0, inc, rn, last; };
+// k lies in segment `seg` or a later one
+__device__ inline void fr_cur_load(const Teeth *t, ToothCur &c, uint32_t seg, uint32_t k) {
+    const uint32_t kmax = t->kmax, nseg = t->nseg;
+    c.k = k; c.seg = seg;
+    if (nseg == 0 || k >= kmax) { c.k0 = k; c.kend = k; c.x0 = 0; c.inc = 0; c.rn = INFINITY; return; }
+    while (seg + 1 < nseg && t->seg[seg + 1].k0 <= k) seg++;
+    const TeethSeg &s = t->seg[seg];
+    const uint32_t nx = seg + 1 < nseg ? t->seg[seg + 1].k0 : 0xFFFFFFFFu;
+    c.seg = seg; c.k0 = s.k0; c.kend = nx < kmax ? nx : kmax; c.x0 = s.x0; c.inc = s.inc;
+    c.rn = s.x0 + (double)(k - s.k0) * s.inc;
+}
+__device__ __forceinline__ void fr_cur_next(const Teeth *t, ToothCur &c) {
+    c.last = c.rn;
+    c.k++;
+    if (c.k < c.kend) c.rn = c.x0 + (double)(c.k - c.k0) * c.inc;
+    else fr_cur_load(t, c, c.seg, c.k);
+}
+__device__ inline void fr_cur_seek_k(const Teeth *t, ToothCur &c, uint32_t k) {
+    int lo = 0, hi = (int)t->nseg - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (t->seg[mid].k0 <= k) lo = mid; else hi = mid - 1;
+    }
+    c.last = -INFINITY;
+    fr_cur_load(t, c, (uint32_t)lo, k);
+}
+// at the first tooth >= S (fr_teeth_below); the quotient is only a first guess that the two loops settle, so a reciprocal does
+__device__ inline void fr_cur_seek_below(const Teeth *t, ToothCur &c, double S) {
+    c.last = -INFINITY;
+    if (t->nseg == 0 || !(t->seg[0].x0 < S)) { fr_cur_load(t, c, 0u, 0u); return; }
+    int lo = 0, hi = (int)t->nseg - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (t->seg[mid].x0 < S) lo = mid; else hi = mid - 1;
+    }
+    const TeethSeg &s = t->seg[lo];
+    long long j;
+    if (s.inc > 0) {
+        const double q = (S - s.x0) * __builtin_amdgcn_rcp(s.inc);
+        j = q < 4.0e9 ? (long long)q : (long long)s.len;
+        if (j < 0) j = 0;
+        if (j > (long long)s.len) j = s.len;
+        while (j < (long long)s.len && s.x0 + (double)j * s.inc < S) j++;
+        while (j > 0 && s.x0 + (double)(j - 1) * s.inc >= S) j--;
+    }
+    else j = s.len;
+    uint32_t k = s.k0 + (uint32_t)j;
+    if (k > t->kmax) k = t->kmax;
+    fr_cur_load(t, c, (uint32_t)lo, k);
+}
+
 // FRIES/compress_utils.cpp:107-127 (seed_sys) for a shard whose lower bound is the sum of
 // the lower-ranked shards' norms.  Returns the first tooth; *unit = spacing.
 __device__ inline double fr_seed_sys(double rn, double lbound, double global_norm, uint32_t n_samp, double *unit) {
