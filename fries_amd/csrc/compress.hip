@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_dots(VecDev V, const det_t *hd, co
         double p = 0;
         if (i < n) {
             uint32_t s = fr_hash_find(V, d[i]);
-            if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) p = w[i] * V.v0[pos]; }
+            if (s != FR_NOPOS) { uint32_t pos = V.hs[s].val; if (pos < V.cap) p = w[i] * V.v0[pos]; }
         }
         prod[threadIdx.x] = p;
         __syncthreads();

@@ -502,7 +502,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     // device allocations are released with the context's device memory pool at process exit;
     // explicit frees for the large arrays:
     VecDev &v = h->c.vec;
-    hipFree(v.dets); hipFree(v.v0); hipFree(v.v1); hipFree(v.diag); hipFree(v.active); hipFree(v.free_stack); hipFree(v.hkeys); hipFree(v.hvals); hipFree(v.st);
+    hipFree(v.dets); hipFree(v.v0); hipFree(v.v1); hipFree(v.diag); hipFree(v.active); hipFree(v.free_stack); hipFree(v.hs); hipFree(v.stat_part); hipFree(v.st);
     CompWork &W = h->c.W;
     for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.el[k].rinv); hipFree(W.el[k].raux); hipFree(W.el[k].det); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
     hipFree(W.wt_remain); hipFree(W.keep); hipFree(W.S); hipFree(W.kin); hipFree(W.cnt); hipFree(W.e_wi); hipFree(W.e_sub); hipFree(W.e_val); hipFree(W.state); hipFree(W.teeth); hipFree(W.fix_list);
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_dot_list(VecDev V, int column, con
         double p = 0;
         if (i < n) {
             uint32_t s = fr_hash_find(V, dets[i]);
-            if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) p = w[i] * col[pos]; }
+            if (s != FR_NOPOS) { uint32_t pos = V.hs[s].val; if (pos < V.cap) p = w[i] * col[pos]; }
         }
         prod[threadIdx.x] = p;
         __syncthreads();
@@ -1067,6 +1067,7 @@ extern "C" int fries_vec_load(fries_ctx *h, const uint64_t *dets, const double *
     VecState s{};
     s.curr_size = (uint32_t)n; s.n_nonz = (int32_t)n; s.n_used = (uint32_t)(v.hcap);   // forces the rebuild below
     FR_HIP(hipMemcpyAsync(v.st, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
+    FR_HIP(hipMemsetAsync(v.stat_part, 0, 8 * (size_t)FR_STAT_STRIPES * FR_STAT_STRIDE, c->stream));
     c->h_vst = s;
     fr_vec_maybe_rebuild(c, &v);
     fr_vec_sync_state(c, &v, &c->h_vst);

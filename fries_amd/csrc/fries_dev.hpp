@@ -14,6 +14,7 @@
 #define FR_TOMB_KEY (~0ull)
 #define FR_NOPOS 0xFFFFFFFFu
 #define FR_NEWBIT 0x80000000u
+#define FR_POSBIT 0x80000000u      // SpawnBuf::slot: the rest is a vector position, not a hash slot
 
 typedef uint64_t det_t;
 
@@ -53,6 +54,13 @@ struct VecState {           // lives in device memory, mirrored to the host on d
     uint32_t err;           // sticky error bits
     unsigned long long nonini_occ_add;
 };
+// One slot of the vector's hash table: key and position side by side, 16 bytes, so that a probe that finds its key has the position in
+// the same load (as two arrays every look-up was two random accesses into 32 + 16 MB at m = 1e6, and the merge made three of them).
+struct alignas(16) HSlot {
+    det_t key;              // FR_EMPTY_KEY / FR_TOMB_KEY / fr_vec_key of the stored index
+    uint32_t val;           // position; FR_NOPOS while empty; FR_NEWBIT|j while being created
+    uint32_t pad;
+};
 struct VecDev {
     uint32_t cap;           // max positions
     uint32_t hcap;          // hash slots in use, a power of two: sized to the live set (grown / shrunk at rebuilds), not to max_dets --
@@ -64,8 +72,11 @@ struct VecDev {
     double *diag;           // cached diagonal element - hf_en; NaN = not yet computed
     uint8_t *active;
     uint32_t *free_stack;   // [n_free-1] is the top (LIFO like std::stack)
-    det_t *hkeys;           // open addressing, linear probing
-    uint32_t *hvals;        // position; FR_NOPOS while empty; FR_NEWBIT|j while being created
+    HSlot *hs;              // open addressing, linear probing
+    // Counters the merge kernels bump from every workgroup, striped over FR_STAT_STRIPES cache lines ([stripe][FR_STAT_STRIDE]: 0 = non-initiator
+    // additions to occupied determinants, 1 = hash slots taken, 2 = tombstones re-used) and folded into *st when the host asks for the state
+    // (fr_vec_sync_state): ~16 000 atomics on ONE address cost 70 us per counter and merge.
+    unsigned long long *stat_part;
     VecState *st;
     // Hubbard-Holstein indices (hh_vec.hpp): electrons in the low 2 * hh_sites bits, 3 bits per phonon above them
     uint32_t hh_sites, hh_nelec, hh_buckets;
@@ -73,6 +84,8 @@ struct VecDev {
     uint32_t n_dense;           // positions [0, n_dense) hold the semi-stochastic dense space: never compressed, never deleted (DistVec::init_dense)
 };
 #define FR_HH_PH_BITS 3
+#define FR_STAT_STRIPES 64
+#define FR_STAT_STRIDE 16
 
 enum { FR_ERR_CAP = 1, FR_ERR_SPAWN_CAP = 2, FR_ERR_NELEC = 4, FR_ERR_HASH_FULL = 8, FR_ERR_ROUNDS = 16, FR_ERR_BACKLOG = 32, FR_ERR_PIV = 64 };
 
@@ -286,7 +299,7 @@ __device__ __forceinline__ uint32_t fr_hash_find(const VecDev &v, det_t dd) {
     const det_t d = fr_vec_key(v, dd);
     uint32_t s = fr_hash_slot(d, v.hcap);
     for (uint32_t probe = 0; probe < v.hcap; probe++) {
-        det_t k = v.hkeys[s];
+        det_t k = v.hs[s].key;
         if (k == d) return s;
         if (k == FR_EMPTY_KEY) return FR_NOPOS;
         s = (s + 1) & (v.hcap - 1);

@@ -288,7 +288,7 @@ void fr_h_apply_list(FriesCtx *c, const std::vector<det_t> &src, const std::vect
     hipFree(used.det); hipFree(used.val); hipFree(used.ini); hipFree(used.slot); hipFree(used.flag);
     for (int h2 = 0; h2 < 2; h2++) { hipFree(used.key[h2]); hipFree(used.pay[h2]); }
     hipFree(used.hist); hipFree(used.pcnt); hipFree(used.n_spawn);
-    hipFree(hv.dets); hipFree(hv.v0); hipFree(hv.v1); hipFree(hv.diag); hipFree(hv.active); hipFree(hv.free_stack); hipFree(hv.hkeys); hipFree(hv.hvals); hipFree(hv.st);
+    hipFree(hv.dets); hipFree(hv.v0); hipFree(hv.v1); hipFree(hv.diag); hipFree(hv.active); hipFree(hv.free_stack); hipFree(hv.hs); hipFree(hv.stat_part); hipFree(hv.st);
     hipFree(d_src); hipFree(d_val); hipFree(d_cnt); hipFree(d_nz); hipFree(d_off); hipFree(d_orbs); hipFree(d_diag);
 }
 

@@ -13,6 +13,16 @@
 #include <cstring>
 
 // ------------------------------------------------------------------ allocation / state
+// every slot empty: key FR_EMPTY_KEY (0), position FR_NOPOS
+static __global__ void __launch_bounds__(FR_BLOCK) k_hash_clear(HSlot *hs, uint32_t n) {
+    const uint4 e = make_uint4(0u, 0u, FR_NOPOS, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) ((uint4 *)hs)[i] = e;
+}
+static void fr_hash_clear(FriesCtx *c, VecDev *v, uint32_t n_slots) {
+    static_assert(FR_EMPTY_KEY == 0ull, "k_hash_clear writes the empty key as zero");
+    unsigned g = fr_blocks(n_slots, FR_BLOCK);
+    FR_LAUNCH(c, "k_hash_clear", k_hash_clear, dim3(g > 2048 ? 2048 : g), dim3(FR_BLOCK), v->hs, n_slots);
+}
 void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
     v->cap = cap; v->n_dense = 0;
     uint32_t h = 1024;
@@ -22,15 +32,16 @@ void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
     v->used_ub = 0;
     v->dets = fr_alloc<det_t>(cap); v->v0 = fr_alloc<double>(cap); v->v1 = fr_alloc<double>(cap);
     v->diag = fr_alloc<double>(cap); v->active = fr_alloc<uint8_t>(cap); v->free_stack = fr_alloc<uint32_t>(cap);
-    v->hkeys = fr_alloc<det_t>(h); v->hvals = fr_alloc<uint32_t>(h);
+    v->hs = fr_alloc<HSlot>(h);
+    v->stat_part = fr_alloc<unsigned long long>((size_t)FR_STAT_STRIPES * FR_STAT_STRIDE);
+    FR_HIP(hipMemsetAsync(v->stat_part, 0, 8 * (size_t)FR_STAT_STRIPES * FR_STAT_STRIDE, c->stream));
     v->st = fr_alloc<VecState>(1);
     FR_HIP(hipMemsetAsync(v->dets, 0, sizeof(det_t) * cap, c->stream));
     FR_HIP(hipMemsetAsync(v->v0, 0, 8 * (size_t)cap, c->stream));
     FR_HIP(hipMemsetAsync(v->v1, 0, 8 * (size_t)cap, c->stream));
     FR_HIP(hipMemsetAsync(v->diag, 0xff, 8 * (size_t)cap, c->stream));     // all-ones = NaN
     FR_HIP(hipMemsetAsync(v->active, 0, cap, c->stream));
-    FR_HIP(hipMemsetAsync(v->hkeys, 0, sizeof(det_t) * h, c->stream));
-    FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)h, c->stream));
+    fr_hash_clear(c, v, h);
     FR_HIP(hipMemsetAsync(v->st, 0, sizeof(VecState), c->stream));
 }
 
@@ -64,25 +75,44 @@ void fr_stream_wait(FriesCtx *c) {
         }
     }
 }
-const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
+static size_t fr_rb_take(FriesCtx *c, size_t bytes, bool held) {
     fr_rb_init(c);
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (bytes == 0 || (bytes & 3) || need > 2048) throw FriesError("fr_readback: bad size");
-    size_t off;
-    if (held) off = FriesCtx::RB_BYTES;         // a slot of its own behind the ring: the ring may wrap any number of times before the caller reads it
-    else {
-        if (c->rb_used + need > FriesCtx::RB_BYTES) c->rb_used = 0;
-        off = c->rb_used;
-        c->rb_used += need;
-    }
+    if (held) return FriesCtx::RB_BYTES;        // a slot of its own behind the ring: the ring may wrap any number of times before the caller reads it
+    if (c->rb_used + need > FriesCtx::RB_BYTES) c->rb_used = 0;
+    const size_t off = c->rb_used;
+    c->rb_used += need;
+    return off;
+}
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
+    const size_t off = fr_rb_take(c, bytes, held);
     FR_LAUNCH(c, "k_readback", k_readback, dim3(1), dim3(64), (const uint32_t *)src, (uint32_t *)(c->d_rb + off), (unsigned)(bytes / 4));
     return c->h_rb + off;
 }
 
+// folds the striped counters into the state, then hands the state to the host block
+static __global__ void __launch_bounds__(64) k_vec_state_out(VecDev V, VecState *dst) {
+    const int l = threadIdx.x;
+    unsigned long long x[3];
+    for (int q = 0; q < 3; q++) {
+        unsigned long long *p = &V.stat_part[(size_t)l * FR_STAT_STRIDE + q];
+        const bool have = V.stat_part && l < FR_STAT_STRIPES;       // (the flat array the pivotal matrix compression wraps in a VecDev has no counters)
+        x[q] = have ? *p : 0ull;
+        if (have) *p = 0ull;
+        for (int off = 32; off > 0; off >>= 1) x[q] += __shfl_xor(x[q], off);
+    }
+    if (l == 0) {
+        VecState s = *V.st;
+        s.nonini_occ_add += x[0]; s.n_used += (uint32_t)x[1]; s.n_tomb -= (uint32_t)x[2];
+        *V.st = s; *dst = s;
+    }
+}
 void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out) {
-    const void *hp = fr_readback(c, v->st, sizeof(VecState));
+    const size_t off = fr_rb_take(c, sizeof(VecState), false);
+    FR_LAUNCH(c, "k_vec_state_out", k_vec_state_out, dim3(1), dim3(64), *v, (VecState *)(c->d_rb + off));
     fr_stream_wait(c);
-    memcpy(out, hp, sizeof(VecState));
+    memcpy(out, c->h_rb + off, sizeof(VecState));
     v->used_ub = out->n_used;
 }
 
@@ -107,7 +137,7 @@ void fr_spawn_alloc(FriesCtx *c, uint32_t cap) {
 __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S, uint32_t n_elec, int mode) {
     const uint32_t n = *S.n_spawn;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    bool created = false, counted = false, reused = false;   // counters are bumped once per wave at the end (one address, ~1e6 lanes)
+    bool created = false, reused = false;   // counters are bumped once per wave at the end (one address, ~1e6 lanes)
     bool bad_nelec = false, hash_full = false;
     if (j < n) {
         const det_t dd = S.det[j];
@@ -117,23 +147,24 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
             if ((uint32_t)__popcll(dd & emask) != n_elec) { bad_nelec = true; S.slot[j] = FR_NOPOS; }
             else {
                 const det_t d = fr_vec_key(V, dd);
-                uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS, first_tomb = FR_NOPOS;
+                uint32_t s = fr_hash_slot(d, V.hcap), found = FR_NOPOS, first_tomb = FR_NOPOS, hv = FR_NEWBIT;
                 // A new entry takes the first tombstone of its probe chain once the chain has been walked to its end without finding the key
                 // (otherwise a determinant that is deleted and spawned again every iteration -- the rule in fciqmc_fp_mol, common in
                 // frisys_mol -- lengthens its own chain by one slot per incarnation until the next rebuild).  Every lane inserting d follows
                 // the same rule, so concurrent inserters of d meet at the same slot and the CAS (old == d) merges them.
                 for (uint32_t probe = 0; probe < V.hcap; probe++) {
-                    det_t k = V.hkeys[s];
-                    if (k == d) { found = s; break; }
+                    const uint4 raw = *(const uint4 *)&V.hs[s];         // key and position in one load
+                    const det_t k = (det_t)raw.x | ((det_t)raw.y << 32);
+                    if (k == d) { found = s; hv = raw.z; break; }
                     if (k == FR_TOMB_KEY && ini && first_tomb == FR_NOPOS) first_tomb = s;
                     if (k == FR_EMPTY_KEY) {
                         if (!ini) break;
                         const bool use_tomb = first_tomb != FR_NOPOS;
                         const uint32_t tgt = use_tomb ? first_tomb : s;
                         const det_t expect = use_tomb ? FR_TOMB_KEY : FR_EMPTY_KEY;
-                        det_t old = atomicCAS((unsigned long long *)&V.hkeys[tgt], (unsigned long long)expect, (unsigned long long)d);
+                        det_t old = atomicCAS((unsigned long long *)&V.hs[tgt].key, (unsigned long long)expect, (unsigned long long)d);
                         if (old == expect) { found = tgt; if (use_tomb) reused = true; else created = true; break; }
-                        if (old == d) { found = tgt; break; }
+                        if (old == d) { found = tgt; hv = V.hs[tgt].val; break; }
                         // another determinant took the slot: probe on from the one after it
                         s = tgt; first_tomb = FR_NOPOS;
                     }
@@ -144,27 +175,33 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_lookup(VecDev V, SpawnBuf S,
                     S.slot[j] = FR_NOPOS;
                 }
                 else {
-                    uint32_t hv = V.hvals[found];
+                    // S.slot: FR_POSBIT | position for a determinant that was stored before this merge, the hash slot for one that is being
+                    // created in it (its position is assigned by k_spawn_assign)
                     if (ini) {
-                        if (hv & FR_NEWBIT) atomicMin(&V.hvals[found], FR_NEWBIT | j);   // being created in this merge
-                        S.slot[j] = found;
+                        if (hv & FR_NEWBIT) { atomicMin(&V.hs[found].val, FR_NEWBIT | j); S.slot[j] = found; }   // being created in this merge
+                        else S.slot[j] = FR_POSBIT | hv;
                     }
-                    else if (mode == 0 || mode == 3) {
-                        // non-initiator spawns only reach determinants that were present before this merge and are
-                        // non-zero in the origin column (vec_utils.hpp:617, 632-637)
-                        if ((hv & FR_NEWBIT) || V.v0[hv] == 0) S.slot[j] = FR_NOPOS;
-                        else { S.slot[j] = found; counted = true; }
+                    else {
+                        // Non-initiator spawns only reach determinants that were present before this merge and are non-zero in the origin
+                        // column (vec_utils.hpp:617, 632-637).  A determinant created in this merge starts with zero in both columns
+                        // (k_spawn_assign), so both conditions are the one test of the origin column k_seg_sum makes per position.
+                        S.slot[j] = (hv & FR_NEWBIT) ? found : (FR_POSBIT | hv);
                     }
-                    else S.slot[j] = found;     // decided in arrival order by k_seg_sum
                 }
             }
         }
     }
-    const unsigned long long mc = __ballot(created), mn = __ballot(counted), mr = __ballot(reused);
-    if (fr_lane() == 0) {
-        if (mc) atomicAdd(&V.st->n_used, (uint32_t)__popcll(mc));
-        if (mr) atomicSub(&V.st->n_tomb, (uint32_t)__popcll(mr));
-        if (mn) atomicAdd(&V.st->nonini_occ_add, (unsigned long long)__popcll(mn));
+    {   // slots taken / tombstones re-used: one striped atomic per workgroup (VecDev::stat_part)
+        __shared__ uint32_t shc[8];
+        const unsigned long long mc = __ballot(created), mr = __ballot(reused);
+        if (fr_lane() == 0) { shc[threadIdx.x >> 6] = (uint32_t)__popcll(mc); shc[4 + (threadIdx.x >> 6)] = (uint32_t)__popcll(mr); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t nc = shc[0] + shc[1] + shc[2] + shc[3], nr = shc[4] + shc[5] + shc[6] + shc[7];
+            unsigned long long *sp = &V.stat_part[(size_t)(blockIdx.x % FR_STAT_STRIPES) * FR_STAT_STRIDE];
+            if (nc) atomicAdd(&sp[1], (unsigned long long)nc);
+            if (nr) atomicAdd(&sp[2], (unsigned long long)nr);
+        }
     }
     if (__any(bad_nelec) && fr_lane() == 0) atomicOr(&V.st->err, FR_ERR_NELEC);
     if (__any(hash_full) && fr_lane() == 0) atomicOr(&V.st->err, FR_ERR_HASH_FULL);
@@ -182,7 +219,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_first(VecDev V, SpawnBuf S) 
         size_t j = base + it;
         if (j >= n) break;
         uint32_t s = S.slot[j], f = 0;
-        if (s != FR_NOPOS && S.ini[j] && V.hvals[s] == (FR_NEWBIT | (uint32_t)j)) f = 1;
+        if (s != FR_NOPOS && !(s & FR_POSBIT) && S.ini[j] && V.hs[s].val == (FR_NEWBIT | (uint32_t)j)) f = 1;
         S.flag[j] = f; cnt += f;
     }
     uint32_t bc = fr_block_sum_u32(cnt, shu);
@@ -215,7 +252,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_assign(VecDev V, SpawnBuf S)
         V.dets[pos] = S.det[j]; V.v0[pos] = 0; V.v1[pos] = 0;
         V.diag[pos] = __longlong_as_double(-1ll);     // NaN: diagonal element not cached yet
         V.active[pos] = 1;
-        V.hvals[S.slot[j]] = pos;
+        V.hs[S.slot[j]].val = pos;
     }
 }
 
@@ -239,7 +276,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_spawn_resolve(VecDev V, SpawnBuf S
     if (j >= n) return;
     uint32_t s = S.slot[j];
     uint32_t k = drop_key;
-    if (s != FR_NOPOS) { uint32_t pos = V.hvals[s]; if (pos < V.cap) k = (pos << 1) | ((mode == 0 && S.ini[j]) ? 1u : 0u); }
+    if (s != FR_NOPOS) { uint32_t pos = (s & FR_POSBIT) ? (s & ~FR_POSBIT) : V.hs[s].val; if (pos < V.cap) k = (pos << 1) | ((mode == 0 && S.ini[j]) ? 1u : 0u); }
     key[j] = k; pay[j] = j;
 }
 
@@ -332,32 +369,73 @@ __global__ void __launch_bounds__(FR_BLOCK) k_rs_scatter(const uint32_t *key, co
     }
 }
 
-// M6: each position sums its contributions sequentially in (pass, arrival) order
+// M6: each position sums its contributions sequentially in (pass, arrival) order.
+// Every lane fetches its own entry of the sorted list -- key, arrival index, initiator flag, origin-column test and value, all independent
+// loads -- into LDS; the lane at the head of a segment then adds the segment up from LDS (walking the list from global memory is three
+// dependent loads per addend), and goes back to global memory only where the segment runs past its workgroup's 256 entries.
 __global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, const uint32_t *key, const uint32_t *pay, uint32_t drop_key, int mode) {
+    __shared__ double sval[FR_BLOCK];
+    __shared__ uint32_t skey[FR_BLOCK];
+    __shared__ uint8_t sfl[FR_BLOCK];           // bit 0: initiator spawn, bit 1: value fetched
     const uint32_t n = *S.n_spawn;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    uint32_t k = key[t];
-    if (k == drop_key) return;
-    uint32_t pos = k >> 1;
-    if (t > 0 && (key[t - 1] >> 1) == pos) return;
-    if (mode == 0 || mode == 3) {
-        double acc = V.v1[pos];
-        for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) acc += S.val[pay[u]];
-        V.v1[pos] = acc;
+    const uint32_t t0 = blockIdx.x * blockDim.x, t = t0 + threadIdx.x;
+    if (t0 >= n) return;
+    const bool rule_fixed = mode == 0 || mode == 3;     // the initiator rule looks at the origin column as it was before the merge
+    const uint32_t k = t < n ? key[t] : drop_key;
+    const bool live = k != drop_key;
+    const uint32_t pos = k >> 1;
+    const uint32_t kprev = (t > 0 && live) ? key[t - 1] : drop_key;
+    uint32_t j = 0; bool ini = false, occ = false;
+    if (live) {
+        j = pay[t];
+        ini = mode == 0 ? (k & 1u) != 0 : S.ini[j] != 0;
+        // non-initiator spawns only reach determinants that are non-zero in the origin column (vec_utils.hpp:617, 632-637); one created
+        // in this merge has zero there (k_spawn_assign)
+        if (rule_fixed) occ = V.v0[pos] != 0;
     }
-    else {
-        // perform_add into the origin column: the initiator rule sees the running value (vec_utils.hpp:632-637)
-        double acc = V.v0[pos];
-        unsigned long long occ_add = 0;
-        for (uint32_t u = t; u < n && (key[u] >> 1) == pos; u++) {
-            uint32_t j = pay[u];
-            bool ini = S.ini[j], nonz = acc != 0;
-            occ_add += (!ini && nonz);
-            if (ini || nonz) acc += S.val[j];
+    const bool fetch = live && (!rule_fixed || ini || occ);
+    const double val = fetch ? S.val[j] : 0.0;
+    skey[threadIdx.x] = k; sval[threadIdx.x] = val; sfl[threadIdx.x] = (uint8_t)((ini ? 1u : 0u) | (fetch ? 2u : 0u));
+    unsigned long long occ_add = (rule_fixed && live && !ini && occ) ? 1ull : 0ull;
+    __syncthreads();
+    const bool head = live && !(t > 0 && kprev != drop_key && (kprev >> 1) == pos);
+    if (head) {
+        double acc = rule_fixed ? V.v1[pos] : V.v0[pos];
+        uint32_t u = threadIdx.x;
+        for (; u < FR_BLOCK; u++) {
+            const uint32_t ku = skey[u];
+            if (ku == drop_key || (ku >> 1) != pos) break;
+            const uint32_t f = sfl[u];
+            if (rule_fixed) { if (f & 2u) acc += sval[u]; }
+            else {
+                const bool nonz = acc != 0;
+                occ_add += (!(f & 1u) && nonz);
+                if ((f & 1u) || nonz) acc += sval[u];
+            }
         }
-        V.v0[pos] = acc;
-        if (occ_add) atomicAdd(&V.st->nonini_occ_add, occ_add);
+        if (u == FR_BLOCK) {            // the segment goes on in the next workgroup's entries
+            for (uint32_t g = t0 + FR_BLOCK; g < n && key[g] != drop_key && (key[g] >> 1) == pos; g++) {
+                const uint32_t jg = pay[g];
+                const bool ini_g = mode == 0 ? (key[g] & 1u) != 0 : S.ini[jg] != 0;
+                if (rule_fixed) { if (ini_g || occ) acc += S.val[jg]; }
+                else {
+                    const bool nonz = acc != 0;
+                    occ_add += (!ini_g && nonz);
+                    if (ini_g || nonz) acc += S.val[jg];
+                }
+            }
+        }
+        if (rule_fixed) V.v1[pos] = acc; else V.v0[pos] = acc;
+    }
+    // one counter, ~1e6 segments: added up per workgroup, then one striped atomic (VecDev::stat_part)
+    for (int off = 32; off > 0; off >>= 1) occ_add += __shfl_xor(occ_add, off);
+    __shared__ unsigned long long sho[4];
+    __syncthreads();
+    if (fr_lane() == 0) sho[threadIdx.x >> 6] = occ_add;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long tot = sho[0] + sho[1] + sho[2] + sho[3];
+        if (tot) atomicAdd(&V.stat_part[(size_t)(blockIdx.x % FR_STAT_STRIPES) * FR_STAT_STRIDE], tot);
     }
 }
 
@@ -435,7 +513,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_del_apply(VecDev V, uint8_t *flags
         r++;
         V.active[i] = 0;
         uint32_t s = fr_hash_find(V, V.dets[i]);
-        if (s != FR_NOPOS) { V.hkeys[s] = FR_TOMB_KEY; V.hvals[s] = FR_NOPOS; }
+        if (s != FR_NOPOS) { V.hs[s].key = FR_TOMB_KEY; V.hs[s].val = FR_NOPOS; }
     }
 }
 __global__ void k_del_finish(VecDev V, const uint32_t *pcnt) {
@@ -459,12 +537,13 @@ __global__ void k_hash_reinsert(VecDev V) {
     const uint32_t n = V.st->curr_size;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { V.st->n_tomb = 0; V.st->n_used = (uint32_t)V.st->n_nonz; }
+    if (i < FR_STAT_STRIPES) { V.stat_part[(size_t)i * FR_STAT_STRIDE + 1] = 0ull; V.stat_part[(size_t)i * FR_STAT_STRIDE + 2] = 0ull; }      // (what the merges counted since the last fold is superseded)
     if (i >= n || !V.active[i]) return;
     det_t d = fr_vec_key(V, V.dets[i]);
     uint32_t s = fr_hash_slot(d, V.hcap);
     for (uint32_t probe = 0; probe < V.hcap; probe++) {
-        det_t old = atomicCAS((unsigned long long *)&V.hkeys[s], (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
-        if (old == FR_EMPTY_KEY) { V.hvals[s] = i; return; }
+        det_t old = atomicCAS((unsigned long long *)&V.hs[s].key, (unsigned long long)FR_EMPTY_KEY, (unsigned long long)d);
+        if (old == FR_EMPTY_KEY) { V.hs[s].val = i; return; }
         s = (s + 1) & (V.hcap - 1);
     }
     atomicOr(&V.st->err, FR_ERR_HASH_FULL);
@@ -473,8 +552,7 @@ __global__ void k_hash_reinsert(VecDev V) {
 // Clears the table and re-inserts every active position into a table of `want` slots (a power of two <= hcap_max).
 static void hash_rebuild(FriesCtx *c, VecDev *v, uint32_t want, uint32_t n_pos_bound) {
     v->hcap = want;
-    FR_HIP(hipMemsetAsync(v->hkeys, 0, sizeof(det_t) * v->hcap, c->stream));
-    FR_HIP(hipMemsetAsync(v->hvals, 0xff, 4 * (size_t)v->hcap, c->stream));
+    fr_hash_clear(c, v, v->hcap);
     FR_LAUNCH(c, "k_hash_reinsert", k_hash_reinsert, dim3(fr_blocks(n_pos_bound ? n_pos_bound : 1, FR_BLOCK)), dim3(FR_BLOCK), *v);
 }
 static uint32_t hash_slots_for(const VecDev *v, uint64_t n_entries) {

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfries_hip.so")
+LIB_PATH = os.environ.get("FRIES_LIB") or os.path.join(_HERE, "libfries_hip.so")      # FRIES_LIB: another build of the same library (A/B timing of kernel variants)
 
 # every symbol include/fries_hip.h declares
 EXPORTS = [
