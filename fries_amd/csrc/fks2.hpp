@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
     if (STAGE != 1) fr_stage_tables(&T, Tg);
 
     unsigned tile_k = 0;
+    bool any_chg = false;           // (wave-uniform) this wave changed a delta somewhere
     for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x, tile_k++) {
         const size_t e = (size_t)tile * FR_BLOCK + threadIdx.x;
         const size_t b = e >> 3;
@@ -679,13 +680,17 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         if (M1) {
             const bool chg = __any(out_changed) != 0;
             if (lane == 0) {
-                if (chg) { if (F.hist[it] == 0) atomicOr(&F.hist[it], 1u); F.cdirty[my_chunk] = (uint32_t)it + 1u; }
+                // (hist[it] only ever becomes 1: a plain store.  The guard `hist[it] == 0` in front of an atomicOr read the wave's own L1, which
+                // never sees another CU's atomic -- in the recording replay, where most waves change something, that was an atomic per wave
+                // on one address)
+                if (chg) { any_chg = true; F.cdirty[my_chunk] = (uint32_t)it + 1u; }
                 if (ig) F.wNp[my_wave] = (uint32_t)n_pass;
             }
         }
         if (lv) { W.keep[e] = kp; if (!FIN) W.wt_remain[e] = wr; }
         if (FIN) final_part();          // MODE 4: with the keep bits just decided
     }
+    if (M1 && any_chg && lane == 0) F.hist[it] = 1u;
 }
 
 // Chunk totals cross from the workgroups of k_fks_scan to the one that finishes last (fused totals) as relaxed device-scope atomics:
@@ -704,8 +709,8 @@ __device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg 
     const unsigned nb8 = S->n_in / 8 + 1;
     const unsigned nchunk = (nb8 + FR_FKS_CHUNK - 1) / FR_FKS_CHUNK;
     const int n_pass = S->n_pass;
-    const int lane = fr_lane(), wv = threadIdx.x >> 6;
-    for (int q = wv; q < FR_FKS_PMAX; q += 4) {
+    const int lane = fr_lane(), wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
+    for (int q = wv; q < FR_FKS_PMAX; q += n_wv) {
         uint32_t rk = 0; double rg = 0, rw = 0;
         if (q <= n_pass) {
             for (unsigned c0 = 0; c0 < nchunk; c0 += 64) {
@@ -737,11 +742,35 @@ __device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg 
     }
 }
 
+// The three block scans of k_fks_scan (samples, norm removed, remaining weight) behind two barriers instead of eleven.  The arithmetic is that of
+// fr_block_scan_u32 / fr_block_excl_f64 operation for operation: Hillis-Steele inside a wave, the waves' sums added in order, the block total
+// = (exclusive prefix of thread 255) + (its own sum).  (Lane 0 of wave w gets the waves' running sum directly: that is the inclusive value
+// of the last lane before it, which fr_block_excl_f64 fetches through LDS behind a barrier of its own.)
+struct FksScan3 { uint32_t k[4]; double g[4], w[4]; uint32_t tk; double tg, tw; };
+__device__ __forceinline__ void fr_block_scan3(uint32_t tk, double tg, double tw, FksScan3 *sh, uint32_t *excl_k, double *excl_g, uint32_t *totk, double *totg, double *totw) {
+    const int lane = fr_lane(), w = threadIdx.x >> 6;
+    uint32_t ik = tk; double ig = tg, iw = tw;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(ik, off); const double b = __shfl_up(ig, off), c = __shfl_up(iw, off);
+        if (lane >= off) { ik += a; ig += b; iw += c; }
+    }
+    if (lane == 63) { sh->k[w] = ik; sh->g[w] = ig; sh->w[w] = iw; }
+    __syncthreads();
+    uint32_t bk = 0; double bg = 0, bw = 0;
+    for (int q = 0; q < w; q++) { bk += sh->k[q]; bg += sh->g[q]; bw += sh->w[q]; }
+    const double incl_g = w ? bg + ig : ig, incl_w = w ? bw + iw : iw;
+    double xg = __shfl_up(incl_g, 1), xw = __shfl_up(incl_w, 1);
+    if (lane == 0) { xg = w ? bg : 0.0; xw = w ? bw : 0.0; }
+    if (threadIdx.x == FR_BLOCK - 1) { sh->tk = bk + ik; sh->tg = xg + tg; sh->tw = xw + tw; }
+    __syncthreads();
+    *excl_k = bk + ik - tk; *excl_g = xg;
+    *totk = sh->tk; *totg = sh->tg; *totw = sh->tw;
+}
+
 // Exclusive prefixes over the 8-blocks inside chunks of 2048 groups (grid: chunks x a few sweep lanes, each looping over the
 // sweeps); chunk totals go to (ck, cg, cw).
 static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it, int light, int fuse, uint32_t *err, FksMsg *msg, int inline_passes) {
-    __shared__ double shd[12];
-    __shared__ uint32_t shu[4];
+    __shared__ FksScan3 sh3;
     __shared__ uint32_t last_wg;
     __shared__ FksMsg sm_tot;
     const FksScal *S = F.scal;
@@ -773,12 +802,9 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
             if ((unsigned)j >= left) { k[j] = 0; g[j] = 0; w[j] = 0; }
             tk += k[j]; tg += g[j]; tw += w[j];
         }
-        uint32_t totk;
-        uint32_t ik = fr_block_scan_u32(tk, shu, &totk);
-        double totg, totw;
-        double eg = fr_block_excl_f64(tg, shd, &totg);
-        fr_block_excl_f64(tw, shd, &totw);
-        uint32_t ek = ik - tk;
+        uint32_t totk, ek;
+        double totg, totw, eg;
+        fr_block_scan3(tk, tg, tw, &sh3, &ek, &eg, &totk, &totg, &totw);
         uint32_t xk[8]; double xg[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) { xk[j] = ek; xg[j] = eg; ek += k[j]; eg += g[j]; }
@@ -793,7 +819,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
             const size_t cx = (size_t)p * FR_FKS_MAXCHUNK + c;
             fr_st_agent(&F.ck[cx], totk); fr_st_agent(&F.cg[cx], totg); fr_st_agent(&F.cw[cx], totw);
         }
-        __syncthreads();        // shd / shu are reused by the next sweep
+        __syncthreads();        // sh3 is reused by the next sweep
     }
     if (!fuse) return;
     // the workgroup that finishes last turns the chunk totals into this replay's sweep totals and the next replay's sweep scalars
@@ -811,7 +837,8 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_scan(Fks2Work F, int it
 
 // (a separate launch: folding it into the last workgroup of k_fks_scan needs a device-scope fence in every workgroup, which on this part
 // writes the L2 back each time -- measured 68 us per replay instead of 9 + 9)
-static __global__ void __launch_bounds__(FR_BLOCK) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
+#define FR_FKS_TOTALS_THREADS 1024      // a wave per sweep (the sweeps are independent until the bookkeeping of one thread at the end)
+static __global__ void __launch_bounds__(FR_FKS_TOTALS_THREADS) k_fks_totals(Fks2Work F, uint32_t *err, FksMsg *msg, int inline_passes, int it) {
     __shared__ FksMsg sm;        // the bookkeeping is one thread chasing ~20 values per sweep: keep them in LDS
     // a replay that changed no delta (the confirming one, and those the host enqueued beyond it) leaves every total and scalar as it is
     if (it > 0 && F.hist[it] == 0u && F.scal->n_pass == F.scal->valid_upto && !F.scal->zero_prefix) {

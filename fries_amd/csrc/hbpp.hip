@@ -483,7 +483,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     const int rec_at = c->fks_rec_at >= 1 && !c->fks_no_light ? c->fks_rec_at : 1;
     auto scan_totals = [&](int k) {
         FR_LAUNCH(c, "k_fks_scan", k_fks_scan, dim3(nchunk, 8), dim3(FR_BLOCK), F, k, k >= rec_at ? 1 : 0, c->fks_fuse_totals ? 1 : 0, c->d_err, msg, xr ? 0 : 1);
-        if (!c->fks_fuse_totals) FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_BLOCK), F, c->d_err, msg, xr ? 0 : 1, k);
+        if (!c->fks_fuse_totals) FR_LAUNCH(c, "k_fks_totals", k_fks_totals, dim3(1), dim3(FR_FKS_TOTALS_THREADS), F, c->d_err, msg, xr ? 0 : 1, k);
         if (xr) {
             const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
             FR_LAUNCH(c, "k_fks_passes", k_fks_passes, dim3(1), dim3(1), F, all, P, k, c->d_err, 0);
