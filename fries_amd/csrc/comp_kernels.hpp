@@ -298,6 +298,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     __shared__ HbTables T;
     __shared__ SeqShared seqsh;
     __shared__ uint32_t shu[4];
+    if (W.seq.skip && *W.seq.skip) return;
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
     const unsigned n_in = fin->n_in;
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
@@ -361,6 +362,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
 // forward sequentially from each flagged element until the tooth index re-synchronises.
 template <int STAGE, bool NEW_HB>
 __global__ void __launch_bounds__(FR_BLOCK) k_sys_fixup(CompWork W, VecDev V, const HbTables *Tg, int cur, double p_doub, uint32_t *err) {
+    if (W.seq.skip && *W.seq.skip) return;
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
     uint32_t nf = fin->n_fix;
     if (nf == 0) return;

@@ -186,7 +186,8 @@ struct FriesCtx {
     uint32_t prop_tag = 0;                   // last tag handed to a comb-repair round (k_sys_walk)
     int fks_rec_at = -1;                     // FRIES_FKS_REC_AT=k: the replay that records the tiles' margins (default: rounds hint - 2)
     bool fks_group_warm_all = true;          // FRIES_GROUP_WARM_ALL=0: only stage 1 starts its first replay from the previous iteration's per-group prefixes
-    bool fks_light_full_grid = false;        // FRIES_FKS_LIGHT_FULL_GRID=1: light replays launch one workgroup per tile
+    bool fks_no_speculation = false;         // FRIES_FKS_NO_SPECULATION=1: nothing is enqueued behind the closing pass before the host has seen its flag
+    bool fks_light_full_grid = true;         // FRIES_FKS_LIGHT_FULL_GRID=1: light replays launch one workgroup per tile
     bool fks_fuse_totals = false;            // FRIES_FKS_FUSE_TOTALS=1: the last workgroup of k_fks_scan does k_fks_totals' work
     bool fks_no_ext = false;                 // FRIES_FKS_NO_EXT=1: a wave re-decides whenever the stage runs another number of sweeps than it last ran
     bool fks_no_group_warm = false;          // FRIES_NO_GROUP_WARM=1
@@ -195,7 +196,7 @@ struct FriesCtx {
     bool fks_no_collapse_walk = false;       // FRIES_FKS_COLLAPSE_WALK=0: keep the parallel replay's result in collapsing stages (fast, not bit-identical to the reference there)
     bool fks_force_seq = false;              // FRIES_FKS_SEQ=1: every stage through the in-order walk (tests)
     uint64_t n_fks_sequential = 0;
-    unsigned fks_grid = 1280;
+    unsigned fks_grid = 1280, fks_grid0 = 1280;
     bool warm_start = true;
     uint32_t *c_pos = nullptr, *c_orbs = nullptr; double *c_val = nullptr;   // compacted apply_HBPP_sys output
     uint32_t *d_nsucc = nullptr;
@@ -299,6 +300,8 @@ const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held = 
 // memory and the host polls that word.  (hipStreamSynchronize returns ~20 us after the stream has drained; the iteration has about a
 // dozen such waits, during each of which the GPU idles.)
 void fr_stream_wait(FriesCtx *c);
+uint32_t fr_stream_ticket(FriesCtx *c);
+void fr_stream_wait_ticket(FriesCtx *c, uint32_t t);
 void fr_rb_init(FriesCtx *c);
 void fr_system_upload(FriesCtx *c, uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h_core, const double *eris);
 void fr_h_trial_setup(FriesCtx *c);

@@ -478,6 +478,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     if (getenv("FRIES_FKS_LIGHT_FULL_GRID")) h->c.fks_light_full_grid = atoi(getenv("FRIES_FKS_LIGHT_FULL_GRID")) != 0;
     if (getenv("FRIES_FKS_FUSE_TOTALS")) h->c.fks_fuse_totals = atoi(getenv("FRIES_FKS_FUSE_TOTALS")) != 0;
     if (getenv("FRIES_FKS_NO_LIGHT")) h->c.fks_no_light = atoi(getenv("FRIES_FKS_NO_LIGHT")) != 0;
+    if (getenv("FRIES_FKS_NO_SPECULATION")) h->c.fks_no_speculation = atoi(getenv("FRIES_FKS_NO_SPECULATION")) != 0;
     if (getenv("FRIES_FKS_NO_CLOSING")) h->c.fks_no_closing = atoi(getenv("FRIES_FKS_NO_CLOSING")) != 0;
     if (getenv("FRIES_FKS_COLLAPSE_WALK")) h->c.fks_no_collapse_walk = atoi(getenv("FRIES_FKS_COLLAPSE_WALK")) == 0;
     if (getenv("FRIES_FKS_SEQ")) h->c.fks_force_seq = atoi(getenv("FRIES_FKS_SEQ")) != 0;
@@ -485,7 +486,9 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     {
         hipDeviceProp_t pr;
         FR_HIP(hipGetDeviceProperties(&pr, device));
-        h->c.fks_grid = 5u * (unsigned)pr.multiProcessorCount;      // k_fks_sweep: <= 92 VGPRs -> 5 waves/SIMD = 5 workgroups per CU
+        h->c.fks_grid = (unsigned)FR_FKS_WPE1 * (unsigned)pr.multiProcessorCount;      // k_fks_sweep: <= 92 VGPRs -> 5 waves/SIMD = 5 workgroups per CU
+        h->c.fks_grid0 = (unsigned)FR_FKS_WPE0 * (unsigned)pr.multiProcessorCount;     // the lean replay
+        if (getenv("FRIES_FKS_GRID0")) h->c.fks_grid0 = (unsigned)atoi(getenv("FRIES_FKS_GRID0"));
         if (getenv("FRIES_FKS_GRID")) h->c.fks_grid = (unsigned)atoi(getenv("FRIES_FKS_GRID"));
     }
     FR_HIP(hipStreamCreate(&h->c.stream));

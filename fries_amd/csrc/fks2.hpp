@@ -276,8 +276,15 @@ __device__ __forceinline__ void fr_fks_save(Fks2Work F) {
     }
 }
 
+// Occupancy targets: the lean replay fits 64 registers (8 waves per SIMD) at the price of a few spilled words; the comparing replays need ~100
+#ifndef FR_FKS_WPE0
+#define FR_FKS_WPE0 5
+#endif
+#ifndef FR_FKS_WPE1
+#define FR_FKS_WPE1 5
+#endif
 template <int STAGE, bool NEW_HB, int MODE>
-__global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
+__global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? FR_FKS_WPE0 : FR_FKS_WPE1))) k_fks_sweep(CompWork W, Fks2Work F, const HbTables *Tg, int cur, int it, double p_doub, int light, int dbg) {
     constexpr bool M1 = MODE == 1 || MODE == 3 || MODE == 4, LIGHT = MODE == 3 || MODE == 4, FIN = MODE == 2 || MODE == 4;       // comparing replays; MODE 3 / 4 skip the waves that stand; MODE 2 / 4 end with the final wt_remain
     __shared__ HbTables T;
     __shared__ FksScal S;

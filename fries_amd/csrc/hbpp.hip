@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_compact(CompWork W, int prev
 // norms: every rank's find_keep_sub result in rank order (compress_utils.cpp:817-818); norms[rank] == *W.seq.total
 static __global__ void __launch_bounds__(64) k_comp_finalize2(CompWork W, Fks2Work F, double rn, const double *norms, int rank, int n_ranks) {
     __shared__ Teeth Tsh;           // the comb is tabulated in LDS by one lane and copied out by the wave
+    if (W.seq.skip && *W.seq.skip) return;
     if (threadIdx.x == 0) {
         const FksScal *S = F.scal;
         CompState s = W.state[0];
@@ -459,6 +460,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     const int warm = c->warm_start ? 1 : 0;
     unsigned gridE = fr_blocks(((size_t)n_bound / 8 + 1) * 8, FR_BLOCK);
     const unsigned gridL = c->fks_light_full_grid ? gridE : (gridE > c->fks_grid ? c->fks_grid : gridE);      // light replays: one tile per workgroup (the test of a tile is two dependent rounds of loads; a workgroup striding over three tiles pays them three times before it may leave)
+    const unsigned gridE0 = gridE > c->fks_grid0 ? c->fks_grid0 : gridE;        // the lean replay's own count
     if (gridE > c->fks_grid) gridE = c->fks_grid;          // persistent workgroups (5 per CU), each strides over the tiles
     unsigned nchunk = fr_blocks((size_t)n_bound / 8 + 1, FR_FKS_CHUNK);
     if (nchunk > FR_FKS_MAXCHUNK) throw FriesError("stage too large for the find_keep_sub scan");
@@ -491,7 +493,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     };
     auto replay = [&](int k) {
         const int light = (k > rec_at && !c->fks_no_light && !c->d_tie) ? (c->fks_no_ext ? 2 : 1) : 0;       // (tie statistics: every wave decides in every replay, so that the records are those of the settled state)       // FRIES_FKS_NO_LIGHT: every tile evaluated in every replay
-        if (k < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, 0, c->dbg);
+        if (k < rec_at) FR_LAUNCH(c, "k_fks_sweep", (k_fks_sweep<STAGE, NEW_HB, 0>), dim3(gridE0), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, 0, c->dbg);
         else if (light) FR_LAUNCH(c, "k_fks_sweep_light", (k_fks_sweep<STAGE, NEW_HB, 3>), dim3(gridL), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, light, c->dbg);
         else FR_LAUNCH(c, "k_fks_sweep_rec", (k_fks_sweep<STAGE, NEW_HB, 1>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, k, c->p_doub, 0, c->dbg);
         scan_totals(k);
@@ -504,6 +506,22 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // The closing pass (k_fks_sweep MODE 4): the light replay that is expected to change nothing and the final pass in one launch.  When it
     // changes no delta the stage has settled and its output stands -- the confirming sweep + scan + totals are never launched.
     const bool closing = !c->fks_no_light && !c->d_tie && !c->fks_no_closing && !c->fks_fuse_totals && rec_at == 1 && !sequential;
+    // what follows a settled stage up to the emission counts, for one rank without the propagation repair (the other cases exchange norms or
+    // look at list lengths on the host in between): skip != nullptr = launched ahead of the host's look at *skip
+    AccWt acc{W.wt_remain, &W.state[0]};
+    auto launch_tail = [&](const uint32_t *skip) {
+        CompWork Wt = W;
+        Wt.seq.skip = skip;
+        FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), Wt.seq, acc);
+        FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
+        FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
+        FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(64), Wt, F, rn, (const double *)Wt.seq.total, c->rank, P);
+        FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), Wt, c->vec, c->d_hb, cur, c->p_doub);
+        FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(FR_BLOCK), Wt, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
+    };
+    const bool simple_tail = !xr && c->rank == 0 && !W.prop;
+    const bool speculate = simple_tail && !c->fks_no_speculation;
+    bool tail_done = false;
     if (closing) {
         int plain = batch < 2 ? 2 : batch;       // replays before the closing pass (replay 1 writes the records the light test needs)
         while (!closed && !sequential) {
@@ -516,7 +534,16 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
                 FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, all, P, it);
             }
             else FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, (const uint32_t *)nullptr, 0, it);
-            fr_stream_wait(c);
+            if (speculate) {
+                // The host needs ~10 us from the ticket to its next launch.  The closing pass settles the stage six times out of seven, so what
+                // follows it -- the exact sum of wt_remain, the comb, the emission counts -- is enqueued behind the ticket and runs while the
+                // host looks at the flag; if the pass did change a delta, these kernels see the same flag and leave at once.
+                const uint32_t tk = fr_stream_ticket(c);
+                launch_tail(&F.hist[it]);
+                fr_stream_wait_ticket(c, tk);
+                tail_done = true;
+            }
+            else fr_stream_wait(c);
             read_host();
             if (sequential) break;
             const volatile FksHost *hm = c->h_fks;
@@ -525,7 +552,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
                 needed = it;
                 for (int j = 2; j < it; j++) if (hm->hist[j] == 0) { needed = j; break; }      // a plain replay already reproduced its predecessor: the closing pass could have come there
             }
-            else { scan_totals(it); it++; plain = it; }       // it was a replay like any other: scan, add up, close again
+            else { tail_done = false; scan_totals(it); it++; plain = it; }       // it was a replay like any other: scan, add up, close again
         }
         if (closed) c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
     }
@@ -545,6 +572,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // (a norm that went negative did so by rounding noise of the same kind)
     if (!sequential && !c->fks_no_collapse_walk && (!(hscal.G_last >= 1e-3 * hscal.psG[0]) || hscal.G_neg < 0) && hscal.psG[0] > 0) sequential = true;
     if (sequential) {
+        tail_done = false;
         if (hscal.overflow) FR_LAUNCH(c, "k_err_clear", k_err_clear, dim3(1), dim3(1), c->d_err, (uint32_t)FR_ERR_ROUNDS);     // FR_ERR_ROUNDS of the abandoned replay only: d_err also carries the flags of earlier stages and iterations of the batch
         run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
     }
@@ -569,56 +597,59 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         // settled: recompute every wt_remain with the budget of its last flagged sweep
         FR_LAUNCH(c, "k_fks_final", (k_fks_sweep<STAGE, NEW_HB, 2>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, 0, 0);
     }
-    AccWt acc{W.wt_remain, &W.state[0]};
-    FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
-    FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
-    FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
-    const double *norms = W.seq.total;
-    if (xr) {
-        // every rank's remaining norm (compress_utils.cpp:817-818), then the in-order lbound chain again from this
-        // rank's offset: a floating-point running sum depends on where it starts
-        FR_LAUNCH(c, "k_put_norm", k_put_norm, dim3(1), dim3(1), W, F, (double *)c->comm.small_send);
-        norms = (const double *)fr_allgather(c, sizeof(double));
-    }
-    FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(64), W, F, rn, norms, c->rank, P);
-    if (c->rank > 0) {
-        SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
-        SeqWork Q2 = W.seq; Q2.total = c->d_seq_scratch;
-        FR_LAUNCH(c, "k_keep_norms", k_keep_norms, dim3(1), dim3(64), norms, P, c->d_norms_keep, W, F);
-        FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc, from);
-        FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
-    }
-    if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
-    FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
-#ifdef FR_SYS_TIMING
-    fr_sys_timing_dump(c, "k_sys_count", STAGE, grid, 6);
-#endif
-    if (W.prop) {
-        // chains of repairs, each walked by one lane (k_sys_walk); a round ends where chains ran into one another, and those are walked
-        // on in the next round.  This is the frisys_hh path, where one stage needs ~1e4 repairs in chains of up to a few hundred
-        // elements; the molecular path keeps the short sequential fix-up below.  Two rounds per host look at the list length.
-        int in = 0;
-        uint32_t na = 0;
-        FR_HIP(hipMemcpyAsync(&na, &W.act_n[0], 4, hipMemcpyDeviceToHost, st));
-        FR_HIP(hipStreamSynchronize(st));
-        if (na > W.cap) throw FriesError("comb repair list overflow");
-        for (int round = 0; na != 0; ) {
-            if (round > 100000) throw FriesError("comb repair did not settle");
-            unsigned gp = fr_blocks(na, FR_BLOCK);
-            if (gp > 1024) gp = 1024;
-            for (int k = 0; k < 2; k++, round++) {      // the next list is never longer than this one
-                const uint32_t tag = ++c->prop_tag;
-                if (tag == 0) throw FriesError("repair tags exhausted");
-                FR_HIP(hipMemsetAsync(&W.act_n[in ^ 1], 0, 4, st));
-                FR_LAUNCH(c, "k_sys_mark", k_sys_mark, dim3(gp), dim3(FR_BLOCK), W, in, tag);
-                FR_LAUNCH(c, "k_sys_walk", (k_sys_walk<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in, tag);
-                in ^= 1;
-            }
-            FR_HIP(hipMemcpyAsync(&na, &W.act_n[in], 4, hipMemcpyDeviceToHost, st));
-            FR_HIP(hipStreamSynchronize(st));
+    if (tail_done) { }
+    else if (simple_tail) launch_tail(nullptr);
+    else {
+        FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
+        FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
+        FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
+        const double *norms = W.seq.total;
+        if (xr) {
+            // every rank's remaining norm (compress_utils.cpp:817-818), then the in-order lbound chain again from this
+            // rank's offset: a floating-point running sum depends on where it starts
+            FR_LAUNCH(c, "k_put_norm", k_put_norm, dim3(1), dim3(1), W, F, (double *)c->comm.small_send);
+            norms = (const double *)fr_allgather(c, sizeof(double));
         }
+        FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(64), W, F, rn, norms, c->rank, P);
+        if (c->rank > 0) {
+            SeqStart from; from.norms = c->d_norms_keep; from.n = c->rank;
+            SeqWork Q2 = W.seq; Q2.total = c->d_seq_scratch;
+            FR_LAUNCH(c, "k_keep_norms", k_keep_norms, dim3(1), dim3(64), norms, P, c->d_norms_keep, W, F);
+            FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Q2, acc, from);
+            FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Q2, acc, from);
+        }
+        if (W.prop) FR_HIP(hipMemsetAsync(W.act_n, 0, 8, st));
+        FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub);
+    #ifdef FR_SYS_TIMING
+        fr_sys_timing_dump(c, "k_sys_count", STAGE, grid, 6);
+    #endif
+        if (W.prop) {
+            // chains of repairs, each walked by one lane (k_sys_walk); a round ends where chains ran into one another, and those are walked
+            // on in the next round.  This is the frisys_hh path, where one stage needs ~1e4 repairs in chains of up to a few hundred
+            // elements; the molecular path keeps the short sequential fix-up below.  Two rounds per host look at the list length.
+            int in = 0;
+            uint32_t na = 0;
+            FR_HIP(hipMemcpyAsync(&na, &W.act_n[0], 4, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+            if (na > W.cap) throw FriesError("comb repair list overflow");
+            for (int round = 0; na != 0; ) {
+                if (round > 100000) throw FriesError("comb repair did not settle");
+                unsigned gp = fr_blocks(na, FR_BLOCK);
+                if (gp > 1024) gp = 1024;
+                for (int k = 0; k < 2; k++, round++) {      // the next list is never longer than this one
+                    const uint32_t tag = ++c->prop_tag;
+                    if (tag == 0) throw FriesError("repair tags exhausted");
+                    FR_HIP(hipMemsetAsync(&W.act_n[in ^ 1], 0, 4, st));
+                    FR_LAUNCH(c, "k_sys_mark", k_sys_mark, dim3(gp), dim3(FR_BLOCK), W, in, tag);
+                    FR_LAUNCH(c, "k_sys_walk", (k_sys_walk<STAGE, NEW_HB>), dim3(gp), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, in, tag);
+                    in ^= 1;
+                }
+                FR_HIP(hipMemcpyAsync(&na, &W.act_n[in], 4, hipMemcpyDeviceToHost, st));
+                FR_HIP(hipStreamSynchronize(st));
+            }
+        }
+        else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     }
-    else FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     // the stage's emission count also goes to the host block (word 16 + slot): a copy into pageable memory would hold the host until it is done
     fr_rb_init(c);
     FR_LAUNCH(c, "k_sys_write", (k_sys_write<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, c->p_doub, c->d_err, out_slot >= 0 ? c->d_misc() + 16 + out_slot : nullptr);

@@ -34,6 +34,7 @@ struct SeqWork {
     SeqRec *subs;       // [FR_MAX_PART * 16]
     double *total;      // [1] exact sum of everything (+ start)
     double *tsum;       // [FR_MAX_PART] the tiles' tree sums again, contiguous (k_seq_maps adds up the ones before its tile)
+    const uint32_t *skip = nullptr;     // launched ahead of the host's look at a flag: *skip != 0 = the input is not final, leave at once (run_stage)
 #ifdef FR_SEQ_TIMING
     int dbg = 0;        // FRIES_SEQ_DBG: k_seq_chain prints where its time goes (build with -DFR_SEQ_TIMING)
 #else
@@ -106,6 +107,7 @@ __device__ __forceinline__ double fr_seq_apply_map(double carry, int e, long lon
 template <class Acc>
 __global__ void __launch_bounds__(FR_BLOCK) k_seq_sums(SeqWork Q, Acc acc) {
     __shared__ double shd[4];
+    if (Q.skip && *Q.skip) return;
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
     if (blockIdx.x >= ntile) return;
@@ -127,6 +129,7 @@ template <class Acc>
 __global__ void __launch_bounds__(FR_BLOCK) k_seq_maps(SeqWork Q, Acc acc, SeqStart st) {
     __shared__ PMap shm[FR_BLOCK];
     __shared__ double shc[4];
+    if (Q.skip && *Q.skip) return;
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
     if (blockIdx.x >= ntile) return;
@@ -309,6 +312,7 @@ __device__ __forceinline__ int fr_seq_n_sub(unsigned n, size_t t_lo) {
 template <class Acc>
 __global__ void __launch_bounds__(FR_BLOCK) k_seq_chain(SeqWork Q, Acc acc, SeqStart st) {
     __shared__ SeqChainSh sh;
+    if (Q.skip && *Q.skip) return;
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;
     const int lane = fr_lane();

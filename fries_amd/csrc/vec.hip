@@ -59,22 +59,30 @@ void fr_rb_init(FriesCtx *c) {
     c->wait_by_sync = getenv("FRIES_WAIT_SYNC") && atoi(getenv("FRIES_WAIT_SYNC")) != 0;
 }
 static __global__ void k_ticket(uint32_t *word, uint32_t ticket) { __hip_atomic_store(word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-void fr_stream_wait(FriesCtx *c) {
+// The wait in two halves: the ticket is enqueued where the host needs the stream's results, kernels enqueued after it run while the host
+// waits for it (run_stage: the kernels that follow a stage's closing pass, which leave at once if the pass did not settle the stage).
+uint32_t fr_stream_ticket(FriesCtx *c) {
     fr_rb_init(c);
-    if (c->wait_by_sync) { FR_HIP(hipStreamSynchronize(c->stream)); return; }
+    if (c->wait_by_sync) return 0u;
     const uint32_t t = ++c->ticket;
     FR_LAUNCH(c, "k_ticket", k_ticket, dim3(1), dim3(1), c->d_misc(), t);
+    return t;
+}
+void fr_stream_wait_ticket(FriesCtx *c, uint32_t t) {
+    if (c->wait_by_sync) { FR_HIP(hipStreamSynchronize(c->stream)); return; }
     volatile uint32_t *w = c->h_misc();
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t spin = 0; __atomic_load_n((const uint32_t *)w, __ATOMIC_ACQUIRE) != t; spin++) {
+    auto reached = [&]() { return (int32_t)(__atomic_load_n((const uint32_t *)w, __ATOMIC_ACQUIRE) - t) >= 0; };      // (a later ticket may already have passed)
+    for (uint64_t spin = 0; !reached(); spin++) {
         __builtin_ia32_pause();
         if ((spin & 0xFFFFF) == 0xFFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {      // a long kernel, or a fault: let the runtime say which
             FR_HIP(hipStreamSynchronize(c->stream));
-            if (__atomic_load_n((const uint32_t *)w, __ATOMIC_ACQUIRE) != t) throw FriesError("fr_stream_wait: the stream drained without the ticket kernel having run");
+            if (!reached()) throw FriesError("fr_stream_wait: the stream drained without the ticket kernel having run");
             break;
         }
     }
 }
+void fr_stream_wait(FriesCtx *c) { fr_stream_wait_ticket(c, fr_stream_ticket(c)); }
 static size_t fr_rb_take(FriesCtx *c, size_t bytes, bool held) {
     fr_rb_init(c);
     const size_t need = (bytes + 63) & ~(size_t)63;
