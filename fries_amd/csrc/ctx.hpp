@@ -48,6 +48,8 @@ struct SpawnBuf {
     uint32_t *n_spawn;                         // device scalar: list length
     // exchange between ranks (n_ranks > 1)
     uint8_t *xkey; uint32_t *xcnt, *xoff, *xbucket;
+    // several perform_add rounds per pass (the Adder filled up, vec.hip fr_xch_rounds): the local list kept across the rounds, and where the rounds end
+    det_t *bdet = nullptr; double *bval = nullptr; uint8_t *bini = nullptr; uint32_t *bn = nullptr; uint32_t *xbounds = nullptr;
 };
 
 // vector-compression scratch (compress.hip)
@@ -155,6 +157,7 @@ struct FriesCtx {
     unsigned long long *hhf_cnt = nullptr;      // frifull_hh: {adds tried, adds written} of the iteration
     uint32_t adder_cap = 0;                  // the reference's Adder capacity per destination (frisys_mol.cpp:109-110)
     uint64_t n_collectives = 0;
+    uint64_t n_adder_rounds = 0;             // perform_add rounds beyond the usual one per pass (the Adder filled up)
     // system
     uint32_t n_orb = 0, n_elec = 0;
     double *d_h = nullptr, *d_eris = nullptr;
@@ -254,7 +257,7 @@ void fr_vec_maybe_rebuild(FriesCtx *c, VecDev *v);
 void fr_vec_reserve_hash(FriesCtx *c, VecDev *v, uint32_t n_new);
 void fr_spawn_alloc(FriesCtx *c, uint32_t cap);
 void fr_xch_alloc(FriesCtx *c, uint32_t cap);
-uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass = 0);      // 0: two passes (frisys_mol); 1: one pass, flag inside an integer value; 2: one pass, flag in bit 63 of the index
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass = 0, bool *merged = nullptr);      // 0: two passes (frisys_mol); 1: one pass, flag inside an integer value; 2: one pass, flag in bit 63 of the index
 // hbpp.hip
 void fr_hbpp_alloc(FriesCtx *c, uint32_t cap);
 void fr_hbpp_apply(FriesCtx *c, uint32_t n_samp, const double rn[5]);

@@ -154,6 +154,7 @@ static void frisys_setup(FriesCtx *c, const fries_frisys_params *p) {
     uint32_t wcap = p->max_dets > p->mat_nonz + 4096 ? p->max_dets : p->mat_nonz + 4096;
     uint32_t spawn_length = (uint32_t)((uint64_t)p->mat_nonz * 4 / c->n_ranks);
     c->adder_cap = spawn_length > 1000000u ? 1000000u : spawn_length;        // :109-110
+    if (getenv("FRIES_ADDER_SIZE")) c->adder_cap = (uint32_t)atol(getenv("FRIES_ADDER_SIZE"));      // a smaller Adder (the DistVec constructor's adder_size): the early perform_add rounds at test sizes
     if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
     if (!c->d_proc_scr) c->d_proc_scr = fr_alloc<uint32_t>(64);
     FR_HIP(hipMemcpyAsync(c->d_proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size(), hipMemcpyHostToDevice, c->stream));
@@ -253,8 +254,9 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
     if (c->num_success > c->sp.cap) throw FriesError("spawn buffer too small");
     if (c->num_success) FR_LAUNCH(c, "k_spawn_build", k_spawn_build, dim3(fr_blocks(c->num_success, FR_BLOCK)), dim3(FR_BLOCK), c->vec, c->sp, c->c_pos, c->c_orbs, c->c_val, c->d_nsucc, c->eps, c->init_thresh);
     uint32_t n_merge = c->num_success;
-    if (c->use_comm) n_merge = fr_spawn_exchange(c, c->num_success);      // every rank takes part, also with nothing to send
-    if (n_merge) fr_vec_merge(c, &c->vec, n_merge, false);
+    bool merged = false;            // the Adder filled up: the passes went through several perform_add rounds, each merged on arrival
+    if (c->use_comm) n_merge = fr_spawn_exchange(c, c->num_success, 0, &merged);      // every rank takes part, also with nothing to send
+    if (n_merge && !merged) fr_vec_merge(c, &c->vec, n_merge, false);
     uint32_t n_merge_dense = 0;
     if (c->n_dense_h_glob) {
         // the dense block of H applied exactly (:480-485): value at the origin x stored element, added as initiator contributions in
@@ -520,6 +522,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     hipFree(h->c.c_pos); hipFree(h->c.c_orbs); hipFree(h->c.c_val); hipFree(h->c.d_nsucc);
     SpawnBuf &s = h->c.sp;
     hipFree(s.det); hipFree(s.val); hipFree(s.ini); hipFree(s.slot); hipFree(s.flag);
+    if (s.bdet) { hipFree(s.bdet); hipFree(s.bval); hipFree(s.bini); hipFree(s.bn); hipFree(s.xbounds); }
     for (int k = 0; k < 2; k++) { hipFree(s.key[k]); hipFree(s.pay[k]); }
     hipFree(s.hist); hipFree(s.pcnt); hipFree(s.n_spawn);
     VcompBuf &b = h->c.vc;

@@ -612,7 +612,11 @@ __device__ __forceinline__ uint32_t fr_proc_of(det_t d, const uint32_t *scr, uin
 }
 
 // bucket = 2 * destination + initiator flag; counts per 256-element tile
-__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt, uint32_t hh_sites, int one_pass) {
+#define FR_XCH_MAXR 1022    // perform_add rounds per pass when the Adder fills up
+// sel != nullptr: only the spawns of pass sel_pass whose index lies in round sel_round of this rank, [sel[r], sel[r + 1]) of
+// sel = bounds + sel_pass * (FR_XCH_MAXR + 2), take part (the others get key 0xFF)
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_t *scr, uint32_t n_ranks, uint8_t *key, uint32_t *tile_cnt, uint32_t hh_sites, int one_pass,
+                                                       const uint32_t *sel, int sel_pass, int sel_round) {
     __shared__ uint32_t wcnt[4][FR_XCH_MAXB];
     const uint32_t n = *S.n_spawn;
     const uint32_t nb = 2 * n_ranks;
@@ -622,7 +626,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_keys(SpawnBuf S, const uint32_
     uint32_t k = 0xFFu;
     if (j < n) {
         uint32_t owner = hh_sites ? (uint32_t)(fr_hh_hash(S.det[j], scr, hh_sites) % n_ranks) : fr_proc_of(S.det[j], scr, n_ranks);
-        k = 2 * owner + ((S.ini[j] && !one_pass) ? 1u : 0u); key[j] = (uint8_t)k;
+        k = 2 * owner + ((S.ini[j] && !one_pass) ? 1u : 0u);
+        if (sel && ((int)(k & 1u) != sel_pass || j < sel[sel_round] || j >= sel[sel_round + 1])) k = 0xFFu;
+        key[j] = (uint8_t)k;
     }
     const int w = threadIdx.x >> 6;
     for (uint32_t b = 0; b < nb; b++) {
@@ -678,7 +684,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_scatter(SpawnBuf S, uint32_t n
         if (k == b) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
     __syncthreads();
-    if (j < n) {
+    if (j < n && k < nb) {
         for (int ww = 0; ww < w; ww++) my_rank += wcnt[ww][k];
         uint32_t o = bucket[nb + k] + tile_off[(size_t)blockIdx.x * nb + k] + my_rank;
         if (o < cap_recs) {
@@ -718,6 +724,54 @@ __global__ void __launch_bounds__(FR_BLOCK) k_xch_unpack(SpawnBuf S, const XchRe
     S.det[j] = r.det; S.val[j] = r.val; S.ini[j] = (j - G.first[s]) >= G.n0[s] ? 1 : 0;
 }
 
+// Where this rank's perform_add rounds end.  Adder::add returns false when a destination's buffer reaches adder_size; the driver then stops
+// adding, every rank calls perform_add, and the walk over the samples goes on where it stopped (vec_utils.hpp:957-971,
+// frisys_mol.cpp:430-471): per pass, round r of this rank is the index range [E_r, E_(r+1)) with E_(r+1) - 1 = the first spawn of the
+// pass at which SOME destination has received adder_size spawns since E_r.  One workgroup, thread b = bucket (destination, pass):
+// counts below an index and the index of the n-th element of a bucket come from the tiles' prefix counts (k_xch_scan) and a walk
+// inside one tile of 256 keys.  bounds[pass][0 .. nr] = E_0 = 0, ..., E_nr = n; msg[pass] = nr.
+__global__ void __launch_bounds__(FR_BLOCK) k_xch_rounds(const uint8_t *key, const uint32_t *n_ptr, uint32_t nb, const uint32_t *tile_off, const uint32_t *bucket_tot, uint32_t cap,
+                                                         uint32_t *bounds, uint32_t *msg, uint32_t *err) {
+    __shared__ uint32_t s_min;
+    const uint32_t n = *n_ptr;
+    const uint32_t ntile = (n + FR_BLOCK - 1) / FR_BLOCK;
+    const uint32_t b = threadIdx.x;
+    for (uint32_t p = 0; p < 2; p++) {
+        uint32_t *bd = bounds + p * (FR_XCH_MAXR + 2);
+        uint32_t E = 0, k = 0;
+        bool too_many = false;
+        if (threadIdx.x == 0) bd[0] = 0;
+        while (true) {
+            if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
+            __syncthreads();
+            if (b < nb && (b & 1u) == p && cap > 0) {
+                uint32_t base;                                  // elements of my bucket below E
+                const uint32_t t = E / FR_BLOCK;
+                if (t >= ntile) base = bucket_tot[b];
+                else { base = tile_off[(size_t)t * nb + b]; for (uint32_t j = t * FR_BLOCK; j < E; j++) base += key[j] == b ? 1u : 0u; }
+                const uint64_t target = (uint64_t)base + cap;   // ordinal (from 1) of the element that fills the buffer
+                if ((uint64_t)bucket_tot[b] >= target) {
+                    uint32_t lo = 0, hi = ntile - 1;            // last tile with fewer than `target` elements of the bucket before it
+                    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if ((uint64_t)tile_off[(size_t)mid * nb + b] < target) lo = mid; else hi = mid - 1; }
+                    uint32_t cnt = tile_off[(size_t)lo * nb + b], x = 0xFFFFFFFFu;
+                    for (uint32_t j = lo * FR_BLOCK; j < n && j < (lo + 1) * FR_BLOCK; j++) if (key[j] == b && (uint64_t)(++cnt) == target) { x = j; break; }
+                    if (x != 0xFFFFFFFFu) atomicMin(&s_min, x);
+                }
+            }
+            __syncthreads();
+            const uint32_t B = s_min;
+            __syncthreads();
+            if (B == 0xFFFFFFFFu) break;
+            E = B + 1; k++;
+            if (k > FR_XCH_MAXR) { too_many = true; k = FR_XCH_MAXR; break; }
+            if (threadIdx.x == 0) bd[k] = E;
+        }
+        k++;
+        if (threadIdx.x == 0) { for (uint32_t q = k; q < FR_XCH_MAXR + 2; q++) bd[q] = n; msg[p] = too_many ? 0xFFFFFFFFu : k; }      // (rounds this rank no longer takes part in are empty: [n, n))
+        __syncthreads();
+    }
+}
+
 void fr_xch_alloc(FriesCtx *c, uint32_t cap) {
     SpawnBuf &S = c->sp;
     if (!c->use_comm) return;
@@ -730,20 +784,19 @@ void fr_xch_alloc(FriesCtx *c, uint32_t cap) {
     if ((size_t)2 * c->n_ranks * 4 > 2048) throw FriesError("too many ranks");
 }
 
-// Ships the n_local spawns in c->sp to their owners; on return c->sp holds what this rank received, in the
-// reference's arrival order.  Returns the number received.
-uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass) {
+// One perform_add: ships the spawns of `src` (the whole list, or with sel the spawns of one pass and round) to their owners; on return
+// c->sp holds what this rank received, in the reference's arrival order.  Returns the number received; *overflow (when asked for) =
+// some (source, destination, pass) has reached the Adder's capacity and nothing was shipped.
+static uint32_t xch_once(FriesCtx *c, const SpawnBuf &src, uint32_t n_local, int one_pass, const uint32_t *sel, int sel_pass, int sel_round, bool *overflow) {
     SpawnBuf &S = c->sp;
     hipStream_t st = c->stream;
     const int P = c->n_ranks;
     const uint32_t nb = 2 * P;
-    if (n_local > S.cap) throw FriesError("spawn list exceeds spawn buffer capacity");
     unsigned g = fr_blocks(n_local ? n_local : 1, FR_BLOCK);
     uint32_t cap_recs = (uint32_t)(c->comm.big_bytes / sizeof(XchRec));
-    if (n_local == 0) FR_HIP(hipMemsetAsync(S.n_spawn, 0, 4, st));
-    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), S, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites, one_pass);
-    FR_LAUNCH(c, "k_xch_scan", k_xch_scan, dim3(1), dim3(FR_BLOCK), S, (uint32_t)P, S.xcnt, S.xoff, S.xbucket, (uint32_t *)c->comm.small_send);
-    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), S, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err, one_pass);
+    FR_LAUNCH(c, "k_xch_keys", k_xch_keys, dim3(g), dim3(FR_BLOCK), src, c->d_proc_scr, (uint32_t)P, S.xkey, S.xcnt, c->vec.hh_sites, one_pass, sel, sel_pass, sel_round);
+    FR_LAUNCH(c, "k_xch_scan", k_xch_scan, dim3(1), dim3(FR_BLOCK), src, (uint32_t)P, S.xcnt, S.xoff, S.xbucket, (uint32_t *)c->comm.small_send);
+    FR_LAUNCH(c, "k_xch_scatter", k_xch_scatter, dim3(g), dim3(FR_BLOCK), src, (uint32_t)P, S.xkey, S.xoff, S.xbucket, (XchRec *)c->comm.big_send, cap_recs, c->d_err, one_pass);
     const uint32_t *all = (const uint32_t *)fr_allgather(c, nb * 4);
     std::vector<uint32_t> cnt((size_t)P * nb);
     FR_HIP(hipMemcpyAsync(cnt.data(), all, cnt.size() * 4, hipMemcpyDeviceToHost, st));
@@ -755,16 +808,22 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass) {
     // Every rank holds the whole P x 2P count matrix, so the limits are checked for ALL (source, destination) pairs on every
     // rank: either everybody raises here or everybody enters the all-to-all -- a rank-local check would leave the peers
     // blocked in the collective while one rank unwinds.  (Capacities are equal on all ranks: same parameters.)
+    bool full = false;
     for (int dst = 0; dst < P; dst++) {
         uint64_t tot = 0;
-        for (int src = 0; src < P; src++) {
-            const uint32_t n0 = cnt[(size_t)src * nb + 2 * dst], n1 = cnt[(size_t)src * nb + 2 * dst + 1];
-            // Adder::add refuses more than adder_size_ pending elements per destination (vec_utils.hpp:957-971); the reference
-            // then flushes early, which would reorder arrivals.  mat_nonz * 4 / n_ranks (capped at 1e6) per pass is that limit.
-            if (n0 >= c->adder_cap || n1 >= c->adder_cap) throw FriesError("a rank has more pending adds for one destination than the reference's Adder holds (early perform_add flushes are not reproduced)");
+        for (int s2 = 0; s2 < P; s2++) {
+            const uint32_t n0 = cnt[(size_t)s2 * nb + 2 * dst], n1 = cnt[(size_t)s2 * nb + 2 * dst + 1];
+            // Adder::add returns false once adder_size_ elements are pending for one destination (vec_utils.hpp:957-971) and the driver flushes
+            // early: the passes then take several perform_add rounds (fr_xch_rounds).  mat_nonz * 4 / n_ranks (capped at 1e6) per pass is that limit.
+            if (!sel && (n0 >= c->adder_cap || n1 >= c->adder_cap)) full = true;
             tot += (uint64_t)n0 + n1;
         }
-        if (tot > S.cap || tot > cap_recs) throw FriesError("received spawns exceed the spawn buffer on some rank");
+        if (!full && (tot > S.cap || tot > cap_recs)) throw FriesError("received spawns exceed the spawn buffer on some rank");
+    }
+    if (full) {
+        if (!overflow) throw FriesError("a rank has more pending adds for one destination than the reference's Adder holds (this driver's loop has no early perform_add)");
+        *overflow = true;
+        return 0;
     }
     for (int p = 0; p < P; p++) {
         const uint32_t *mine = &cnt[(size_t)c->rank * nb], *theirs = &cnt[(size_t)p * nb];
@@ -778,4 +837,57 @@ uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass) {
     c->n_collectives++;
     FR_LAUNCH(c, "k_xch_unpack", k_xch_unpack, dim3(fr_blocks(n_recv ? n_recv : 1, FR_BLOCK)), dim3(FR_BLOCK), S, (const XchRec *)c->comm.big_recv, G, (uint32_t)n_recv, one_pass);
     return (uint32_t)n_recv;
+}
+
+// The passes in several perform_add rounds, each merged into the vector before the next is shipped -- what the reference's loop does when
+// Adder::add reports a full buffer (frisys_mol.cpp:430-471): arrival order = (pass, round, source rank, order of the adds).  The keys and
+// the tiles' prefix counts of the whole list are in S.xkey / S.xoff / S.xbucket (the attempt that found the buffer full).
+static uint32_t fr_xch_rounds(FriesCtx *c, uint32_t n_local) {
+    SpawnBuf &S = c->sp;
+    hipStream_t st = c->stream;
+    const int P = c->n_ranks;
+    if (!S.bdet) {
+        S.bdet = fr_alloc<det_t>(S.cap); S.bval = fr_alloc<double>(S.cap); S.bini = fr_alloc<uint8_t>(S.cap); S.bn = fr_alloc<uint32_t>(1);
+        S.xbounds = fr_alloc<uint32_t>(2 * (FR_XCH_MAXR + 2));
+    }
+    FR_HIP(hipMemcpyAsync(S.bdet, S.det, sizeof(det_t) * (size_t)n_local, hipMemcpyDeviceToDevice, st));
+    FR_HIP(hipMemcpyAsync(S.bval, S.val, 8 * (size_t)n_local, hipMemcpyDeviceToDevice, st));
+    FR_HIP(hipMemcpyAsync(S.bini, S.ini, (size_t)n_local, hipMemcpyDeviceToDevice, st));
+    FR_HIP(hipMemcpyAsync(S.bn, S.n_spawn, 4, hipMemcpyDeviceToDevice, st));
+    FR_LAUNCH(c, "k_xch_rounds", k_xch_rounds, dim3(1), dim3(FR_BLOCK), S.xkey, S.bn, (uint32_t)(2 * P), S.xoff, S.xbucket, c->adder_cap, S.xbounds, (uint32_t *)c->comm.small_send, c->d_err);
+    const uint32_t *all = (const uint32_t *)fr_allgather(c, 8);
+    std::vector<uint32_t> nr((size_t)2 * P);
+    FR_HIP(hipMemcpyAsync(nr.data(), all, nr.size() * 4, hipMemcpyDeviceToHost, st));
+    FR_HIP(hipStreamSynchronize(st));
+    SpawnBuf src = S;
+    src.det = S.bdet; src.val = S.bval; src.ini = S.bini; src.n_spawn = S.bn;
+    uint64_t total = 0;
+    for (int p = 0; p < 2; p++) {
+        uint32_t rounds = 0;
+        for (int r = 0; r < P; r++) rounds = nr[(size_t)2 * r + p] > rounds ? nr[(size_t)2 * r + p] : rounds;       // the loop runs while any rank still adds
+        if (rounds == 0xFFFFFFFFu) throw FriesError("a pass needs more perform_add rounds than FR_XCH_MAXR (every rank raises this)");
+        for (uint32_t k = 0; k < rounds; k++) {
+            // a rank that has run out of rounds ships nothing: its bounds beyond the last round all read n
+            const uint32_t n_recv = xch_once(c, src, n_local, 0, S.xbounds + p * (FR_XCH_MAXR + 2), p, (int)k, nullptr);
+            if (n_recv) fr_vec_merge(c, &c->vec, n_recv, false);
+            total += n_recv;
+            c->n_adder_rounds++;
+        }
+    }
+    return (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
+}
+
+// Ships the n_local spawns in c->sp to their owners; on return c->sp holds what this rank received, in the
+// reference's arrival order.  Returns the number received.  merged != nullptr (frisys_mol's two-pass loop): should the Adder fill up,
+// the passes run in rounds, every round is merged into the vector here, *merged = true and the return value is the total received.
+uint32_t fr_spawn_exchange(FriesCtx *c, uint32_t n_local, int one_pass, bool *merged) {
+    SpawnBuf &S = c->sp;
+    if (n_local > S.cap) throw FriesError("spawn list exceeds spawn buffer capacity");
+    if (n_local == 0) FR_HIP(hipMemsetAsync(S.n_spawn, 0, 4, c->stream));
+    if (merged) *merged = false;
+    bool full = false;
+    const uint32_t n_recv = xch_once(c, S, n_local, one_pass, nullptr, 0, 0, (merged && one_pass == 0) ? &full : nullptr);
+    if (!full) return n_recv;
+    *merged = true;
+    return fr_xch_rounds(c, n_local);
 }

@@ -43,6 +43,12 @@ MPI_RUNS = {
     "n2_m10000_unnorm_p4": (4, ("N2", 40, 7, 0.01, 10000, 10000, 80000, 1.0, 5000.0, "HB_unnorm")),
     "h2o_m5000_hb_p3": (3, ("H2O", 40, 99, 0.005, 5000, 8000, 80000, 3.0, 2000.0, "HB")),
 }
+# the same with a smaller Adder (FRIES_ADDER_SIZE = the adder_size argument of the reference's DistVec): Adder::add reports a full buffer and the
+# loop of frisys_mol.cpp:430-471 takes several perform_add rounds per pass.  name -> (n_ranks, adder_size, tuple as above)
+ADDER_RUNS = {
+    "n2_m10000_unnorm_p2_adder300": (2, 300, ("N2", 30, 7, 0.01, 10000, 10000, 80000, 1.0, 5000.0, "HB_unnorm")),
+    "h2o_m5000_hb_p3_adder25": (3, 25, ("H2O", 30, 99, 0.005, 5000, 8000, 80000, 3.0, 2000.0, "HB")),
+}
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 # fciqmc_mol, near-uniform excitation generator, one rank: name -> (shape, n_iter, seed, eps, target_walkers, max_dets, initiator)
@@ -195,6 +201,7 @@ def gen_multi(manifest):
 PIN_RUNS = {
     "pin_n2_m1e6": (1, "N2", 20250215, 0.01, 1000000, 4000000, "HB_unnorm", 777, 100),           # BASELINE config 2 = bench.py's workload
     "pin_h2o_m1e7_p8": (8, "H2O", 20250215, 0.01, 10000000, 5815536, "HB_unnorm", 777, 24),      # BASELINE config 4: mpiexec -n 8
+    "pin_h2o_m1e7_p2": (2, "H2O", 20250215, 0.01, 10000000, 23065536, "HB_unnorm", 777, 6),       # the same on 2 ranks: > 1e6 spawns per (source, destination, pass) fill the Adder
 }
 
 
@@ -277,6 +284,21 @@ def gen_reload(manifest):
                                                  target_norm=tgt, distribution=dist)
 
 
+def gen_adder(manifest, tmp):
+    manifest["adder_runs"] = {}
+    for name, (n_ranks, adder, (shape, n_iter, seed, eps, vnz, mnz, maxd, ini, tgt, dist)) in ADDER_RUNS.items():
+        mol = fcidump.synthetic(shape)
+        path = os.path.join(tmp, shape + ".FCIDUMP")
+        if not os.path.exists(path):
+            fcidump.write_fcidump(path, mol)
+        out = os.path.join(GOLD, name + ".traj")
+        cmd = [MPIEXEC, "-n", str(n_ranks), HARNESS, "frisys_mpi", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz),
+               str(maxd), repr(ini), repr(tgt), dist, out]
+        subprocess.run(cmd, check=True, env=dict(os.environ, FRIES_ADDER_SIZE=str(adder)))
+        manifest["adder_runs"][name] = dict(n_ranks=n_ranks, adder_size=adder, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz,
+                                            max_dets=maxd, initiator=ini, target_norm=tgt, distribution=dist)
+
+
 def gen_pin(manifest, only=None):
     manifest.setdefault("pin_runs", {})
     with tempfile.TemporaryDirectory() as tmp:
@@ -357,6 +379,12 @@ def main():
         with open(os.path.join(GOLD, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-adder":      # the early-flush runs alone
+        manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_adder(manifest, tmp)
+        json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=1, sort_keys=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--only-pin":      # minutes of CPU each: the BASELINE sizes
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
@@ -460,6 +488,7 @@ def main():
             subprocess.run(cmd, check=True)
             manifest["mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz,
                                               max_dets=maxd, initiator=ini, target_norm=tgt, distribution=dist)
+        gen_adder(manifest, tmp)
         manifest["fciqmc_runs"] = {}
         for name, (shape, n_iter, seed, eps, tw, maxd, ini, dist) in FCIQMC_RUNS.items():
             mol = fcidump.synthetic(shape)

@@ -353,6 +353,7 @@ struct RefRun {
     std::vector<uint32_t> proc_scr, vec_scr;
     std::vector<fo::det_t> trial_in_det, ini_in_det; std::vector<double> trial_in_val, ini_in_val;      // what the text files held
     size_t max_dets_ = 0, adder_size_ = 0;
+    unsigned long long n_perform_add = 0;      // perform_add calls of the spawning loop (2 passes x (rounds + the empty closing one) per iteration)
     std::function<double(const uint8_t *)> diag_sc_;
     // --det_space (frisys_mol.cpp:236-239, 347-401): the dense subspace through the reference's own init_dense, and H inside it
     size_t n_determ = 0, determ_h_size = 0;
@@ -377,6 +378,7 @@ struct RefRun {
         MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
         unsigned spawn_length = mat_nonz * 4 / n_procs;
         size_t adder_size = spawn_length > 1000000 ? 1000000 : spawn_length;
+        if (getenv("FRIES_ADDER_SIZE")) adder_size = (size_t)atol(getenv("FRIES_ADDER_SIZE"));      // a smaller Adder (the DistVec constructor's argument): the loop's early perform_add rounds at test sizes
         unsigned no = n_orb, ne = n_elec; double hfe = hf_en;
         std::function<double(const uint8_t *)> diag_sc = [no, eris, h_core, ne, hfe](const uint8_t *occ) { return diag_matrel(occ, no, *eris, *h_core, 0, ne) - hfe; };
         sing_sc = [no, eris, h_core, ne](uint8_t *ex, uint8_t *occ) { return sing_matr_el_nosgn(ex, occ, no, *eris, *h_core, 0, ne); };
@@ -535,6 +537,7 @@ struct RefRun {
                     if (!sol_vec.add(nd, add_el, ini)) break;
                 }
                 sol_vec.perform_add(0);
+                n_perform_add++;
                 sol_vec.set_curr_vec_idx(0);
                 before = sol_vec.values();
                 sol_vec.set_curr_vec_idx(1);
@@ -1015,7 +1018,7 @@ static int run_frisys_mpi(int argc, char **argv) {
         fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rr.numer, rr.denom, rr.glob_norm, rr.en_shift, rr.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), rr.num_success, hsh);
     }
     fclose(f);
-    if (rr.proc_rank == 0) printf("FRISYS_MPI ranks=%d iters=%u\n", rr.n_procs, n_iter);
+    if (rr.proc_rank == 0) printf("FRISYS_MPI ranks=%d iters=%u perform_add=%llu\n", rr.n_procs, n_iter, rr.n_perform_add);
     return 0;
 }
 

@@ -58,6 +58,7 @@ def _rank_thread_run(name, r, P):
             eng.close()
             out[k] = (fails, dict(n_allgather=comms[k].n_allgather, n_alltoallv=comms[k].n_alltoallv, iters=len(g["rows"])))
         except Exception as e:
+            print("rank", k, "raised", repr(e), file=sys.stderr, flush=True)     # (the other ranks then wait in their next collective)
             out[k] = ([("exception", repr(e))], {})
 
     th = [threading.Thread(target=work, args=(k,)) for k in range(P)]
@@ -76,6 +77,19 @@ def test_rank_goldens_through_native_local_transport(name):
     for k, (fails, info) in enumerate(res):
         assert not fails, (name, k, fails[:6])
         assert info["n_alltoallv"] == info["iters"]         # one spawn exchange per iteration
+
+
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("adder_runs", {})))
+def test_adder_rounds_match_reference(name, monkeypatch):
+    """Adder::add reports a full buffer, the spawning loop flushes early and a pass takes several perform_add rounds
+    (vec_utils.hpp:957-971, frisys_mol.cpp:430-471): the reference under mpiexec with a small Adder (FRIES_ADDER_SIZE = the adder_size
+    argument of its DistVec) against the engine's rounds (vec.hip fr_xch_rounds), rank by rank."""
+    r = golden_io.manifest()["adder_runs"][name]
+    monkeypatch.setenv("FRIES_ADDER_SIZE", str(r["adder_size"]))
+    res = _rank_thread_run(name, r, r["n_ranks"])
+    for k, (fails, info) in enumerate(res):
+        assert not fails, (name, k, fails[:6])
+        assert info["n_alltoallv"] > 2 * info["iters"], info         # several exchanges per iteration: the rounds did take place
 
 
 _RCCL_ONE = r"""
