@@ -66,6 +66,7 @@ struct FksHost {
 
 struct Fks2Work {
     FksHost *hm;                            // device-visible address of the host block
+    int hm_close;                           // 1 (one rank): the closing pass raises hm->hist[it] itself -- no k_fks_close_flag launch behind it
     uint32_t nb8_cap;
     uint32_t *dk8; double *dg8, *ws8;       // [FR_FKS_PMAX][nb8_cap] group deltas of the latest evaluation of every group
     // Per (wave of 64 elements = 8 groups, sweep): the start state the wave was last evaluated with -- running norm and remaining budget at
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     double *const dg8 = F.dg8, *const ws8 = F.ws8;
     const int lane = fr_lane(), f = lane & 7;
     // a replay without comparison, or with a different number of sweeps than its predecessor, always counts as changed
-    if (MODE != 2 && (MODE == 0 || S.n_pass != S.valid_upto) && blockIdx.x == 0 && threadIdx.x == 0) F.hist[it] = 1u;
+    if (MODE != 2 && (MODE == 0 || S.n_pass != S.valid_upto) && blockIdx.x == 0 && threadIdx.x == 0) { F.hist[it] = 1u; if (MODE == 4 && F.hm_close && it < FR_MAX_ROUNDS) F.hm->hist[it] = 1u; }
     if (MODE != 2 && dbg == 3 && it < FR_MAX_ROUNDS && blockIdx.x == 0 && threadIdx.x == 0) F.dbg_cnt[it * 4] = (uint32_t)n_pass;
 
     // Light replay: has anything this WAVE's decisions depend on moved by more than its tightest comparison tolerates?
@@ -697,7 +698,7 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         if (lv) { W.keep[e] = kp; if (!FIN) W.wt_remain[e] = wr; }
         if (FIN) final_part();          // MODE 4: with the keep bits just decided
     }
-    if (M1 && any_chg && lane == 0) F.hist[it] = 1u;
+    if (M1 && any_chg && lane == 0) { F.hist[it] = 1u; if (MODE == 4 && F.hm_close && it < FR_MAX_ROUNDS) F.hm->hist[it] = 1u; }
 }
 
 // Chunk totals cross from the workgroups of k_fks_scan to the one that finishes last (fused totals) as relaxed device-scope atomics:
@@ -745,6 +746,7 @@ __device__ __forceinline__ void fr_fks_totals(Fks2Work F, uint32_t *err, FksMsg 
         if (inline_passes) {
             fr_fks2_passes(S, sm, 1, nullptr, F.hm, it);
             if (S->overflow) atomicOr(err, FR_ERR_ROUNDS);
+            if (F.hm && it + 1 < FR_MAX_ROUNDS) F.hm->hist[it + 1] = 0u;        // the next replay may be a closing pass, which only ever raises its flag
         }
     }
 }
@@ -849,7 +851,7 @@ static __global__ void __launch_bounds__(FR_FKS_TOTALS_THREADS) k_fks_totals(Fks
     __shared__ FksMsg sm;        // the bookkeeping is one thread chasing ~20 values per sweep: keep them in LDS
     // a replay that changed no delta (the confirming one, and those the host enqueued beyond it) leaves every total and scalar as it is
     if (it > 0 && F.hist[it] == 0u && F.scal->n_pass == F.scal->valid_upto && !F.scal->zero_prefix) {
-        if (threadIdx.x == 0) { msg->changed = 0u; if (inline_passes && F.hm && it < FR_MAX_ROUNDS) F.hm->hist[it] = 0u; }
+        if (threadIdx.x == 0) { msg->changed = 0u; if (inline_passes && F.hm && it < FR_MAX_ROUNDS) { F.hm->hist[it] = 0u; if (it + 1 < FR_MAX_ROUNDS) F.hm->hist[it + 1] = 0u; } }
         return;
     }
     fr_fks_totals(F, err, msg, inline_passes, it, &sm);

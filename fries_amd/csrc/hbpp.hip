@@ -467,6 +467,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     const int P = c->n_ranks;
     FksMsg *msg = (FksMsg *)c->comm.small_send;
     const bool xr = c->use_comm;        // totals travel through the all-gather (also with one rank, when a comm was given)
+    F.hm_close = xr ? 0 : 1;
     FR_LAUNCH(c, "k_fks_init", k_fks_init, dim3(1), dim3(FR_BLOCK), W, F, msg, xr ? 0 : 1, warm);
     if (xr) {
         const FksMsg *all = (const FksMsg *)fr_allgather(c, sizeof(FksMsg));
@@ -533,7 +534,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
                 const uint32_t *all = (const uint32_t *)fr_allgather(c, 16);
                 FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, all, P, it);
             }
-            else FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, (const uint32_t *)nullptr, 0, it);
+            // (one rank: the closing pass has written hm->hist[it] itself, Fks2Work::hm_close)
             if (speculate) {
                 // The host needs ~10 us from the ticket to its next launch.  The closing pass settles the stage six times out of seven, so what
                 // follows it -- the exact sum of wt_remain, the comb, the emission counts -- is enqueued behind the ticket and runs while the
