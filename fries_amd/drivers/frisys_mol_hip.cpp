@@ -16,7 +16,7 @@
 // Ranks (the reference under mpiexec -n P: hash-sharded vector, MPI_Alltoallv of the adds, rank-ordered sums):
 //   * one process per MI355X over librccl: start P copies with RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun's names;
 //     OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK and PMI_RANK / PMI_SIZE are understood too) and the same --result_dir: rank 0
-//     writes the RCCL id to <result_dir>.rccl_id, the others wait for it; rank r uses GPU LOCAL_RANK (or --device);
+//     writes the RCCL id to <result_dir>.rccl_id[.<launch nonce>], the others wait for it; rank r uses GPU LOCAL_RANK (or --device);
 //   * --ranks P: P host threads of this one process (fries_local_*), each with its own context, on --device (several ranks may
 //     share a GPU) or on --devices 0,1,...: for machines with fewer GPUs than ranks, and for tests.
 // Every rank writes dets<rank>.dat / vals<rank>.dat; the rank that owns the HF determinant writes the text outputs, rank 0
@@ -260,9 +260,14 @@ int main(int argc, char **argv) {
             if (rank < 0 || rank >= env_size) throw std::runtime_error("WORLD_SIZE is set but RANK is not a rank of it");
             const int device = args.have_device ? (int)args.device : (lrank >= 0 ? lrank : rank);
             if (rank == 0) std::cout << "seed on process 0 is " << seed << std::endl;
-            const std::string idf = args.result_dir + ".rccl_id", tmpf = idf + ".tmp";
+            // The file's name carries a per-launch nonce (the launcher's rendezvous port or job id) so that the id a run left behind when it died
+            // between publishing and removing it is never taken for this run's; rank 0 also removes any file of that name before it publishes.
+            std::string nonce;
+            for (const char *k : {"MASTER_PORT", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PMI_ID", "OMPI_MCA_ess_base_jobid"}) if (const char *v = getenv(k)) { nonce = std::string(".") + v; break; }
+            const std::string idf = args.result_dir + ".rccl_id" + nonce, tmpf = idf + ".tmp";
             uint8_t id[128];
             if (rank == 0) {
+                remove(idf.c_str());
                 ck(fries_rccl_unique_id(id));
                 { std::ofstream f(tmpf, std::ios::binary); f.write((const char *)id, 128); }
                 if (rename(tmpf.c_str(), idf.c_str())) throw std::runtime_error("cannot publish the RCCL id at " + idf);
@@ -279,7 +284,13 @@ int main(int argc, char **argv) {
             fries_transport *tr = nullptr;
             ck(fries_rccl_create(&tr, id, rank, env_size, device, big_bytes));       // collective: returns once every rank has joined
             if (rank == 0) remove(idf.c_str());
-            run_rank(args, in, seed, rank, env_size, device, tr);
+            try { run_rank(args, in, seed, rank, env_size, device, tr); }
+            catch (std::exception &ex) {
+                // The other ranks sit in their next collective, which has no timeout: leave at once with a failure code (no destructor, no
+                // communicator teardown that would itself wait for them) so that the launcher tears the job down.
+                std::cerr << "\nException on rank " << rank << " : " << ex.what() << "\n" << std::flush;
+                _exit(3);
+            }
             fries_transport_destroy(tr);
         }
         else {

@@ -228,6 +228,11 @@ def gen_hh_scale(manifest):
 RELOAD_RUNS = {
     "ne_m2000_reload": ("Ne", 60, 30, 20250215, 0.01, 2000, 2000, 20000, 1.0, 150.0, "HB_unnorm"),
 }
+# the same with a dense space: the first run gets --det_space, the restarted one takes the space from the checkpoint's dense.txt (frisys_mol.cpp:234, :258);
+# name -> (tuple as above, det-space file of DENSE_RUNS)
+RELOAD_DENSE_RUNS = {
+    "ne_m2000_dense_reload": (("Ne", 40, 30, 33, 0.01, 2000, 20000, 20000, 1.0, 150.0, "HB_unnorm"), "ne_m2000_dense_space.txt"),
+}
 
 
 # --det_space (semi-stochastic): name -> ((shape, n_iter, seed, eps, vec_nonz, mat_nonz, max_dets, initiator, target, dist), n_dense): the dense space is the
@@ -282,6 +287,17 @@ def gen_reload(manifest):
                             os.path.join(GOLD, name + ".traj"), str(n2), ck], check=True)
             manifest["reload_runs"][name] = dict(shape=shape, n1=n1, n2=n2, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini,
                                                  target_norm=tgt, distribution=dist)
+        for name, ((shape, n1, n2, seed, eps, vnz, mnz, maxd, ini, tgt, dist), space) in RELOAD_DENSE_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            ck = os.path.join(tmp, name + "_ck") + "/"
+            os.makedirs(ck)
+            env = dict(os.environ, FRIES_DETSPACE=os.path.join(GOLD, space), FRIES_DETSPACE_DIR=tmp + "/")
+            subprocess.run([HARNESS, "reload", path, mol.point_group, str(n1), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), dist,
+                            os.path.join(GOLD, name + ".traj"), str(n2), ck], check=True, env=env)
+            manifest["reload_runs"][name] = dict(shape=shape, n1=n1, n2=n2, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini,
+                                                 target_norm=tgt, distribution=dist, det_space=space)
 
 
 def gen_adder(manifest, tmp):

@@ -353,6 +353,7 @@ struct RefRun {
     std::vector<uint32_t> proc_scr, vec_scr;
     std::vector<fo::det_t> trial_in_det, ini_in_det; std::vector<double> trial_in_val, ini_in_val;      // what the text files held
     size_t max_dets_ = 0, adder_size_ = 0;
+    bool skip_init_dense = false;              // the restarted run of `reload`: frisys_mol --load_dir takes the dense space from the checkpoint (:234, :258)
     unsigned long long n_perform_add = 0;      // perform_add calls of the spawning loop (2 passes x (rounds + the empty closing one) per iteration)
     std::function<double(const uint8_t *)> diag_sc_;
     // --det_space (frisys_mol.cpp:236-239, 347-401): the dense subspace through the reference's own init_dense, and H inside it
@@ -426,7 +427,7 @@ struct RefRun {
         size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec, n_orb, (uint8_t (*)[4])scratch.data(), in->symm);
         size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec, basis_symm);
         p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-        if (getenv("FRIES_DETSPACE")) {  // --det_space (:236-239)
+        if (getenv("FRIES_DETSPACE") && !skip_init_dense) {  // --det_space (:236-239); not with --load_dir (:234)
             std::string dir = getenv("FRIES_DETSPACE_DIR") ? getenv("FRIES_DETSPACE_DIR") : "/tmp/";
             n_determ = sol->init_dense(std::string(getenv("FRIES_DETSPACE")), dir);
             for (size_t i = 0; i < n_determ; i++) det_space_in.push_back(to_u64(sol->indices()[i], det_size));
@@ -445,7 +446,12 @@ struct RefRun {
         sol->perform_add(0);
         hb = set_up(n_orb, n_orb, *eris);
         srt.resize(sol->max_size()); keep.assign(sol->max_size(), false);
-        // H inside the dense space (:347-401), with the reference's allocation sizes and its scratch use of orb_indices1
+        build_dense_h();
+    }
+
+    // H inside the dense space (:347-401), with the reference's allocation sizes and its scratch use of orb_indices1
+    void build_dense_h() {
+        Matrix<double> *h_core = in->hcore; SymmERIs *eris = &in->eris;
         determ_h_size = n_determ * n_elec * n_elec * (n_orb - n_elec / 2) * (n_orb - n_elec / 2);
         n_determ_h = 0;
         determ_from = (size_t *)malloc(determ_h_size * sizeof(size_t));
@@ -1157,9 +1163,11 @@ static int run_reload(int argc, char **argv) {
     for (unsigned it = 0; it < n1; it++) r1.iterate();
     r1.sol->save(dir);
     RefRun rr;
+    rr.skip_init_dense = true;
     rr.setup(path, pg, seed, eps, vnz, mnz, max_dets, ini, tgt, nhb);
     rr.replace_vector({}, {});                 // a fresh, empty DistVec with the same scramblers
-    rr.sol->load(dir);
+    rr.n_determ = rr.sol->load(dir);           // frisys_mol.cpp:258: the dense space is the one dense.txt records
+    if (rr.n_determ) { rr.build_dense_h(); for (size_t i = 0; i < rr.n_determ; i++) rr.det_space_in.push_back(to_u64(rr.sol->indices()[i], rr.det_size)); }
     rr.en_shift = r1.en_shift; rr.last_one_norm = 0; rr.iterat = 0;
     rr.mt.seed(seed); rr.mt.discard(2 * rr.n_orb);
     FILE *f = fopen(argv[13], "w");

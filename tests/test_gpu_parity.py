@@ -659,8 +659,13 @@ def test_cli_load_dir_matches_reference_restart(name, tmp_path):
     base = [build.DRIVER, "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--vec_nonz", str(r["vec_nonz"]),
             "--mat_nonz", str(r["mat_nonz"]), "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--initiator", repr(r["initiator"]),
             "--epsilon", repr(r["epsilon"]), "--seed", str(r["seed"])]
-    res = subprocess.run(base + ["--max_iter", str(r["n1"]), "--result_dir", out1], capture_output=True, text=True, timeout=300)
+    # a dense (semi-stochastic) space: the first run is given --det_space, the restarted one takes it from the checkpoint's dense.txt
+    # like the reference (frisys_mol.cpp:234, :258; DistVec::load keeps the first n_dense entries whatever their values)
+    first = ["--det_space", os.path.join(golden_io.GOLD, r["det_space"])] if r.get("det_space") else []
+    res = subprocess.run(base + first + ["--max_iter", str(r["n1"]), "--result_dir", out1], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
+    if first:
+        assert open(out1 + "dense.txt").read().strip() not in ("", "0")
     nb = (2 * mol.n_orb + 7) // 8
     assert os.path.getsize(out1 + "dets0.dat") // nb == loaded["saved"]
     assert np.loadtxt(out1 + "S.txt").reshape(-1)[-1] == loaded["shift"]
