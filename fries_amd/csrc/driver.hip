@@ -331,7 +331,6 @@ static void frisys_iterate(FriesCtx *c, fries_iter_log *lg) {
 // ------------------------------------------------------------------ frifull_mol (FRIES_bin/frifull_mol.cpp)
 static void frifull_setup(FriesCtx *c, const fries_frifull_params *p) {
     if (!c->d_eris) throw FriesError("fries_set_molecule must be called first");
-    if (c->n_ranks > 1) throw FriesError("frifull_mol runs on one rank in this version");
     if (p->max_dets == 0 || p->vec_nonz == 0) throw FriesError("max_dets and vec_nonz must be positive");
     c->eps = p->epsilon; c->target_norm = p->target_norm; c->init_thresh = 0;
     c->vec_nonz = p->vec_nonz; c->mat_nonz = 0; c->full_mode = true;
@@ -343,10 +342,22 @@ static void frifull_setup(FriesCtx *c, const fries_frifull_params *p) {
     if (!c->comm.small_send) { c->own_small = fr_alloc<uint8_t>(2048); c->comm.small_send = c->own_small; }
     uint32_t scap = p->spawn_cap ? p->spawn_cap : 8000000u;
     if (scap > 8000000u) scap = 8000000u;           // one merge handles FR_MAX_PART tiles of spawns
+    {   // frifull_mol.cpp:68-70: the Adder holds min(1e6, target_nonz / n_procs * num_ex / n_procs / 4) elements per destination (32-bit arithmetic there)
+        const uint32_t nv = c->n_orb - c->n_elec / 2;
+        const uint32_t num_ex = c->n_elec * c->n_elec * nv * nv;
+        const uint32_t spawn_len = p->vec_nonz / (uint32_t)c->n_ranks * num_ex / (uint32_t)c->n_ranks / 4u;
+        c->adder_cap = spawn_len > 1000000u ? 1000000u : spawn_len;
+        if (getenv("FRIES_ADDER_SIZE")) c->adder_cap = (uint32_t)atol(getenv("FRIES_ADDER_SIZE"));
+    }
+    if (!c->d_proc_scr) c->d_proc_scr = fr_alloc<uint32_t>(64);
+    FR_HIP(hipMemcpyAsync(c->d_proc_scr, c->proc_scr.data(), 4 * c->proc_scr.size(), hipMemcpyHostToDevice, c->stream));
+    c->hf_proc = fr_host_idx_to_proc(c, c->hf_det);
     fr_vec_alloc(c, &c->vec, p->max_dets);
     fr_spawn_alloc(c, scap);
+    fr_xch_alloc(c, scap);
     fr_vcomp_alloc(c, p->max_dets);
     c->W.kin = fr_alloc<uint32_t>(p->max_dets);     // sys_comp's tooth-index scratch (the HB-PP arrays are not allocated here)
+    if (!c->d_norms_keep) { c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1); }        // sys_comp over ranks: the other ranks' norms, the second in-order sum
     // trial vector = HF (:121-147); there is no H * trial in this driver
     c->n_trial = 1; c->n_htrial = 0;
     c->tr_det = fr_alloc<det_t>(1); c->tr_val = fr_alloc<double>(1);
@@ -354,7 +365,7 @@ static void frifull_setup(FriesCtx *c, const fries_frifull_params *p) {
     double one = 1.0;
     FR_HIP(hipMemcpyAsync(c->tr_det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
     FR_HIP(hipMemcpyAsync(c->tr_val, &one, 8, hipMemcpyHostToDevice, c->stream));
-    {   // start from 100 * |HF> (:186-190)
+    if (c->rank == (int)c->hf_proc) {   // start from 100 * |HF> on the rank that owns it (:186-190)
         double v = 100; uint8_t ini = 1; uint32_t n1 = 1;
         FR_HIP(hipMemcpyAsync(c->sp.det, &c->hf_det, 8, hipMemcpyHostToDevice, c->stream));
         FR_HIP(hipMemcpyAsync(c->sp.val, &v, 8, hipMemcpyHostToDevice, c->stream));

@@ -389,7 +389,64 @@ __global__ void __launch_bounds__(FR_BLOCK) k_src_write(VecDev V, const uint32_t
 // every stored determinant in storage order, then every double, each worth value * h_fac * <j|H|i>; the annihilating
 // merge takes them in that order.  The spawn buffer holds sp.cap entries, so the list is produced and merged in chunks of
 // whole determinants (the reference's Adder does the same every 1e6 adds).  Returns the number of non-zero adds.
+// With ranks (frifull_mol under mpiexec, molecule.cpp:553-660): the singles of every stored determinant are one pass of adds, the doubles
+// another; each pass is shipped to the owners like frisys_mol's spawns -- in several perform_add rounds when a destination's Adder buffer
+// fills (fr_spawn_exchange, vec.hip) -- and every rank takes part in both exchanges, also with nothing to send.
+static uint64_t fr_h_offdiag_vec_ranks(FriesCtx *c, double h_fac) {
+    hipStream_t st = c->stream;
+    fr_vec_sync_state(c, &c->vec, &c->h_vst);
+    const uint32_t ns = c->h_vst.curr_size;
+    SysDev S; S.n_orb = c->n_orb; S.n_elec = c->n_elec; S.h_core = c->d_h; S.eris = c->d_eris; S.hb = c->d_hb; S.hf_en = c->hf_en; S.spin_parity = c->spin_parity;
+    if (c->full_cap < ns || !c->full_cnt) {
+        if (c->full_cnt) { FR_HIP(hipFree(c->full_cnt)); FR_HIP(hipFree(c->full_nz)); FR_HIP(hipFree(c->full_off)); FR_HIP(hipFree(c->full_list)); }
+        c->full_cap = c->vec.cap;
+        c->full_cnt = fr_alloc<uint32_t>(2 * (size_t)c->full_cap); c->full_nz = fr_alloc<uint32_t>(2 * (size_t)c->full_cap); c->full_off = fr_alloc<uint32_t>(2 * (size_t)c->full_cap);
+        c->full_list = fr_alloc<uint32_t>(c->full_cap);
+    }
+    uint32_t nl = 0;
+    if (ns) {
+        const unsigned gt = fr_blocks(ns, FR_TILE);
+        FR_LAUNCH(c, "k_src_count", k_src_count, dim3(gt), dim3(FR_BLOCK), c->vec, c->sp.pcnt);
+        FR_LAUNCH(c, "k_src_write", k_src_write, dim3(gt), dim3(FR_BLOCK), c->vec, c->sp.pcnt, c->full_list, c->full_off);
+        FR_HIP(hipMemcpyAsync(&nl, c->full_off, 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+    }
+    EnumOut eo{nullptr, nullptr, nullptr};
+    std::vector<uint32_t> nz(2 * (size_t)nl + 2), off(2 * (size_t)nl + 2);
+    if (nl) {
+        for (int mode = 0; mode < 2; mode++)
+            FR_LAUNCH(c, "k_enum", k_enum, dim3(nl), dim3(FR_BLOCK), c->vec.dets, c->vec.v0, nl, S, mode, 0, c->full_cnt, c->full_nz, c->full_off, eo, h_fac, c->full_list);
+        FR_HIP(hipMemcpyAsync(nz.data(), c->full_nz, 8 * (size_t)nl, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+    }
+    eo.det = c->sp.det; eo.val = c->sp.val;
+    uint64_t n_add = 0;
+    for (int mode = 0; mode < 2; mode++) {
+        uint64_t tot64 = 0;
+        for (uint32_t d = 0; d < nl; d++) { off[2 * (size_t)d + mode] = (uint32_t)tot64; tot64 += nz[2 * (size_t)d + mode]; }
+        // (a rank whose pass does not fit raises here and the others wait in the exchange: size spawn_cap for the largest pass)
+        if (tot64 > c->sp.cap) throw FriesError("frifull_mol over ranks: a pass of the Hamiltonian (all singles, or all doubles, of this rank's determinants) must fit the spawn buffer: raise spawn_cap");
+        const uint32_t tot = (uint32_t)tot64;
+        FR_HIP(hipMemsetAsync(c->sp.ini, 1, c->sp.cap, st));        // every add of H * v carries the initiator flag (molecule.cpp:599, :649)
+        if (tot) {
+            FR_HIP(hipMemcpyAsync(c->full_off, off.data(), 8 * (size_t)nl, hipMemcpyHostToDevice, st));
+            FR_LAUNCH(c, "k_enum", k_enum, dim3(nl), dim3(FR_BLOCK), c->vec.dets, c->vec.v0, nl, S, mode, 1, c->full_cnt, c->full_nz, c->full_off, eo, h_fac, c->full_list);
+        }
+        FR_HIP(hipMemcpyAsync(c->sp.n_spawn, &tot, 4, hipMemcpyHostToDevice, st));
+        FR_HIP(hipStreamSynchronize(st));       // tot and off are host temporaries
+        bool merged = false;
+        const uint32_t n_recv = fr_spawn_exchange(c, tot, 0, &merged);
+        if (n_recv && !merged) fr_vec_merge(c, &c->vec, n_recv, false);
+        fr_vec_sync_state(c, &c->vec, &c->h_vst);
+        if (c->h_vst.err) return n_add;
+        fr_vec_maybe_rebuild(c, &c->vec);
+        n_add += tot;
+    }
+    return n_add;
+}
+
 uint64_t fr_h_offdiag_vec(FriesCtx *c, double h_fac) {
+    if (c->use_comm) return fr_h_offdiag_vec_ranks(c, h_fac);
     hipStream_t st = c->stream;
     fr_vec_sync_state(c, &c->vec, &c->h_vst);
     const uint32_t ns = c->h_vst.curr_size;

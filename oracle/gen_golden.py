@@ -73,6 +73,27 @@ FULL_RUNS = {
     "full_h2o_m200": ("H2O", 30, 11, 0.005, 200, 1000000, 110.0),
 }
 
+# frifull_mol under mpiexec -n P (frifull_mol.cpp's own Adder size; the excitations of a pass go through several perform_add rounds when a buffer fills):
+# name -> (n_ranks, tuple as FULL_RUNS)
+FULL_MPI_RUNS = {
+    "full_ne_m300_p2": (2, ("Ne", 30, 5, 0.01, 300, 400000, 120.0)),
+    "full_h2o_m200_p3": (3, ("H2O", 24, 11, 0.005, 200, 1000000, 110.0)),
+}
+
+
+def gen_full_mpi(manifest):
+    manifest["full_mpi_runs"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (n_ranks, (shape, n_iter, seed, eps, vnz, maxd, tgt)) in FULL_MPI_RUNS.items():
+            mol = fcidump.synthetic(shape)
+            path = os.path.join(tmp, shape + ".FCIDUMP")
+            fcidump.write_fcidump(path, mol)
+            out = os.path.join(GOLD, name + ".traj")
+            subprocess.run([MPIEXEC, "-n", str(n_ranks), HARNESS, "frifull_mpi", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(maxd), repr(tgt),
+                            str(mol.n_orb), str(mol.n_elec), out], check=True)
+            manifest["full_mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, max_dets=maxd, target_norm=tgt)
+
+
 # frisys_hh (1-D Hubbard-Holstein): name -> (n_ranks, n_iter, seed, n_elec, n_sites, eps, U, omega, g, gs_energy, vec_nonz, max_dets, initiator, target)
 HH_RUNS = {
     "hh_l6_m2000": (1, 60, 5, 6, 6, 0.01, 2.0, 0.5, 0.3, -3.0, 2000, 20000, 1.0, 1000.0),
@@ -395,6 +416,11 @@ def main():
         with open(os.path.join(GOLD, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-full-mpi":
+        manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+        gen_full_mpi(manifest)
+        json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=1, sort_keys=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--only-adder":      # the early-flush runs alone
         manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
         with tempfile.TemporaryDirectory() as tmp:
@@ -505,6 +531,7 @@ def main():
             manifest["mpi_runs"][name] = dict(n_ranks=n_ranks, shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz,
                                               max_dets=maxd, initiator=ini, target_norm=tgt, distribution=dist)
         gen_adder(manifest, tmp)
+        gen_full_mpi(manifest)
         manifest["fciqmc_runs"] = {}
         for name, (shape, n_iter, seed, eps, tw, maxd, ini, dist) in FCIQMC_RUNS.items():
             mol = fcidump.synthetic(shape)

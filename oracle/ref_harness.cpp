@@ -353,6 +353,7 @@ struct RefRun {
     std::vector<uint32_t> proc_scr, vec_scr;
     std::vector<fo::det_t> trial_in_det, ini_in_det; std::vector<double> trial_in_val, ini_in_val;      // what the text files held
     size_t max_dets_ = 0, adder_size_ = 0;
+    size_t adder_size_override = 0;
     bool skip_init_dense = false;              // the restarted run of `reload`: frisys_mol --load_dir takes the dense space from the checkpoint (:234, :258)
     unsigned long long n_perform_add = 0;      // perform_add calls of the spawning loop (2 passes x (rounds + the empty closing one) per iteration)
     std::function<double(const uint8_t *)> diag_sc_;
@@ -379,6 +380,7 @@ struct RefRun {
         MPI_Comm_rank(MPI_COMM_WORLD, &proc_rank);
         unsigned spawn_length = mat_nonz * 4 / n_procs;
         size_t adder_size = spawn_length > 1000000 ? 1000000 : spawn_length;
+        if (adder_size_override) adder_size = adder_size_override;       // frifull_mol.cpp:68-70 sizes its Adder differently
         if (getenv("FRIES_ADDER_SIZE")) adder_size = (size_t)atol(getenv("FRIES_ADDER_SIZE"));      // a smaller Adder (the DistVec constructor's argument): the loop's early perform_add rounds at test sizes
         unsigned no = n_orb, ne = n_elec; double hfe = hf_en;
         std::function<double(const uint8_t *)> diag_sc = [no, eris, h_core, ne, hfe](const uint8_t *occ) { return diag_matrel(occ, no, *eris, *h_core, 0, ne) - hfe; };
@@ -591,7 +593,13 @@ struct RefFull {
     int vec_idx = 0;
     std::vector<uint8_t> scratch;
     double numer = 0, denom = 0, glob_norm = 0; unsigned nkept = 0;
-    void setup(const char *path, const char *pg, uint32_t seed, double eps, uint32_t vnz, size_t max_dets, double tgt) {
+    void setup(const char *path, const char *pg, uint32_t seed, double eps, uint32_t vnz, size_t max_dets, double tgt, unsigned n_orb_hint = 0, unsigned n_elec_hint = 0) {
+        if (n_orb_hint) {      // frifull_mol.cpp:68-70: num_ex = n_elec^2 (n_orb - n_elec / 2)^2, spawn_len = target_nonz / n_procs * num_ex / n_procs / 4
+            int np = 1; MPI_Comm_size(MPI_COMM_WORLD, &np);
+            const unsigned num_ex = n_elec_hint * n_elec_hint * (n_orb_hint - n_elec_hint / 2) * (n_orb_hint - n_elec_hint / 2);
+            const unsigned spawn_len = vnz / np * num_ex / np / 4;
+            rr.adder_size_override = spawn_len > 1000000 ? 1000000 : spawn_len;
+        }
         rr.setup(path, pg, seed, eps, vnz, vnz, max_dets, 0.0, tgt, 1);
         scratch.resize(4 * (size_t)rr.n_orb * rr.n_orb * rr.n_elec * rr.n_elec);
     }
@@ -599,13 +607,16 @@ struct RefFull {
         DistVec<double> &sol_vec = *rr.sol;
         const double eps = rr.eps;
         denom = sol_vec.dot(rr.trial->indices(), rr.trial->values(), rr.trial->curr_size(), rr.trial_hashes);
+        denom = sum_mpi(denom, rr.proc_rank, rr.n_procs);
         unsigned n_samp = rr.vec_nonz;
-        double loc_norms[1];
+        double loc_norms[64];
         if (sol_vec.max_size() > rr.srt.size()) { rr.srt.resize(sol_vec.max_size()); rr.keep.resize(sol_vec.max_size(), false); }
-        loc_norms[0] = find_preserve(sol_vec.values(), rr.srt, rr.keep, sol_vec.curr_size(), &n_samp, &glob_norm);
+        loc_norms[rr.proc_rank] = find_preserve(sol_vec.values(), rr.srt, rr.keep, sol_vec.curr_size(), &n_samp, &glob_norm);
+        MPI_Allgather(MPI_IN_PLACE, 0, MPI_DOUBLE, loc_norms, 1, MPI_DOUBLE, MPI_COMM_WORLD);       // :264
         nkept = rr.vec_nonz - n_samp;
         if ((rr.iterat + 1) % 10 == 0) adjust_shift(&rr.en_shift, glob_norm, &rr.last_one_norm, rr.target, 0.05 / 10 / eps);
-        double rn_sys = rr.mt() / (1. + UINT32_MAX);
+        double rn_sys = 0;
+        if (rr.proc_rank == 0) rn_sys = rr.mt() / (1. + UINT32_MAX);       // :279-281 (sys_comp broadcasts rank 0's)
         sys_comp(sol_vec.values(), sol_vec.curr_size(), loc_norms, n_samp, rr.keep, rn_sys);
         for (size_t i = 0; i < sol_vec.curr_size(); i++) if (rr.keep[i]) { sol_vec.del_at_pos(i); rr.keep[i] = 0; }
         h_op_diag(sol_vec, !vec_idx, 1 + eps * rr.en_shift, -eps);
@@ -613,6 +624,7 @@ struct RefFull {
         h_op_offdiag(sol_vec, rr.in->symm, rr.n_orb, rr.in->eris, *rr.in->hcore, scratch.data(), scratch.size(), 0, rr.n_elec, !vec_idx, -eps, 0);
         vec_idx = !vec_idx;
         numer = sol_vec.dot(rr.trial->indices(), rr.trial->values(), rr.trial->curr_size(), rr.trial_hashes);
+        numer = sum_mpi(numer, rr.proc_rank, rr.n_procs);
         numer = ((1 + eps * rr.en_shift) * denom - numer) / eps;
         rr.iterat++;
     }
@@ -662,6 +674,31 @@ static int run_frifull(int argc, char **argv) {
     fclose(f);
     printf("FRIFULL iters=%u checks=%d fails=%d final n_nonz=%d\n", n_iter, n_chk, n_fail, rr.sol->n_nonz());
     return n_fail != 0;
+}
+
+// mpiexec -n P ref_harness frifull_mpi <fcidump> <pg> <n_iter> <seed> <eps> <vec_nonz> <max_dets> <target> <n_orb> <n_elec> <out>: the reference's frifull_mol loop
+// on P ranks with frifull_mol.cpp's Adder size; every rank writes <out>.r<rank> (rows as in the frisys_mpi files, num_success = 0)
+static int run_frifull_mpi(int argc, char **argv) {
+    if (argc < 13) { fprintf(stderr, "usage: see header\n"); return 2; }
+    const char *path = argv[2], *pg = argv[3];
+    unsigned n_iter = atoi(argv[4]); uint32_t seed = strtoul(argv[5], 0, 10);
+    double eps = atof(argv[6]); uint32_t vnz = strtoul(argv[7], 0, 10);
+    size_t max_dets = strtoull(argv[8], 0, 10); double tgt = atof(argv[9]);
+    RefFull rf;
+    rf.setup(path, pg, seed, eps, vnz, max_dets, tgt, atoi(argv[10]), atoi(argv[11]));
+    RefRun &rr = rf.rr;
+    char name[1024];
+    snprintf(name, sizeof name, "%s.r%d", argv[12], rr.proc_rank);
+    FILE *f = fopen(name, "w");
+    fprintf(f, "# golden trajectory from the reference's frifull_mol loop under mpiexec -n %d, rank %d; cols: it numer denom norm shift nkept n_nonz curr_size num_success digest\n", rr.n_procs, rr.proc_rank);
+    fprintf(f, "# p_doub %a hf_en %a n_htrial %zu hf_proc %u\n", 0.0, rr.hf_en, (size_t)0, rr.hf_proc);
+    for (unsigned it = 0; it < n_iter; it++) {
+        rf.iterate();
+        fprintf(f, "%u %a %a %a %a %u %d %zu %zu %016" PRIx64 "\n", it, rf.numer, rf.denom, rf.glob_norm, rr.en_shift, rf.nkept, rr.sol->n_nonz(), (size_t)rr.sol->curr_size(), (size_t)0, rr.digest());
+    }
+    fclose(f);
+    if (rr.proc_rank == 0) printf("FRIFULL_MPI ranks=%d iters=%u\n", rr.n_procs, n_iter);
+    return 0;
 }
 
 static void setup_oracle_from_ref(fo::Frisys &fr, RefRun &rr, uint32_t seed, size_t max_dets) {
@@ -2113,6 +2150,7 @@ int main(int argc, char **argv) {
     else if (argc >= 2 && !strcmp(argv[1], "frisys")) rc = run_frisys(argc, argv, false);
     else if (argc >= 2 && !strcmp(argv[1], "time")) rc = run_frisys(argc, argv, true);
     else if (argc >= 2 && !strcmp(argv[1], "frisys_mpi")) rc = run_frisys_mpi(argc, argv);
+    else if (argc >= 2 && !strcmp(argv[1], "frifull_mpi")) rc = run_frifull_mpi(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "restart")) rc = run_restart(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "pin")) rc = run_pin(argc, argv);
     else if (argc >= 2 && !strcmp(argv[1], "reload")) rc = run_reload(argc, argv);

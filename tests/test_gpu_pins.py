@@ -92,6 +92,52 @@ def test_adder_rounds_match_reference(name, monkeypatch):
         assert info["n_alltoallv"] > 2 * info["iters"], info         # several exchanges per iteration: the rounds did take place
 
 
+@pytest.mark.parametrize("name", sorted(golden_io.manifest().get("full_mpi_runs", {})))
+def test_frifull_over_ranks_matches_reference(name):
+    """frifull_mol under mpiexec -n P (FRIES_bin/frifull_mol.cpp:258-304 with h_op_offdiag's two passes of adds, molecule.cpp:553-660): rank threads
+    over the native local transport against what every rank of the reference logged -- counts, norm and shift as doubles, numerator and
+    denominator to 1e-10, the shard's digest every iteration."""
+    from fries_amd.comm import LocalGroup
+    from fries_amd.engine import FriEngine
+    r = golden_io.manifest()["full_mpi_runs"][name]
+    P = r["n_ranks"]
+    mol = fcidump.synthetic(r["shape"])
+    cap = 3000000
+    grp = LocalGroup(P, cap)
+    comms = [grp.comm(k, 0) for k in range(P)]
+    out = [None] * P
+
+    def work(k):
+        fails = []
+        try:
+            g = golden_io.read_traj(name, rank=k)
+            eng = FriEngine(mol, device=0, comm=comms[k])
+            eng.setup_full(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], max_dets=r["max_dets"], target_norm=r["target_norm"], seed=r["seed"], spawn_cap=cap)
+            for row in g["rows"]:
+                lg = eng.iterate_full(1)[0]
+                row = dict(row, num_success=int(lg["num_success"]))         # (the golden does not record the number of adds)
+                pin_replay._check_row(lg, row, fails, "full")
+                d, v = eng.vector()
+                if golden_io.vec_hash(d, v) != row["hash"]:
+                    fails.append(("full", row["it"], "digest"))
+                if len(fails) > 6:
+                    break
+            eng.close()
+        except Exception as e:
+            print("rank", k, "raised", repr(e), file=sys.stderr, flush=True)
+            fails.append(("exception", repr(e)))
+        out[k] = fails
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    grp.destroy()
+    for k in range(P):
+        assert not out[k], (name, k, out[k][:6])
+
+
 _RCCL_ONE = r"""
 import sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
