@@ -261,9 +261,13 @@ REPLAY_KNOBS = [
     {"FRIES_GROUP_WARM_ALL": "0"},          # stages 2-5 start from the per-chunk profile
     {"FRIES_NO_GROUP_WARM": "1"},
     {"FRIES_FKS_FUSE_TOTALS": "1"},         # totals by the last workgroup of the scan
-    {"FRIES_FKS_LIGHT_FULL_GRID": "1"},
+    {"FRIES_FKS_LIGHT_FULL_GRID": "0"},     # light replays on the persistent grid instead of one workgroup per tile
     {"FRIES_FKS_WARM_EXTRAP": "1.0"},
     {"FRIES_FKS_REC_AT": "3"},              # margins recorded by replay 3 instead of replay 1
+    {"FRIES_FKS_NO_CLOSING": "1"},          # no closing pass: a confirming replay and a final pass of their own
+    {"FRIES_FKS_NO_SPECULATION": "1"},      # nothing enqueued behind the closing pass before the host has seen its flag
+    {"FRIES_WAIT_SYNC": "1"},               # the host waits with hipStreamSynchronize instead of polling the ticket word
+    {"FRIES_FKS_GRID": "512", "FRIES_FKS_GRID0": "700"},     # other persistent grids (more tiles per workgroup)
 ]
 
 
