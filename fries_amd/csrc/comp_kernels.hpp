@@ -95,6 +95,10 @@ struct CompWork {
     uint32_t *fix_list;           // elements with a tooth backlog (rare)
     SeqWork seq;                  // exact in-order sum of wt_remain
     double row1[2];               // stage-1 sub-weights (fr_row1)
+    // Emissions staged by k_sys_count so that k_sys_write does not replay sys_sub a second time: FR_STG_SLOTS records per lane (its four
+    // elements' emissions in order), what does not fit in a per-tile spill list; a tile the comb repair touched, or whose spill list
+    // overflowed, is flagged and written the old way (rows evaluated again).  nullptr: no staging (propagation repair: frisys_hh).
+    uint4 *stg, *spill; uint32_t *spill_cnt; uint8_t *tile_dirty;
 #ifdef FR_SYS_TIMING
     unsigned long long *tdbg;     // FRIES_SYS_DBG: [workgroup][8] time stamps of k_sys_count / k_sys_write (build with -DFR_SYS_TIMING)
 #endif
@@ -234,18 +238,28 @@ __device__ __forceinline__ void fr_load_elems(const CompWork &W, const VecDev &V
     for (int it = 0; it < N; it++) { const size_t e = base + it; x[it].det = (STAGE != 1) ? E.det[e < n_in ? e : last] : 0ull; }
 }
 
-// Returns the number of emissions; the cursor advances over consumed teeth.  When EMIT, writes
-// (wi, sub, value) triples starting at slot `out`.
-template <int STAGE, bool NEW_HB, bool EMIT>
+#define FR_STG_SLOTS 8          // staged records per lane (the mean is 4: one per element)
+#define FR_STG_SPILL 16384      // spill records per tile of 1024 elements (the head tiles of stages 2-4, where the heavy determinants' children keep most of their sub-weights, spill 7-9 000)
+// where a lane of k_sys_count stages its emissions: record = {value (2 words), sub | item << 16, lane << 16 | ordinal within the lane}
+struct StageOut { uint4 *slots; uint4 *spill; uint32_t *spill_n /* LDS */; uint32_t n_lane; uint32_t item; };
+// Returns the number of emissions; the cursor advances over consumed teeth.  EMIT 1: writes (wi, sub, value) triples starting at slot `out`;
+// EMIT 2: stages them through *so (k_sys_count); EMIT 0: counts only.
+template <int STAGE, bool NEW_HB, int EMIT>
 __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTables &T, const Teeth *th, const ElemIn &x,
-                                                   size_t e, double lbound, ToothCur &cur, double unit, double p_doub, size_t out) {
+                                                   size_t e, double lbound, ToothCur &cur, double unit, double p_doub, size_t out, StageOut *so = nullptr) {
     const double v = x.v;
     if (v == 0) return 0;
     const uint32_t nd = x.nd, kp = x.kp;
     uint32_t n = 0;
     const double wr = x.wr;
     auto emit = [&](uint32_t sub, double val) {
-        if (EMIT) { size_t o = out + n; if (o < W.cap) { W.e_wi[o] = (uint32_t)e; W.e_sub[o] = sub; W.e_val[o] = val; } }
+        if (EMIT == 1) { size_t o = out + n; if (o < W.cap) { W.e_wi[o] = (uint32_t)e; W.e_sub[o] = sub; W.e_val[o] = val; } }
+        if (EMIT == 2) {
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(val);
+            const uint32_t ord = so->n_lane++;
+            if (ord < FR_STG_SLOTS) { *so->slots = make_uint4((uint32_t)vb, (uint32_t)(vb >> 32), sub | so->item, 0u); so->slots += FR_BLOCK; }      // slot q of the workgroup's 256 lanes side by side: coalesced in k_sys_write
+            else { const uint32_t q = atomicAdd(so->spill_n, 1u); if (q < FR_STG_SPILL) so->spill[q] = make_uint4((uint32_t)vb, (uint32_t)(vb >> 32), sub | so->item, (threadIdx.x << 16) | (ord & 0xffffu)); }
+        }
         n++;
     };
     if (nd > 0) {
@@ -282,7 +296,7 @@ __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTa
     return n;
 }
 // the same from a comb index (the repair kernels, which re-evaluate single elements)
-template <int STAGE, bool NEW_HB, bool EMIT>
+template <int STAGE, bool NEW_HB, int EMIT>
 __device__ __forceinline__ uint32_t fr_sys_element(const CompWork &W, const HbTables &T, const Teeth *th, const ElemIn &x,
                                                    size_t e, double lbound, uint32_t *k, double unit, double p_doub, size_t out) {
     ToothCur cur;
@@ -298,11 +312,13 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     __shared__ HbTables T;
     __shared__ SeqShared seqsh;
     __shared__ uint32_t shu[4];
+    __shared__ uint32_t sh_spill;
     if (W.seq.skip && *W.seq.skip) return;
     CompState *fin = &W.state[FR_MAX_ROUNDS + 1];
     const unsigned n_in = fin->n_in;
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
+    if (threadIdx.x == 0) sh_spill = 0;         // (the barriers of the staging below lie between this and the first emission)
     FR_SYS_T(0);
     if (STAGE != 1) fr_stage_tables(&T, Tg);
     __shared__ Teeth Tsh;
@@ -327,6 +343,11 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     // the tooth it stands at is not below its lbound and the last one it took is -- the successor continues from the cursor.
     ToothCur tc;
     bool have = false;
+    const bool staging = W.stg != nullptr;
+    StageOut so;
+    so.slots = staging ? W.stg + (size_t)blockIdx.x * FR_BLOCK * FR_STG_SLOTS + threadIdx.x : nullptr;
+    so.spill = staging ? W.spill + (size_t)blockIdx.x * FR_STG_SPILL : nullptr;
+    so.spill_n = &sh_spill; so.n_lane = 0; so.item = 0;
 #pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + it;
@@ -335,7 +356,9 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
         if (!have) { if (e == 0) fr_cur_seek_k(th, tc, 0u); else fr_cur_seek_below(th, tc, Sprev); }
         tc.last = -INFINITY;
         const uint32_t kin = tc.k;
-        uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x[it], e, Se, tc, unit, p_doub, 0);
+        so.item = (uint32_t)it << 16;
+        uint32_t c = staging ? fr_sys_element<STAGE, NEW_HB, 2>(W, T, th, x[it], e, Se, tc, unit, p_doub, 0, &so)
+                             : fr_sys_element<STAGE, NEW_HB, 0>(W, T, th, x[it], e, Se, tc, unit, p_doub, 0);
         const uint32_t k = tc.k;
         W.S[e] = Se; W.kin[e] = kin; W.cnt[e] = c;
         cnt_t += c;
@@ -354,7 +377,10 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_count(CompWork W, VecDev V, co
     }
     FR_SYS_T(4);
     uint32_t bc = fr_block_sum_u32(cnt_t, shu);
-    if (threadIdx.x == 0) W.pcnt[1][blockIdx.x] = bc;
+    if (threadIdx.x == 0) {
+        W.pcnt[1][blockIdx.x] = bc;
+        if (staging) { W.spill_cnt[blockIdx.x] = sh_spill; W.tile_dirty[blockIdx.x] = sh_spill > FR_STG_SPILL ? 1 : 0; }       // (the raw count: a flagged tile's list is not read)
+    }
     FR_SYS_T(5);
 }
 
@@ -379,14 +405,15 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_fixup(CompWork W, VecDev V, co
         uint32_t k = W.kin[e];
         ElemIn x1[1];
         fr_load_elems<STAGE, 1>(W, V, cur, e, n_in, x1);
-        fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x1[0], e, W.S[e], &k, fin->unit, p_doub, 0);
+        fr_sys_element<STAGE, NEW_HB, 0>(W, T, th, x1[0], e, W.S[e], &k, fin->unit, p_doub, 0);
         for (size_t e2 = e + 1; e2 < n_in; e2++) {
             uint32_t kin = k;
             fr_load_elems<STAGE, 1>(W, V, cur, e2, n_in, x1);
-            uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, th, x1[0], e2, W.S[e2], &k, fin->unit, p_doub, 0);
+            uint32_t c = fr_sys_element<STAGE, NEW_HB, 0>(W, T, th, x1[0], e2, W.S[e2], &k, fin->unit, p_doub, 0);
             uint32_t old = W.cnt[e2];
             W.kin[e2] = kin; W.cnt[e2] = c;
             W.pcnt[1][e2 / FR_TILE] += c - old;
+            if (W.tile_dirty) W.tile_dirty[e2 / FR_TILE] = 1;        // what k_sys_count staged for this tile is stale: written from the rows again
             done_upto = e2 + 1;
             if (k == fr_teeth_below(th, W.S[e2])) break;
         }
@@ -416,7 +443,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_prop(CompWork W, VecDev V, con
         ElemIn x1[1];
         fr_load_elems<STAGE, 1>(W, V, cur, e, n_in, x1);
         uint32_t k = kin_new;
-        const uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, &Tsh, x1[0], e, W.S[e], &k, fin->unit, p_doub, 0);
+        const uint32_t c = fr_sys_element<STAGE, NEW_HB, 0>(W, T, &Tsh, x1[0], e, W.S[e], &k, fin->unit, p_doub, 0);
         const uint32_t old = W.cnt[e];
         W.kin[e] = kin_new; W.cnt[e] = c;
         if (c != old) atomicAdd(&W.pcnt[1][e / FR_TILE], c - old);
@@ -455,7 +482,7 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_walk(CompWork W, VecDev V, con
             ElemIn x1[1];
             fr_load_elems<STAGE, 1>(W, V, cur, e, n_in, x1);
             uint32_t k = kin_new;
-            const uint32_t c = fr_sys_element<STAGE, NEW_HB, false>(W, T, &Tsh, x1[0], e, W.S[e], &k, unit, p_doub, 0);
+            const uint32_t c = fr_sys_element<STAGE, NEW_HB, 0>(W, T, &Tsh, x1[0], e, W.S[e], &k, unit, p_doub, 0);
             const uint32_t old = W.cnt[e];
             W.kin[e] = kin_new; W.cnt[e] = c;
             if (c != old) atomicAdd(&W.pcnt[1][e / FR_TILE], c - old);
@@ -477,11 +504,22 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     const unsigned nblk = (n_in + FR_TILE - 1) / FR_TILE;
     if (blockIdx.x >= nblk) return;
     FR_SYS_T(0);
-    if (STAGE != 1) fr_stage_tables(&T, Tg);
+    const bool copy_path = W.stg && !W.tile_dirty[blockIdx.x];        // (uniform over the workgroup) the staged emissions stand: no table, no comb needed
+    if (!copy_path && STAGE != 1) fr_stage_tables(&T, Tg);
     __shared__ Teeth Tsh;
-    fr_stage_teeth(&Tsh, W.teeth);
+    if (!copy_path) fr_stage_teeth(&Tsh, W.teeth);
     const Teeth *th = &Tsh;
     FR_SYS_T(1);
+    // copy path: the lane's staged records and the tile's spill count are requested before anything else (whether a slot is in use is only
+    // known after the counts and two block scans: fetched then, every step would be a memory round trip of its own)
+    uint4 rec[FR_STG_SLOTS];
+    uint32_t n_sp = 0;
+    if (copy_path) {
+        const uint4 *slots = W.stg + (size_t)blockIdx.x * FR_BLOCK * FR_STG_SLOTS + threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < FR_STG_SLOTS; q++) rec[q] = slots[(size_t)q * FR_BLOCK];
+        n_sp = W.spill_cnt[blockIdx.x];
+    }
     const uint32_t *pc = W.pcnt[1];
     uint32_t off;
     {
@@ -497,6 +535,39 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
     uint32_t incl = fr_block_scan_u32(tsum, shu, &tot);
     size_t o = (size_t)off + (incl - tsum);
     FR_SYS_T(2);
+    if (copy_path) {
+        FR_SYS_T(3);
+        // the emissions as k_sys_count staged them: a copy, no row is evaluated again
+        __shared__ uint32_t sh_o[FR_BLOCK];
+        sh_o[threadIdx.x] = (uint32_t)o;
+        const uint32_t n_st = tsum < FR_STG_SLOTS ? tsum : FR_STG_SLOTS;
+#pragma unroll
+        for (int q = 0; q < FR_STG_SLOTS; q++) if ((uint32_t)q < n_st) {
+            const size_t p = o + (size_t)q;
+            if (p < W.cap) { W.e_wi[p] = (uint32_t)(base + (rec[q].z >> 16)); W.e_sub[p] = rec[q].z & 0xffffu; W.e_val[p] = __longlong_as_double((long long)(((unsigned long long)rec[q].y << 32) | rec[q].x)); }
+        }
+#pragma unroll
+        for (int it = 0; it < FR_ITEMS; it++) { const size_t e = base + it; if (e < n_in) W.keep[e] = 0; }
+        __syncthreads();
+        const uint4 *sp = W.spill + (size_t)blockIdx.x * FR_STG_SPILL;
+        const size_t tile_base = (size_t)blockIdx.x * FR_TILE;
+        // (eight records per lane in flight: a head tile lists ~9 000, and one load per trip would make the loop a chain of memory latencies)
+        const uint32_t n_list = n_sp < FR_STG_SPILL ? n_sp : FR_STG_SPILL;
+        for (uint32_t i0 = threadIdx.x; i0 < n_list; i0 += 8 * FR_BLOCK) {
+            uint4 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const uint32_t i = i0 + (uint32_t)k * FR_BLOCK; r[k] = sp[i < n_list ? i : n_list - 1]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (i0 + (uint32_t)k * FR_BLOCK >= n_list) break;
+                const uint32_t lane_t = r[k].w >> 16;
+                const size_t p = (size_t)sh_o[lane_t] + (r[k].w & 0xffffu);
+                if (p < W.cap) { W.e_wi[p] = (uint32_t)(tile_base + (size_t)lane_t * FR_ITEMS + (r[k].z >> 16)); W.e_sub[p] = r[k].z & 0xffffu; W.e_val[p] = __longlong_as_double((long long)(((unsigned long long)r[k].y << 32) | r[k].x)); }
+            }
+        }
+        o += tsum;
+    }
+    else {
     ElemIn x[FR_ITEMS];
     fr_load_elems<STAGE, FR_ITEMS>(W, V, cur, base, n_in, x);
     uint32_t kin4[FR_ITEMS]; double S4[FR_ITEMS];
@@ -515,10 +586,11 @@ __global__ void __launch_bounds__(FR_BLOCK) k_sys_write(CompWork W, VecDev V, co
         if (c[it]) {
             if (!have || tc.k != kin4[it]) fr_cur_seek_k(th, tc, kin4[it]);
             have = true;
-            fr_sys_element<STAGE, NEW_HB, true>(W, T, th, x[it], e, S4[it], tc, fin->unit, p_doub, o);
+            fr_sys_element<STAGE, NEW_HB, 1>(W, T, th, x[it], e, S4[it], tc, fin->unit, p_doub, o);
         }
         W.keep[e] = 0;
         o += c[it];
+    }
     }
     FR_SYS_T(4);
     if (blockIdx.x == nblk - 1 && threadIdx.x == FR_BLOCK - 1) {

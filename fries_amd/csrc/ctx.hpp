@@ -155,6 +155,7 @@ struct FriesCtx {
     FlatPiv flat;                   // apply_HBPP_piv
     uint32_t *pv_goff = nullptr;    // first long index of every short element's group (W.cap)
     unsigned long long *hhf_cnt = nullptr;      // frifull_hh: {adds tried, adds written} of the iteration
+    uint4 *stg_mem = nullptr, *spill_mem = nullptr; uint32_t *spill_cnt_mem = nullptr; uint8_t *tile_dirty_mem = nullptr;      // CompWork::stg etc. (set per stage: not with the propagation repair)
     uint32_t adder_cap = 0;                  // the reference's Adder capacity per destination (frisys_mol.cpp:109-110)
     uint64_t n_collectives = 0;
     uint64_t n_adder_rounds = 0;             // perform_add rounds beyond the usual one per pass (the Adder filled up)

@@ -522,6 +522,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     CompWork &W = h->c.W;
     for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.el[k].rinv); hipFree(W.el[k].raux); hipFree(W.el[k].det); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
     hipFree(W.wt_remain); hipFree(W.keep); hipFree(W.S); hipFree(W.kin); hipFree(W.cnt); hipFree(W.e_wi); hipFree(W.e_sub); hipFree(W.e_val); hipFree(W.state); hipFree(W.teeth); hipFree(W.fix_list);
+    if (h->c.stg_mem) { hipFree(h->c.stg_mem); hipFree(h->c.spill_mem); hipFree(h->c.spill_cnt_mem); hipFree(h->c.tile_dirty_mem); }
     {   // the find_keep_sub replay's arrays (allocated with the work arrays: hbpp.hip)
         Fks2Work &F = h->c.F2;
         if (F.dk8) {

@@ -270,7 +270,7 @@ static void fr_sys_timing_dump(FriesCtx *c, const char *name, int stage, unsigne
     static int calls = 0;
     if (!c->W.tdbg) return;
     calls++;
-    if (calls < 400 || calls > 420) return;
+    if (calls < 100 || calls > 110) return;
     FR_HIP(hipStreamSynchronize(c->stream));
     const unsigned nb = grid < 8192 ? grid : 8192;
     std::vector<unsigned long long> h((size_t)nb * 8);
@@ -288,6 +288,9 @@ static void fr_sys_timing_dump(FriesCtx *c, const char *name, int stage, unsigne
     }
     fprintf(stderr, "[%s stage %d] %u workgroups, span %.1f us; mean us per phase:", name, stage, cnt, (double)(t1 - t0) * 0.01);
     for (int k = 1; k < n_stamp; k++) fprintf(stderr, " %.2f", ph[k] / (cnt ? cnt : 1));
+    if (c->tile_dirty_mem) { std::vector<uint8_t> td(nb); std::vector<uint32_t> sc(nb); FR_HIP(hipMemcpy(td.data(), c->tile_dirty_mem, nb, hipMemcpyDeviceToHost)); FR_HIP(hipMemcpy(sc.data(), c->spill_cnt_mem, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        unsigned nd = 0; unsigned long long ns = 0; uint32_t mx = 0; for (unsigned b = 0; b < nb; b++) { nd += td[b]; ns += sc[b]; mx = sc[b] > mx ? sc[b] : mx; }
+        fprintf(stderr, " | dirty tiles %u, spills per tile %.1f (max %u)", nd, (double)ns / nb, mx); }
     fprintf(stderr, " | starts by eighth of the span:");
     for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", start_hist[k]);
     fprintf(stderr, "\n");
@@ -308,6 +311,12 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     W.kend = nullptr; W.act[0] = W.act[1] = nullptr; W.act_n = nullptr; W.kstart = nullptr; W.prop = 0;
     W.e_wi = fr_alloc<uint32_t>(cap); W.e_sub = fr_alloc<uint32_t>(cap); W.e_val = fr_alloc<double>(cap);
     W.state = fr_alloc<CompState>(FR_MAX_ROUNDS + 2);
+    W.stg = nullptr; W.spill = nullptr; W.spill_cnt = nullptr; W.tile_dirty = nullptr;
+    if (!(getenv("FRIES_NO_STAGING") && atoi(getenv("FRIES_NO_STAGING")))) {       // emissions staged by k_sys_count (comp_kernels.hpp); FRIES_NO_STAGING=1: k_sys_write evaluates the rows again
+        const size_t ntile = fr_blocks(cap, FR_TILE) + 1;
+        c->stg_mem = fr_alloc<uint4>(ntile * FR_BLOCK * FR_STG_SLOTS); c->spill_mem = fr_alloc<uint4>(ntile * FR_STG_SPILL);
+        c->spill_cnt_mem = fr_alloc<uint32_t>(ntile); c->tile_dirty_mem = fr_alloc<uint8_t>(ntile);
+    }
     W.teeth = fr_alloc<Teeth>(1);
     W.fix_list = fr_alloc<uint32_t>(FR_MAX_FIX);
     W.seq.tiles = fr_alloc<SeqRec>(FR_MAX_PART); W.seq.subs = fr_alloc<SeqRec>((size_t)FR_MAX_PART * FR_SUBS_PER_TILE); W.seq.total = fr_alloc<double>(1); W.seq.tsum = fr_alloc<double>(FR_MAX_PART);
@@ -450,6 +459,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (STAGE == 1) FR_LAUNCH(c, "k_prep1", k_prep1, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
     else if (hh_stage2) FR_LAUNCH(c, "k_prep_hh2", k_prep_hh2, dim3(grid), dim3(FR_BLOCK), W, c->vec, cur, n_samp);
     else FR_LAUNCH(c, "k_prep", (k_prep<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, c->d_hb, cur, n_samp, c->p_doub);
+    const bool stage_emissions = c->stg_mem && !W.prop;
+    W.stg = stage_emissions ? c->stg_mem : nullptr; W.spill = stage_emissions ? c->spill_mem : nullptr;
+    W.spill_cnt = stage_emissions ? c->spill_cnt_mem : nullptr; W.tile_dirty = stage_emissions ? c->tile_dirty_mem : nullptr;
     Fks2Work F = c->F2;
     F.saved = c->fks_saved + STAGE; F.wk = c->fks_wk + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wg = c->fks_wg + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;
     F.wkx = c->fks_wkx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK; F.wgx = c->fks_wgx + (size_t)STAGE * FR_FKS_PMAX * FR_FKS_MAXCHUNK;

@@ -268,6 +268,7 @@ REPLAY_KNOBS = [
     {"FRIES_FKS_NO_SPECULATION": "1"},      # nothing enqueued behind the closing pass before the host has seen its flag
     {"FRIES_WAIT_SYNC": "1"},               # the host waits with hipStreamSynchronize instead of polling the ticket word
     {"FRIES_FKS_GRID": "512", "FRIES_FKS_GRID0": "700"},     # other persistent grids (more tiles per workgroup)
+    {"FRIES_NO_STAGING": "1"},              # k_sys_write replays sys_sub instead of copying the emissions k_sys_count staged
 ]
 
 
