@@ -270,7 +270,7 @@ static void fr_sys_timing_dump(FriesCtx *c, const char *name, int stage, unsigne
     static int calls = 0;
     if (!c->W.tdbg) return;
     calls++;
-    if (calls < 100 || calls > 110) return;
+    if (calls < 200 || calls > 220) return;
     FR_HIP(hipStreamSynchronize(c->stream));
     const unsigned nb = grid < 8192 ? grid : 8192;
     std::vector<unsigned long long> h((size_t)nb * 8);
@@ -530,6 +530,9 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
         FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
         FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(64), Wt, F, rn, (const double *)Wt.seq.total, c->rank, P);
         FR_LAUNCH(c, "k_sys_count", (k_sys_count<STAGE, NEW_HB>), dim3(grid), dim3(FR_BLOCK), Wt, c->vec, c->d_hb, cur, c->p_doub);
+#ifdef FR_SYS_TIMING
+        if (!skip) fr_sys_timing_dump(c, "k_sys_count", STAGE, grid, 6);
+#endif
         FR_LAUNCH(c, "k_sys_fixup", (k_sys_fixup<STAGE, NEW_HB>), dim3(1), dim3(FR_BLOCK), Wt, c->vec, c->d_hb, cur, c->p_doub, c->d_err);
     };
     const bool simple_tail = !xr && c->rank == 0 && !W.prop;
