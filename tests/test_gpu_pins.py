@@ -286,6 +286,34 @@ def test_cpp_driver_thread_ranks_match_mpiexec_goldens(name, tmp_path):
     assert open(out + "dense.txt").read() == ",".join(["0"] * P) + "\n"
 
 
+def test_frifull_cli_thread_ranks_match_mpiexec_golden(tmp_path):
+    """frifull_mol_hip --ranks 2 (two rank threads of one C++ process over the native local transport) against what the HF owner of the
+    reference's frifull_mol loop wrote under mpiexec -n 2: projected energy, preserved counts, shift and norm every ten iterations."""
+    from fries_amd import build
+    name = "full_ne_m300_p2"
+    r = golden_io.manifest()["full_mpi_runs"][name]
+    P = r["n_ranks"]
+    mol = fcidump.synthetic(r["shape"])
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    out = str(tmp_path / "run") + "/"
+    os.makedirs(out)
+    cmd = [build.DRIVERS["frifull_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--epsilon", repr(r["epsilon"]), "--vec_nonz", str(r["vec_nonz"]),
+           "--max_dets", str(r["max_dets"]), "--target", repr(r["target_norm"]), "--seed", str(r["seed"]), "--max_iter", str(r["n_iter"]), "--result_dir", out,
+           "--ranks", str(P), "--spawn_cap", "3000000"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-3000:]
+    gs = [golden_io.read_traj(name, rank=k) for k in range(P)]
+    rows = gs[gs[0]["hf_proc"]]["rows"]
+    num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nk = np.loadtxt(out + "nkept.txt")
+    sh = np.loadtxt(out + "S.txt").reshape(-1); nm = np.loadtxt(out + "norm.txt").reshape(-1)
+    assert num.size == r["n_iter"]
+    for i, row in enumerate(rows):
+        assert abs(num[i] - row["numer"]) <= 1e-10 * max(1.0, abs(row["numer"])) and abs(den[i] - row["denom"]) <= 1e-10 * abs(row["denom"]) and int(nk[i]) == row["nkept"], i
+    for k in range(r["n_iter"] // 10):
+        assert sh[k] == rows[10 * k + 9]["shift"] and nm[k] == rows[10 * k + 9]["norm"], k
+
+
 def test_cpp_driver_rccl_process_rank(tmp_path):
     """frisys_mol_hip launched as a rank (RANK / WORLD_SIZE in the environment): librccl communicator from the id file in the
     result directory, every collective of the iteration a real RCCL call from C++; world of one here (one GPU per box)."""
