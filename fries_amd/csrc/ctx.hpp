@@ -175,6 +175,10 @@ struct FriesCtx {
     uint32_t *fks_sxk8 = nullptr; double *fks_sxg8 = nullptr;
     FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
     struct FksSeq *fks_seq = nullptr;        // sequential find_keep_sub (fks_seq.hpp)
+    FksSq fsq{};                             // ... its parallel form: work arrays, knobs, statistics
+    bool fsq_walk_only = false;              // FRIES_FKS_SEQ_WALK=1: the one-wave walk for every sweep
+    int fsq_guess_rounds = 24, fsq_exact_rounds = 6;
+    uint64_t n_fsq_guess = 0, n_fsq_exact = 0, n_fsq_chain_tiles = 0, n_fsq_walk = 0, n_fsq_walk_tiles = 0;
     FksHost *h_fks = nullptr;                // host side of Fks2Work::hm
     // small device-to-host readbacks (state structs, counters, norms): a one-wave kernel copies them into a pinned, host-coherent block
     // mapped into the device's address space; the host reads it after the stream synchronisation it needs anyway.  (hipMemcpy of a few

@@ -523,6 +523,16 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     for (int k = 0; k < 2; k++) { hipFree(W.el[k].val); hipFree(W.el[k].pos); hipFree(W.el[k].code); hipFree(W.el[k].ndiv); hipFree(W.el[k].nsub); hipFree(W.el[k].rinv); hipFree(W.el[k].raux); hipFree(W.el[k].det); hipFree(W.psum[k]); hipFree(W.pcnt[k]); }
     hipFree(W.wt_remain); hipFree(W.keep); hipFree(W.S); hipFree(W.kin); hipFree(W.cnt); hipFree(W.e_wi); hipFree(W.e_sub); hipFree(W.e_val); hipFree(W.state); hipFree(W.teeth); hipFree(W.fix_list);
     if (h->c.stg_mem) { hipFree(h->c.stg_mem); hipFree(h->c.spill_mem); hipFree(h->c.spill_cnt_mem); hipFree(h->c.tile_dirty_mem); }
+    {
+        FriesCtx &c = h->c;
+        if (c.dbg >= 1 && c.n_fks_sequential)
+            fprintf(stderr, "[fries] find_keep_sub in the reference's order: %llu stages; %llu guess rounds, %llu exact rounds over %llu tiles, %llu walks over %llu tiles\n",
+                    (unsigned long long)c.n_fks_sequential, (unsigned long long)c.n_fsq_guess, (unsigned long long)c.n_fsq_exact, (unsigned long long)c.n_fsq_chain_tiles,
+                    (unsigned long long)c.n_fsq_walk, (unsigned long long)c.n_fsq_walk_tiles);
+        FksSq &SQ = c.fsq;
+        hipFree(SQ.dl); hipFree(SQ.nwr); hipFree(SQ.nkp); hipFree(SQ.gb); hipFree(SQ.lb); hipFree(SQ.dgb); hipFree(SQ.kb); hipFree(SQ.dk);
+        hipFree(SQ.tk); hipFree(SQ.tkx); hipFree(SQ.tg); hipFree(SQ.tgx); hipFree(SQ.tany); hipFree(SQ.ctl);
+    }
     {   // the find_keep_sub replay's arrays (allocated with the work arrays: hbpp.hip)
         Fks2Work &F = h->c.F2;
         if (F.dk8) {

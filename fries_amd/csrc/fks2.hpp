@@ -879,4 +879,15 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_
     if (fr_lane() == 0 && m < INFINITY) atomicMin(&tie[0], __float_as_uint(m));
 }
 
+// work arrays of the parallel form of the in-order sweep (fks_seq.hpp)
+#define FR_SQ_TILE 256u             // elements per workgroup of k_fsq_spec = 32 blocks of 8
+#define FR_SQ_INF 0xFFFFFFFFu
+struct FksSqCtl { uint32_t first_changed; uint32_t K_tot; double G_end, L_end; };
+struct FksSq {
+    double *dl, *nwr; uint32_t *nkp;            // per element: change of this sweep, wt_remain and keep after it
+    double *gb, *lb, *dgb; uint32_t *kb, *dk;   // per block of 8: norm (global, local) and count entering it; change and count of the block
+    uint32_t *tk, *tkx; double *tg, *tgx;       // per tile: count and change, their exclusive prefixes (tgx: norm entering the tile, approximate)
+    uint8_t *tany;                              // per tile: the sweep touches an element of it
+    FksSqCtl *ctl;
+};
 

@@ -363,6 +363,17 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
     }
     c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1);
     c->fks_seq = fr_alloc<FksSeq>(1);
+    {   // work arrays of the parallel form of the in-order sweep (fks_seq.hpp)
+        FksSq &SQ = c->fsq;
+        const size_t nt = fr_blocks(cap, FR_SQ_TILE) + 1, ne = nt * FR_SQ_TILE, nb = nt * 32;
+        SQ.dl = fr_alloc<double>(ne); SQ.nwr = fr_alloc<double>(ne); SQ.nkp = fr_alloc<uint32_t>(ne);
+        SQ.gb = fr_alloc<double>(nb); SQ.lb = fr_alloc<double>(nb); SQ.dgb = fr_alloc<double>(nb); SQ.kb = fr_alloc<uint32_t>(nb); SQ.dk = fr_alloc<uint32_t>(nb);
+        SQ.tk = fr_alloc<uint32_t>(nt); SQ.tkx = fr_alloc<uint32_t>(nt); SQ.tg = fr_alloc<double>(nt); SQ.tgx = fr_alloc<double>(nt); SQ.tany = fr_alloc<uint8_t>(nt);
+        SQ.ctl = fr_alloc<FksSqCtl>(1);
+        c->fsq_walk_only = getenv("FRIES_FKS_SEQ_WALK") && atoi(getenv("FRIES_FKS_SEQ_WALK"));
+        if (getenv("FRIES_FSQ_GUESS_ROUNDS")) c->fsq_guess_rounds = atoi(getenv("FRIES_FSQ_GUESS_ROUNDS"));
+        if (getenv("FRIES_FSQ_EXACT_ROUNDS")) c->fsq_exact_rounds = atoi(getenv("FRIES_FSQ_EXACT_ROUNDS"));
+    }
     c->c_pos = fr_alloc<uint32_t>(cap); c->c_orbs = fr_alloc<uint32_t>(cap); c->c_val = fr_alloc<double>(cap);
     c->d_nsucc = fr_alloc<uint32_t>(1);
     FR_HIP(hipMemset(W.state, 0, sizeof(CompState) * (FR_MAX_ROUNDS + 2)));
@@ -414,12 +425,61 @@ static __global__ void k_err_clear(uint32_t *err, uint32_t bits) { atomicAnd(err
 
 // find_keep_sub of this stage in the reference's order (fks_seq.hpp): sweeps driven from the host, one sum_mpi before and one
 // after each, as in compress_utils.cpp:153-265
+// one sweep of it in the parallel form (fks_seq.hpp, second half): guesses settled with tree-summed norms, then the exact chain and
+// the comparison against it, repeated from the first tile that differs; the one-wave walk from there if that does not close
 template <int STAGE, bool NEW_HB>
-static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) {
+static void run_fsq_sweep(FriesCtx *c, int cur, uint32_t n_tiles) {
+    CompWork &W = c->W;
+    hipStream_t st = c->stream;
+    FksSeq *Q = c->fks_seq;
+    FksSq &SQ = c->fsq;
+    auto first_changed = [&]() {
+        uint32_t fc;
+        FR_HIP(hipMemcpyAsync(&fc, &SQ.ctl->first_changed, 4, hipMemcpyDeviceToHost, st));
+        FR_HIP(hipStreamSynchronize(st));
+        if (fc != FR_SQ_INF) FR_HIP(hipMemsetAsync(&SQ.ctl->first_changed, 0xff, 4, st));
+        return fc;
+    };
+    auto spec = [&](uint32_t from) { FR_LAUNCH(c, "k_fsq_spec", (k_fsq_spec<STAGE, NEW_HB>), dim3(n_tiles - from), dim3(FR_BLOCK), W, c->d_hb, cur, c->p_doub, Q, SQ, from); };
+    auto prefixes = [&](uint32_t from, int approx) {
+        FR_LAUNCH(c, "k_fsq_scan", k_fsq_scan, dim3(1), dim3(1024), SQ, from, n_tiles);
+        FR_LAUNCH(c, "k_fsq_expand", k_fsq_expand, dim3(fr_blocks(n_tiles - from, FR_BLOCK / 32)), dim3(FR_BLOCK), SQ, from, n_tiles, approx);
+    };
+    FR_LAUNCH(c, "k_fsq_init", k_fsq_init, dim3(n_tiles), dim3(FR_BLOCK), W, Q, SQ);
+    uint32_t from = 0, fc = 0;
+    for (int r = 0; r < c->fsq_guess_rounds; r++) {
+        spec(from);
+        c->n_fsq_guess++;
+        fc = first_changed();
+        if (fc == FR_SQ_INF) break;
+        from = fc / 32;
+        prefixes(from, 1);
+    }
+    from = 0;
+    for (int x = 0; ; x++) {
+        FR_LAUNCH(c, "k_fsq_chain", k_fsq_chain, dim3(1), dim3(64), Q, SQ.dl, SQ.tany, SQ.gb, SQ.lb, SQ.ctl, from, n_tiles);
+        spec(from);
+        c->n_fsq_exact++; c->n_fsq_chain_tiles += n_tiles - from;
+        fc = first_changed();
+        if (fc == FR_SQ_INF) { FR_LAUNCH(c, "k_fsq_commit", k_fsq_commit, dim3(n_tiles), dim3(FR_BLOCK), W, Q, SQ, n_tiles, 1); return; }
+        from = fc / 32;
+        prefixes(from, 0);
+        if (x >= c->fsq_exact_rounds) break;
+    }
+    // not closed: blocks before `from` are final; the walk goes on from there with the state the last chain and scan left at that tile
+    FR_LAUNCH(c, "k_fsq_commit", k_fsq_commit, dim3(n_tiles), dim3(FR_BLOCK), W, Q, SQ, from, 0);
+    FR_LAUNCH(c, "k_fks_seq_sweep", (k_fks_seq_sweep<STAGE, NEW_HB>), dim3(1), dim3(64), W, c->d_hb, cur, c->p_doub, Q, from, SQ.gb, SQ.lb, SQ.kb);
+    c->n_fsq_walk++; c->n_fsq_walk_tiles += n_tiles - from;
+}
+
+template <int STAGE, bool NEW_HB>
+static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F, uint32_t n_bound) {
     CompWork &W = c->W;
     hipStream_t st = c->stream;
     const int P = c->n_ranks;
     FksSeq *Q = c->fks_seq;
+    uint32_t n_tiles = fr_blocks(n_bound, FR_SQ_TILE);
+    if (n_tiles == 0) n_tiles = 1;
     FR_LAUNCH(c, "k_fks_seq_reset", k_fks_seq_reset, dim3(grid < 1024 ? grid : 1024), dim3(FR_BLOCK), W, cur);
     AccVal av{W.el[cur].val, &W.state[0]};
     FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccVal>), dim3(grid), dim3(FR_BLOCK), W.seq, av);
@@ -431,7 +491,8 @@ static void run_fks_sequential(FriesCtx *c, int cur, unsigned grid, Fks2Work F) 
         if (sweep > 4096) throw FriesError("sequential find_keep_sub did not terminate");
         const double *alln = (const double *)fr_allgather(c, sizeof(double));
         FR_LAUNCH(c, "k_fks_seq_norm", k_fks_seq_norm, dim3(1), dim3(1), Q, alln, P);
-        FR_LAUNCH(c, "k_fks_seq_sweep", (k_fks_seq_sweep<STAGE, NEW_HB>), dim3(1), dim3(64), W, c->d_hb, cur, c->p_doub, Q);
+        if (c->fsq_walk_only) FR_LAUNCH(c, "k_fks_seq_sweep", (k_fks_seq_sweep<STAGE, NEW_HB>), dim3(1), dim3(64), W, c->d_hb, cur, c->p_doub, Q, 0u, (const double *)nullptr, (const double *)nullptr, (const uint32_t *)nullptr);
+        else run_fsq_sweep<STAGE, NEW_HB>(c, cur, n_tiles);
         FR_LAUNCH(c, "k_fks_seq_put_k", k_fks_seq_put_k, dim3(1), dim3(1), Q, (uint32_t *)c->comm.small_send);
         const uint32_t *allk = (const uint32_t *)fr_allgather(c, sizeof(uint32_t));
         FR_LAUNCH(c, "k_fks_seq_post", k_fks_seq_post, dim3(1), dim3(1), Q, allk, P, (double *)c->comm.small_send);
@@ -590,7 +651,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (sequential) {
         tail_done = false;
         if (hscal.overflow) FR_LAUNCH(c, "k_err_clear", k_err_clear, dim3(1), dim3(1), c->d_err, (uint32_t)FR_ERR_ROUNDS);     // FR_ERR_ROUNDS of the abandoned replay only: d_err also carries the flags of earlier stages and iterations of the batch
-        run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F);
+        run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F, n_bound);
     }
     else if (!closing) c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
     c->fks_iters[STAGE] = it;

@@ -269,6 +269,11 @@ REPLAY_KNOBS = [
     {"FRIES_WAIT_SYNC": "1"},               # the host waits with hipStreamSynchronize instead of polling the ticket word
     {"FRIES_FKS_GRID": "512", "FRIES_FKS_GRID0": "700"},     # other persistent grids (more tiles per workgroup)
     {"FRIES_NO_STAGING": "1"},              # k_sys_write replays sys_sub instead of copying the emissions k_sys_count staged
+    {"FRIES_FKS_SEQ": "1"},                 # every stage in the reference's own order: guesses, exact chain, comparison (fks_seq.hpp)
+    {"FRIES_FKS_SEQ": "1", "FRIES_FKS_SEQ_WALK": "1"},          # ... by the one-wave walk
+    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_GUESS_ROUNDS": "1"},      # ... the chain run on the first guess
+    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_GUESS_ROUNDS": "0"},      # ... and on no guess at all
+    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_GUESS_ROUNDS": "1", "FRIES_FSQ_EXACT_ROUNDS": "0"},      # ... the walk taking over at the first tile the comparison rejects
 ]
 
 
