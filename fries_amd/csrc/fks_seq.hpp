@@ -313,7 +313,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fsq_expand(FksSq SQ, uint32
 // next tile's are in flight meanwhile.  Lane j (and 32 + j) keeps the value block j of the tile is entered with.
 static __global__ void __launch_bounds__(64) k_fsq_chain(const FksSeq *Q, const double *__restrict__ dl, const uint8_t *__restrict__ tany,
                                                          double *__restrict__ gb, double *__restrict__ lb, FksSqCtl *__restrict__ ctl,
-                                                         uint32_t from_tile, uint32_t n_tiles) {
+                                                         uint32_t from_tile, uint32_t n_tiles, int sparse_max) {
     __shared__ double2 sh[FR_SQ_TILE / 2];
     if (!Q->go) return;
     const int lane = fr_lane(), j = lane & 31;
@@ -332,7 +332,23 @@ static __global__ void __launch_bounds__(64) k_fsq_chain(const FksSeq *Q, const 
         const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_any);
         issue(t + 1);
         double C = X;
-        if (any) {
+        unsigned long long m0 = 0, m1 = 0;
+        if (any) { m0 = __ballot(c0.x != 0.0 || c0.y != 0.0); m1 = __ballot(c1.x != 0.0 || c1.y != 0.0); }
+        if (any && __popcll(m0) + __popcll(m1) <= sparse_max) {
+            // few touched elements (the later sweeps of a stage): only the pairs that hold one, in order; lane i of c0 holds elements
+            // 2i, 2i + 1 of the tile (block i / 4), lane i of c1 elements 128 + 2i, 129 + 2i (block 16 + i / 4)
+            for (int h = 0; h < 2; h++) {
+                unsigned long long m = h ? m1 : m0;
+                const double2 src = h ? c1 : c0;
+                while (m) {
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    X -= fr_bcast_f64(src.x, i); X -= fr_bcast_f64(src.y, i);
+                    if (j > (i >> 2) + 16 * h) C = X;          // the blocks behind this pair are entered with the new value
+                }
+            }
+        }
+        else if (any) {
             sh[lane] = c0; sh[64 + lane] = c1;              // one wave: its LDS accesses execute in program order
             // the reads of two blocks ahead are issued before a block's eight subtractions
             double2 r[3][4];

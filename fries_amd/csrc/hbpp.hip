@@ -373,6 +373,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         c->fsq_walk_only = getenv("FRIES_FKS_SEQ_WALK") && atoi(getenv("FRIES_FKS_SEQ_WALK"));
         if (getenv("FRIES_FSQ_GUESS_ROUNDS")) c->fsq_guess_rounds = atoi(getenv("FRIES_FSQ_GUESS_ROUNDS"));
         if (getenv("FRIES_FSQ_EXACT_ROUNDS")) c->fsq_exact_rounds = atoi(getenv("FRIES_FSQ_EXACT_ROUNDS"));
+        if (getenv("FRIES_FSQ_SPARSE_MAX")) c->fsq_sparse_max = atoi(getenv("FRIES_FSQ_SPARSE_MAX"));
     }
     c->c_pos = fr_alloc<uint32_t>(cap); c->c_orbs = fr_alloc<uint32_t>(cap); c->c_val = fr_alloc<double>(cap);
     c->d_nsucc = fr_alloc<uint32_t>(1);
@@ -447,19 +448,30 @@ static void run_fsq_sweep(FriesCtx *c, int cur, uint32_t n_tiles) {
     };
     FR_LAUNCH(c, "k_fsq_init", k_fsq_init, dim3(n_tiles), dim3(FR_BLOCK), W, Q, SQ);
     uint32_t from = 0, fc = 0;
+    int n_guess = 0;
     for (int r = 0; r < c->fsq_guess_rounds; r++) {
         spec(from);
-        c->n_fsq_guess++;
+        c->n_fsq_guess++; n_guess++;
         fc = first_changed();
-        if (fc == FR_SQ_INF) break;
+        if (fc == FR_SQ_INF) {
+            if (r == 0) {
+                // Nothing moves under (the sweep's start norm, no sample taken) -- and with nothing moving that IS every block's entry
+                // state: the sweep is settled (the two closing sweeps of every stage end here)
+                FR_LAUNCH(c, "k_fsq_commit", k_fsq_commit, dim3(n_tiles), dim3(FR_BLOCK), W, Q, SQ, n_tiles, 1);
+                if (c->dbg >= 2) fprintf(stderr, "[fries]   in-order sweep: %u tiles, untouched\n", n_tiles);
+                return;
+            }
+            break;
+        }
         from = fc / 32;
         prefixes(from, 1);
     }
     from = 0;
     for (int x = 0; ; x++) {
-        FR_LAUNCH(c, "k_fsq_chain", k_fsq_chain, dim3(1), dim3(64), Q, SQ.dl, SQ.tany, SQ.gb, SQ.lb, SQ.ctl, from, n_tiles);
+        FR_LAUNCH(c, "k_fsq_chain", k_fsq_chain, dim3(1), dim3(64), Q, SQ.dl, SQ.tany, SQ.gb, SQ.lb, SQ.ctl, from, n_tiles, c->fsq_sparse_max);
         spec(from);
         c->n_fsq_exact++; c->n_fsq_chain_tiles += n_tiles - from;
+        if (c->dbg >= 2) fprintf(stderr, "[fries]   in-order sweep: %u tiles, %d guess rounds, exact round %d from tile %u\n", n_tiles, n_guess, x, from);
         fc = first_changed();
         if (fc == FR_SQ_INF) { FR_LAUNCH(c, "k_fsq_commit", k_fsq_commit, dim3(n_tiles), dim3(FR_BLOCK), W, Q, SQ, n_tiles, 1); return; }
         from = fc / 32;
