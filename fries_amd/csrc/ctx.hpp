@@ -219,6 +219,7 @@ struct FriesCtx {
     uint32_t *d_tie = nullptr;               // [2] tie statistics when enabled (fries_tie_margins): float bits of the smallest relative margin in find_keep_sub / find_preserve
     // optional driver inputs, set before fries_frisys_setup: --trial_vec, --ini_vec, --ham_shift (frisys_mol.cpp:95-98, 157-181, 264-274)
     std::vector<det_t> in_trial_det, in_ini_det; std::vector<double> in_trial_val, in_ini_val;
+    bool fq_ini_real = false;                // the --ini_vec values are reals (frimulti_mol; fciqmc_fp_mol says so through its parameters)
     // --det_space (semi-stochastic, one rank): the dense determinants (positions 0 .. n-1 of the vector) and H inside that space
     // times -eps, per determinant its singles then its doubles (frisys_mol.cpp:236-239, 347-401)
     std::vector<det_t> in_det_space;

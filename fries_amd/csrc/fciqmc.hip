@@ -564,15 +564,15 @@ void fr_fq_setup(FriesCtx *c, const fries_fciqmc_params *p) {
     if (p->real_walkers) {             // fciqmc_fp_mol
         if (c->use_comm && c->n_ranks > 1 && 2 * c->n_orb > 63) throw FriesError("fciqmc_fp_mol over ranks needs bit 63 of the index for the initiator flag (at most 31 orbitals)");
         c->dots_slot0_from_hf = true;      // fciqmc_fp_mol.cpp:461-462
-        if (!c->in_ini_det.empty() || !c->in_trial_det.empty()) throw FriesError("fciqmc_fp_mol: --ini_vec / --trial_vec are not provided");
         Q.multi = 2; Q.n_walk = fr_alloc<uint32_t>(Q.cap_d);
     }
     if (p->heat_bath && (c->n_elec > 32 || c->n_orb - c->n_elec / 2 > 32)) throw FriesError("heat-bath sampling supports at most 32 electrons / 32 virtual orbitals per spin");
     fr_h_trial_setup(c);        // HF trial vector, H * trial, p_doub (:139-191, as in frisys_mol)
-    if (!c->in_ini_det.empty()) {                            // --ini_vec (:226-237): integer walkers, entries add()ed in file order from rank 0
-        std::vector<det_t> d; std::vector<double> v;
+    if (!c->in_ini_det.empty()) {                            // --ini_vec (:226-237): entries add()ed in file order from rank 0; integer walkers (the reader
+        std::vector<det_t> d; std::vector<double> v;         // fills an int array), real values in fciqmc_fp_mol.cpp:233-246 and frimulti_mol.cpp:205-215
+        const bool real_valued = p->real_walkers || c->fq_ini_real;
         for (size_t i = 0; i < c->in_ini_det.size(); i++) {
-            const double w = (double)(int)c->in_ini_val[i];
+            const double w = real_valued ? c->in_ini_val[i] : (double)(int)c->in_ini_val[i];
             if (w != 0 && fr_host_idx_to_proc(c, c->in_ini_det[i]) == c->rank) { d.push_back(c->in_ini_det[i]); v.push_back(w); }
         }
         uint32_t m = (uint32_t)d.size();
@@ -692,6 +692,11 @@ void fr_fq_iterate(FriesCtx *c, fries_fciqmc_log *lg) {
 void fr_multi_setup(FriesCtx *c, const fries_frimulti_params *p) {
     if (c->use_comm && c->n_ranks > 1 && 2 * c->n_orb > 63) throw FriesError("frimulti_mol over ranks needs bit 63 of the index for the initiator flag (at most 31 orbitals)");
     if (p->vec_nonz == 0 || p->mat_nonz < 10 || p->max_dets == 0) throw FriesError("vec_nonz, max_dets must be positive and mat_nonz at least 10 (the first iterations use a tenth of it)");
+    // --trial_vec: frimulti_mol.cpp:149-157 throws when an add() reports a full Adder, and trial_vec's Adder holds exactly n_trial entries: on one rank the
+    // reference refuses EVERY trial file with this message (over several ranks its non-root ranks build zero-sized vectors, io_utils.cpp:410-444, and abort
+    // inside MPI).  Same behaviour here; the HF trial vector is the one this driver can use.
+    if (!c->in_trial_det.empty()) throw FriesError("Insufficient memory allocated in adder");
+    c->fq_ini_real = true;              // --ini_vec: real values (:205-215)
     fries_fciqmc_params q{};
     q.epsilon = p->epsilon; q.target_walkers = p->mat_nonz; q.initiator = 0; q.max_dets = p->max_dets; q.seed = p->seed; q.heat_bath = 1;
     fr_fq_setup(c, &q);                 // scramblers, vector, work arrays, H * trial, 100 x HF -- as there (frimulti_mol.cpp:84-233)

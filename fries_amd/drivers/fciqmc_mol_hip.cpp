@@ -2,7 +2,7 @@
 //
 //   fciqmc_mol_hip --fcidump_path F --point_group D2h --distribution NU|HB --target W --max_dets N --epsilon E
 //                  [--initiator I] [--max_iter K] [--result_dir DIR/] [--ini_vec PREFIX] [--trial_vec PREFIX] [--seed S] [--device D]
-//                  [--fp 1]       (fciqmc_fp_mol: real-valued walkers; without --ini_vec / --trial_vec)
+//                  [--fp 1]       (fciqmc_fp_mol: real-valued walkers; --ini_vec then holds reals, fciqmc_fp_mol.cpp:233-246)
 //                  [--load_dir DIR/]   (fciqmc_mol.cpp:122-124, 214-222, 250-252: proc scrambler from hash.dat, DistVec<int>::load of
 //                                       dets0.dat / vals0.dat, shift from S.txt's last line, last walker number = the loaded one)
 //

@@ -280,8 +280,14 @@ class FriEngine:
         return logs
 
     # ---- frimulti_mol
-    def setup_multi(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0):
-        """frimulti_mol (FRIES_bin/frimulti_mol.cpp, --distribution HB): multinomial matrix compression, systematic vector compression."""
+    def setup_multi(self, *, epsilon, vec_nonz, mat_nonz, max_dets, target_norm=0.0, initiator=0.0, seed=0, trial=None, ini=None):
+        """frimulti_mol (FRIES_bin/frimulti_mol.cpp, --distribution HB): multinomial matrix compression, systematic vector compression.
+        ini: (dets, vals) of --ini_vec; trial: --trial_vec, which the reference refuses ("Insufficient memory allocated in adder") and so does this."""
+        for pair, fn in ((trial, self.lib.fries_set_trial_vector), (ini, self.lib.fries_set_initial_vector)):
+            if pair is not None:
+                d = np.ascontiguousarray(pair[0], dtype=np.uint64)
+                v = np.ascontiguousarray(pair[1], dtype=np.float64)
+                self._ck(fn(self.h, _ptr(d), _ptr(v), min(d.size, v.size)))
         p = FrimultiParams(epsilon, target_norm, initiator, vec_nonz, mat_nonz, max_dets, seed)
         self._ck(self.lib.fries_frimulti_setup(self.h, C.byref(p)))
         self.max_dets = max_dets

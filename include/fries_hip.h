@@ -134,7 +134,9 @@ typedef struct {
 
 /* Optional inputs of the frisys_mol and fciqmc_mol drivers, each before fries_frisys_setup / fries_fciqmc_setup (for fciqmc_mol the
  * initial values are walker numbers, and the last entry of the trial file counts twice in the trial vector, as in the
- * reference's `while (!add) perform_add` loop, fciqmc_mol.cpp:163-170):
+ * reference's `while (!add) perform_add` loop, fciqmc_mol.cpp:163-170; fciqmc_fp_mol, real_walkers = 1, keeps the initial values real,
+ * fciqmc_fp_mol.cpp:157-185, 233-246; fries_frimulti_setup takes --ini_vec with real values, frimulti_mol.cpp:205-215, and answers a trial vector with the
+ * reference's own error "Insufficient memory allocated in adder", frimulti_mol.cpp:149-157, which that driver raises for every trial file):
  *   --trial_vec (frisys_mol.cpp:157-181): the vector the energy is projected on, entries add()ed in the given order;
  *   --ini_vec   (:264-274): the starting vector instead of 100 x HF, entries add()ed in the given order (from rank 0);
  *   --ham_shift (:95-98): the offset subtracted from every diagonal element instead of the HF energy (pass ham_shift - core_en). */

@@ -2566,6 +2566,11 @@ void Fciqmc::setup() {
         tv.init(n_trial, n_trial, n_elec, 1, cm, proc_scr.data());
         ht.init(n_trial * n_ex / cm.size, n_trial * n_ex / cm.size, n_elec, 2, cm, proc_scr.data());
         if (cm.rank == 0) for (size_t i = 0; i < n_trial; i++) {
+            if (par.multi) {        // frimulti_mol.cpp:149-157: a filled Adder is an error there -- on one rank the last entry of ANY trial file fills trial_vec's
+                if (!tv.add(trial_in_det[i], trial_in_val[i], 1)) throw std::runtime_error("Insufficient memory allocated in adder");
+                if (!ht.add(trial_in_det[i], trial_in_val[i], 1)) throw std::runtime_error("Insufficient memory allocated in adder");
+                continue;
+            }
             while (!tv.add(trial_in_det[i], trial_in_val[i], 1)) tv.perform_add(0);
             while (!ht.add(trial_in_det[i], trial_in_val[i], 1)) ht.perform_add(0);
         }
@@ -2644,7 +2649,12 @@ void Fciqmc::setup() {
         p_doub = (double)n_doub / (n_sing2 + n_doub);
     }
     }
-    if (!ini_det.empty()) { if (cm.rank == 0) for (size_t i = 0; i < ini_det.size(); i++) while (!sol.add(ini_det[i], ini_val[i], 1)) sol.perform_add(0); }      // :226-237
+    if (!ini_det.empty()) {      // fciqmc_mol.cpp:226-237 / fciqmc_fp_mol.cpp:233-246: `while (!add) perform_add`; frimulti_mol.cpp:205-215: plain add()
+        if (cm.rank == 0) for (size_t i = 0; i < ini_det.size(); i++) {
+            if (par.multi) sol.add(ini_det[i], ini_val[i], 1);
+            else while (!sol.add(ini_det[i], ini_val[i], 1)) sol.perform_add(0);
+        }
+    }
     else if (cm.rank == hf_proc) sol.add(hf_det, 100, 1);      // :239-243
     sol.perform_add(0);
     if (par.heat_bath) sys.hb.set_up(sys.ints);       // :310-313

@@ -452,7 +452,7 @@ struct Fciqmc {
     int hf_proc = 0;
     // --trial_vec / --ini_vec (fciqmc_mol.cpp:150-177, 226-241): text vectors, added with `while (!add) perform_add` loops
     std::vector<det_t> trial_in_det, ini_det;
-    std::vector<double> trial_in_val; std::vector<int> ini_val;
+    std::vector<double> trial_in_val, ini_val;       // ini_val: integers for fciqmc_mol (its reader fills an int array), reals for fciqmc_fp_mol / frimulti_mol
     // frimulti_mol state: every rank's norm after the last compression, the global norm before it (frimulti_mol.cpp:227-233, 393, 414)
     std::vector<double> loc_norms; double glob_norm = 0;
     std::vector<size_t> srt; std::vector<uint8_t> keep;

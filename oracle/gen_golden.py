@@ -174,6 +174,17 @@ def gen_fp(manifest):
             out = os.path.join(GOLD, name + ".traj")
             subprocess.run([HARNESS, "fciqmc_fp", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(tw), str(maxd), str(ini), out, dist], check=True)
             manifest["fciqmc_fp_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, target_walkers=tw, max_dets=maxd, initiator=ini, distribution=dist, fp=True)
+        # fciqmc_fp_mol with --trial_vec / --ini_vec (fciqmc_fp_mol.cpp:157-185, 233-246): the 25-determinant N2 trial fixture and the real-valued start vector of the
+        # frisys_mol run with the same options
+        name = "fciqmc_fp_n2_trial_ini"
+        mol = fcidump.synthetic("N2")
+        path = os.path.join(tmp, "N2.FCIDUMP")
+        fcidump.write_fcidump(path, mol)
+        out = os.path.join(GOLD, name + ".traj")
+        env = dict(os.environ, FRIES_TRIAL=os.path.join(GOLD, "n2_trial_"), FRIES_INI=os.path.join(GOLD, "n2_ini_"))
+        subprocess.run([HARNESS, "fciqmc_fp", path, mol.point_group, "150", "9", "0.004", "20000", "100000", "2", out, "NU"], check=True, env=env)
+        manifest["fciqmc_fp_runs"][name] = dict(shape="N2", n_iter=150, seed=9, epsilon=0.004, target_walkers=20000, max_dets=100000, initiator=2, distribution="NU", fp=True,
+                                                trial="n2_trial_", ini="n2_ini_")
 
 
 def gen_hhfull(manifest):
@@ -215,6 +226,22 @@ def gen_multi(manifest):
             out = os.path.join(GOLD, name + ".traj")
             subprocess.run([HARNESS, "frimulti", path, mol.point_group, str(n_iter), str(seed), repr(eps), str(vnz), str(mnz), str(maxd), repr(ini), repr(tgt), out], check=True)
             manifest["multi_runs"][name] = dict(shape=shape, n_iter=n_iter, seed=seed, epsilon=eps, vec_nonz=vnz, mat_nonz=mnz, max_dets=maxd, initiator=ini, target_norm=tgt)
+        # frimulti_mol with --ini_vec (frimulti_mol.cpp:205-215): the real-valued start vector of the frisys_mol run with that option
+        name = "multi_n2_ini"
+        mol = fcidump.synthetic("N2")
+        path = os.path.join(tmp, "N2.FCIDUMP")
+        fcidump.write_fcidump(path, mol)
+        out = os.path.join(GOLD, name + ".traj")
+        env = dict(os.environ, FRIES_INI=os.path.join(GOLD, "n2_ini_"))
+        subprocess.run([HARNESS, "frimulti", path, mol.point_group, "40", "3", "0.01", "5000", "20000", "200000", "1.0", "2500.0", out], check=True, env=env)
+        manifest["multi_runs"][name] = dict(shape="N2", n_iter=40, seed=3, epsilon=0.01, vec_nonz=5000, mat_nonz=20000, max_dets=200000, initiator=1.0, target_norm=2500.0, ini="n2_ini_")
+        # ... and --trial_vec (:139-163).  On ONE rank the reference refuses every trial file: trial_vec's Adder holds n_trial entries, add() reports the entry that
+        # fills it, and this driver throws on that report ("Insufficient memory allocated in adder") where fciqmc_mol flushes.  Recorded as the expected error.  (Over
+        # several ranks load_vec_txt returns 0 on the non-root ranks, io_utils.cpp:410-444, which then build zero-sized vectors and abort inside MPI_Alltoallv: no golden.)
+        r = subprocess.run([HARNESS, "frimulti", path, mol.point_group, "5", "3", "0.01", "5000", "20000", "200000", "1.0", "2500.0", os.path.join(tmp, "x.traj")],
+                           env=dict(os.environ, FRIES_TRIAL=os.path.join(GOLD, "n2_trial_")), capture_output=True, text=True)
+        assert r.returncode != 0 and "Insufficient memory allocated in adder" in r.stderr, (r.returncode, r.stderr[-300:])
+        manifest["multi_trial_one_rank_error"] = dict(shape="N2", trial="n2_trial_", error="Insufficient memory allocated in adder")
 
 
 # BASELINE sizes pinned by the reference (ref_harness pin: bench.py's filler + restart, then n_iter iterations with digests):

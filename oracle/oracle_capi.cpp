@@ -11,6 +11,7 @@ using namespace fo;
 
 struct OracleLog { double numer, denom, shift, norm; uint32_t nkept; int32_t n_nonz; uint32_t curr_size, num_success; uint32_t comp_len[5]; uint32_t err; };
 
+static std::string g_last_error;
 extern "C" {
 
 // the per-iteration digest oracle/ref_harness.cpp logs: FNV-style over (determinant, value bits, position) of the non-zero entries
@@ -509,6 +510,27 @@ void *fo_fciqmc_create_ex(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps
     f->setup();
     return f;
 }
+// the general form: fciqmc_mol / fciqmc_fp_mol (flags bit 2) / frimulti_mol (flags bit 3: vec_nonz, mat_nonz, initiator_f, target_norm apply) with
+// --trial_vec / --ini_vec, the initial vector's values as doubles (n == 0: default)
+void *fo_fq_create_vecs(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
+                        double eps, uint32_t target_walkers, uint32_t init_thresh, uint32_t max_dets, uint32_t seed, int flags,
+                        uint32_t vec_nonz, uint32_t mat_nonz, double initiator_f, double target_norm,
+                        const uint64_t *tr_det, const double *tr_val, size_t n_tr, const uint64_t *in_det, const double *in_val, size_t n_in) {
+    Fciqmc *f = new Fciqmc();
+    f->par.heat_bath = (flags & 2) != 0; f->par.counter_rng = (flags & 1) != 0; f->par.fp = (flags & 4) != 0;
+    f->sys.n_orb = n_orb; f->sys.n_elec = n_elec;
+    f->sys.ints.n_orb = n_orb;
+    f->sys.ints.h.assign(h, h + (size_t)n_orb * n_orb);
+    f->sys.ints.eri.assign(eris, eris + Integrals::packed_len(n_orb));
+    f->sys.symm.init(irreps, n_orb);
+    f->par.eps = eps; f->par.target_walkers = target_walkers; f->par.init_thresh = init_thresh; f->par.max_dets = max_dets; f->par.seed = seed;
+    if (flags & 8) { f->par.heat_bath = true; f->par.multi = true; f->par.vec_nonz = vec_nonz; f->par.mat_nonz = mat_nonz; f->par.init_thresh_f = initiator_f; f->par.target_norm = target_norm; }
+    if (n_tr) { f->trial_in_det.assign(tr_det, tr_det + n_tr); f->trial_in_val.assign(tr_val, tr_val + n_tr); }
+    if (n_in) { f->ini_det.assign(in_det, in_det + n_in); f->ini_val.assign(in_val, in_val + n_in); }
+    try { f->setup(); } catch (std::exception &e) { g_last_error = e.what(); delete f; return nullptr; }       // (frimulti_mol refuses every --trial_vec on one rank)
+    return f;
+}
+const char *fo_last_error() { return g_last_error.c_str(); }
 // frimulti_mol: the same object in its multinomial mode (fo::Fciqmc::iterate_multi); flags bit 0 = counter-based uniforms
 void *fo_frimulti_create(uint32_t n_orb, uint32_t n_elec, const uint8_t *irreps, const double *h, const double *eris,
                          double eps, uint32_t vec_nonz, uint32_t mat_nonz, uint32_t max_dets, uint32_t seed, double initiator, double target_norm, int flags) {

@@ -1609,7 +1609,7 @@ static int run_fciqmc(int argc, char **argv) {
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
     fq.par.heat_bath = heat_bath;
-    fq.trial_in_det = tin_det; fq.trial_in_val = tin_val; fq.ini_det = iin_det; fq.ini_val = iin_val;
+    fq.trial_in_det = tin_det; fq.trial_in_val = tin_val; fq.ini_det = iin_det; fq.ini_val.assign(iin_val.begin(), iin_val.end());
     if (lockstep) fq.setup();
     hb_info *hb_probs = heat_bath ? set_up(tot_orb, n_orb, *eris) : NULL;
     if (lockstep) CHECK(same_bits(fq.p_doub, p_doub), "fciqmc p_doub");
@@ -1816,10 +1816,27 @@ static int run_frimulti(int argc, char **argv) {
     uint8_t (*sing_orbs)[2] = (uint8_t (*)[2])spawn_orbs_v.data();
     uint8_t (*doub_orbs)[4] = (uint8_t (*)[4])spawn_orbs_v.data();
     size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
-    DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
-    DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    // --trial_vec (frimulti_mol.cpp:139-163): the reference's own text reader, through the solution vector's arrays; a full Adder is an error there
+    const char *trial_prefix = getenv("FRIES_TRIAL");
+    size_t n_trial = 1;
+    std::vector<fo::det_t> tin_det; std::vector<double> tin_val;
+    if (trial_prefix) {
+        n_trial = load_vec_txt(std::string(trial_prefix), sol_vec.indices(), sol_vec.values());
+        for (size_t i = 0; i < n_trial; i++) { tin_det.push_back(to_u64(sol_vec.indices()[i], det_size)); tin_val.push_back(sol_vec.values()[i]); }
+    }
+    DistVec<double> trial_vec(trial_prefix ? n_trial : 4, trial_prefix ? n_trial : 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
+    DistVec<double> htrial_vec(trial_prefix ? n_trial * n_ex / n_procs : 2 * n_ex, trial_prefix ? n_trial * n_ex / n_procs : 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
     unsigned hf_proc = sol_vec.idx_to_proc(hf_det);
-    if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
+    if (trial_prefix) {
+        Matrix<uint8_t> &load_dets = sol_vec.indices();
+        double *load_vals = sol_vec.values();
+        for (size_t i = 0; i < n_trial; i++) {
+            if (!trial_vec.add(load_dets[i], load_vals[i], 1)) throw std::runtime_error("Insufficient memory allocated in adder");
+            if (!htrial_vec.add(load_dets[i], load_vals[i], 1)) throw std::runtime_error("Insufficient memory allocated in adder");
+        }
+        memset(sol_vec.values(), 0, (n_trial + 1) * sizeof(double));
+    }
+    else if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
     trial_vec.perform_add(0); htrial_vec.perform_add(0);
     trial_vec.collect_procs();
     std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
@@ -1836,7 +1853,17 @@ static int run_frimulti(int argc, char **argv) {
     size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, (uint8_t (*)[4])scratch.data(), symm);
     size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
     double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-    if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
+    std::vector<fo::det_t> iin_det; std::vector<double> iin_val;
+    if (getenv("FRIES_INI")) {       // --ini_vec (frimulti_mol.cpp:205-215): plain add() calls
+        Matrix<uint8_t> &load_dets = sol_vec.indices();
+        double *load_vals = sol_vec.values();
+        size_t n_dets = load_vec_txt(std::string(getenv("FRIES_INI")), load_dets, load_vals);
+        std::vector<std::vector<uint8_t>> keep_d(n_dets, std::vector<uint8_t>(det_size)); std::vector<double> keep_v(n_dets);
+        for (size_t i = 0; i < n_dets; i++) { memcpy(keep_d[i].data(), load_dets[i], det_size); keep_v[i] = load_vals[i]; iin_det.push_back(to_u64(load_dets[i], det_size)); iin_val.push_back(load_vals[i]); }
+        memset(load_vals, 0, (n_dets + 1) * sizeof(double));       // the reference adds straight out of the vector's own arrays; keep the harness well defined
+        for (size_t i = 0; i < n_dets; i++) sol_vec.add(keep_d[i].data(), keep_v[i], 1);
+    }
+    else if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
     sol_vec.perform_add(0);
     double loc_norms[64], glob_norm;
     loc_norms[proc_rank] = sol_vec.local_norm();
@@ -1852,6 +1879,7 @@ static int run_frimulti(int argc, char **argv) {
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false; fq.par.heat_bath = true;
     fq.par.multi = true; fq.par.vec_nonz = target_nonz; fq.par.mat_nonz = matr_samp; fq.par.target_norm = target_norm; fq.par.init_thresh_f = init_thresh;
+    fq.trial_in_det = tin_det; fq.trial_in_val = tin_val; fq.ini_det = iin_det; fq.ini_val = iin_val;
     if (lockstep) { fq.setup(); CHECK(same_bits(fq.p_doub, p_doub), "frimulti p_doub"); }
 
     double en_shift = 0, last_one_norm = 0;
@@ -2003,10 +2031,27 @@ static int run_fciqmc_fp(int argc, char **argv) {
     uint8_t (*sing_orbs)[2] = (uint8_t (*)[2])spawn_orbs_v.data();
     uint8_t (*doub_orbs)[4] = (uint8_t (*)[4])spawn_orbs_v.data();
     size_t n_ex = (size_t)n_orb * n_orb * n_elec_unf * n_elec_unf;
-    DistVec<double> trial_vec(4, 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
-    DistVec<double> htrial_vec(2 * n_ex, 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
+    // --trial_vec (fciqmc_fp_mol.cpp:157-185): the reference's own text reader, through the solution vector's arrays, `while (!add) perform_add`
+    const char *trial_prefix = getenv("FRIES_TRIAL");
+    size_t n_trial = 1;
+    std::vector<fo::det_t> tin_det; std::vector<double> tin_val;
+    if (trial_prefix) {
+        n_trial = load_vec_txt(std::string(trial_prefix), sol_vec.indices(), sol_vec.values());
+        for (size_t i = 0; i < n_trial; i++) { tin_det.push_back(to_u64(sol_vec.indices()[i], det_size)); tin_val.push_back(sol_vec.values()[i]); }
+    }
+    DistVec<double> trial_vec(trial_prefix ? n_trial : 4, trial_prefix ? n_trial : 4, n_orb * 2, n_elec_unf, n_procs, proc_scrambler, vec_scrambler);
+    DistVec<double> htrial_vec(trial_prefix ? n_trial * n_ex / n_procs : 2 * n_ex, trial_prefix ? n_trial * n_ex / n_procs : 2 * n_ex, n_orb * 2, n_elec_unf, n_procs, diag_shortcut, 2, proc_scrambler, vec_scrambler);
     unsigned hf_proc = sol_vec.idx_to_proc(hf_det);
-    if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
+    if (trial_prefix) {
+        Matrix<uint8_t> &load_dets = sol_vec.indices();
+        double *load_vals = sol_vec.values();
+        for (size_t i = 0; i < n_trial; i++) {
+            while (!trial_vec.add(load_dets[i], load_vals[i], 1)) trial_vec.perform_add(0);
+            while (!htrial_vec.add(load_dets[i], load_vals[i], 1)) htrial_vec.perform_add(0);
+        }
+        memset(sol_vec.values(), 0, (n_trial + 1) * sizeof(double));
+    }
+    else if ((int)hf_proc == proc_rank) { trial_vec.add(hf_det, 1, 1); htrial_vec.add(hf_det, 1, 1); }
     trial_vec.perform_add(0); htrial_vec.perform_add(0);
     trial_vec.collect_procs();
     std::vector<uintmax_t> trial_hashes(trial_vec.curr_size());
@@ -2022,7 +2067,17 @@ static int run_fciqmc_fp(int argc, char **argv) {
     size_t n_hf_doub = doub_ex_symm(hf_det, tmp_orbs, n_elec_unf, n_orb, doub_orbs, symm);
     size_t n_hf_sing = count_singex(hf_det, tmp_orbs, n_elec_unf, &symm_basis);
     double p_doub = (double)n_hf_doub / (n_hf_sing + n_hf_doub);
-    if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
+    std::vector<fo::det_t> iin_det; std::vector<double> iin_val;
+    if (getenv("FRIES_INI")) {       // --ini_vec (fciqmc_fp_mol.cpp:233-246): real values, `while (!add) perform_add`
+        Matrix<uint8_t> &load_dets = sol_vec.indices();
+        double *load_vals = sol_vec.values();
+        size_t n_dets = load_vec_txt(std::string(getenv("FRIES_INI")), load_dets, load_vals);
+        std::vector<std::vector<uint8_t>> keep_d(n_dets, std::vector<uint8_t>(det_size)); std::vector<double> keep_v(n_dets);
+        for (size_t i = 0; i < n_dets; i++) { memcpy(keep_d[i].data(), load_dets[i], det_size); keep_v[i] = load_vals[i]; iin_det.push_back(to_u64(load_dets[i], det_size)); iin_val.push_back(load_vals[i]); }
+        memset(load_vals, 0, (n_dets + 1) * sizeof(double));       // the reference adds straight out of the vector's own arrays; keep the harness well defined
+        for (size_t i = 0; i < n_dets; i++) while (!sol_vec.add(keep_d[i].data(), keep_v[i], 1)) sol_vec.perform_add(0);
+    }
+    else if ((int)hf_proc == proc_rank) sol_vec.add(hf_det, 100, 1);
     sol_vec.perform_add(0);
     double en_shift = 0, last_norm = 0, glob_norm = 0;
     const bool lockstep = n_procs == 1;
@@ -2034,6 +2089,7 @@ static int run_fciqmc_fp(int argc, char **argv) {
     fq.sys.symm.init(symm, n_orb);
     fq.par.eps = eps; fq.par.target_walkers = target_walkers; fq.par.init_thresh = init_thresh; fq.par.max_dets = max_n_dets; fq.par.seed = seed; fq.par.counter_rng = false;
     fq.par.heat_bath = heat_bath; fq.par.fp = true;
+    fq.trial_in_det = tin_det; fq.trial_in_val = tin_val; fq.ini_det = iin_det; fq.ini_val = iin_val;
     if (lockstep) { fq.setup(); CHECK(same_bits(fq.p_doub, p_doub), "fciqmc_fp p_doub"); }
 
     std::string out_name(argv[10]);

@@ -417,6 +417,26 @@ FQLOG_DTYPE = np.dtype([("numer", "f8"), ("denom", "f8"), ("shift", "f8"), ("nor
                         ("n_spawn", "u4")], align=True)
 
 
+def _fq_create_vecs(lib, mol, epsilon, target_walkers, initiator, max_dets, seed, flags, vec_nonz, mat_nonz, initiator_f, target_norm, trial, ini, truncate_ini):
+    """fo_fq_create_vecs: fo::Fciqmc in any of its three modes with --trial_vec / --ini_vec; truncate_ini: fciqmc_mol's reader fills an int array."""
+    lib.fo_fq_create_vecs.restype = C.c_void_p
+    lib.fo_fq_create_vecs.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+    irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
+    hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
+    er = np.ascontiguousarray(mol.eris, dtype=np.float64)
+    td, tv = (np.ascontiguousarray(trial[0], dtype=np.uint64), np.ascontiguousarray(trial[1], dtype=np.float64)) if trial is not None else (np.zeros(1, np.uint64), np.zeros(1))
+    idd, iv = (np.ascontiguousarray(ini[0], dtype=np.uint64), np.ascontiguousarray(ini[1], dtype=np.float64)) if ini is not None else (np.zeros(1, np.uint64), np.zeros(1))
+    if truncate_ini:
+        iv = np.trunc(iv)
+    h = lib.fo_fq_create_vecs(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, flags, vec_nonz, mat_nonz, initiator_f, target_norm,
+                              _p(td), _p(tv), td.size if trial is not None else 0, _p(idd), _p(iv), idd.size if ini is not None else 0)
+    if not h:
+        lib.fo_last_error.restype = C.c_char_p
+        raise RuntimeError(lib.fo_last_error().decode())
+    return h
+
+
 class OracleFciqmc:
     """fo::Fciqmc -- CPU restatement of fciqmc_mol (near-uniform generator, one rank).  counter_rng=False consumes the
     reference's sequential mt19937 stream (pinned against the reference loop); counter_rng=True uses the counter-based
@@ -434,10 +454,7 @@ class OracleFciqmc:
         if trial is None and ini is None:
             self.h = self.lib.fo_fciqmc_create(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, flags)
         else:
-            td, tv = (np.ascontiguousarray(trial[0], dtype=np.uint64), np.ascontiguousarray(trial[1], dtype=np.float64)) if trial is not None else (np.zeros(1, np.uint64), np.zeros(1))
-            idd, iv = (np.ascontiguousarray(ini[0], dtype=np.uint64), np.ascontiguousarray(ini[1], dtype=np.int32)) if ini is not None else (np.zeros(1, np.uint64), np.zeros(1, np.int32))
-            self.h = self.lib.fo_fciqmc_create_ex(mol.n_orb, mol.n_elec, _p(irr), _p(hc), _p(er), epsilon, target_walkers, initiator, max_dets, seed, flags,
-                                                  _p(td), _p(tv), td.size if trial is not None else 0, _p(idd), _p(iv), idd.size if ini is not None else 0)
+            self.h = _fq_create_vecs(self.lib, mol, epsilon, target_walkers, initiator, max_dets, seed, flags, 0, 0, 0.0, 0.0, trial, ini, truncate_ini=not fp)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -472,8 +489,13 @@ class OracleMulti(OracleFciqmc):
     """fo::Fciqmc in its frimulti_mol mode (FRIES_bin/frimulti_mol.cpp, --distribution HB): counter_rng=False is the reference's mt19937
     stream (pinned against the reference loop), counter_rng=True the counter-based stream the GPU replays."""
 
-    def __init__(self, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, initiator=0.0, target_norm=0.0, seed=0, counter_rng=False):
+    def __init__(self, mol, *, epsilon, vec_nonz, mat_nonz, max_dets, initiator=0.0, target_norm=0.0, seed=0, counter_rng=False, trial=None, ini=None):
         self.lib = load()
+        self.lib.fo_frimulti_nkept.restype = C.c_uint32
+        self.lib.fo_frimulti_nkept.argtypes = [C.c_void_p]
+        if trial is not None or ini is not None:
+            self.h = _fq_create_vecs(self.lib, mol, epsilon, 0, 0, max_dets, seed, int(counter_rng) | 8, vec_nonz, mat_nonz, float(initiator), float(target_norm), trial, ini, truncate_ini=False)
+            return
         irr = np.ascontiguousarray(mol.irreps, dtype=np.uint8)
         hc = np.ascontiguousarray(mol.h_core, dtype=np.float64)
         er = np.ascontiguousarray(mol.eris, dtype=np.float64)

@@ -437,8 +437,11 @@ def test_oracle_frimulti_matches_reference(oracle, name):
     r = golden_io.manifest()["multi_runs"][name]
     rows = golden_io.read_multi_traj(name)
     mol = fcidump.synthetic(r["shape"])
+    kw = {}
+    if "ini" in r:          # --ini_vec (frimulti_mol.cpp:205-215): real values through the reference's text reader
+        kw["ini"] = golden_io.read_text_vector(r["ini"])
     orc = oracle.OracleMulti(mol, epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], initiator=r["initiator"],
-                             target_norm=r["target_norm"], seed=r["seed"])
+                             target_norm=r["target_norm"], seed=r["seed"], **kw)
     for row in rows:
         lg = orc.iterate(1)[0]
         for f in ("numer", "denom", "norm", "shift"):
@@ -448,6 +451,15 @@ def test_oracle_frimulti_matches_reference(oracle, name):
         assert orc.nkept == row["nkept"]
     d, v = orc.vector()
     assert golden_io.vec_hash(d, v) == rows[-1]["hash"]
+
+
+def test_oracle_frimulti_refuses_a_trial_vector_like_the_reference(oracle):
+    """frimulti_mol --trial_vec on one rank: trial_vec's Adder holds n_trial entries, add() reports the entry that fills it, and this driver throws on that
+    report (frimulti_mol.cpp:149-157) where fciqmc_mol flushes -- every trial file is refused.  The reference run that recorded the message: gen_golden.py."""
+    r = golden_io.manifest()["multi_trial_one_rank_error"]
+    mol = fcidump.synthetic(r["shape"])
+    with pytest.raises(RuntimeError, match=r["error"]):
+        oracle.OracleMulti(mol, epsilon=0.01, vec_nonz=5000, mat_nonz=20000, max_dets=200000, initiator=1.0, target_norm=2500.0, seed=3, trial=golden_io.read_text_vector(r["trial"]))
 
 
 @pytest.mark.parametrize("name", sorted(golden_io.manifest().get("multi_mpi_runs", {})))

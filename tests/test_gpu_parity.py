@@ -741,6 +741,10 @@ def test_fciqmc_fp_matches_oracle_counter_stream(oracle, name, tmp_path):
     mol = fcidump.synthetic(r["shape"])
     par = dict(epsilon=r["epsilon"], target_walkers=r["target_walkers"], max_dets=r["max_dets"], initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"], fp=True)
     n_it = r["n_iter"]
+    if "trial" in r:        # --trial_vec / --ini_vec (fciqmc_fp_mol.cpp:157-185, 233-246)
+        par["trial"] = golden_io.read_text_vector(r["trial"])
+    if "ini" in r:
+        par["ini"] = golden_io.read_text_vector(r["ini"])
     orc = oracle.OracleFciqmc(mol, counter_rng=True, **par)
     eng = FriEngine(mol)
     eng.setup_fciqmc(**par)
@@ -758,7 +762,7 @@ def test_fciqmc_fp_matches_oracle_counter_stream(oracle, name, tmp_path):
     assert np.array_equal(gd[nz], od[nz])
     assert int(lo["n_nonz"][-1]) > 30 and np.any(ov != np.round(ov))          # the walkers spread, and some are not integers
     eng.close()
-    if name != "fciqmc_fp_ne":
+    if name not in ("fciqmc_fp_ne", "fciqmc_fp_n2_trial_ini"):
         return
     import subprocess
     from fries_amd import build
@@ -766,9 +770,10 @@ def test_fciqmc_fp_matches_oracle_counter_stream(oracle, name, tmp_path):
     fcidump.write_fcidump(fc, mol)
     out = str(tmp_path / "out") + "/"
     os.makedirs(out)
+    vec_flags = (["--trial_vec", os.path.join(golden_io.GOLD, r["trial"])] if "trial" in r else []) + (["--ini_vec", os.path.join(golden_io.GOLD, r["ini"])] if "ini" in r else [])
     res = subprocess.run([build.DRIVERS["fciqmc_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", r["distribution"], "--target", str(r["target_walkers"]),
                           "--max_dets", str(r["max_dets"]), "--epsilon", repr(r["epsilon"]), "--initiator", str(r["initiator"]), "--max_iter", str(n_it), "--result_dir", out,
-                          "--seed", str(r["seed"]), "--fp", "1"], capture_output=True, text=True, timeout=300)
+                          "--seed", str(r["seed"]), "--fp", "1"] + vec_flags, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "Exception" not in res.stderr, res.stderr[-2000:]
     num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nini = np.loadtxt(out + "nini.txt")
     assert np.array_equal(den, lo["denom"]) and np.all(np.abs(num - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
@@ -776,7 +781,7 @@ def test_fciqmc_fp_matches_oracle_counter_stream(oracle, name, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,n_it", [("multi_ne_m1000", 60), ("multi_n2_m5000_ini0", 40)])
+@pytest.mark.parametrize("name,n_it", [("multi_ne_m1000", 60), ("multi_n2_m5000_ini0", 40), ("multi_n2_ini", 40)])
 def test_frimulti_matches_oracle_counter_stream(oracle, name, n_it):
     """frimulti_mol (multinomial matrix compression) on the device against the CPU restatement, both on the counter-based uniform stream,
     in the configurations whose mt19937 runs are pinned against the reference loop (tests/golden/multi_*.traj, CPU suite): samples per
@@ -785,6 +790,8 @@ def test_frimulti_matches_oracle_counter_stream(oracle, name, n_it):
     r = golden_io.manifest()["multi_runs"][name]
     mol = fcidump.synthetic(r["shape"])
     par = dict(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=r["max_dets"], initiator=r["initiator"], target_norm=r["target_norm"], seed=r["seed"])
+    if "ini" in r:          # --ini_vec (frimulti_mol.cpp:205-215)
+        par["ini"] = golden_io.read_text_vector(r["ini"])
     orc = oracle.OracleMulti(mol, counter_rng=True, **par)
     eng = FriEngine(mol)
     eng.setup_multi(**par)
@@ -820,6 +827,27 @@ def test_frimulti_matches_oracle_counter_stream(oracle, name, n_it):
         num = np.loadtxt(out + "projnum.txt"); den = np.loadtxt(out + "projden.txt"); nm = np.loadtxt(out + "norm.txt"); nini = np.loadtxt(out + "nini.txt")
         assert np.array_equal(den, lo["denom"]) and np.all(np.abs(num - lo["numer"]) <= 1e-10 * np.maximum(1.0, np.abs(lo["numer"])))
         assert np.array_equal(nm, lo["norm"][9::10]) and np.array_equal(nini.astype(np.int64), lo["n_ini"].astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_frimulti_refuses_a_trial_vector_like_the_reference(tmp_path):
+    """frimulti_mol --trial_vec: the reference throws "Insufficient memory allocated in adder" for every trial file on one rank (frimulti_mol.cpp:149-157; the
+    run that recorded it: oracle/gen_golden.py, manifest key multi_trial_one_rank_error).  The engine and the command-line driver end the same way."""
+    import subprocess
+    from fries_amd import build
+    from fries_amd.engine import FriEngine
+    r = golden_io.manifest()["multi_trial_one_rank_error"]
+    mol = fcidump.synthetic(r["shape"])
+    eng = FriEngine(mol)
+    with pytest.raises(RuntimeError, match=r["error"]):
+        eng.setup_multi(epsilon=0.01, vec_nonz=5000, mat_nonz=20000, max_dets=200000, initiator=1.0, target_norm=2500.0, seed=3, trial=golden_io.read_text_vector(r["trial"]))
+    eng.close()
+    fc = str(tmp_path / "mol.FCIDUMP")
+    fcidump.write_fcidump(fc, mol)
+    res = subprocess.run([build.DRIVERS["frimulti_mol_hip"], "--fcidump_path", fc, "--point_group", mol.point_group, "--distribution", "HB", "--vec_nonz", "5000", "--mat_nonz", "20000",
+                          "--max_dets", "200000", "--epsilon", "0.01", "--max_iter", "2", "--result_dir", str(tmp_path) + "/", "--seed", "3",
+                          "--trial_vec", os.path.join(golden_io.GOLD, r["trial"])], capture_output=True, text=True, timeout=120)
+    assert r["error"] in res.stderr
 
 
 @pytest.mark.gpu
