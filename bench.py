@@ -43,6 +43,9 @@ ALG_BYTES = {
 }
 
 
+STARTUP = {}      # the filler run from the Hartree-Fock determinant up to m determinants: the start-up ("collapse") regime, outside the timed region
+
+
 def build_state(mol, m_glob, max_dets, seed, device, comm, dist):
     """Filler run (initiator 0) -> this rank's shard of a vector with ~m_glob determinants at norm ~ m_glob."""
     from fries_amd.engine import FriEngine
@@ -57,10 +60,15 @@ def build_state(mol, m_glob, max_dets, seed, device, comm, dist):
         dist.all_reduce(t)
         return float(t.item())
 
+    t0 = time.perf_counter()
+    n_fill = 0
     for _ in range(200):
         lg = eng.iterate(5)
+        n_fill += 5
         if glob(lg["n_nonz"][-1]) >= m_glob:
             break
+    # (iterate() returns after the device has finished: each call reads its log back)
+    STARTUP.update(iterations=n_fill, seconds=time.perf_counter() - t0)
     eng.iterate(10)
     dets, vals = eng.vector()
     eng.close()
@@ -211,6 +219,9 @@ def run_workload(args, shape, m_glob, world, rank, device, dist, steps, warmup, 
     }
     if comm is not None:
         result["collectives_per_iter"] = n_coll / max(1, steps)
+    if STARTUP:
+        result["startup"] = {"iterations": STARTUP["iterations"], "ms_per_iter": 1e3 * STARTUP["seconds"] / max(1, STARTUP["iterations"]),
+                             "note": "filler run from the HF determinant to m determinants (initiator 0), find_keep_sub in the reference's own order where its running norm collapses (DESIGN.md section 2); not part of `value`"}
     if not primary:
         eng.close()
         return result if rank == 0 else None
