@@ -178,6 +178,7 @@ struct FriesCtx {
     FksSq fsq{};                             // ... its parallel form: work arrays, knobs, statistics
     bool fsq_walk_only = false;              // FRIES_FKS_SEQ_WALK=1: the one-wave walk for every sweep
     int fsq_guess_rounds = 24, fsq_exact_rounds = 6;
+    bool fsq_use_maps = true, fsq_check = false;   // the chain as integer arithmetic inside a binade (FRIES_FSQ_MAPS=0: element by element); FRIES_FSQ_CHECK=1: both, compared
     int fsq_sparse_max = 32;                 // k_fsq_chain: a tile with at most this many touched element pairs (of 128) is walked pair by pair
     uint64_t n_fsq_guess = 0, n_fsq_exact = 0, n_fsq_chain_tiles = 0, n_fsq_walk = 0, n_fsq_walk_tiles = 0;
     FksHost *h_fks = nullptr;                // host side of Fks2Work::hm

@@ -525,13 +525,19 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     if (h->c.stg_mem) { hipFree(h->c.stg_mem); hipFree(h->c.spill_mem); hipFree(h->c.spill_cnt_mem); hipFree(h->c.tile_dirty_mem); }
     {
         FriesCtx &c = h->c;
-        if (c.dbg >= 1 && c.n_fks_sequential)
-            fprintf(stderr, "[fries] find_keep_sub in the reference's order: %llu stages; %llu guess rounds, %llu exact rounds over %llu tiles, %llu walks over %llu tiles\n",
+        if (c.dbg >= 1 && c.n_fks_sequential) {
+            FksSqCtl hc{};
+            hipMemcpy(&hc, c.fsq.ctl, sizeof(hc), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[fries] find_keep_sub in the reference's order: %llu stages; %llu guess rounds, %llu exact rounds over %llu tiles (touched tiles taken as one integer step: %llu, element by element: %llu), %llu walks over %llu tiles\n",
                     (unsigned long long)c.n_fks_sequential, (unsigned long long)c.n_fsq_guess, (unsigned long long)c.n_fsq_exact, (unsigned long long)c.n_fsq_chain_tiles,
-                    (unsigned long long)c.n_fsq_walk, (unsigned long long)c.n_fsq_walk_tiles);
+                    hc.n_fast, hc.n_dense, (unsigned long long)c.n_fsq_walk, (unsigned long long)c.n_fsq_walk_tiles);
+        }
         FksSq &SQ = c.fsq;
         hipFree(SQ.dl); hipFree(SQ.nwr); hipFree(SQ.nkp); hipFree(SQ.gb); hipFree(SQ.lb); hipFree(SQ.dgb); hipFree(SQ.kb); hipFree(SQ.dk);
-        hipFree(SQ.tk); hipFree(SQ.tkx); hipFree(SQ.tg); hipFree(SQ.tgx); hipFree(SQ.tany); hipFree(SQ.ctl);
+        hipFree(SQ.tk); hipFree(SQ.tkx); hipFree(SQ.tg); hipFree(SQ.tgx); hipFree(SQ.tany);
+        hipFree(SQ.mG); hipFree(SQ.mL); hipFree(SQ.sabs); hipFree(SQ.gt); hipFree(SQ.lt); hipFree(SQ.eG); hipFree(SQ.eL); hipFree(SQ.mflag); hipFree(SQ.fast);
+        if (SQ.gb2) { hipFree(SQ.gb2); hipFree(SQ.lb2); }
+        hipFree(SQ.ctl);
     }
     {   // the find_keep_sub replay's arrays (allocated with the work arrays: hbpp.hip)
         Fks2Work &F = h->c.F2;

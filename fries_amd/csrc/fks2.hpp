@@ -882,12 +882,17 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_
 // work arrays of the parallel form of the in-order sweep (fks_seq.hpp)
 #define FR_SQ_TILE 256u             // elements per workgroup of k_fsq_spec = 32 blocks of 8
 #define FR_SQ_INF 0xFFFFFFFFu
-struct FksSqCtl { uint32_t first_changed; uint32_t K_tot; double G_end, L_end; };
+struct FksSqCtl { uint32_t first_changed; uint32_t K_tot; double G_end, L_end; uint32_t n_mismatch; uint32_t pad; unsigned long long n_fast, n_dense; };
 struct FksSq {
     double *dl, *nwr; uint32_t *nkp;            // per element: change of this sweep, wt_remain and keep after it
     double *gb, *lb, *dgb; uint32_t *kb, *dk;   // per block of 8: norm (global, local) and count entering it; change and count of the block
     uint32_t *tk, *tkx; double *tg, *tgx;       // per tile: count and change, their exclusive prefixes (tgx: norm entering the tile, approximate)
     uint8_t *tany;                              // per tile: the sweep touches an element of it
+    // the chain as integer arithmetic (k_fsq_maps): per tile and chain (G: global norm, L: local norm) the binade the tile is assumed to be entered in, the
+    // tile's total decrement in units of that binade's ulp, the sum of |change| (bounds the excursion), usable flag; what the chain found: exact entry
+    // norms per tile, and whether the tile went through as one integer step
+    double *mG, *mL, *sabs, *gt, *lt; int32_t *eG, *eL; uint8_t *mflag, *fast;
+    double *gb2, *lb2;                          // FRIES_FSQ_CHECK: the element-by-element chain's entries, compared with the integer form's
     FksSqCtl *ctl;
 };
 

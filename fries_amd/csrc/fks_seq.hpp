@@ -183,7 +183,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fsq_init(CompWork W, const 
     const bool live = e < n_in;
     SQ.dl[e] = 0.0; SQ.nwr[e] = live ? W.wt_remain[e] : 0.0; SQ.nkp[e] = live ? W.keep[e] : 0u;
     if ((threadIdx.x & 7) == 0) { const size_t b = e >> 3; SQ.gb[b] = Q->G; SQ.lb[b] = Q->L; SQ.kb[b] = 0u; SQ.dk[b] = 0u; SQ.dgb[b] = 0.0; }
-    if (threadIdx.x == 0) { SQ.tk[blockIdx.x] = 0u; SQ.tg[blockIdx.x] = 0.0; SQ.tany[blockIdx.x] = 0; }
+    if (threadIdx.x == 0) { SQ.tk[blockIdx.x] = 0u; SQ.tg[blockIdx.x] = 0.0; SQ.tany[blockIdx.x] = 0; SQ.tgx[blockIdx.x] = Q->G; SQ.mflag[blockIdx.x] = 0; SQ.fast[blockIdx.x] = 0; }
     if (e == 0) { SQ.ctl->first_changed = FR_SQ_INF; SQ.ctl->K_tot = 0u; SQ.ctl->G_end = Q->G; SQ.ctl->L_end = Q->L; }
 }
 
@@ -307,69 +307,206 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fsq_expand(FksSq SQ, uint32
     if (approx) SQ.gb[b] = SQ.tgx[t] - (ig - g);
 }
 
-// The reference's running norms (compress_utils.cpp:190-192, 246-247: glob_one_norm -= change, loc_one_norm -= change per touched element,
-// in storage order), given the changes: one wave.  Lanes 0-31 carry the global norm, lanes 32-63 the local one, so one dependent
-// v_add_f64 per element advances both; the changes of a tile reach every lane as LDS broadcast reads (16 bytes = two elements each), the
-// next tile's are in flight meanwhile.  Lane j (and 32 + j) keeps the value block j of the tile is entered with.
-static __global__ void __launch_bounds__(64) k_fsq_chain(const FksSeq *Q, const double *__restrict__ dl, const uint8_t *__restrict__ tany,
-                                                         double *__restrict__ gb, double *__restrict__ lb, FksSqCtl *__restrict__ ctl,
-                                                         uint32_t from_tile, uint32_t n_tiles, int sparse_max) {
+// ---- the chain.  The reference's running norms (compress_utils.cpp:190-192, 246-247: glob_one_norm -= change, loc_one_norm -= change per touched
+// element, in storage order) are one dependent subtraction per element: 8.5 cycles each on one lane, 3.5 ms per million, however it is fed.  But while the
+// norm X stays inside one binade [2^e, 2^(e+1)) every value it takes is an integer multiple of u = 2^(e-52), and fl(X - d) = X - D u with
+// D = d / u rounded to the nearest integer (the remainder decides; an exact half is a tie, settled by the parity of X / u -- rare, and left to the walk).
+// So for a tile that is entered and left in the same binade the chain is X <- X - (sum of D) u: the D of its 256 elements and their sum are formed by all
+// lanes of a workgroup BEFORE the chain (k_fsq_maps<0>, with the binade read off the tree-summed norm the guesses already use), the one-wave chain
+// (k_fsq_chain) checks with the EXACT norm that the assumption holds -- same exponent, and the sum of |change| plus rounding slop keeps every intermediate
+// value inside the binade -- and takes the tile in one multiply-subtract; k_fsq_maps<1> then expands the entries of the tile's 32 blocks from the exact
+// tile entry.  A tile that fails the check -- the norm crosses a power of two inside it, a tie, a norm gone to zero or below (the last tiles of a
+// collapsing sweep) -- is walked element by element as before.  Nothing rests on the approximation: it only proposes the binade.
+__device__ __forceinline__ double fr_pow2(int n) { return __longlong_as_double((long long)(n + 1023) << 52); }      // -1022 <= n <= 1023
+__device__ __forceinline__ int fr_expo(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff) - 1023; }  // x > 0, normal
+// d in units of u (inv_u = 1 / u, a power of two): false if the remainder is an exact half or the quotient is out of range
+__device__ __forceinline__ bool fr_fsq_units(double d, double inv_u, double *D) {
+    const double t = d * inv_u;
+    if (!(fabs(t) < 9007199254740992.0)) return false;
+    const double q = floor(t), r = t - q;
+    if (r == 0.5) return false;
+    *D = q + (r > 0.5 ? 1.0 : 0.0);
+    return true;
+}
+__device__ __forceinline__ bool fr_fsq_expo_ok(double x, int *e) {
+    if (!(x > 0.0) || !(x < INFINITY)) return false;
+    const int k = fr_expo(x);
+    if (k < -900 || k > 900) return false;
+    *e = k;
+    return true;
+}
+// every value X - (partial sums of the changes) of a tile entered with X stays in [2^e, 2^(e+1)), rounding included
+__device__ __forceinline__ bool fr_fsq_clean(double X, int e, double sabs) {
+    if (!(X > 0.0) || !(X < INFINITY) || fr_expo(X) != e) return false;
+    const double p = fr_pow2(e), u = fr_pow2(e - 52);
+    const double B = sabs * (1.0 + 1e-9) + 600.0 * u;          // 256 roundings of at most u / 2 each, the tree sum's own error, slack
+    return X - B >= p && X + B < 2.0 * p;
+}
+
+// MODE 0: the tiles' integer decrements under the binade their approximate entry norm lies in.  MODE 1 (after the chain): entries of the blocks of the
+// tiles the chain took in one step, and of the tiles the sweep does not touch
+template <int MODE>
+__global__ void __launch_bounds__(FR_BLOCK) k_fsq_maps(const FksSeq *Q, FksSq SQ, uint32_t from_tile) {
+    __shared__ double sh_a[4], sh_b[4], sh_c[4]; __shared__ uint32_t sh_bad[4];
+    __shared__ double sh_pg[32], sh_pl[32];
+    if (!Q->go) return;
+    const unsigned tile = from_tile + blockIdx.x;
+    const size_t e = (size_t)tile * FR_SQ_TILE + threadIdx.x;
+    const int lane = fr_lane(), f = lane & 7, wv = threadIdx.x >> 6;
+    const bool any = SQ.tany[tile] != 0;
+    if (MODE == 1) {
+        const bool fast = SQ.fast[tile] != 0;
+        if (any && !fast) return;                       // walked by the chain, which left its entries
+        if (!any) { if (threadIdx.x < 32) { SQ.gb[(size_t)tile * 32 + threadIdx.x] = SQ.gt[tile]; SQ.lb[(size_t)tile * 32 + threadIdx.x] = SQ.lt[tile]; } return; }
+    }
+    else if (!any) { if (threadIdx.x == 0) SQ.mflag[tile] = 0; return; }
+    const double d = SQ.dl[e];
+    int eg = 0, el = 0;
+    bool ok;
+    if (MODE == 0) {
+        const double ga = SQ.tgx[tile], la = ga - (Q->G - Q->L);
+        ok = fr_fsq_expo_ok(ga, &eg) && fr_fsq_expo_ok(la, &el);
+    }
+    else { eg = SQ.eG[tile]; el = SQ.eL[tile]; ok = true; }
+    double DG = 0.0, DL = 0.0;
+    bool mine = ok && fr_fsq_units(d, fr_pow2(52 - eg), &DG) && fr_fsq_units(d, fr_pow2(52 - el), &DL);
+    if (MODE == 0) {
+        double a = DG, bsum = DL, c = fabs(d);
+        for (int o = 32; o >= 1; o >>= 1) { a += __shfl_down(a, o); bsum += __shfl_down(bsum, o); c += __shfl_down(c, o); }       // integers below 2^53 (or the tile is refused): exact in any order
+        const unsigned long long bad = __ballot(!mine);
+        if (lane == 0) { sh_a[wv] = a; sh_b[wv] = bsum; sh_c[wv] = c; sh_bad[wv] = bad ? 1u : 0u; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double mg = (sh_a[0] + sh_a[1]) + (sh_a[2] + sh_a[3]), ml = (sh_b[0] + sh_b[1]) + (sh_b[2] + sh_b[3]);
+            const bool good = !(sh_bad[0] | sh_bad[1] | sh_bad[2] | sh_bad[3]) && mg < 9007199254740992.0 && ml < 9007199254740992.0 && mg > -4503599627370496.0 && ml > -4503599627370496.0;
+            SQ.mG[tile] = mg; SQ.mL[tile] = ml; SQ.sabs[tile] = (sh_c[0] + sh_c[1]) + (sh_c[2] + sh_c[3]); SQ.eG[tile] = eg; SQ.eL[tile] = el; SQ.mflag[tile] = good ? 1 : 0;
+        }
+    }
+    else {
+        // (mine holds for every lane: the same arithmetic on the same numbers as in MODE 0, which accepted the tile)
+        const double bg = fr_grp8_sum(DG), bl = fr_grp8_sum(DL);
+        if (f == 0) { sh_pg[threadIdx.x >> 3] = bg; sh_pl[threadIdx.x >> 3] = bl; }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double pg = 0.0, pl = 0.0;
+            for (unsigned q = 0; q < threadIdx.x; q++) { pg += sh_pg[q]; pl += sh_pl[q]; }
+            SQ.gb[(size_t)tile * 32 + threadIdx.x] = SQ.gt[tile] - pg * fr_pow2(eg - 52);
+            SQ.lb[(size_t)tile * 32 + threadIdx.x] = SQ.lt[tile] - pl * fr_pow2(el - 52);
+        }
+    }
+}
+
+// one wave: the tiles in order.  use_maps = 0: every touched tile element by element (the fallback's and the check's form)
+static __global__ void __launch_bounds__(64) k_fsq_chain(const FksSeq *Q, FksSq SQ, double *gb, double *lb, uint32_t from_tile, uint32_t n_tiles, int sparse_max, int use_maps) {
     __shared__ double2 sh[FR_SQ_TILE / 2];
     if (!Q->go) return;
     const int lane = fr_lane(), j = lane & 31;
     const bool is_loc = lane >= 32;
-    double X;
-    if (from_tile == 0) X = is_loc ? Q->L : Q->G; else X = is_loc ? lb[(size_t)from_tile * 32] : gb[(size_t)from_tile * 32];
+    double XG, XL;                                       // the same value in every lane
+    if (from_tile == 0) { XG = Q->G; XL = Q->L; } else { XG = SQ.gt[from_tile]; XL = SQ.lt[from_tile]; }
     double *const out = is_loc ? lb : gb;
-    double2 n0 = make_double2(0, 0), n1 = n0; uint32_t n_any = 0;
-    auto issue = [&](uint32_t t) {
-        if (t < n_tiles) { const double2 *p = (const double2 *)(dl + (size_t)t * FR_SQ_TILE); n0 = p[lane]; n1 = p[64 + lane]; n_any = tany[t]; }
-        else n_any = 0;
-    };
-    issue(from_tile);
-    for (uint32_t t = from_tile; t < n_tiles; t++) {
-        const double2 c0 = n0, c1 = n1;
-        const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_any);
-        issue(t + 1);
-        double C = X;
-        unsigned long long m0 = 0, m1 = 0;
-        if (any) { m0 = __ballot(c0.x != 0.0 || c0.y != 0.0); m1 = __ballot(c1.x != 0.0 || c1.y != 0.0); }
-        if (any && __popcll(m0) + __popcll(m1) <= sparse_max) {
-            // few touched elements (the later sweeps of a stage): only the pairs that hold one, in order; lane i of c0 holds elements
-            // 2i, 2i + 1 of the tile (block i / 4), lane i of c1 elements 128 + 2i, 129 + 2i (block 16 + i / 4)
-            for (int h = 0; h < 2; h++) {
-                unsigned long long m = h ? m1 : m0;
-                const double2 src = h ? c1 : c0;
-                while (m) {
-                    const int i = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    X -= fr_bcast_f64(src.x, i); X -= fr_bcast_f64(src.y, i);
-                    if (j > (i >> 2) + 16 * h) C = X;          // the blocks behind this pair are entered with the new value
+    unsigned long long n_fast = 0, n_dense = 0;
+    for (uint32_t base = from_tile; base < n_tiles; base += 64) {
+        const uint32_t tl = base + lane;
+        const bool on = tl < n_tiles;
+        const uint32_t a_any = on ? SQ.tany[tl] : 0u, a_flag = (on && use_maps) ? SQ.mflag[tl] : 0u;
+        const double a_mG = (on && use_maps) ? SQ.mG[tl] : 0.0, a_mL = (on && use_maps) ? SQ.mL[tl] : 0.0, a_sabs = (on && use_maps) ? SQ.sabs[tl] : 0.0;
+        const int a_eG = (on && use_maps) ? SQ.eG[tl] : 0, a_eL = (on && use_maps) ? SQ.eL[tl] : 0;
+        double capG = 0.0, capL = 0.0; uint32_t a_fast = 0u;
+        const int cnt = n_tiles - base < 64u ? (int)(n_tiles - base) : 64;
+        // All 64 tiles at once when the touched ones share one binade per chain (most batches: the norm halves at 1/2, 3/4, 7/8 ... of the way):
+        // the entry of tile i is X - (decrements of the tiles before it) u, integers again, so a wave scan gives every lane its tile's entry and
+        // every lane makes its own check.  One tile that fails sends the batch through the tile-by-tile loop below.
+        {
+            const unsigned long long am = __ballot(a_any != 0u);
+            if (am) {
+                const int first = __ffsll((long long)am) - 1;
+                const int eg0 = __builtin_amdgcn_readlane(a_eG, first), el0 = __builtin_amdgcn_readlane(a_eL, first);
+                if (!__ballot(a_any != 0u && (a_flag == 0u || a_eG != eg0 || a_eL != el0))) {
+                    const double ug = fr_pow2(eg0 - 52), ul = fr_pow2(el0 - 52);
+                    double pg = a_any ? a_mG : 0.0, pl = a_any ? a_mL : 0.0;
+                    for (int o = 1; o < 64; o <<= 1) { const double x = __shfl_up(pg, o), y = __shfl_up(pl, o); if (lane >= o) { pg += x; pl += y; } }
+                    const double myG = XG - (pg - (a_any ? a_mG : 0.0)) * ug, myL = XL - (pl - (a_any ? a_mL : 0.0)) * ul;
+                    const bool bad = a_any != 0u && !(fr_fsq_clean(myG, eg0, a_sabs) && fr_fsq_clean(myL, el0, a_sabs));
+                    // (a prefix that is not exact -- sums beyond 2^53 -- gives a lane a wrong entry, but then a tile before it fails its own check)
+                    if (!__ballot(bad)) {
+                        if (on) { SQ.gt[tl] = myG; SQ.lt[tl] = myL; SQ.fast[tl] = a_any ? 1 : 0; }
+                        XG -= fr_bcast_f64(pg, 63) * ug; XL -= fr_bcast_f64(pl, 63) * ul;
+                        n_fast += (unsigned long long)__popcll(am);
+                        continue;
+                    }
                 }
             }
         }
-        else if (any) {
-            sh[lane] = c0; sh[64 + lane] = c1;              // one wave: its LDS accesses execute in program order
-            // the reads of two blocks ahead are issued before a block's eight subtractions
-            double2 r[3][4];
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) r[q][k] = sh[q * 4 + k];
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-                if (q + 2 < 32) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) r[(q + 2) % 3][k] = sh[(q + 2) * 4 + k];
+        for (int i = 0; i < cnt; i++) {
+            if (lane == i) { capG = XG; capL = XL; }
+            if (!__builtin_amdgcn_readlane((int)a_any, i)) continue;
+            if (__builtin_amdgcn_readlane((int)a_flag, i)) {
+                const int eg = __builtin_amdgcn_readlane(a_eG, i), el = __builtin_amdgcn_readlane(a_eL, i);
+                const double sab = fr_bcast_f64(a_sabs, i);
+                if (fr_fsq_clean(XG, eg, sab) && fr_fsq_clean(XL, el, sab)) {
+                    XG -= fr_bcast_f64(a_mG, i) * fr_pow2(eg - 52);
+                    XL -= fr_bcast_f64(a_mL, i) * fr_pow2(el - 52);
+                    if (lane == i) a_fast = 1u;
+                    n_fast++;
+                    continue;
                 }
-                if (j == q) C = X;
-                const double2 *a = r[q % 3];
-                X -= a[0].x; X -= a[0].y; X -= a[1].x; X -= a[1].y; X -= a[2].x; X -= a[2].y; X -= a[3].x; X -= a[3].y;
             }
+            // element by element: lanes 0-31 carry the global norm, lanes 32-63 the local one, so one dependent v_add_f64 per element advances
+            // both; the changes reach every lane as LDS broadcast reads (16 bytes = two elements each).  Lane j (and 32 + j) keeps the value block j
+            // of the tile is entered with.
+            n_dense++;
+            const uint32_t t = base + (uint32_t)i;
+            const double2 *p = (const double2 *)(SQ.dl + (size_t)t * FR_SQ_TILE);
+            const double2 c0 = p[lane], c1 = p[64 + lane];
+            double X = is_loc ? XL : XG;
+            double C = X;
+            const unsigned long long m0 = __ballot(c0.x != 0.0 || c0.y != 0.0), m1 = __ballot(c1.x != 0.0 || c1.y != 0.0);
+            if (__popcll(m0) + __popcll(m1) <= sparse_max) {
+                // few touched elements: only the pairs that hold one, in order; lane i of c0 holds elements 2i, 2i + 1 of the tile (block i / 4),
+                // lane i of c1 elements 128 + 2i, 129 + 2i (block 16 + i / 4)
+                for (int h = 0; h < 2; h++) {
+                    unsigned long long m = h ? m1 : m0;
+                    const double2 src = h ? c1 : c0;
+                    while (m) {
+                        const int k = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        X -= fr_bcast_f64(src.x, k); X -= fr_bcast_f64(src.y, k);
+                        if (j > (k >> 2) + 16 * h) C = X;          // the blocks behind this pair are entered with the new value
+                    }
+                }
+            }
+            else {
+                sh[lane] = c0; sh[64 + lane] = c1;              // one wave: its LDS accesses execute in program order
+                // the reads of two blocks ahead are issued before a block's eight subtractions
+                double2 r[3][4];
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) r[q][k] = sh[q * 4 + k];
+#pragma unroll
+                for (int q = 0; q < 32; q++) {
+                    if (q + 2 < 32) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) r[(q + 2) % 3][k] = sh[(q + 2) * 4 + k];
+                    }
+                    if (j == q) C = X;
+                    const double2 *a = r[q % 3];
+                    X -= a[0].x; X -= a[0].y; X -= a[1].x; X -= a[1].y; X -= a[2].x; X -= a[2].y; X -= a[3].x; X -= a[3].y;
+                }
+            }
+            out[(size_t)t * 32 + j] = C;
+            XG = fr_bcast_f64(X, 0); XL = fr_bcast_f64(X, 32);
         }
-        out[(size_t)t * 32 + j] = C;
+        if (on) { SQ.gt[tl] = capG; SQ.lt[tl] = capL; SQ.fast[tl] = (uint8_t)a_fast; }
     }
-    if (j == 0) { if (is_loc) ctl->L_end = X; else ctl->G_end = X; }
+    if (lane == 0) { SQ.ctl->G_end = XG; SQ.ctl->L_end = XL; atomicAdd(&SQ.ctl->n_fast, n_fast); atomicAdd(&SQ.ctl->n_dense, n_dense); }
+}
+// FRIES_FSQ_CHECK: the entries the integer form produced (gb, lb) against those of the element-by-element chain (gb2, lb2), bit for bit
+static __global__ void __launch_bounds__(FR_BLOCK) k_fsq_compare(FksSq SQ, uint32_t from_tile, uint32_t n_tiles) {
+    const size_t b = (size_t)from_tile * 32 + (size_t)blockIdx.x * FR_BLOCK + threadIdx.x;
+    if (b >= (size_t)n_tiles * 32) return;
+    if (__double_as_longlong(SQ.gb[b]) != __double_as_longlong(SQ.gb2[b]) || __double_as_longlong(SQ.lb[b]) != __double_as_longlong(SQ.lb2[b])) atomicAdd(&SQ.ctl->n_mismatch, 1u);
 }
 
 // stores the sweep: elements of the tiles before upto_tile; fin: the whole sweep was settled here (else the walk finishes it and leaves the scalars)

@@ -370,6 +370,12 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         SQ.gb = fr_alloc<double>(nb); SQ.lb = fr_alloc<double>(nb); SQ.dgb = fr_alloc<double>(nb); SQ.kb = fr_alloc<uint32_t>(nb); SQ.dk = fr_alloc<uint32_t>(nb);
         SQ.tk = fr_alloc<uint32_t>(nt); SQ.tkx = fr_alloc<uint32_t>(nt); SQ.tg = fr_alloc<double>(nt); SQ.tgx = fr_alloc<double>(nt); SQ.tany = fr_alloc<uint8_t>(nt);
         SQ.ctl = fr_alloc<FksSqCtl>(1);
+        FR_HIP(hipMemset(SQ.ctl, 0, sizeof(FksSqCtl)));
+        SQ.mG = fr_alloc<double>(nt); SQ.mL = fr_alloc<double>(nt); SQ.sabs = fr_alloc<double>(nt); SQ.gt = fr_alloc<double>(nt); SQ.lt = fr_alloc<double>(nt);
+        SQ.eG = fr_alloc<int32_t>(nt); SQ.eL = fr_alloc<int32_t>(nt); SQ.mflag = fr_alloc<uint8_t>(nt); SQ.fast = fr_alloc<uint8_t>(nt);
+        c->fsq_check = getenv("FRIES_FSQ_CHECK") && atoi(getenv("FRIES_FSQ_CHECK"));
+        if (getenv("FRIES_FSQ_MAPS")) c->fsq_use_maps = atoi(getenv("FRIES_FSQ_MAPS")) != 0;
+        SQ.gb2 = c->fsq_check ? fr_alloc<double>(nb) : nullptr; SQ.lb2 = c->fsq_check ? fr_alloc<double>(nb) : nullptr;
         c->fsq_walk_only = getenv("FRIES_FKS_SEQ_WALK") && atoi(getenv("FRIES_FKS_SEQ_WALK"));
         if (getenv("FRIES_FSQ_GUESS_ROUNDS")) c->fsq_guess_rounds = atoi(getenv("FRIES_FSQ_GUESS_ROUNDS"));
         if (getenv("FRIES_FSQ_EXACT_ROUNDS")) c->fsq_exact_rounds = atoi(getenv("FRIES_FSQ_EXACT_ROUNDS"));
@@ -468,7 +474,19 @@ static void run_fsq_sweep(FriesCtx *c, int cur, uint32_t n_tiles) {
     }
     from = 0;
     for (int x = 0; ; x++) {
-        FR_LAUNCH(c, "k_fsq_chain", k_fsq_chain, dim3(1), dim3(64), Q, SQ.dl, SQ.tany, SQ.gb, SQ.lb, SQ.ctl, from, n_tiles, c->fsq_sparse_max);
+        if (c->fsq_use_maps) FR_LAUNCH(c, "k_fsq_maps", k_fsq_maps<0>, dim3(n_tiles - from), dim3(FR_BLOCK), Q, SQ, from);
+        FR_LAUNCH(c, "k_fsq_chain", k_fsq_chain, dim3(1), dim3(64), Q, SQ, SQ.gb, SQ.lb, from, n_tiles, c->fsq_sparse_max, c->fsq_use_maps ? 1 : 0);
+        FR_LAUNCH(c, "k_fsq_entries", k_fsq_maps<1>, dim3(n_tiles - from), dim3(FR_BLOCK), Q, SQ, from);
+        if (c->fsq_check) {         // the same chain element by element into a second pair of arrays; every entry must agree bit for bit
+            FR_LAUNCH(c, "k_fsq_chain", k_fsq_chain, dim3(1), dim3(64), Q, SQ, SQ.gb2, SQ.lb2, from, n_tiles, c->fsq_sparse_max, 0);
+            FksSq S2 = SQ; S2.gb = SQ.gb2; S2.lb = SQ.lb2;
+            FR_LAUNCH(c, "k_fsq_entries", k_fsq_maps<1>, dim3(n_tiles - from), dim3(FR_BLOCK), Q, S2, from);
+            FR_LAUNCH(c, "k_fsq_compare", k_fsq_compare, dim3(fr_blocks((n_tiles - from) * 32, FR_BLOCK)), dim3(FR_BLOCK), SQ, from, n_tiles);
+            uint32_t bad = 0;
+            FR_HIP(hipMemcpyAsync(&bad, &SQ.ctl->n_mismatch, 4, hipMemcpyDeviceToHost, st));
+            FR_HIP(hipStreamSynchronize(st));
+            if (bad) throw FriesError("FRIES_FSQ_CHECK: the integer form of the chain differs from the element-by-element chain in " + std::to_string(bad) + " block entries");
+        }
         spec(from);
         c->n_fsq_exact++; c->n_fsq_chain_tiles += n_tiles - from;
         if (c->dbg >= 2) fprintf(stderr, "[fries]   in-order sweep: %u tiles, %d guess rounds, exact round %d from tile %u\n", n_tiles, n_guess, x, from);

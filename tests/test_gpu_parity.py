@@ -273,7 +273,9 @@ REPLAY_KNOBS = [
     {"FRIES_FKS_SEQ": "1", "FRIES_FKS_SEQ_WALK": "1"},          # ... by the one-wave walk
     {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_GUESS_ROUNDS": "1"},      # ... the chain run on the first guess
     {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_GUESS_ROUNDS": "0"},      # ... and on no guess at all
-    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_SPARSE_MAX": "128"},      # ... every tile of the chain walked pair by pair
+    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_MAPS": "0", "FRIES_FSQ_SPARSE_MAX": "128"},      # ... every tile of the chain walked pair by pair
+    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_MAPS": "0"},              # ... the chain element by element (no integer steps)
+    {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_CHECK": "1"},             # ... both forms of the chain, every block entry compared bit for bit
     {"FRIES_FKS_SEQ": "1", "FRIES_FSQ_GUESS_ROUNDS": "1", "FRIES_FSQ_EXACT_ROUNDS": "0"},      # ... the walk taking over at the first tile the comparison rejects
 ]
 
