@@ -8,8 +8,8 @@
 // cannot reproduce it.  So when the settled replay reports a collapse (remaining norm < 1e-3 of the norm entering the
 // stage) the stage is redone here: one wave walks the elements in order and performs the reference's subtractions one by
 // one.  Sweep scalars travel over the ranks exactly as in the reference (sum_mpi before and after every sweep).
-// Steady-state stages (remaining norm ~ 0.3 of the start) never come here; this path is slow by design (~30 ms per sweep
-// and million elements) and only has to be right.
+// Steady-state stages (remaining norm ~ 0.3 of the start) never come here.  The one-wave walk of this first half (~80 ms per sweep and million
+// elements) is the fallback of the parallel form in the second half of this file.
 #pragma once
 #include "fks2.hpp"
 
@@ -166,8 +166,9 @@ __global__ void __launch_bounds__(64) k_fks_seq_sweep(CompWork W, const HbTables
 //                   order settled over DPP as in the replay -- and writes its elements' new state and change aside;
 //   2. k_fsq_scan / k_fsq_expand   kb[] = exact prefix sums of the blocks' counts (and, while the entry norms are still guesses,
 //                   gb[] = start norm minus a tree-summed prefix of the changes: good to a rounding error, which is all a guess needs);
-//   3. k_fsq_chain  ONE wave performs the reference's subtractions on the changes (a stream of doubles read through the scalar
-//                   cache: two dependent v_add_f64 per element and nothing else) and leaves the exact entry norm of every block;
+//   3. k_fsq_maps<0> / k_fsq_chain / k_fsq_maps<1>   the reference's subtractions on the changes, exactly: tile by tile as integer arithmetic while
+//                   the norm stays inside a binade, element by element (one wave, one dependent v_add_f64 per element) where it does not -- see
+//                   "the chain" below; leaves the exact entry norm of every block;
 //   4. k_fsq_spec again with the exact entry states.  The first block whose output differs from the one the chain was run on is
 //                   where the assumed sequence left the true one: everything before it is final (its inputs came from final
 //                   outputs), and steps 2-4 repeat from that tile.  No difference: the sweep is done, k_fsq_commit stores it.
