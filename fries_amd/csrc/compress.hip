@@ -191,8 +191,9 @@ void fr_find_preserve(FriesCtx *c, uint32_t *n_samp_io, double *glob_norm) {
             FR_LAUNCH(c, "k_fp_round", k_fp_round, dim3(grid), dim3(FR_BLOCK), c->vec, B, r, all, P, c->d_tie);
         }
         const void *h_cs = fr_readback(c, &B.state[r], sizeof(CompState));
-        const void *h_gn = fr_readback(c, B.gnorm, 8);
-        fr_stream_wait(c);
+        uint32_t tk = 0;
+        const void *h_gn = fr_readback(c, B.gnorm, 8, false, &tk);
+        fr_stream_wait_ticket(c, tk);
         memcpy(&hs, h_cs, sizeof(CompState)); memcpy(glob_norm, h_gn, 8);
         batch = 2;
     }

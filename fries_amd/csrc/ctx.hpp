@@ -306,7 +306,8 @@ int fr_host_idx_to_proc(const FriesCtx *c, det_t d);
 void fr_dense_h_setup(FriesCtx *c);      // system.hip
 // enqueue a copy of `bytes` (a multiple of 4, <= 2 KB) at device address src into the readback block; -> host address to read AFTER the next
 // synchronisation of the stream.  The block is a ring: a slot stays valid until ~RB_BYTES more have been asked for.  (vec.hip)
-const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held = false);
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held = false, uint32_t *ticket = nullptr);      // ticket != nullptr: the copy raises a ticket itself (fr_stream_wait_ticket)
+uint32_t fr_ticket_reserve(FriesCtx *c);
 // Waits until everything enqueued on the context's stream so far has run: a one-thread kernel stores a ticket into host-coherent pinned
 // memory and the host polls that word.  (hipStreamSynchronize returns ~20 us after the stream has drained; the iteration has about a
 // dozen such waits, during each of which the GPU idles.)

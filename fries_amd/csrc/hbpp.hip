@@ -613,10 +613,12 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // what follows a settled stage up to the emission counts, for one rank without the propagation repair (the other cases exchange norms or
     // look at list lengths on the host in between): skip != nullptr = launched ahead of the host's look at *skip
     AccWt acc{W.wt_remain, &W.state[0]};
-    auto launch_tail = [&](const uint32_t *skip) {
+    auto launch_tail = [&](const uint32_t *skip, uint32_t ticket = 0u) {
         CompWork Wt = W;
         Wt.seq.skip = skip;
-        FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), Wt.seq, acc);
+        SeqWork first = Wt.seq;
+        if (ticket) { first.tk_word = c->d_misc(); first.tk = ticket; }      // the first kernel of the tail tells the host that the closing pass is through
+        FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), first, acc);
         FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
         FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
         FR_LAUNCH(c, "k_comp_finalize", k_comp_finalize2, dim3(1), dim3(64), Wt, F, rn, (const double *)Wt.seq.total, c->rank, P);
@@ -645,8 +647,8 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
                 // The host needs ~10 us from the ticket to its next launch.  The closing pass settles the stage six times out of seven, so what
                 // follows it -- the exact sum of wt_remain, the comb, the emission counts -- is enqueued behind the ticket and runs while the
                 // host looks at the flag; if the pass did change a delta, these kernels see the same flag and leave at once.
-                const uint32_t tk = fr_stream_ticket(c);
-                launch_tail(&F.hist[it]);
+                const uint32_t tk = fr_ticket_reserve(c);
+                launch_tail(&F.hist[it], tk);
                 fr_stream_wait_ticket(c, tk);
                 tail_done = true;
             }
@@ -805,8 +807,9 @@ static void hbpp_apply_t(FriesCtx *c, uint32_t n_samp, const double rn[5], int u
     FR_LAUNCH(c, "k_final_eval", (k_final_eval<NEW_HB>), dim3(grid), dim3(FR_BLOCK), W, c->vec, S, 0, c->p_doub, unit_matrel, f_val, f_orbs, W.pcnt[0]);
     FR_LAUNCH(c, "k_final_compact", k_final_compact, dim3(grid), dim3(FR_BLOCK), W, 0, f_val, f_orbs, W.pcnt[0], c->c_pos, c->c_orbs, c->c_val, c->d_nsucc);
     {
-        const void *h_ns = fr_readback(c, c->d_nsucc, 4);
-        fr_stream_wait(c);
+        uint32_t tk = 0;
+        const void *h_ns = fr_readback(c, c->d_nsucc, 4, false, &tk);
+        fr_stream_wait_ticket(c, tk);
         memcpy(&c->num_success, h_ns, 4);
         for (int k = 0; k < 5; k++) c->comp_len[k] = c->h_misc()[16 + k];
     }

@@ -35,6 +35,7 @@ struct SeqWork {
     double *total;      // [1] exact sum of everything (+ start)
     double *tsum;       // [FR_MAX_PART] the tiles' tree sums again, contiguous (k_seq_maps adds up the ones before its tile)
     const uint32_t *skip = nullptr;     // launched ahead of the host's look at a flag: *skip != 0 = the input is not final, leave at once (run_stage)
+    uint32_t *tk_word = nullptr; uint32_t tk = 0;      // k_seq_sums only: raise this ticket when the kernel starts (everything enqueued before it has finished; fr_ticket_reserve)
 #ifdef FR_SEQ_TIMING
     int dbg = 0;        // FRIES_SEQ_DBG: k_seq_chain prints where its time goes (build with -DFR_SEQ_TIMING)
 #else
@@ -107,6 +108,7 @@ __device__ __forceinline__ double fr_seq_apply_map(double carry, int e, long lon
 template <class Acc>
 __global__ void __launch_bounds__(FR_BLOCK) k_seq_sums(SeqWork Q, Acc acc) {
     __shared__ double shd[4];
+    if (Q.tk_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(Q.tk_word, Q.tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (Q.skip && *Q.skip) return;
     const unsigned n = acc.count();
     const unsigned ntile = (n + FR_SEQ_TILE - 1) / FR_SEQ_TILE;

@@ -45,8 +45,10 @@ void fr_vec_alloc(FriesCtx *c, VecDev *v, uint32_t cap) {
     FR_HIP(hipMemsetAsync(v->st, 0, sizeof(VecState), c->stream));
 }
 
-static __global__ void __launch_bounds__(64) k_readback(const uint32_t *src, uint32_t *dst, unsigned n_words) {
+// (word != nullptr: the copy is what the host waits for -- the wave raises the ticket itself once its stores are out, instead of a k_ticket launch behind it)
+static __global__ void __launch_bounds__(64) k_readback(const uint32_t *src, uint32_t *dst, unsigned n_words, uint32_t *word, uint32_t ticket) {
     for (unsigned i = threadIdx.x; i < n_words; i += 64) dst[i] = src[i];
+    if (word && threadIdx.x == 0) __hip_atomic_store(word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // one wave: the release waits for every lane's stores
 }
 void fr_rb_init(FriesCtx *c) {
     if (c->h_rb) return;
@@ -67,6 +69,13 @@ uint32_t fr_stream_ticket(FriesCtx *c) {
     const uint32_t t = ++c->ticket;
     FR_LAUNCH(c, "k_ticket", k_ticket, dim3(1), dim3(1), c->d_misc(), t);
     return t;
+}
+// A ticket that a kernel of the caller's raises itself (k_readback at its end; k_seq_sums when it STARTS: everything enqueued before it has finished
+// then, which is all a ticket says) -- no launch of its own.  0: the host waits by hipStreamSynchronize, nobody raises anything.
+uint32_t fr_ticket_reserve(FriesCtx *c) {
+    fr_rb_init(c);
+    if (c->wait_by_sync) return 0u;
+    return ++c->ticket;
 }
 void fr_stream_wait_ticket(FriesCtx *c, uint32_t t) {
     if (c->wait_by_sync) { FR_HIP(hipStreamSynchronize(c->stream)); return; }
@@ -93,14 +102,16 @@ static size_t fr_rb_take(FriesCtx *c, size_t bytes, bool held) {
     c->rb_used += need;
     return off;
 }
-const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held) {
+const void *fr_readback(FriesCtx *c, const void *src, size_t bytes, bool held, uint32_t *ticket) {
     const size_t off = fr_rb_take(c, bytes, held);
-    FR_LAUNCH(c, "k_readback", k_readback, dim3(1), dim3(64), (const uint32_t *)src, (uint32_t *)(c->d_rb + off), (unsigned)(bytes / 4));
+    const uint32_t t = ticket ? fr_ticket_reserve(c) : 0u;
+    if (ticket) *ticket = t;
+    FR_LAUNCH(c, "k_readback", k_readback, dim3(1), dim3(64), (const uint32_t *)src, (uint32_t *)(c->d_rb + off), (unsigned)(bytes / 4), t ? c->d_misc() : (uint32_t *)nullptr, t);
     return c->h_rb + off;
 }
 
 // folds the striped counters into the state, then hands the state to the host block
-static __global__ void __launch_bounds__(64) k_vec_state_out(VecDev V, VecState *dst) {
+static __global__ void __launch_bounds__(64) k_vec_state_out(VecDev V, VecState *dst, uint32_t *word, uint32_t ticket) {
     const int l = threadIdx.x;
     unsigned long long x[3];
     for (int q = 0; q < 3; q++) {
@@ -114,12 +125,14 @@ static __global__ void __launch_bounds__(64) k_vec_state_out(VecDev V, VecState 
         VecState s = *V.st;
         s.nonini_occ_add += x[0]; s.n_used += (uint32_t)x[1]; s.n_tomb -= (uint32_t)x[2];
         *V.st = s; *dst = s;
+        if (word) __hip_atomic_store(word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 void fr_vec_sync_state(FriesCtx *c, VecDev *v, VecState *out) {
     const size_t off = fr_rb_take(c, sizeof(VecState), false);
-    FR_LAUNCH(c, "k_vec_state_out", k_vec_state_out, dim3(1), dim3(64), *v, (VecState *)(c->d_rb + off));
-    fr_stream_wait(c);
+    const uint32_t t = fr_ticket_reserve(c);
+    FR_LAUNCH(c, "k_vec_state_out", k_vec_state_out, dim3(1), dim3(64), *v, (VecState *)(c->d_rb + off), t ? c->d_misc() : (uint32_t *)nullptr, t);
+    fr_stream_wait_ticket(c, t);
     memcpy(out, c->h_rb + off, sizeof(VecState));
     v->used_ub = out->n_used;
 }
