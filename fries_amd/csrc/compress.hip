@@ -35,14 +35,40 @@ __global__ void __launch_bounds__(FR_BLOCK) k_death_clone(VecDev V, VcompBuf B, 
     }
     if (blockIdx.x >= nblk) return;
     size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
-    double sum = 0;
+    // Determinants created by the last merges have no diagonal element yet (NaN).  A few per wave: evaluated where they stand, each would hold its whole
+    // wave for the ~100 dependent integral reads of one Slater-Condon diagonal, item after item.  They are listed in LDS instead and evaluated side by
+    // side, one lane each (the sum inside an element keeps its order: same bits).
+    __shared__ uint32_t sh_n, sh_idx[FR_TILE];
+    __shared__ double sh_d[FR_TILE];
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    double vv[FR_ITEMS], dd[FR_ITEMS]; int slot[FR_ITEMS];
+#pragma unroll
     for (int it = 0; it < FR_ITEMS; it++) {
-        size_t i = base + (size_t)it * FR_BLOCK;
+        const size_t i = base + (size_t)it * FR_BLOCK;
+        vv[it] = 0; dd[it] = 0; slot[it] = -1;
+        if (i >= n) continue;
+        vv[it] = V.v0[i];
+        if (i < vec_size_before && vv[it] != 0) {
+            dd[it] = V.diag[i];
+            if (dd[it] != dd[it]) { slot[it] = (int)atomicAdd(&sh_n, 1u); sh_idx[slot[it]] = (uint32_t)i; }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < sh_n; k += FR_BLOCK) {
+        const uint32_t i = sh_idx[k];
+        const double d = fr_diag_matrel(V.dets[i], S.h_core, S.eris, S.n_orb) - S.hf_en;
+        V.diag[i] = d; sh_d[k] = d;
+    }
+    __syncthreads();
+    double sum = 0;
+#pragma unroll
+    for (int it = 0; it < FR_ITEMS; it++) {
+        const size_t i = base + (size_t)it * FR_BLOCK;
         if (i >= n) break;
-        double v = V.v0[i];
+        double v = vv[it];
         if (i < vec_size_before && v != 0) {
-            double d = V.diag[i];
-            if (d != d) { d = fr_diag_matrel(V.dets[i], S.h_core, S.eris, S.n_orb) - S.hf_en; V.diag[i] = d; }
+            const double d = slot[it] >= 0 ? sh_d[slot[it]] : dd[it];
             v *= 1 - eps * (d - shift);
         }
         if (add_col1) { v += V.v1[i] * 1.0; V.v0[i] = v; V.v1[i] = 0; }

@@ -147,12 +147,39 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_eval(CompWork W, VecDev V, S
     const unsigned n_orb = T.n_orb;
     size_t base = (size_t)blockIdx.x * FR_TILE + threadIdx.x;      // lane-contiguous: coalesced loads and stores
     uint32_t cnt = 0;
+    // The single excitations (a few per wave) cost a loop over the occupied orbitals each -- the virtual orbital from its index, the allowed
+    // occupied orbitals, the one-body element with its 2 n_elec integral reads -- and where they stand each holds its wave while the other lanes have
+    // long finished their doubles.  They are listed in LDS and evaluated side by side afterwards, one lane each.
+    __shared__ uint32_t sh_ns, sh_sing[FR_TILE];
+    if (threadIdx.x == 0) sh_ns = 0;
+    __syncthreads();
+    auto single = [&](size_t e) {
+        const uint32_t wi = W.e_wi[e];
+        const double val = W.e_val[e];
+        const uint32_t pos = P.pos[wi], pc = P.code[wi];
+        const det_t det = V.dets[pos];
+        double el = 0;
+        uint32_t orbs = 0;
+        unsigned o1 = fr_nth_bit(det, fr_c(pc, 1));
+        unsigned u1 = fr_virt_from_idx(T, det, T.irrep[o1 % n_orb], n_orb * (o1 / n_orb), fr_c(pc, 2));
+        if (u1 != 255) {
+            orbs = fr_code(o1, u1, 0, 0);
+            unsigned n_occ = fr_count_sing_allowed(T, det);
+            el = unit_matrel ? 1.0 : fr_sing_matrel(det, o1, u1, S.h_core, S.eris, n_orb);
+            el *= val / (1 - p_doub) * n_occ * fr_c(pc, 3);
+            if (fabs(el) > 1e-9) el *= fr_sing_parity(det, o1, u1);
+            else el = 0;
+        }
+        f_val[e] = el; f_orbs[e] = orbs;
+        cnt += (el != 0);
+    };
     for (int it = 0; it < FR_ITEMS; it++) {
         size_t e = base + (size_t)it * FR_BLOCK;
         if (e >= n_in) break;
         uint32_t wi = W.e_wi[e], sub = W.e_sub[e];
         double val = W.e_val[e];
         uint32_t pos = P.pos[wi], pc = P.code[wi];
+        if (fr_c(pc, 0) != 0) { sh_sing[atomicAdd(&sh_ns, 1u)] = (uint32_t)(e - (size_t)blockIdx.x * FR_TILE); continue; }
         det_t det = V.dets[pos];
         unsigned o1_idx = fr_c(pc, 1);
         double el = 0;
@@ -172,21 +199,11 @@ __global__ void __launch_bounds__(FR_BLOCK) k_final_eval(CompWork W, VecDev V, S
                 else el = 0;
             }
         }
-        else {
-            unsigned o1 = fr_nth_bit(det, o1_idx);
-            unsigned u1 = fr_virt_from_idx(T, det, T.irrep[o1 % n_orb], n_orb * (o1 / n_orb), fr_c(pc, 2));
-            if (u1 != 255) {
-                orbs = fr_code(o1, u1, 0, 0);
-                unsigned n_occ = fr_count_sing_allowed(T, det);
-                el = unit_matrel ? 1.0 : fr_sing_matrel(det, o1, u1, S.h_core, S.eris, n_orb);
-                el *= val / (1 - p_doub) * n_occ * fr_c(pc, 3);
-                if (fabs(el) > 1e-9) el *= fr_sing_parity(det, o1, u1);
-                else el = 0;
-            }
-        }
         f_val[e] = el; f_orbs[e] = orbs;
         cnt += (el != 0);
     }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < sh_ns; k += FR_BLOCK) single((size_t)blockIdx.x * FR_TILE + sh_sing[k]);
     uint32_t bc = fr_block_sum_u32(cnt, shu);
     if (threadIdx.x == 0) pcnt[blockIdx.x] = bc;
 }

@@ -12,7 +12,7 @@ import json, sys
 v, rep = sys.argv[1], sys.argv[2]
 d = json.loads(open(f"gpurun_out/ab_{v}_{rep}.json").read().strip().splitlines()[-1])
 tk = d["top_kernels"]
-want = ["k_fks_sweep", "k_fks_sweep_rec", "k_fks_sweep_light", "k_fks_close", "k_sys_count", "k_sys_write", "k_prep", "k_fks_scan", "k_fks_totals", "k_seq_chain", "k_spawn_lookup", "k_final_eval"]
+want = ["k_fks_sweep", "k_fks_sweep_rec", "k_fks_sweep_light", "k_fks_close", "k_sys_count", "k_sys_write", "k_prep", "k_fks_scan", "k_fks_totals", "k_seq_chain", "k_spawn_lookup", "k_final_eval", "k_death_clone", "k_seg_sum"]
 print(f"{v:8s} {rep} {d['value']:7.2f} it/s  ktime {d['kernel_time_ms_per_iter']:.3f} | " + " ".join(f"{k[2:]}={tk[k]['ms_per_iter']*1000/max(tk[k]['calls_per_iter'],1e-9):.1f}" for k in want if k in tk))
 PY
 done
