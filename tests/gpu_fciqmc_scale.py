@@ -33,3 +33,8 @@ lg = eng.iterate_fciqmc(50)
 t0 = time.time(); lg = eng.iterate_fciqmc(200); dt = time.time() - t0
 d, v = eng.vector()
 print("x%d: walkers %d n_nonz %d: %.1f it/s, %.3g attempts/s, %.3g spawns/s" % (mult, int(np.abs(v).sum()), int(lg["n_nonz"][-1]), 200 / dt, lg["n_attempts"].sum() / dt, lg["n_spawn"].sum() / dt))
+if os.environ.get("FQ_PROF") == "1":          # where a 1e6-walker iteration goes (HIP events per kernel)
+    eng.prof_enable(True)
+    eng.iterate_fciqmc(100)
+    for name, (ms, calls) in sorted(eng.prof_report().items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"  {name:24s} {ms / 100:9.4f} ms per iteration  {calls / 100:6.1f} calls  {1e3 * ms / max(calls, 1):9.1f} us each")
