@@ -398,31 +398,41 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, cons
     __shared__ double sval[FR_BLOCK];
     __shared__ uint32_t skey[FR_BLOCK];
     __shared__ uint8_t sfl[FR_BLOCK];           // bit 0: initiator spawn, bit 1: value fetched
+    __shared__ uint32_t sh_cont, sh_done;       // the head whose segment runs past this workgroup's 256 entries (thread + 1; at most one: the last segment)
     const uint32_t n = *S.n_spawn;
     const uint32_t t0 = blockIdx.x * blockDim.x, t = t0 + threadIdx.x;
     if (t0 >= n) return;
     const bool rule_fixed = mode == 0 || mode == 3;     // the initiator rule looks at the origin column as it was before the merge
-    const uint32_t k = t < n ? key[t] : drop_key;
+    if (threadIdx.x == 0) { sh_cont = 0u; sh_done = 0u; }
+    // entry g of the sorted list into slot threadIdx.x of the LDS arrays: key, initiator flag, origin-column test and value -- all independent loads
+    auto stage = [&](uint32_t g, uint32_t *k_out, bool *ini_out, bool *occ_out) {
+        const uint32_t k = g < n ? key[g] : drop_key;
+        const bool live = k != drop_key;
+        bool ini = false, occ = false;
+        uint32_t j = 0;
+        if (live) {
+            j = pay[g];
+            ini = mode == 0 ? (k & 1u) != 0 : S.ini[j] != 0;
+            // non-initiator spawns only reach determinants that are non-zero in the origin column (vec_utils.hpp:617, 632-637); one created
+            // in this merge has zero there (k_spawn_assign)
+            if (rule_fixed) occ = V.v0[k >> 1] != 0;
+        }
+        const bool fetch = live && (!rule_fixed || ini || occ);
+        const double val = fetch ? S.val[j] : 0.0;
+        skey[threadIdx.x] = k; sval[threadIdx.x] = val; sfl[threadIdx.x] = (uint8_t)((ini ? 1u : 0u) | (fetch ? 2u : 0u));
+        *k_out = k; *ini_out = ini; *occ_out = occ;
+    };
+    uint32_t k; bool ini, occ;
+    stage(t, &k, &ini, &occ);
     const bool live = k != drop_key;
     const uint32_t pos = k >> 1;
     const uint32_t kprev = (t > 0 && live) ? key[t - 1] : drop_key;
-    uint32_t j = 0; bool ini = false, occ = false;
-    if (live) {
-        j = pay[t];
-        ini = mode == 0 ? (k & 1u) != 0 : S.ini[j] != 0;
-        // non-initiator spawns only reach determinants that are non-zero in the origin column (vec_utils.hpp:617, 632-637); one created
-        // in this merge has zero there (k_spawn_assign)
-        if (rule_fixed) occ = V.v0[pos] != 0;
-    }
-    const bool fetch = live && (!rule_fixed || ini || occ);
-    const double val = fetch ? S.val[j] : 0.0;
-    skey[threadIdx.x] = k; sval[threadIdx.x] = val; sfl[threadIdx.x] = (uint8_t)((ini ? 1u : 0u) | (fetch ? 2u : 0u));
     unsigned long long occ_add = (rule_fixed && live && !ini && occ) ? 1ull : 0ull;
     __syncthreads();
     const bool head = live && !(t > 0 && kprev != drop_key && (kprev >> 1) == pos);
-    if (head) {
-        double acc = rule_fixed ? V.v1[pos] : V.v0[pos];
-        uint32_t u = threadIdx.x;
+    double acc = 0;
+    // the segment's entries in the LDS arrays from slot u on; returns the slot it stopped at (FR_BLOCK: the segment may go on)
+    auto add_up = [&](uint32_t u) {
         for (; u < FR_BLOCK; u++) {
             const uint32_t ku = skey[u];
             if (ku == drop_key || (ku >> 1) != pos) break;
@@ -434,19 +444,28 @@ __global__ void __launch_bounds__(FR_BLOCK) k_seg_sum(VecDev V, SpawnBuf S, cons
                 if ((f & 1u) || nonz) acc += sval[u];
             }
         }
-        if (u == FR_BLOCK) {            // the segment goes on in the next workgroup's entries
-            for (uint32_t g = t0 + FR_BLOCK; g < n && key[g] != drop_key && (key[g] >> 1) == pos; g++) {
-                const uint32_t jg = pay[g];
-                const bool ini_g = mode == 0 ? (key[g] & 1u) != 0 : S.ini[jg] != 0;
-                if (rule_fixed) { if (ini_g || occ) acc += S.val[jg]; }
-                else {
-                    const bool nonz = acc != 0;
-                    occ_add += (!ini_g && nonz);
-                    if (ini_g || nonz) acc += S.val[jg];
-                }
-            }
+        return u;
+    };
+    bool mine_goes_on = false;
+    if (head) {
+        acc = rule_fixed ? V.v1[pos] : V.v0[pos];
+        if (add_up(threadIdx.x) == FR_BLOCK && t0 + FR_BLOCK < n) { mine_goes_on = true; sh_cont = threadIdx.x + 1u; }
+        else if (rule_fixed) V.v1[pos] = acc; else V.v0[pos] = acc;
+    }
+    __syncthreads();
+    // A segment that runs past the workgroup's entries (a determinant that many spawns reach: one lane walking the list in global memory pays three
+    // dependent loads per addend, and that one lane was the kernel's time): the workgroup stages the next 256 entries the same way and the head goes on
+    // in LDS.  The workgroup those entries belong to sees no head there and leaves them alone.
+    if (sh_cont) {
+        for (uint32_t g0 = t0 + FR_BLOCK; g0 < n; g0 += FR_BLOCK) {
+            uint32_t k2; bool i2, o2;
+            stage(g0 + threadIdx.x, &k2, &i2, &o2);
+            __syncthreads();
+            if (mine_goes_on && add_up(0u) < FR_BLOCK) sh_done = 1u;
+            __syncthreads();
+            if (sh_done) break;
         }
-        if (rule_fixed) V.v1[pos] = acc; else V.v0[pos] = acc;
+        if (mine_goes_on) { if (rule_fixed) V.v1[pos] = acc; else V.v0[pos] = acc; }
     }
     // one counter, ~1e6 segments: added up per workgroup, then one striped atomic (VecDev::stat_part)
     for (int off = 32; off > 0; off >>= 1) occ_add += __shfl_xor(occ_add, off);
