@@ -9,7 +9,7 @@
 #define FR_WAVE 64
 #define FR_BLOCK 256            // 4 waves, one per SIMD
 #define FR_MAX_ORB 32           // 2*n_orb <= 64 bits per determinant
-#define FR_MAX_PART 32768       // max blocks whose partials one consumer block re-reduces (capacity: 33.5e6 elements per array)
+#define FR_MAX_PART 131072      // max blocks whose partials one consumer block re-reduces (capacity: 134e6 elements per array; the re-reduction reads the LIVE tiles before its own, not the capacity)
 #define FR_EMPTY_KEY 0ull
 #define FR_TOMB_KEY (~0ull)
 #define FR_NOPOS 0xFFFFFFFFu

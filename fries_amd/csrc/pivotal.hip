@@ -605,7 +605,7 @@ void fr_piv_comp(FriesCtx *c, uint32_t compress_size, uint32_t *n_kept, double *
 void fr_piv_flat_reserve(FriesCtx *c, uint32_t cap) {
     FlatPiv &F = c->flat;
     if (F.cap >= cap) return;
-    if (fr_blocks(cap, FR_TILE) > FR_MAX_PART) throw FriesError("pivotal matrix compression: a factor expands to more elements than the work arrays index (33.5e6)");
+    if (fr_blocks(cap, FR_TILE) > FR_MAX_PART) throw FriesError("pivotal matrix compression: a factor expands to more elements than the work arrays index (134e6)");
     if (F.cap) {
         FR_HIP(hipStreamSynchronize(c->stream));
         FR_HIP(hipFree(F.vals)); FR_HIP(hipFree(F.parent));

@@ -302,7 +302,7 @@ int fries_apply_hbpp_sys(fries_ctx *ctx, uint32_t n_samp, const double rn[5], in
 /* apply_HBPP_piv (heat_bathPP.cpp:1014-1419; spin_parity = what fries_set_spin_parity set): every factor multiplied out into the long vector, compressed by
  * piv_comp_parallel to n_samp elements and collapsed; outputs as comp_scratch->{det_indices2, orb_indices1, vec1}.  The uniforms
  * come from the context's generator in the reference's order (seed it with fries_frisys_restart), because their number
- * depends on the data.  stage_len[k] = elements after the k-th compression.  One factor may expand to at most 33.5e6 values. */
+ * depends on the data.  stage_len[k] = elements after the k-th compression.  One factor may expand to at most 134e6 values. */
 int fries_apply_hbpp_piv(fries_ctx *ctx, uint32_t n_samp, int unit_matrel,
                          uint32_t *det_pos, uint8_t *orbs, double *vals, size_t cap, size_t *n_out, uint32_t stage_len[5]);
 /* find_preserve + sys_comp on column 0 (compress_utils.cpp:29-105, 283-327) followed by the deletes
