@@ -18,6 +18,7 @@ step rehearsal; FRIES_BENCH_SHARE_GPU=1 FRIES_BENCH_BACKEND=gloo FRIES_BENCH_TRA
 step fks_stats; timeout -k 10 200 python tests/gpu_fks_stats.py > $O/fks_replay_stats.txt 2>&1; echo "fks stats rc=$?"
 step soak; timeout -k 10 300 python tests/gpu_soak.py 1000000 3000 > $O/soak.txt 2>&1; echo "soak rc=$?"
 step facade; timeout -k 10 400 python tests/gpu_facade_cost.py > $O/facade_cost.txt 2>&1; echo "facade rc=$?"
+step hh; timeout -k 10 200 python tests/gpu_hh_scale.py 12 1000000 -1 10 > $O/hh_scale.txt 2>&1; echo "hh rc=$?"
 step done
 ls -la $O
 tail -1 $O/bench.json | cut -c1-400
