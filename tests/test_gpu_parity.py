@@ -305,6 +305,24 @@ def test_every_replay_strategy_reproduces_the_reference(Engine, mols, name, knob
     eng.close()
 
 
+def test_capacity_beyond_the_old_tile_limit_changes_nothing(Engine, mols):
+    """max_dets = 4e7 (39 063 tiles of 1024 per array; FR_MAX_PART was 32 768 until round 3 and refused this) with the golden run's other parameters: the
+    reference's trajectory, bit for bit -- the capacity sizes arrays and nothing else."""
+    name = "n2_m30000_unnorm"
+    r = golden_io.manifest()["runs"][name]
+    g = golden_io.read_traj(name)
+    eng = Engine(mols(r["shape"]))
+    eng.setup(epsilon=r["epsilon"], vec_nonz=r["vec_nonz"], mat_nonz=r["mat_nonz"], max_dets=40_000_000, target_norm=r["target_norm"],
+              initiator=r["initiator"], seed=r["seed"], distribution=r["distribution"])
+    for row in g["rows"][:12]:
+        lg = eng.iterate(1)[0]
+        for f in ("nkept", "n_nonz", "curr_size", "num_success"):
+            assert int(lg[f]) == row[f], (row["it"], f)
+        assert float(lg["norm"]) == row["norm"] and float(lg["shift"]) == row["shift"], row["it"]
+        assert int(lg["err"]) == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("name", sorted(golden_io.manifest()["extra_runs"]))
 def test_frisys_driver_options_match_reference_golden(Engine, mols, name):
     """--trial_vec (a 25-determinant trial vector: H * trial by full enumeration of every entry), --ini_vec and --ham_shift on
