@@ -1,7 +1,8 @@
 """Ad-hoc: the allocations one rank of the 8-GPU bench makes (vec_nonz = mat_nonz = 8e6 global, max_dets = 4e6 per rank) on one GPU,
 with a 1e6-element shard loaded: setup, a few iterations, memory in use."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
 import numpy as np
 import bench
 from fries_amd import fcidump

@@ -2,7 +2,8 @@
 wall time and a digest of the vector at the end (scratch; run once per setting of FRIES_FKS_SEQ_WALK to compare the one-wave walk with the
 parallel form of the in-order sweep, fks_seq.hpp)."""
 import os, sys, time, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
 import numpy as np
 from fries_amd import fcidump
 from fries_amd.engine import FriEngine

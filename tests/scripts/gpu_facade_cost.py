@@ -7,7 +7,7 @@ mirrors of the device vector cross PCIe every iteration.  This script restarts t
 reference's format: hash.dat, dets0.dat, vals0.dat, dense.txt, S.txt) at vec_nonz = mat_nonz = target = m and reports iterations/s and
 PCIe bytes per iteration (FRIES_FACADE_STATS=1, include/FRIES/backend.hpp), beside the engine's own loop (fries_iterate) on the same state.
 
-usage: python tests/gpu_facade_cost.py [m] [iterations]
+usage: python tests/scripts/gpu_facade_cost.py [m] [iterations]
 """
 import os
 import re
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

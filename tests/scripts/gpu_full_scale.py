@@ -1,8 +1,9 @@
 """Ad-hoc: frifull_mol on the device at N2, vec_nonz = 1e3: excitations added per second, per-kernel time, and the CPU
 restatement (1 core) on the same run beside it."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/ (golden_io, oracle_lib)
 import numpy as np
 from fries_amd import fcidump
 from fries_amd.engine import FriEngine

@@ -1,8 +1,9 @@
 """Ad-hoc: apply_HBPP_piv (pivotal compression of every HB-PP factor) on a full vector: device against the CPU restatement on the same
 vector and generator, per-kernel time.  usage: gpu_hbpiv_scale.py [m] [n_samp] [n_iter] [HB|HB_unnorm]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/ (golden_io, oracle_lib)
 import numpy as np
 from fries_amd import fcidump
 from fries_amd.engine import FriEngine

@@ -1,6 +1,7 @@
 """Ad-hoc: frisys_hh on the GPU at a large budget (BASELINE config 5 is a 4x4 lattice the reference cannot run; this is its 1-D model)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
 import numpy as np
 from fries_amd.engine import FriEngine
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 12

@@ -2,8 +2,9 @@
 trajectory, so they must give the same one: counts, norm and shift bit for bit every iteration, the vector digest at the end.
 usage: gpu_light_selfcheck.py [m] [iterations]"""
 import os, sys, subprocess, json, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/ (golden_io, oracle_lib)
 import numpy as np
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000

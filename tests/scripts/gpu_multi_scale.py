@@ -1,7 +1,8 @@
 """Ad-hoc: frimulti_mol on the device at scale: growth from 100 x HF, then timed iterations; per-kernel time.
 usage: gpu_multi_scale.py [vec_nonz] [mat_nonz] [n_grow] [n_timed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
 import numpy as np
 from fries_amd import fcidump
 from fries_amd.engine import FriEngine

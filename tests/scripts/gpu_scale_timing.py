@@ -1,6 +1,7 @@
 """scratch: wall-clock of frisys_hh (L = 12, budget 1e6) iteration by iteration, and of apply_HBPP_piv at n_samp = 1e6 on the bench's state"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/ (golden_io, oracle_lib); _TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
 import numpy as np
 import golden_io
 from fries_amd.engine import FriEngine

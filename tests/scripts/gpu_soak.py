@@ -1,6 +1,7 @@
 """Ad-hoc: long runs at bench size -- no replay / repair / capacity error, population under shift control, timings stable."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
 import numpy as np
 import bench
 from fries_amd import fcidump

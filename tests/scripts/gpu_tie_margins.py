@@ -2,12 +2,13 @@
 find_keep_sub comparison (sub-weight x budget >= running norm) and of any find_preserve comparison (|v| >= norm / budget) from
 flipping, over the whole run.  The device forms the norms as prefix sums where the reference keeps running sums (relative difference
 ~1e-16 x norm entering the stage / norm at the comparison); a stage whose norm collapses by > 1e3 is redone in the reference's own
-order (fks_seq.hpp) and has no margin to report.  Usage: python tests/gpu_tie_margins.py > profiles/r02_tie_margins.txt"""
+order (fks_seq.hpp) and has no margin to report.  Usage: python tests/scripts/gpu_tie_margins.py > profiles/r02_tie_margins.txt"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TESTS); sys.path.insert(0, os.path.dirname(_TESTS))      # tests/ (golden_io, oracle_lib) and the repository root (bench, fries_amd)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/ (golden_io, oracle_lib)
 import numpy as np
 
 import golden_io
