@@ -142,6 +142,9 @@ static std::map<std::string, std::string> parse_kv(int argc, char **argv) {
     }
     return kv;
 }
+// digits of the doubles in the output files: 17 (round-trip exact; what the tests compare) unless --precision N is given; --precision 6 is the reference's
+// own format (its drivers stream doubles with the default precision), for byte-wise comparison of result files
+static inline int out_precision(std::map<std::string, std::string> &kv) { return kv.count("precision") ? std::stoi(kv["precision"]) : 17; }
 static uint32_t wall_clock_seed() { return (uint32_t)std::chrono::high_resolution_clock::now().time_since_epoch().count(); }
 
 // read_dets + load_vec_txt (FRIES/io_utils.cpp:447-482, 565-586): <prefix>dets holds one determinant per token as a signed 64-bit

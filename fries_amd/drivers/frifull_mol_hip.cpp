@@ -39,7 +39,7 @@ static void run_rank(std::map<std::string, std::string> kv, const Fcidump &in, d
         num_file.open(rd + "projnum.txt", std::ofstream::app); den_file.open(rd + "projden.txt", std::ofstream::app); shift_file.open(rd + "S.txt", std::ofstream::app);
         norm_file.open(rd + "norm.txt", std::ofstream::app); nkept_file.open(rd + "nkept.txt", std::ofstream::app);
         if (!num_file.is_open()) throw std::runtime_error("Could not open file for writing in directory " + rd);
-        num_file.precision(17); den_file.precision(17); shift_file.precision(17); norm_file.precision(17);
+        num_file.precision(out_precision(kv)); den_file.precision(out_precision(kv)); shift_file.precision(out_precision(kv)); norm_file.precision(out_precision(kv));
         std::ofstream param_f(rd + "params.txt");
         param_f << "FRI calculation\n" << (kv.count("hf_path") ? "HF path: " + kv["hf_path"] : "FCIDUMP path: " + kv["fcidump_path"]) << "\nepsilon (imaginary time step): " << p.epsilon << "\nTarget norm " << p.target_norm
                 << "\nVector nonzero: " << p.vec_nonz << "\nInitializing calculation from HF unit vector\n";

@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
         std::ofstream num_file(rd + "projnum.txt", std::ofstream::app), den_file(rd + "projden.txt", std::ofstream::app), shift_file(rd + "S.txt", std::ofstream::app),
             norm_file(rd + "norm.txt", std::ofstream::app);
         if (!num_file.is_open()) throw std::runtime_error("Could not open file for writing in directory " + rd);
-        num_file.precision(17); den_file.precision(17); shift_file.precision(17); norm_file.precision(17);
+        num_file.precision(out_precision(kv)); den_file.precision(out_precision(kv)); shift_file.precision(out_precision(kv)); norm_file.precision(out_precision(kv));
         {
             std::ofstream param_f(rd + "params.txt");
             param_f << "FRI calculation\nHubbard-Holstein parameters path: " << kv["params_path"] << "\nepsilon (imaginary time step): " << p.eps << "\nTarget norm " << p.target_norm

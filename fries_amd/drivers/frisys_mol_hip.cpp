@@ -28,6 +28,7 @@
 #include <unistd.h>
 
 struct Args {
+    int precision = 17;      // digits in the output files (--precision; 6 = the reference's stream format)
     std::string fcidump_path, point_group = "C1", dist = "HB_unnorm", result_dir = "./", load_dir, ini_vec, trial_vec, det_space;
     bool have_ham_shift = false; double ham_shift = 0;
     double target = 0, initiator = 0, epsilon = 0.01;
@@ -44,6 +45,7 @@ static Args parse_args(int argc, char **argv) {
     r.fcidump_path = need("fcidump_path"); r.vec_nonz = (uint32_t)std::stoul(need("vec_nonz")); r.mat_nonz = (uint32_t)std::stoul(need("mat_nonz"));
     r.max_dets = (uint32_t)std::stoul(need("max_dets"));
     if (kv.count("point_group")) r.point_group = kv["point_group"];
+    r.precision = out_precision(kv);
     if (kv.count("distribution")) r.dist = kv["distribution"];
     if (kv.count("result_dir")) r.result_dir = kv["result_dir"];
     if (kv.count("load_dir")) r.load_dir = kv["load_dir"];
@@ -186,7 +188,7 @@ static void run_rank(const Args &args, const Fcidump &in, uint32_t seed, int ran
         num_file.open(rd + "projnum.txt", std::ofstream::app); den_file.open(rd + "projden.txt", std::ofstream::app);
         shift_file.open(rd + "S.txt", std::ofstream::app); norm_file.open(rd + "norm.txt", std::ofstream::app); nkept_file.open(rd + "nkept.txt", std::ofstream::app);
         if (!num_file.is_open()) throw std::runtime_error("Could not open file for writing in directory " + rd);
-        num_file.precision(17); den_file.precision(17); shift_file.precision(17); norm_file.precision(17);
+        num_file.precision(args.precision); den_file.precision(args.precision); shift_file.precision(args.precision); norm_file.precision(args.precision);
         std::ofstream param_f(rd + "params.txt");
         param_f << "FRI calculation\nFCIDUMP path: " << args.fcidump_path << "\nepsilon (imaginary time step): " << args.epsilon << "\nTarget norm " << args.target
                 << "\nInitiator threshold: " << args.initiator << "\nMatrix nonzero: " << args.mat_nonz << "\nVector nonzero: " << args.vec_nonz << "\n";

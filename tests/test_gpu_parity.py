@@ -660,6 +660,17 @@ def test_cli_driver_reproduces_reference_outputs(tmp_path):
     assert np.loadtxt(out2 + "projnum.txt").size == 5
     keep = vals[:n_saved] != 0
     assert np.fromfile(out2 + "dets0.dat", dtype=np.uint8).size // nb > 0 and int(keep.sum()) > 0
+    # --precision 6: the text files in the reference's own format (its drivers stream doubles with the default precision, "%g" with six digits)
+    out3 = str(tmp_path / "run3") + "/"
+    os.makedirs(out3)
+    cmd3 = cmd[:]
+    cmd3[cmd3.index("--result_dir") + 1] = out3
+    cmd3[cmd3.index("--max_iter") + 1] = "20"
+    res3 = subprocess.run(cmd3 + ["--precision", "6"], capture_output=True, text=True, timeout=300)
+    assert res3.returncode == 0 and "Exception" not in res3.stderr, res3.stderr[-2000:]
+    assert open(out3 + "projnum.txt").read().split() == ["%g" % x for x in num[:20]]
+    assert open(out3 + "projden.txt").read().split() == ["%g" % x for x in den[:20]]
+    assert open(out3 + "S.txt").read().split() == ["%g" % x for x in sh[:2]] and open(out3 + "norm.txt").read().split() == ["%g" % x for x in nm[:2]]
 
 
 @pytest.mark.gpu
