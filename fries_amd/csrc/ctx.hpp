@@ -176,6 +176,8 @@ struct FriesCtx {
     FksSaved *fks_saved = nullptr; uint32_t *fks_wk = nullptr, *fks_wkx = nullptr; double *fks_wg = nullptr, *fks_wgx = nullptr;    // per-stage warm-start records
     struct FksSeq *fks_seq = nullptr;        // sequential find_keep_sub (fks_seq.hpp)
     FksSq fsq{};                             // ... its parallel form: work arrays, knobs, statistics
+    bool fks_no_merged_norm = false;         // FRIES_FKS_NO_MERGED_NORM=1 (ranks): the remaining norms in a message of their own instead of riding with the closing pass's flag
+    double *d_norms_all = nullptr;           // ... where k_fks_close_flag2 leaves them
     bool fsq_walk_only = false;              // FRIES_FKS_SEQ_WALK=1: the one-wave walk for every sweep
     int fsq_guess_rounds = 24, fsq_exact_rounds = 6;
     bool fsq_use_maps = true, fsq_check = false;   // the chain as integer arithmetic inside a binade (FRIES_FSQ_MAPS=0: element by element); FRIES_FSQ_CHECK=1: both, compared

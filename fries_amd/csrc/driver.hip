@@ -495,6 +495,7 @@ extern "C" int fries_ctx_create(fries_ctx **out, int device) {
     if (getenv("FRIES_FKS_NO_CLOSING")) h->c.fks_no_closing = atoi(getenv("FRIES_FKS_NO_CLOSING")) != 0;
     if (getenv("FRIES_FKS_COLLAPSE_WALK")) h->c.fks_no_collapse_walk = atoi(getenv("FRIES_FKS_COLLAPSE_WALK")) == 0;
     if (getenv("FRIES_FKS_SEQ")) h->c.fks_force_seq = atoi(getenv("FRIES_FKS_SEQ")) != 0;
+    if (getenv("FRIES_FKS_NO_MERGED_NORM")) h->c.fks_no_merged_norm = atoi(getenv("FRIES_FKS_NO_MERGED_NORM")) != 0;
     if (getenv("FRIES_NO_WARM")) h->c.warm_start = false;
     {
         hipDeviceProp_t pr;

@@ -859,6 +859,19 @@ static __global__ void __launch_bounds__(FR_FKS_TOTALS_THREADS) k_fks_totals(Fks
 
 // after the closing pass (k_fks_sweep MODE 4): did any rank change a delta?  The host reads hm->hist[it].
 static __global__ void k_fks_close_put(Fks2Work F, uint32_t *send, int it) { send[0] = F.hist[it]; send[1] = 0u; send[2] = 0u; send[3] = 0u; }
+// ranks: the closing pass's flag and -- computed behind it, ahead of the host's look -- this rank's remaining norm in ONE 16-byte message
+// (the norm is what k_put_norm hands over: 0 when the budget is spent, compress_utils.cpp:267-269; garbage when this rank's flag is set, and then unused)
+static __global__ void k_fks_close_put2(Fks2Work F, uint32_t *send, int it, const double *loc_total) {
+    const FksScal *S = F.scal;
+    send[0] = F.hist[it]; send[1] = 0u;
+    ((double *)send)[1] = (S->G_last / S->n_last < 1e-8) ? 0.0 : *loc_total;
+}
+static __global__ void k_fks_close_flag2(Fks2Work F, const uint32_t *all, int n_ranks, int it, double *norms_out) {
+    uint32_t ch = F.hist[it];
+    for (int r = 0; r < n_ranks; r++) { ch |= all[4 * r]; norms_out[r] = ((const double *)all)[2 * r + 1]; }
+    F.hist[it] = ch;
+    if (it < FR_MAX_ROUNDS) F.hm->hist[it] = ch;
+}
 static __global__ void k_fks_close_flag(Fks2Work F, const uint32_t *all, int n_ranks, int it) {
     uint32_t ch = F.hist[it];
     for (int r = 0; r < n_ranks; r++) ch |= all[4 * r];

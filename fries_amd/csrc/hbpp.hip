@@ -378,7 +378,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         c->fks_wk = fr_alloc<uint32_t>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK); c->fks_wg = fr_alloc<double>((size_t)8 * FR_FKS_PMAX * FR_FKS_MAXCHUNK);
         FR_HIP(hipMemset(F.scal, 0, sizeof(FksScal)));
     }
-    c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1);
+    c->d_norms_keep = fr_alloc<double>(FR_MAX_RANKS); c->d_seq_scratch = fr_alloc<double>(1); c->d_norms_all = fr_alloc<double>(FR_MAX_RANKS);
     c->fks_seq = fr_alloc<FksSeq>(1);
     {   // work arrays of the parallel form of the in-order sweep (fks_seq.hpp)
         FksSq &SQ = c->fsq;
@@ -648,13 +648,29 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     const bool simple_tail = !xr && c->rank == 0 && !W.prop;
     const bool speculate = simple_tail && !c->fks_no_speculation;
     bool tail_done = false;
+    // ranks: the remaining norms already gathered with the closing pass's flag (FRIES_FKS_NO_MERGED_NORM=1: a message of their own, as before)
+    const bool merge_norm = xr && !c->fks_no_merged_norm && !W.prop;
+    bool norms_done = false;
     if (closing) {
         int plain = batch < 2 ? 2 : batch;       // replays before the closing pass (replay 1 writes the records the light test needs)
         while (!closed && !sequential) {
             if (plain > 47) { sequential = true; break; }       // does not settle (e.g. the reference's own 0/0 corner): walk the stage in order instead
             for (; it < plain; it++) replay(it);
             FR_LAUNCH(c, "k_fks_close", (k_fks_sweep<STAGE, NEW_HB, 4>), dim3(gridE), dim3(FR_BLOCK), W, F, c->d_hb, cur, it, c->p_doub, c->fks_no_ext ? 2 : 1, c->dbg);
-            if (xr) {       // every rank must see whether ANY rank changed a delta
+            if (xr && merge_norm) {
+                // every rank must see whether ANY rank changed a delta; the exact sum of this rank's wt_remain is formed at once (it leaves at once
+                // if this rank's own flag is up) and travels with the flag: one all-gather per closing pass instead of two
+                CompWork Wt = W;
+                Wt.seq.skip = &F.hist[it];
+                FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), Wt.seq, acc);
+                FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
+                FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), Wt.seq, acc, fr_seq_from_zero());
+                FR_LAUNCH(c, "k_fks_close_put", k_fks_close_put2, dim3(1), dim3(1), F, (uint32_t *)c->comm.small_send, it, (const double *)W.seq.total);
+                const uint32_t *all = (const uint32_t *)fr_allgather(c, 16);
+                FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag2, dim3(1), dim3(1), F, all, P, it, c->d_norms_all);
+                norms_done = true;
+            }
+            else if (xr) {       // every rank must see whether ANY rank changed a delta
                 FR_LAUNCH(c, "k_fks_close_put", k_fks_close_put, dim3(1), dim3(1), F, (uint32_t *)c->comm.small_send, it);
                 const uint32_t *all = (const uint32_t *)fr_allgather(c, 16);
                 FR_LAUNCH(c, "k_fks_close_flag", k_fks_close_flag, dim3(1), dim3(1), F, all, P, it);
@@ -678,7 +694,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
                 needed = it;
                 for (int j = 2; j < it; j++) if (hm->hist[j] == 0) { needed = j; break; }      // a plain replay already reproduced its predecessor: the closing pass could have come there
             }
-            else { tail_done = false; scan_totals(it); it++; plain = it; }       // it was a replay like any other: scan, add up, close again
+            else { tail_done = false; norms_done = false; scan_totals(it); it++; plain = it; }       // it was a replay like any other: scan, add up, close again
         }
         if (closed) c->rounds_hint[STAGE] = needed > 2 ? needed : 2;
     }
@@ -698,7 +714,7 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     // (a norm that went negative did so by rounding noise of the same kind)
     if (!sequential && !c->fks_no_collapse_walk && (!(hscal.G_last >= 1e-3 * hscal.psG[0]) || hscal.G_neg < 0) && hscal.psG[0] > 0) sequential = true;
     if (sequential) {
-        tail_done = false;
+        tail_done = false; norms_done = false;
         if (hscal.overflow) FR_LAUNCH(c, "k_err_clear", k_err_clear, dim3(1), dim3(1), c->d_err, (uint32_t)FR_ERR_ROUNDS);     // FR_ERR_ROUNDS of the abandoned replay only: d_err also carries the flags of earlier stages and iterations of the batch
         run_fks_sequential<STAGE, NEW_HB>(c, cur, grid, F, n_bound);
     }
@@ -726,11 +742,13 @@ static void run_stage(FriesCtx *c, int cur, uint32_t n_bound, uint32_t n_samp, d
     if (tail_done) { }
     else if (simple_tail) launch_tail(nullptr);
     else {
+        if (!norms_done) {
         FR_LAUNCH(c, "k_seq_sums", (k_seq_sums<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc);
         FR_LAUNCH(c, "k_seq_maps", (k_seq_maps<AccWt>), dim3(grid), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
         FR_LAUNCH(c, "k_seq_chain", (k_seq_chain<AccWt>), dim3(1), dim3(FR_BLOCK), W.seq, acc, fr_seq_from_zero());
-        const double *norms = W.seq.total;
-        if (xr) {
+        }
+        const double *norms = norms_done ? c->d_norms_all : W.seq.total;
+        if (xr && !norms_done) {
             // every rank's remaining norm (compress_utils.cpp:817-818), then the in-order lbound chain again from this
             // rank's offset: a floating-point running sum depends on where it starts
             FR_LAUNCH(c, "k_put_norm", k_put_norm, dim3(1), dim3(1), W, F, (double *)c->comm.small_send);
