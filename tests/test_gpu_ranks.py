@@ -61,6 +61,25 @@ def test_sharded_engine_matches_reference_ranks(name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_sharded_engine_with_the_norms_in_a_message_of_their_own(tmp_path):
+    """FRIES_FKS_NO_MERGED_NORM=1: the ranks' remaining norms gathered after the host has seen the closing pass's flag (two all-gathers per stage, the
+    sequence until round 3) instead of riding with the flag -- the same trajectories per rank."""
+    name = "n2_m10000_unnorm_p2"
+    r = _RANK_RUNS[name]
+    P = r["n_ranks"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", FRIES_FKS_NO_MERGED_NORM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ranks_worker.py"), name, "gloo", str(tmp_path)]
+    res = _run_ranks(cmd, env, 300)
+    for k in range(P):
+        fn = tmp_path / f"rank{k}.json"
+        assert fn.exists(), res.stdout[-2000:] + res.stderr[-4000:]
+        rep = json.loads(fn.read_text())
+        assert rep["ok"], rep["fails"]
+    assert res.returncode == 0, res.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_one_rank_communicator_over_rccl(tmp_path):
     """backend "nccl" (RCCL) with a world of one: every all-gather and the spawn all-to-all run as real RCCL
     collectives enqueued under the engine's stream, and the run must still equal the one-rank golden."""
