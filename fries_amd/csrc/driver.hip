@@ -543,7 +543,7 @@ extern "C" void fries_ctx_destroy(fries_ctx *h) {
     {   // the find_keep_sub replay's arrays (allocated with the work arrays: hbpp.hip)
         Fks2Work &F = h->c.F2;
         if (F.dk8) {
-            hipFree(F.dk8); hipFree(F.dg8); hipFree(F.ws8); hipFree(F.cdirty); hipFree(F.wG); hipFree(F.wR); hipFree(F.wM); hipFree(F.wK); hipFree(F.wdK); hipFree(F.wdG); hipFree(F.wNp);
+            hipFree(F.dk8); hipFree(F.dg8); hipFree(F.ws8); hipFree(F.cdirty); hipFree(F.wrec); hipFree(F.wNp);
             hipFree(F.xk8); hipFree(F.xg8); hipFree(F.scal); hipFree(F.hist); hipFree(F.ck); hipFree(F.cg); hipFree(F.cw); hipFree(F.ckx); hipFree(F.cgx); hipFree(F.dbg_cnt);
             hipFree(h->c.fks_wkx); hipFree(h->c.fks_wgx); hipFree(h->c.fks_wk); hipFree(h->c.fks_wg); hipFree(h->c.fks_sxk8); hipFree(h->c.fks_sxg8); hipFree(h->c.fks_saved);
         }

@@ -64,6 +64,9 @@ struct FksHost {
     int n_pass;
 };
 
+// what a wave of 64 elements recorded about one sweep of the recording replay: the state it entered the sweep with, its tightest comparison, the
+// smallest norm any of its comparisons saw, and by how much its own deltas moved afterwards
+struct alignas(32) FksWRec { double G; uint32_t K; float R; float M; uint32_t dK; float dG; uint32_t pad; };
 struct Fks2Work {
     FksHost *hm;                            // device-visible address of the host block
     int hm_close;                           // 1 (one rank): the closing pass raises hm->hist[it] itself -- no k_fks_close_flag launch behind it
@@ -75,7 +78,8 @@ struct Fks2Work {
     // decision of the wave and skips it ("light" replays).  wdK / wdG: by how much that evaluation moved the wave's own deltas (samples,
     // norm; summed over its groups) -- the prefixes INSIDE the wave have moved by at most that much since its groups were evaluated.
     // [FR_FKS_PMAX][nwv_cap]; wNp[nwv_cap] = sweeps the wave last ran.
-    double *wG; float *wR, *wM, *wdG; uint32_t *wK, *wdK; uint32_t *wNp; uint32_t nwv_cap;
+    FksWRec *wrec;                          // [wave][sweep]: a wave's records of one replay lie side by side (the light test reads them as one or two cache lines)
+    uint32_t *wNp; uint32_t nwv_cap;
     uint32_t *cdirty;                       // [FR_FKS_MAXCHUNK] it + 1 of the last replay that changed a delta inside the chunk
     uint32_t *xk8; double *xg8;             // exclusive prefixes over the groups of a chunk, same shape
     uint32_t *ck; double *cg, *cw;          // [FR_FKS_PMAX][FR_FKS_MAXCHUNK] totals per chunk of 2048 groups
@@ -366,11 +370,11 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             }
             if (ext) k7 = F.xk8[(size_t)q * stride + bl] - F.xk8[(size_t)q * stride + b0];      // (q <= vup: checked above)
             const double G_in = S.psG[p] - xg; const uint32_t K_in = S.psN[p] - xk;
-            const size_t wx = (size_t)q * wstride + wv;
-            const uint32_t K_old = F.wK[wx]; const double G_old = F.wG[wx];
-            const double rmar = (double)F.wR[wx];
-            const double ik = (double)F.wdK[wx], ig_ = (double)F.wdG[wx];       // the wave's own deltas moved by this much after its groups were evaluated
-            const double gmin = (double)F.wM[wx] - ig_;
+            const FksWRec rec = F.wrec[wv * FR_FKS_PMAX + (size_t)q];
+            const uint32_t K_old = rec.K; const double G_old = rec.G;
+            const double rmar = (double)rec.R;
+            const double ik = (double)rec.dK, ig_ = (double)rec.dG;       // the wave's own deltas moved by this much after its groups were evaluated
+            const double gmin = (double)rec.M - ig_;
             int okp = 0;
             if (rmar == INFINITY) okp = 1;                  // the wave compared nothing in this sweep
             else if ((double)K_in > 2.0 * ((double)k7 + ik) + 64.0 && (double)K_old > 2.0 * ((double)k7 + ik) + 64.0 && gmin > 0 && G_old >= gmin) {
@@ -419,8 +423,8 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(M
                     }
                 }
                 if (lane >= (int)rec_np && lane < n_pass) {
-                    const size_t wx = (size_t)lane * wstride + wv;
-                    F.wG[wx] = ext_G; F.wK[wx] = ext_K; F.wR[wx] = (float)ext_r * 0.9999f; F.wM[wx] = (float)ext_m; F.wdK[wx] = 0u; F.wdG[wx] = 0.0f;
+                    FksWRec rn; rn.G = ext_G; rn.K = ext_K; rn.R = (float)ext_r * 0.9999f; rn.M = (float)ext_m; rn.dK = 0u; rn.dG = 0.0f; rn.pad = 0u;
+                    F.wrec[wv * FR_FKS_PMAX + (size_t)lane] = rn;
                 }
             }
             if (lane == 0) F.wNp[wv] = (uint32_t)n_pass;
@@ -666,7 +670,10 @@ __global__ void __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(M
                     for (int q = 0; q < 64; q += 16) { sk += (uint32_t)__builtin_amdgcn_readlane((int)dki, q); sg += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dgi), q)); }
                     sg *= 1.0001f;
                 }
-                if (lane == 0 && ig) { const size_t wx = (size_t)p * wstride + my_wave; F.wG[wx] = glob0; F.wK[wx] = S.psN[p] - xk; F.wR[wx] = __uint_as_float(rec_r); F.wM[wx] = __uint_as_float(rec_g); F.wdK[wx] = sk; F.wdG[wx] = sg; }
+                if (lane == 0 && ig) {
+                    FksWRec rn; rn.G = glob0; rn.K = S.psN[p] - xk; rn.R = __uint_as_float(rec_r); rn.M = __uint_as_float(rec_g); rn.dK = sk; rn.dG = sg; rn.pad = 0u;
+                    F.wrec[my_wave * FR_FKS_PMAX + (size_t)p] = rn;
+                }
             }
         }
         // one sweep beyond: keeps nothing, but its wt_remain sum is what a re-summed norm would be
@@ -887,7 +894,7 @@ static __global__ void __launch_bounds__(FR_BLOCK) k_fks_tie(Fks2Work F, uint32_
     const size_t stride = F.nwv_cap, nwv = ((size_t)nb8 + 7) / 8;
     float m = INFINITY;
     for (int p = 0; p < n_pass; p++)
-        for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwv; w += (size_t)gridDim.x * blockDim.x) { const float r = F.wR[(size_t)p * stride + w]; m = r < m ? r : m; }
+        for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwv; w += (size_t)gridDim.x * blockDim.x) { const float r = F.wrec[w * FR_FKS_PMAX + (size_t)p].R; m = r < m ? r : m; }
     for (int off = 32; off > 0; off >>= 1) { const float t = __shfl_xor(m, off); m = t < m ? t : m; }
     if (fr_lane() == 0 && m < INFINITY) atomicMin(&tie[0], __float_as_uint(m));
 }

@@ -358,7 +358,7 @@ void fr_hbpp_alloc(FriesCtx *c, uint32_t cap) {
         }
         F.nwv_cap = F.nb8_cap / 8;
         const size_t nw = (size_t)FR_FKS_PMAX * F.nwv_cap;
-        F.wG = fr_alloc<double>(nw); F.wR = fr_alloc<float>(nw); F.wM = fr_alloc<float>(nw); F.wK = fr_alloc<uint32_t>(nw); F.wdK = fr_alloc<uint32_t>(nw); F.wdG = fr_alloc<float>(nw); F.wNp = fr_alloc<uint32_t>(F.nwv_cap);
+        F.wrec = fr_alloc<FksWRec>(nw); F.wNp = fr_alloc<uint32_t>(F.nwv_cap);
         FR_HIP(hipMemset(F.wNp, 0xff, 4 * (size_t)F.nwv_cap));
         F.xk8 = fr_alloc<uint32_t>(n8); F.xg8 = fr_alloc<double>(n8);
         F.scal = fr_alloc<FksScal>(1); F.hist = fr_alloc<uint32_t>(FR_MAX_ROUNDS + 2);
